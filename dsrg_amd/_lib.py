@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI in include/dsrg_hip.h (libdsrg_hip.so).
+
+There is deliberately no fallback: if the shared library is missing or a call
+fails, an exception is raised.  The product never routes through the CPU oracle.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  — loaded first so libdsrg_hip.so binds to torch's libamdhip64.so.7
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsrg_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4
+
+
+class DsrgError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libdsrg_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class CrfParams(ctypes.Structure):
+    """dsrg_crf_params (include/dsrg_hip.h) — the arguments of krahenbuhl2013.CRF (CRF.py:25-35)."""
+    _fields_ = [("w_bilateral", ctypes.c_float), ("theta_alpha_x", ctypes.c_float),
+                ("theta_alpha_y", ctypes.c_float), ("theta_beta_r", ctypes.c_float),
+                ("theta_beta_g", ctypes.c_float), ("theta_beta_b", ctypes.c_float),
+                ("w_gaussian", ctypes.c_float), ("theta_gamma_x", ctypes.c_float),
+                ("theta_gamma_y", ctypes.c_float), ("n_iters", ctypes.c_int32)]
+
+    @classmethod
+    def from_crf_args(cls, maxiter=10, scale_factor=1.0, color_factor=13):
+        # same Python-double arithmetic as CRF.py:31-32, rounded to float at the C boundary
+        return cls(10.0, 80 / scale_factor, 80 / scale_factor, color_factor, color_factor, color_factor,
+                   3.0, 3 / scale_factor, 3 / scale_factor, int(maxiter))
+
+
+_vp, _i, _f, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/dsrg_hip.h declares
+SIGNATURES = {
+    "dsrg_last_error": (ctypes.c_char_p, []),
+    "dsrg_device_count": (_i, []),
+    "dsrg_crf_create": (_i, [_i, _i, _i, ctypes.POINTER(_vp)]),
+    "dsrg_crf_destroy": (_i, [_vp]),
+    "dsrg_crf_set_unary_energy": (_i, [_vp, _vp]),
+    "dsrg_crf_add_pairwise_energy": (_i, [_vp] + [_f] * 9 + [_vp]),
+    "dsrg_crf_inference": (_i, [_vp, _i, _vp]),
+    "dsrg_crf_map": (_i, [_vp, _i, _vp]),
+    "dsrg_crf_npixels": (_i, [_vp]),
+    "dsrg_crf_nlabels": (_i, [_vp]),
+    "dsrg_crf_lattice_size": (_i, [_vp, _i]),
+    "dsrg_ctx_create": (_i, [_i, _i, _i, _i, ctypes.POINTER(_vp)]),
+    "dsrg_ctx_destroy": (_i, [_vp]),
+    "dsrg_crf_refine_batch": (_i, [_vp, _i, _vp, _vp, _i, _i, ctypes.POINTER(CrfParams), _vp, _vp, _vp]),
+    "dsrg_crf_meanfield_batch": (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(CrfParams), _vp, _vp]),
+    "dsrg_ctx_lattice_sizes": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "dsrg_crf_layer_backward": (_i, [_sz, _vp, _vp, _vp, _vp]),
+    "dsrg_srg_grow_batch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _d, _d, _vp, _vp]),
+    "dsrg_softmax_forward": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "dsrg_softmax_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dsrg_seed_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dsrg_constrain_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dsrg_supervision_step": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _d, _d, ctypes.POINTER(CrfParams),
+                                   _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libdsrg_hip.so (built by dsrg_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing — build it with `make -C dsrg_amd/csrc` (hipcc --offload-arch=gfx950) or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != OK:
+        raise DsrgError(rc, lib().dsrg_last_error().decode("utf-8", "replace"))
+
+
+def require_gpu():
+    if lib().dsrg_device_count() < 1:
+        raise DsrgError(ERR_HIP, "no HIP device visible — the DSRG supervision kernels need an MI355X "
+                                 "(gfx950); there is no CPU fallback")

@@ -1,0 +1,322 @@
+// C ABI of libdsrg_hip.so (include/dsrg_hip.h): contexts, workspaces, launch sequences.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "common.h"
+
+namespace dsrg {
+
+static thread_local char g_err[512] = "";
+int set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace dsrg
+
+using namespace dsrg;
+
+// ---------------------------------------------------------------------------------
+struct dsrg_ctx_s {
+    int maxB, C, H, W, N;
+    void *arena;                 // one hipMalloc for everything below
+    LatticeView Lg, Lb;
+    LatticeFeat Fg_built;        // parameters the cached Gaussian lattice was built with
+    bool gauss_valid;
+    MeanfieldBufs mf;
+    unsigned char *im_u8;        // (maxB, N, 3)
+    // fused-step blobs
+    float *probs, *logq, *seeds;
+    double *refined;
+    double *stats;               // (maxB, 5)
+};
+
+extern "C" const char *dsrg_last_error(void) { return g_err; }
+
+extern "C" int dsrg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *out) {
+    if (!out || max_batch < 1 || C < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "bad ctx shape");
+    if (C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "at most %d labels", kMaxLabels);
+    const int N = H * W;
+    if (!lattice_supported(2, N) || !lattice_supported(5, N))
+        return set_error(DSRG_ERR_UNSUPPORTED,
+                         "%dx%d map: lattices do not fit the LDS-resident path of this build", H, W);
+    if (dsrg_device_count() < 1) return set_error(DSRG_ERR_HIP, "no HIP device visible");
+    dsrg_ctx_s *c = new (std::nothrow) dsrg_ctx_s();
+    if (!c) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+    c->maxB = max_batch; c->C = C; c->H = H; c->W = W; c->N = N; c->gauss_valid = false;
+    const size_t blob = align256(sizeof(float) * (size_t)max_batch * C * N);
+    const size_t szLg = align256(lattice_bytes(2, N, 1)), szLb = align256(lattice_bytes(5, N, max_batch));
+    const size_t szIm = align256((size_t)max_batch * N * 3);
+    const size_t szRef = align256(sizeof(double) * (size_t)max_batch * C * N);
+    const size_t szStats = align256(sizeof(double) * (size_t)max_batch * 5);
+    const size_t total = szLg + szLb + 3 * blob /*mf*/ + szIm + 3 * blob /*probs,logq,seeds*/ + szRef + szStats;
+    hipError_t e = hipMalloc(&c->arena, total);
+    if (e != hipSuccess) {
+        delete c;
+        return set_error(DSRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    }
+    unsigned char *p = static_cast<unsigned char *>(c->arena);
+    lattice_carve(c->Lg, p, 2, N, 1); p += szLg;
+    lattice_carve(c->Lb, p, 5, N, max_batch); p += szLb;
+    c->mf.q = reinterpret_cast<float *>(p); p += blob;
+    c->mf.msg_g = reinterpret_cast<float *>(p); p += blob;
+    c->mf.msg_b = reinterpret_cast<float *>(p); p += blob;
+    c->im_u8 = p; p += szIm;
+    c->probs = reinterpret_cast<float *>(p); p += blob;
+    c->logq = reinterpret_cast<float *>(p); p += blob;
+    c->seeds = reinterpret_cast<float *>(p); p += blob;
+    c->refined = reinterpret_cast<double *>(p); p += szRef;
+    c->stats = reinterpret_cast<double *>(p); p += szStats;
+    *out = c;
+    return DSRG_OK;
+}
+
+extern "C" int dsrg_ctx_destroy(dsrg_ctx_t c) {
+    if (!c) return DSRG_OK;
+    if (c->arena) (void)hipFree(c->arena);
+    delete c;
+    return DSRG_OK;
+}
+
+static int check_params(const dsrg_crf_params *p) {
+    if (!p) return set_error(DSRG_ERR_INVALID, "params is NULL");
+    if (p->n_iters < 0) return set_error(DSRG_ERR_INVALID, "n_iters < 0");
+    if (!(p->theta_alpha_x > 0 && p->theta_alpha_y > 0 && p->theta_beta_r > 0 && p->theta_beta_g > 0 &&
+          p->theta_beta_b > 0 && p->theta_gamma_x > 0 && p->theta_gamma_y > 0))
+        return set_error(DSRG_ERR_INVALID, "kernel widths must be positive");
+    return DSRG_OK;
+}
+
+// build lattices for B images from im_u8 (B,N,3), then run the mean field
+static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,
+                   const dsrg_crf_params *prm, float *q_out, double *refined, float *logq, hipStream_t s) {
+    LatticeFeat Fg, Fb;
+    lattice_feat_init(Fg, 2, c->W, c->H, prm->theta_gamma_x, prm->theta_gamma_y, 1.f, 1.f, 1.f);
+    lattice_feat_init(Fb, 5, c->W, c->H, prm->theta_alpha_x, prm->theta_alpha_y, prm->theta_beta_r,
+                      prm->theta_beta_g, prm->theta_beta_b);
+    int rc;
+    // the Gaussian lattice depends only on (W,H,theta_gamma): build once, reuse across calls
+    if (!c->gauss_valid || memcmp(&Fg, &c->Fg_built, sizeof(Fg)) != 0) {
+        rc = launch_lattice_build(c->Lg, Fg, nullptr, 1, s);
+        if (rc) return rc;
+        c->Fg_built = Fg;
+        c->gauss_valid = true;
+    }
+    rc = launch_lattice_build(c->Lb, Fb, im_u8, B, s);
+    if (rc) return rc;
+    return launch_meanfield(c->Lg, c->Lb, c->mf, B, c->C, neg_unary, prm->w_gaussian, prm->w_bilateral,
+                            prm->n_iters, q_out, refined, logq, s);
+}
+
+extern "C" int dsrg_crf_refine_batch(dsrg_ctx_t c, int B, float *probs, const float *images, int img_h, int img_w,
+                                     const dsrg_crf_params *prm, double *refined, float *logq, void *stream) {
+    if (!c || !probs || !images || !refined) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
+    if (img_h < 1 || img_w < 1) return set_error(DSRG_ERR_INVALID, "bad image size");
+    int rc = check_params(prm);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = launch_clip_min(probs, (size_t)B * c->C * c->N, s);                    // pylayers.py:67
+    if (rc) return rc;
+    rc = launch_prepare_images(images, B, img_h, img_w, c->H, c->W, c->im_u8, s);   // pylayers.py:70-75
+    if (rc) return rc;
+    return crf_run(c, B, probs, c->im_u8, prm, nullptr, refined, logq, s);    // CRF.py:28: -(-unary) = probs
+}
+
+extern "C" int dsrg_crf_meanfield_batch(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,
+                                        const dsrg_crf_params *prm, float *q, void *stream) {
+    if (!c || !neg_unary || !im_u8 || !q) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
+    int rc = check_params(prm);
+    if (rc) return rc;
+    return crf_run(c, B, neg_unary, im_u8, prm, q, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dsrg_ctx_lattice_sizes(dsrg_ctx_t c, int B, int32_t *m_gauss, int32_t *m_bil, void *stream) {
+    if (!c || B < 0 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (m_gauss) DSRG_HIP_CHECK(hipMemcpyAsync(m_gauss, c->Lg.M, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (m_bil && B > 0)
+        DSRG_HIP_CHECK(hipMemcpyAsync(m_bil, c->Lb.M, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    DSRG_HIP_CHECK(hipStreamSynchronize(s));
+    return DSRG_OK;
+}
+
+extern "C" int dsrg_crf_layer_backward(size_t n, const double *refined, const float *td, float *bd, void *stream) {
+    if (!refined || !td || !bd) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_crf_bwd(n, refined, td, bd, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dsrg_srg_grow_batch(int B, int C, int H, int W, const float *labels, const float *cues,
+                                   const double *refined, double th1, double th2, float *seeds, void *stream) {
+    if (!labels || !cues || !refined || !seeds) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "bad shape");
+    return launch_srg(B, C, H, W, labels, cues, refined, th1, th2, seeds, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dsrg_softmax_forward(int B, int C, int HW, const float *x, float *p, void *stream) {
+    if (!x || !p || B < 1 || HW < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return launch_softmax_fwd(B, C, HW, x, p, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_softmax_backward(int B, int C, int HW, const float *x, const float *td, float *bd, void *stream) {
+    if (!x || !td || !bd || B < 1 || HW < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return launch_softmax_bwd(B, C, HW, x, td, bd, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_seed_loss(int B, int C, int HW, const float *probs, const float *seeds, float *loss,
+                              float *grad, void *stream) {
+    if (!probs || !seeds || B < 1 || C < 1 || HW < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return launch_seed_loss(B, C, HW, probs, seeds, loss, grad, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_constrain_loss(int B, int C, int HW, const float *probs, const float *logq, float *loss,
+                                   float *gp, float *glq, void *stream) {
+    if (!probs || !logq || B < 1 || C < 1 || HW < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return launch_constrain_loss(B, C, HW, probs, logq, loss, gp, glq, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, const float *images, int img_h,
+                                     int img_w, const float *labels, const float *cues, double th1, double th2,
+                                     const dsrg_crf_params *prm, float *losses, float *grad_logits,
+                                     float *probs_out, float *seeds_out, float *logq_out, void *stream) {
+    if (!c || !logits || !images || !labels || !cues || !losses || !grad_logits)
+        return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int C = c->C, N = c->N;
+    const size_t nb = sizeof(float) * (size_t)B * C * N;
+    int rc = launch_softmax_fwd(B, C, N, logits, c->probs, s);                     // Softmax
+    if (rc) return rc;
+    rc = dsrg_crf_refine_batch(c, B, c->probs, images, img_h, img_w, prm, c->refined, c->logq, stream);   // CRF (once)
+    if (rc) return rc;
+    rc = launch_srg(B, C, c->H, c->W, labels, cues, c->refined, th1, th2, c->seeds, s);    // DSRG
+    if (rc) return rc;
+    rc = launch_sup_loss_backward(B, C, N, logits, c->probs, c->seeds, c->logq, c->refined, c->stats, grad_logits,
+                                  losses, s);                                        // losses + backward
+    if (rc) return rc;
+    if (probs_out) DSRG_HIP_CHECK(hipMemcpyAsync(probs_out, c->probs, nb, hipMemcpyDeviceToDevice, s));
+    if (seeds_out) DSRG_HIP_CHECK(hipMemcpyAsync(seeds_out, c->seeds, nb, hipMemcpyDeviceToDevice, s));
+    if (logq_out) DSRG_HIP_CHECK(hipMemcpyAsync(logq_out, c->logq, nb, hipMemcpyDeviceToDevice, s));
+    return DSRG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// single-image object (DenseCRFWrapper): host pointers, synchronous
+struct dsrg_crf_s {
+    int W, H, M;
+    dsrg_ctx_t ctx;
+    float *neg_unary;            // device (M,N) planes = -U
+    float *q;                    // device (M,N)
+    float *stage;                // device N*M label-fastest staging
+    unsigned char *im;           // device N*3
+    int32_t *lab;                // device N
+    bool have_unary, have_pairwise;
+    dsrg_crf_params prm;
+};
+
+extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) {
+    if (!out || W < 1 || H < 1 || nlabels < 1) return set_error(DSRG_ERR_INVALID, "bad CRF shape");
+    dsrg_crf_s *h = new (std::nothrow) dsrg_crf_s();
+    if (!h) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+    memset(h, 0, sizeof(*h));
+    h->W = W; h->H = H; h->M = nlabels;
+    int rc = dsrg_ctx_create(1, nlabels, H, W, &h->ctx);
+    if (rc) { delete h; return rc; }
+    const size_t n = (size_t)W * H * nlabels;
+    hipError_t e = hipMalloc(&h->neg_unary, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMalloc(&h->q, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMalloc(&h->stage, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMalloc(&h->im, (size_t)W * H * 3);
+    if (e == hipSuccess) e = hipMalloc(&h->lab, sizeof(int32_t) * (size_t)W * H);
+    if (e != hipSuccess) { dsrg_crf_destroy(h); return set_error(DSRG_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    *out = h;
+    return DSRG_OK;
+}
+extern "C" int dsrg_crf_destroy(dsrg_crf_t h) {
+    if (!h) return DSRG_OK;
+    if (h->neg_unary) (void)hipFree(h->neg_unary);
+    if (h->q) (void)hipFree(h->q);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->im) (void)hipFree(h->im);
+    if (h->lab) (void)hipFree(h->lab);
+    dsrg_ctx_destroy(h->ctx);
+    delete h;
+    return DSRG_OK;
+}
+extern "C" int dsrg_crf_npixels(dsrg_crf_t h) { return h ? h->W * h->H : 0; }
+extern "C" int dsrg_crf_nlabels(dsrg_crf_t h) { return h ? h->M : 0; }
+
+extern "C" int dsrg_crf_set_unary_energy(dsrg_crf_t h, const float *unary_host) {
+    if (!h || !unary_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    const int N = h->W * h->H;
+    DSRG_HIP_CHECK(hipMemcpy(h->stage, unary_host, sizeof(float) * (size_t)N * h->M, hipMemcpyHostToDevice));
+    int rc = launch_lf_to_planes(N, h->M, h->stage, h->neg_unary, 1, nullptr);   // inference uses -unary (densecrf.cpp:120,122)
+    if (rc) return rc;
+    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));
+    h->have_unary = true;
+    return DSRG_OK;
+}
+extern "C" int dsrg_crf_add_pairwise_energy(dsrg_crf_t h, float w1, float ta1, float ta2, float tb1, float tb2,
+                                            float tb3, float w2, float tg1, float tg2, const unsigned char *im_host) {
+    if (!h || !im_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    dsrg_crf_params p;
+    p.w_bilateral = w1; p.theta_alpha_x = ta1; p.theta_alpha_y = ta2;
+    p.theta_beta_r = tb1; p.theta_beta_g = tb2; p.theta_beta_b = tb3;
+    p.w_gaussian = w2; p.theta_gamma_x = tg1; p.theta_gamma_y = tg2; p.n_iters = 0;
+    int rc = check_params(&p);
+    if (rc) return rc;
+    DSRG_HIP_CHECK(hipMemcpy(h->im, im_host, (size_t)h->W * h->H * 3, hipMemcpyHostToDevice));
+    h->prm = p;
+    h->have_pairwise = true;
+    return DSRG_OK;
+}
+static int crf_infer(dsrg_crf_t h, int n_iters) {
+    if (n_iters < 0) return set_error(DSRG_ERR_INVALID, "n_iters < 0");
+    const int N = h->W * h->H;
+    if (!h->have_unary) {    // DenseCRF::inference starts from a zero unary when none was set (densecrf.cpp:117-119)
+        DSRG_HIP_CHECK(hipMemset(h->neg_unary, 0, sizeof(float) * (size_t)N * h->M));
+        h->have_unary = true;
+    }
+    if (!h->have_pairwise)
+        return set_error(DSRG_ERR_INVALID, "add_pairwise_energy must be called before inference");
+    dsrg_crf_params p = h->prm;
+    p.n_iters = n_iters;
+    return dsrg_crf_meanfield_batch(h->ctx, 1, h->neg_unary, h->im, &p, h->q, nullptr);
+}
+extern "C" int dsrg_crf_inference(dsrg_crf_t h, int n_iters, float *out_host) {
+    if (!h || !out_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    int rc = crf_infer(h, n_iters);
+    if (rc) return rc;
+    const int N = h->W * h->H;
+    rc = launch_planes_to_lf(N, h->M, h->q, h->stage, nullptr);
+    if (rc) return rc;
+    DSRG_HIP_CHECK(hipMemcpy(out_host, h->stage, sizeof(float) * (size_t)N * h->M, hipMemcpyDeviceToHost));
+    return DSRG_OK;
+}
+extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
+    if (!h || !labels_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    int rc = crf_infer(h, n_iters);
+    if (rc) return rc;
+    const int N = h->W * h->H;
+    rc = launch_argmax_planes(N, h->M, h->q, h->lab, nullptr);
+    if (rc) return rc;
+    DSRG_HIP_CHECK(hipMemcpy(labels_host, h->lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+    return DSRG_OK;
+}
+extern "C" int dsrg_crf_lattice_size(dsrg_crf_t h, int k) {
+    if (!h || !h->ctx || k < 0 || k > 1) return -1;
+    int32_t m = -1;
+    if (hipMemcpy(&m, k == 0 ? h->ctx->Lg.M : h->ctx->Lb.M, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return m;
+}

@@ -1,0 +1,99 @@
+// Internal declarations shared by the HIP translation units of libdsrg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/dsrg_hip.h"
+
+namespace dsrg {
+
+// ---- error plumbing --------------------------------------------------------
+int set_error(int code, const char *fmt, ...);
+#define DSRG_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return ::dsrg::set_error(DSRG_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
+                                     hipGetErrorString(_e), __FILE__, __LINE__);          \
+    } while (0)
+#define DSRG_LAUNCH_CHECK() DSRG_HIP_CHECK(hipGetLastError())
+
+constexpr int kWG = 1024;          // threads per workgroup of the lattice kernels (16 waves)
+constexpr int kMaxLabels = 64;     // per-pixel label loops keep at most this many values in registers
+constexpr float kMinProb = 0.0001f;
+
+// ---- permutohedral lattice, device-resident ----------------------------------
+// One lattice = one (image, kernel) pair.  All arrays are sized for the worst
+// case Mcap = Npad*(d+1) vertices so nothing depends on the data-dependent M.
+// Vertex ids and pixel indices fit uint16 on this path (Mcap+1, N < 65536).
+struct LatticeView {
+    int d;                 // feature dimension (2 Gaussian, 5 bilateral)
+    int N;                 // pixels
+    int Mcap;              // capacity = ((N+3)/4*4)*(d+1); index Mcap is the zero sentinel
+    int nlat;              // number of lattices in this set (1 for the shared Gaussian, B for bilateral)
+    // per lattice, strided by the quantities in brackets
+    int *M;                // [1]        vertex count
+    uint16_t *vid;         // [(d+1)*N]  vertex id of simplex corner r of pixel i   (r-major)
+    float *bary;           // [(d+1)*N]  barycentric weight                         (r-major)
+    uint32_t *nb;          // [(d+1)*Mcap] blur neighbours along axis j: n1 | n2<<16 (Mcap = none)
+    uint32_t *row_start;   // [Mcap+1]   CSR of the splat: entries of vertex v
+    uint16_t *csr_pix;     // [(d+1)*N]  source pixel of each entry, entry order = reference splat order
+    float *csr_w;          // [(d+1)*N]  weight of each entry
+    float *norm;           // [N]        1/sqrt(K 1 + 1e-20)
+    // build scratch
+    uint32_t *key_e;       // [Epad*KW]  packed keys of every (pixel, corner) entry, Epad = Npad*(d+1)
+    uint16_t *slot_e;      // [Epad]     hash slot of every entry
+    uint32_t *key_v;       // [Mcap*KW]  packed key of every vertex
+};
+
+struct LatticeFeat {
+    // feature = coordinate / sigma  (densecrf.cpp:61-81); fp32 divisions
+    float sx, sy, sr, sg, sb;
+    float scale[5];        // E's diagonal (permutohedral.cpp:179-182), evaluated on the host
+    int W, H;
+};
+
+size_t lattice_bytes(int d, int N, int nlat);
+// carve a LatticeView out of one allocation (base must be 256-B aligned)
+void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat);
+void lattice_feat_init(LatticeFeat &F, int d, int W, int H, float sx, float sy, float sr, float sg, float sb);
+
+// builds `nlat` lattices (im = nullptr for the Gaussian, (nlat, N, 3) uint8 for the bilateral)
+int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsigned char *im, int nlat,
+                         hipStream_t stream);
+bool lattice_supported(int d, int N);
+
+// ---- mean field -------------------------------------------------------------------
+struct MeanfieldBufs {
+    float *q;        // (B,C,N) current marginals
+    float *msg_g;    // (B,C,N) normalised Gaussian message  K~_g Q
+    float *msg_b;    // (B,C,N) normalised bilateral message K~_b Q
+};
+int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C,
+                     const float *neg_unary, float wg, float wb, int n_iters, float *q_out,
+                     double *refined_out, float *logq_out, hipStream_t stream);
+
+// ---- pointwise / prep ----------------------------------------------------------------
+int launch_clip_min(float *p, size_t n, hipStream_t stream);
+int launch_prepare_images(const float *images, int B, int Hi, int Wi, int H, int W, unsigned char *im_u8,
+                          hipStream_t stream);
+
+int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream);
+int launch_softmax_bwd(int B, int C, int HW, const float *x, const float *g, float *dx, hipStream_t stream);
+int launch_crf_bwd(size_t n, const double *refined, const float *td, float *bd, hipStream_t stream);
+int launch_seed_loss(int B, int C, int HW, const float *p, const float *S, float *loss, float *grad,
+                     hipStream_t stream);
+int launch_constrain_loss(int B, int C, int HW, const float *p, const float *lq, float *loss, float *gp,
+                          float *glq, hipStream_t stream);
+int launch_sup_loss_backward(int B, int C, int HW, const float *logits, const float *probs, const float *seeds,
+                             const float *logq, const double *refined, double *stats, float *grad_logits,
+                             float *losses, hipStream_t stream);
+int launch_lf_to_planes(int N, int M, const float *in, float *out, int negate, hipStream_t stream);
+int launch_planes_to_lf(int N, int M, const float *in, float *out, hipStream_t stream);
+int launch_argmax_planes(int N, int M, const float *q, int32_t *lab, hipStream_t stream);
+
+// ---- seeded region growing ---------------------------------------------------------------
+int launch_srg(int B, int C, int H, int W, const float *labels, const float *cues, const double *refined,
+               double th1, double th2, float *seeds, hipStream_t stream);
+
+}  // namespace dsrg

@@ -1,0 +1,426 @@
+// Pointwise layers and input preparation of the DSRG supervision path (gfx950).
+// NCHW float32 blobs; lanes map to pixels so every label plane is read coalesced.
+//
+// Replaces SoftmaxLayer, CRFLayer's pre/post-processing and backward,
+// BalancedSeedLossLayer and ConstrainLossLayer of pylayers/pylayers/pylayers.py
+// (line numbers on each kernel).  The Theano graphs are restated in closed form.
+#include <math.h>
+#include "common.h"
+
+namespace dsrg {
+
+// probs[probs < min_prob] = min_prob, in place   (pylayers.py:67,312)
+__global__ void clip_min_kernel(float *__restrict__ p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float v = p[i];
+        if (v < kMinProb) p[i] = kMinProb;
+    }
+}
+int launch_clip_min(float *p, size_t n, hipStream_t stream) {
+    const int threads = 256;
+    const int blocks = (int)((n + threads - 1) / threads < 2048 ? (n + threads - 1) / threads : 2048);
+    hipLaunchKernelGGL(clip_min_kernel, dim3(blocks > 0 ? blocks : 1), dim3(threads), 0, stream, p, n);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// zoom(order=1) to (H,W) with the (in-1)/(out-1) mapping, + mean pixel, np.round, astype(ubyte)
+// (pylayers.py:70-75, CRF.py:32).  images (B,3,Hi,Wi) f32 -> im (B,H*W,3) u8.
+__global__ void prepare_images_kernel(const float *__restrict__ images, int B, int Hi, int Wi, int H, int W,
+                                      unsigned char *__restrict__ im) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = H * W;
+    if (idx >= B * N) return;
+    const int b = idx / N, p = idx - b * N, y = p / W, x = p - y * W;
+    const double mean_pixel[3] = {104.0, 117.0, 123.0};
+    const double sy = H > 1 ? (double)y * (double)(Hi - 1) / (double)(H - 1) : 0.0;
+    const double sx = W > 1 ? (double)x * (double)(Wi - 1) / (double)(W - 1) : 0.0;
+    const int y0 = (int)floor(sy), x0 = (int)floor(sx);
+    const double fy = sy - y0, fx = sx - x0;
+    const int y1 = y0 + 1 < Hi ? y0 + 1 : y0, x1 = x0 + 1 < Wi ? x0 + 1 : x0;
+    for (int ch = 0; ch < 3; ch++) {
+        const float *pl = images + ((size_t)b * 3 + ch) * Hi * Wi;
+        double v;
+        if (fy == 0.0 && fx == 0.0) v = (double)pl[(size_t)y0 * Wi + x0];
+        else {
+            const double a = (1.0 - fy) * (double)pl[(size_t)y0 * Wi + x0] + fy * (double)pl[(size_t)y1 * Wi + x0];
+            const double c = (1.0 - fy) * (double)pl[(size_t)y0 * Wi + x1] + fy * (double)pl[(size_t)y1 * Wi + x1];
+            v = (1.0 - fx) * a + fx * c;
+        }
+        const float vf = (float)v;
+        const double r = rint((double)vf + mean_pixel[ch]);      // half-even, like np.round
+        im[((size_t)b * N + p) * 3 + ch] = (unsigned char)(long long)r;
+    }
+}
+int launch_prepare_images(const float *images, int B, int Hi, int Wi, int H, int W, unsigned char *im_u8,
+                          hipStream_t stream) {
+    const int threads = 256, blocks = (B * H * W + threads - 1) / threads;
+    hipLaunchKernelGGL(prepare_images_kernel, dim3(blocks), dim3(threads), 0, stream, images, B, Hi, Wi, H, W, im_u8);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// ---- SoftmaxLayer (pylayers.py:30-51) ----------------------------------------------------
+// forward: s = softmax_c(x); p = (s + 1e-4) / sum_c(s + 1e-4), fp32
+template <int CT>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int C, int HW, const float *__restrict__ x,
+                                                          float *__restrict__ p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = idx / HW, i = idx - b * HW;
+    const size_t base = (size_t)b * C * HW + i;
+    float t[CT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) { t[c] = x[base + (size_t)c * HW]; mx = fmaxf(mx, t[c]); }
+    float z = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) { t[c] = expf(t[c] - mx); z = z + t[c]; }
+    float z2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) { t[c] = t[c] / z + kMinProb; z2 = z2 + t[c]; }
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) p[base + (size_t)c * HW] = t[c] / z2;
+}
+// backward = T.grad(sum(probs*g), preds):  dx_j = s_j (g_j - sum_k s_k g_k) / Z,  Z = sum_c (s_c + 1e-4)
+template <int CT>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, const float *__restrict__ x,
+                                                          const float *__restrict__ g, float *__restrict__ dx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = idx / HW, i = idx - b * HW;
+    const size_t base = (size_t)b * C * HW + i;
+    float s[CT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) { s[c] = x[base + (size_t)c * HW]; mx = fmaxf(mx, s[c]); }
+    float z = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) { s[c] = expf(s[c] - mx); z += s[c]; }
+    float Z = 0.0f, sg = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) { s[c] = s[c] / z; Z += s[c] + kMinProb; sg += s[c] * g[base + (size_t)c * HW]; }
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) dx[base + (size_t)c * HW] = s[c] * (g[base + (size_t)c * HW] - sg) / Z;
+}
+int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream) {
+    if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
+    const int threads = 256, blocks = (B * HW + threads - 1) / threads;
+    if (C <= 21) hipLaunchKernelGGL(softmax_fwd_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p);
+    else hipLaunchKernelGGL(softmax_fwd_kernel<kMaxLabels>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+int launch_softmax_bwd(int B, int C, int HW, const float *x, const float *g, float *dx, hipStream_t stream) {
+    if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
+    const int threads = 256, blocks = (B * HW + threads - 1) / threads;
+    if (C <= 21) hipLaunchKernelGGL(softmax_bwd_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, g, dx);
+    else hipLaunchKernelGGL(softmax_bwd_kernel<kMaxLabels>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, g, dx);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// ---- CRFLayer.backward (pylayers.py:90-92) -------------------------------------------------
+__global__ void crf_bwd_kernel(size_t n, const double *__restrict__ refined, const float *__restrict__ td,
+                               float *__restrict__ bd) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) bd[i] = (float)((1.0 - refined[i]) * (double)td[i]);
+}
+int launch_crf_bwd(size_t n, const double *refined, const float *td, float *bd, hipStream_t stream) {
+    const int threads = 256;
+    size_t blocks = (n + threads - 1) / threads;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(crf_bwd_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, n, refined, td, bd);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// ---- workgroup reduction helper (double) ---------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void block_reduce_sum(double (&v)[NV], double *scratch /* [NV*16] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; q++) scratch[q * 16 + wave] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+        double s = 0.0;
+        for (int w = 0; w < nw; w++) s += scratch[q * 16 + w];    // fixed order: deterministic
+        v[q] = s;
+    }
+}
+
+// ---- BalancedSeedLossLayer (pylayers.py:126-152) -------------------------------------------------
+// per-image statistics: {count_bg, count_fg, sum S0 log p0, sum S_fg log p_fg}
+__device__ __forceinline__ void seed_stats(int C, int HW, const float *__restrict__ pb,
+                                           const float *__restrict__ Sb, double (&st)[4], double *scratch) {
+    st[0] = st[1] = st[2] = st[3] = 0.0;
+    const int n = C * HW;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float s = Sb[i];
+        if (s != 0.0f) {
+            const double t = (double)s * (double)logf(pb[i]);
+            if (i < HW) { st[0] += s; st[2] += t; } else { st[1] += s; st[3] += t; }
+        }
+    }
+    block_reduce_sum<4>(st, scratch);
+}
+// forward: one workgroup walks the images in order (deterministic sum over the batch)
+__global__ __launch_bounds__(1024) void seed_loss_fwd_kernel(int B, int C, int HW, const float *__restrict__ p,
+                                                             const float *__restrict__ S,
+                                                             float *__restrict__ loss) {
+    __shared__ double scratch[4 * 16];
+    double acc = 0.0;
+    for (int b = 0; b < B; b++) {
+        double st[4];
+        seed_stats(C, HW, p + (size_t)b * C * HW, S + (size_t)b * C * HW, st, scratch);
+        const double dbg = st[0] > 1e-4 ? st[0] : 1e-4, dfg = st[1] > 1e-4 ? st[1] : 1e-4;
+        acc += -(st[2] / dbg) / B - (st[3] / dfg) / B;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)acc;
+}
+// backward: grad = -S / (p * max(count,1e-4) * B); one workgroup per image
+__global__ __launch_bounds__(1024) void seed_loss_bwd_kernel(int B, int C, int HW, const float *__restrict__ p,
+                                                             const float *__restrict__ S,
+                                                             float *__restrict__ grad) {
+    __shared__ double scratch[4 * 16];
+    const int b = blockIdx.x;
+    const float *pb = p + (size_t)b * C * HW, *Sb = S + (size_t)b * C * HW;
+    float *gb = grad + (size_t)b * C * HW;
+    double st[4];
+    seed_stats(C, HW, pb, Sb, st, scratch);
+    const float dbg = (float)(st[0] > 1e-4 ? st[0] : 1e-4), dfg = (float)(st[1] > 1e-4 ? st[1] : 1e-4);
+    const int n = C * HW;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        gb[i] = -Sb[i] / (pb[i] * (i < HW ? dbg : dfg) * (float)B);
+}
+int launch_seed_loss(int B, int C, int HW, const float *p, const float *S, float *loss, float *grad,
+                     hipStream_t stream) {
+    if (loss) {
+        hipLaunchKernelGGL(seed_loss_fwd_kernel, dim3(1), dim3(1024), 0, stream, B, C, HW, p, S, loss);
+        DSRG_LAUNCH_CHECK();
+    }
+    if (grad) {
+        hipLaunchKernelGGL(seed_loss_bwd_kernel, dim3(B), dim3(1024), 0, stream, B, C, HW, p, S, grad);
+        DSRG_LAUNCH_CHECK();
+    }
+    return DSRG_OK;
+}
+
+// ---- ConstrainLossLayer (pylayers.py:160-180) ------------------------------------------------------
+__device__ __forceinline__ float constrain_term(float p, float lq, float &dp, float &dlq) {
+    const float q = expf(lq);
+    const float r = q / p;
+    const bool in = (r >= 0.05f) && (r <= 20.0f);          // T.clip's gradient is 1 on the closed interval
+    const float rc = fminf(fmaxf(r, 0.05f), 20.0f);
+    const float l = logf(rc);
+    dp = in ? -(q / p) : 0.0f;
+    dlq = q * (l + (in ? 1.0f : 0.0f));
+    return q * l;
+}
+__global__ __launch_bounds__(1024) void constrain_fwd_kernel(size_t n, double inv, const float *__restrict__ p,
+                                                             const float *__restrict__ lq,
+                                                             float *__restrict__ loss) {
+    __shared__ double scratch[16];
+    double acc[1] = {0.0};
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float dp, dlq;
+        acc[0] += (double)constrain_term(p[i], lq[i], dp, dlq);
+    }
+    block_reduce_sum<1>(acc, scratch);
+    if (threadIdx.x == 0) *loss = (float)(acc[0] * inv);
+}
+__global__ void constrain_bwd_kernel(size_t n, float inv, const float *__restrict__ p,
+                                     const float *__restrict__ lq, float *__restrict__ gp,
+                                     float *__restrict__ glq) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float dp, dlq;
+        constrain_term(p[i], lq[i], dp, dlq);
+        if (gp) gp[i] = dp * inv;
+        if (glq) glq[i] = dlq * inv;
+    }
+}
+int launch_constrain_loss(int B, int C, int HW, const float *p, const float *lq, float *loss, float *gp,
+                          float *glq, hipStream_t stream) {
+    const size_t n = (size_t)B * C * HW;
+    const double inv = 1.0 / ((double)B * (double)HW);
+    if (loss) {
+        hipLaunchKernelGGL(constrain_fwd_kernel, dim3(1), dim3(1024), 0, stream, n, inv, p, lq, loss);
+        DSRG_LAUNCH_CHECK();
+    }
+    if (gp || glq) {
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(constrain_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, (float)inv, p, lq,
+                           gp, glq);
+        DSRG_LAUNCH_CHECK();
+    }
+    return DSRG_OK;
+}
+
+// ---- fused loss + backward of the five layers (train-s.prototxt:746-810) ------------------
+// stage 1: per-image statistics {count_bg, count_fg, seed_bg, seed_fg, constrain}
+__global__ __launch_bounds__(1024) void sup_stats_kernel(int C, int HW, const float *__restrict__ probs,
+                                                         const float *__restrict__ seeds,
+                                                         const float *__restrict__ logq,
+                                                         double *__restrict__ stats /* [B][5] */) {
+    __shared__ double scratch[5 * 16];
+    const int b = blockIdx.x;
+    const float *pb = probs + (size_t)b * C * HW, *Sb = seeds + (size_t)b * C * HW, *lb = logq + (size_t)b * C * HW;
+    double st[5] = {0, 0, 0, 0, 0};
+    const int n = C * HW;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float s = Sb[i], p = pb[i];
+        if (s != 0.0f) {
+            const double t = (double)s * (double)logf(p);
+            if (i < HW) { st[0] += s; st[2] += t; } else { st[1] += s; st[3] += t; }
+        }
+        float dp, dlq;
+        st[4] += (double)constrain_term(p, lb[i], dp, dlq);
+    }
+    block_reduce_sum<5>(st, scratch);
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 5; q++) stats[(size_t)b * 5 + q] = st[q];
+}
+// stage 2: per pixel: total gradient wrt the (clipped) softmax blob, then SoftmaxLayer.backward;
+// thread 0 of block 0 also finalises the two loss scalars in image order.
+template <int CT>
+__global__ __launch_bounds__(256) void sup_grad_kernel(int B, int C, int HW, const float *__restrict__ logits,
+                                                       const float *__restrict__ probs,
+                                                       const float *__restrict__ seeds,
+                                                       const float *__restrict__ logq,
+                                                       const double *__restrict__ refined,
+                                                       const double *__restrict__ stats,
+                                                       float *__restrict__ grad_logits,
+                                                       float *__restrict__ losses) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) {
+        double ls = 0.0, lc = 0.0;
+        for (int b = 0; b < B; b++) {
+            const double *st = stats + (size_t)b * 5;
+            const double dbg = st[0] > 1e-4 ? st[0] : 1e-4, dfg = st[1] > 1e-4 ? st[1] : 1e-4;
+            ls += -(st[2] / dbg) / B - (st[3] / dfg) / B;
+            lc += st[4];
+        }
+        losses[0] = (float)ls;
+        losses[1] = (float)(lc / ((double)B * (double)HW));
+    }
+    if (idx >= B * HW) return;
+    const int b = idx / HW, i = idx - b * HW;
+    const size_t base = (size_t)b * C * HW + i;
+    const double *st = stats + (size_t)b * 5;
+    const float dbg = (float)(st[0] > 1e-4 ? st[0] : 1e-4), dfg = (float)(st[1] > 1e-4 ? st[1] : 1e-4);
+    const float inv = (float)(1.0 / ((double)B * (double)HW));
+    float s[CT], g[CT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) { s[c] = logits[base + (size_t)c * HW]; mx = fmaxf(mx, s[c]); }
+    float z = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) { s[c] = expf(s[c] - mx); z += s[c]; }
+    float Z = 0.0f, sg = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        if (c < C) {
+            const size_t o = base + (size_t)c * HW;
+            const float p = probs[o];
+            // BalancedSeedLoss.backward + ConstrainLoss.backward[0] + CRFLayer.backward(ConstrainLoss.backward[1])
+            float dp, dlq;
+            constrain_term(p, logq[o], dp, dlq);
+            const float gseed = -seeds[o] / (p * (c == 0 ? dbg : dfg) * (float)B);
+            const float gcrf = (float)((1.0 - refined[o]) * (double)(dlq * inv));
+            g[c] = gseed + dp * inv + gcrf;
+            s[c] = s[c] / z;
+            Z += s[c] + kMinProb;
+            sg += s[c] * g[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+        if (c < C) grad_logits[base + (size_t)c * HW] = s[c] * (g[c] - sg) / Z;
+}
+int launch_sup_loss_backward(int B, int C, int HW, const float *logits, const float *probs, const float *seeds,
+                             const float *logq, const double *refined, double *stats, float *grad_logits,
+                             float *losses, hipStream_t stream) {
+    if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
+    hipLaunchKernelGGL(sup_stats_kernel, dim3(B), dim3(1024), 0, stream, C, HW, probs, seeds, logq, stats);
+    DSRG_LAUNCH_CHECK();
+    const int threads = 256, blocks = (B * HW + threads - 1) / threads;
+    if (C <= 21)
+        hipLaunchKernelGGL(sup_grad_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, logits, probs, seeds,
+                           logq, refined, stats, grad_logits, losses);
+    else
+        hipLaunchKernelGGL(sup_grad_kernel<kMaxLabels>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, logits,
+                           probs, seeds, logq, refined, stats, grad_logits, losses);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// ---- layout helpers for the single-image (host pointer, label-fastest) API ---------------------------
+// in [N][M] label-fastest -> out [M][N] planes, optionally negated
+__global__ void lf_to_planes_kernel(int N, int M, const float *__restrict__ in, float *__restrict__ out, int negate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * M) return;
+    const int c = idx / N, i = idx - c * N;
+    const float v = in[(size_t)i * M + c];
+    out[idx] = negate ? -v : v;
+}
+__global__ void planes_to_lf_kernel(int N, int M, const float *__restrict__ in, float *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * M) return;
+    const int i = idx / M, c = idx - i * M;
+    out[idx] = in[(size_t)c * N + i];
+}
+__global__ void argmax_planes_kernel(int N, int M, const float *__restrict__ q, int32_t *__restrict__ lab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int m = 0;
+    float best = q[i];
+    for (int c = 1; c < M; c++) {
+        const float v = q[(size_t)c * N + i];
+        if (v > best) { best = v; m = c; }      // first maximum wins (Eigen maxCoeff, densecrf.cpp:136-140)
+    }
+    lab[i] = m;
+}
+int launch_lf_to_planes(int N, int M, const float *in, float *out, int negate, hipStream_t stream) {
+    hipLaunchKernelGGL(lf_to_planes_kernel, dim3((N * M + 255) / 256), dim3(256), 0, stream, N, M, in, out, negate);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+int launch_planes_to_lf(int N, int M, const float *in, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(planes_to_lf_kernel, dim3((N * M + 255) / 256), dim3(256), 0, stream, N, M, in, out);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+int launch_argmax_planes(int N, int M, const float *q, int32_t *lab, hipStream_t stream) {
+    hipLaunchKernelGGL(argmax_planes_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, M, q, lab);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+}  // namespace dsrg

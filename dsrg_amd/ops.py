@@ -1,0 +1,204 @@
+"""Torch-tensor front-end of libdsrg_hip.so: device pointers in, device pointers out.
+
+PyTorch is plumbing here (HBM allocations, streams); all arithmetic happens in the
+HIP kernels behind the C ABI (include/dsrg_hip.h).  Every function below names the
+reference routine it replaces.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CrfParams, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32c(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous float32 CUDA tensor" % name)
+    return t
+
+
+class Context(object):
+    """dsrg_ctx_t: device workspace for up to max_batch images of shape (C,H,W)."""
+
+    def __init__(self, max_batch, C, H, W):
+        _lib.require_gpu()
+        self.max_batch, self.C, self.H, self.W = int(max_batch), int(C), int(H), int(W)
+        self.device = torch.cuda.current_device()
+        h = ctypes.c_void_p()
+        check(_lib.lib().dsrg_ctx_create(self.max_batch, self.C, self.H, self.W, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().dsrg_ctx_destroy(h)
+            self._h = None
+
+    def lattice_sizes(self, B):
+        """(M_gaussian, [M_bilateral per image]) of the lattices built by the last CRF call."""
+        mg = ctypes.c_int32(0)
+        mb = (ctypes.c_int32 * max(B, 1))()
+        check(_lib.lib().dsrg_ctx_lattice_sizes(self._h, B, ctypes.byref(mg), mb, _stream()))
+        return mg.value, [mb[i] for i in range(B)]
+
+
+_CTX_CACHE = {}
+
+
+def get_context(B, C, H, W):
+    key = (torch.cuda.current_device(), C, H, W)
+    ctx = _CTX_CACHE.get(key)
+    if ctx is None or ctx.max_batch < B:
+        ctx = Context(max(B, 1), C, H, W)
+        _CTX_CACHE[key] = ctx
+    return ctx
+
+
+def softmax_forward(x):
+    """SoftmaxLayer.forward (pylayers.py:46-47)."""
+    _f32c(x, "x")
+    B, C, H, W = x.shape
+    p = torch.empty_like(x)
+    check(_lib.lib().dsrg_softmax_forward(B, C, H * W, _ptr(x), _ptr(p), _stream()))
+    return p
+
+
+def softmax_backward(x, top_diff):
+    """SoftmaxLayer.backward (pylayers.py:49-51)."""
+    _f32c(x, "x"), _f32c(top_diff, "top_diff")
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().dsrg_softmax_backward(B, C, H * W, _ptr(x), _ptr(top_diff), _ptr(dx), _stream()))
+    return dx
+
+
+def crf_refine(probs, images, scale_factor=12.0, maxiter=10, ctx=None, want_log=True):
+    """CRFLayer.forward / DSRGLayer.refinement (pylayers.py:63-88,310-331).
+
+    probs (B,C,H,W) f32 is clipped IN PLACE (as the reference does to its bottom blob);
+    returns (refined float64 (B,C,H,W), log-marginals float32 or None)."""
+    _f32c(probs, "probs"), _f32c(images, "images")
+    B, C, H, W = probs.shape
+    if images.shape[0] != B or images.shape[1] != 3:
+        raise ValueError("images must be (B,3,Hi,Wi)")
+    ctx = ctx or get_context(B, C, H, W)
+    refined = torch.empty((B, C, H, W), dtype=torch.float64, device=probs.device)
+    logq = torch.empty_like(probs) if want_log else None
+    prm = CrfParams.from_crf_args(maxiter, scale_factor)
+    check(_lib.lib().dsrg_crf_refine_batch(ctx._h, B, _ptr(probs), _ptr(images), images.shape[2], images.shape[3],
+                                           ctypes.byref(prm), _ptr(refined), _ptr(logq), _stream()))
+    return refined, logq
+
+
+def crf_meanfield(unary, im_u8, maxiter=10, scale_factor=1.0, color_factor=13, ctx=None):
+    """krahenbuhl2013.CRF on device blobs: unary (B,C,H,W) f32 (the `unary` argument of CRF.py:28,
+    i.e. minus the energy), im_u8 (B,H,W,3) uint8 -> marginals (B,C,H,W) f32."""
+    _f32c(unary, "unary")
+    if not (im_u8.is_cuda and im_u8.dtype == torch.uint8 and im_u8.is_contiguous()):
+        raise ValueError("im_u8 must be a contiguous uint8 CUDA tensor")
+    B, C, H, W = unary.shape
+    ctx = ctx or get_context(B, C, H, W)
+    q = torch.empty_like(unary)
+    prm = CrfParams.from_crf_args(maxiter, scale_factor, color_factor)
+    check(_lib.lib().dsrg_crf_meanfield_batch(ctx._h, B, _ptr(unary), _ptr(im_u8), ctypes.byref(prm), _ptr(q),
+                                              _stream()))
+    return q
+
+
+def crf_layer_backward(refined, top_diff):
+    """CRFLayer.backward (pylayers.py:90-92)."""
+    _f32c(top_diff, "top_diff")
+    if not (refined.is_cuda and refined.dtype == torch.float64 and refined.is_contiguous()):
+        raise ValueError("refined must be a contiguous float64 CUDA tensor")
+    out = torch.empty_like(top_diff)
+    check(_lib.lib().dsrg_crf_layer_backward(refined.numel(), _ptr(refined), _ptr(top_diff), _ptr(out), _stream()))
+    return out
+
+
+def srg_grow(labels, cues, refined, th1=0.99, th2=0.85):
+    """DSRGLayer.generate_seed -> generate_seed_step (pylayers.py:237-275,333-344)."""
+    _f32c(labels, "labels"), _f32c(cues, "cues")
+    if not (refined.is_cuda and refined.dtype == torch.float64 and refined.is_contiguous()):
+        raise ValueError("refined must be a contiguous float64 CUDA tensor")
+    B, C, H, W = cues.shape
+    if labels.numel() != B * C:
+        raise ValueError("labels must hold B*C values")
+    seeds = torch.empty_like(cues)
+    check(_lib.lib().dsrg_srg_grow_batch(B, C, H, W, _ptr(labels), _ptr(cues), _ptr(refined), float(th1), float(th2),
+                                         _ptr(seeds), _stream()))
+    return seeds
+
+
+def seed_loss(probs, seeds, want_grad=True):
+    """BalancedSeedLossLayer.forward/backward (pylayers.py:147-152) -> (loss[1], grad or None)."""
+    _f32c(probs, "probs"), _f32c(seeds, "seeds")
+    B, C, H, W = probs.shape
+    loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+    grad = torch.empty_like(probs) if want_grad else None
+    check(_lib.lib().dsrg_seed_loss(B, C, H * W, _ptr(probs), _ptr(seeds), _ptr(loss), _ptr(grad), _stream()))
+    return loss, grad
+
+
+def constrain_loss(probs, logq, want_grad=True):
+    """ConstrainLossLayer.forward/backward (pylayers.py:173-180) -> (loss[1], grad_probs, grad_logq)."""
+    _f32c(probs, "probs"), _f32c(logq, "logq")
+    B, C, H, W = probs.shape
+    loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+    gp = torch.empty_like(probs) if want_grad else None
+    gq = torch.empty_like(probs) if want_grad else None
+    check(_lib.lib().dsrg_constrain_loss(B, C, H * W, _ptr(probs), _ptr(logq), _ptr(loss), _ptr(gp), _ptr(gq),
+                                         _stream()))
+    return loss, gp, gq
+
+
+def supervision_step(logits, images, labels, cues, th1=0.99, th2=0.85, scale_factor=12.0, maxiter=10,
+                     ctx=None, want_blobs=False):
+    """The five Python layers of train-s.prototxt:746-810, forward and backward, in one
+    stream-ordered launch sequence (CRF computed once).
+
+    Returns (losses[2] = {loss-Seed, loss-Constrain}, d(sum)/d logits, blobs or None)."""
+    _f32c(logits, "logits"), _f32c(images, "images"), _f32c(labels, "labels"), _f32c(cues, "cues")
+    B, C, H, W = logits.shape
+    ctx = ctx or get_context(B, C, H, W)
+    losses = torch.empty(2, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits)
+    blobs = None
+    if want_blobs:
+        blobs = dict(probs=torch.empty_like(logits), seeds=torch.empty_like(logits), logq=torch.empty_like(logits))
+    prm = CrfParams.from_crf_args(maxiter, scale_factor)
+    check(_lib.lib().dsrg_supervision_step(
+        ctx._h, B, _ptr(logits), _ptr(images), images.shape[2], images.shape[3], _ptr(labels), _ptr(cues),
+        float(th1), float(th2), ctypes.byref(prm), _ptr(losses), _ptr(grad),
+        _ptr(blobs["probs"]) if blobs else None, _ptr(blobs["seeds"]) if blobs else None,
+        _ptr(blobs["logq"]) if blobs else None, _stream()))
+    return losses, grad, blobs
+
+
+class DSRGSupervision(torch.autograd.Function):
+    """loss-Seed + loss-Constrain as a differentiable function of the fc8 logits."""
+
+    @staticmethod
+    def forward(ctx, logits, images, labels, cues, th1, th2, scale_factor, maxiter):
+        losses, grad, _ = supervision_step(logits.contiguous(), images, labels, cues, th1, th2, scale_factor, maxiter)
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(losses)
+        return losses.sum(), losses
+
+    @staticmethod
+    def backward(ctx, g_total, _g_losses):
+        (grad,) = ctx.saved_tensors
+        return grad * g_total, None, None, None, None, None, None, None
+
+
+def dsrg_supervision_loss(logits, images, labels, cues, th1=0.99, th2=0.85, scale_factor=12.0, maxiter=10):
+    """-> (total loss (differentiable wrt logits), tensor [loss-Seed, loss-Constrain])."""
+    return DSRGSupervision.apply(logits, images, labels, cues, th1, th2, scale_factor, maxiter)

@@ -1,0 +1,167 @@
+/*
+ * dsrg_hip.h — C ABI of libdsrg_hip.so, the MI355X (gfx950) implementation of
+ * the DSRG per-iteration supervision path.
+ *
+ * Every entry point replaces one interface of the reference (speedinghzl/DSRG);
+ * the reference file:line it stands in for is cited on each declaration.  The
+ * library has no CPU fallback: every compute entry point launches HIP kernels
+ * and returns an error code when no device / too large a problem is given.
+ *
+ * Conventions
+ *   - return value: 0 = DSRG_OK, negative = error (dsrg_last_error() has text)
+ *   - "dev" pointers are device (HBM) pointers owned by the caller; "host"
+ *     pointers are ordinary host memory
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); device
+ *     entry points are stream-ordered and never synchronise the host
+ *   - layouts: blobs are NCHW float32, C-contiguous, exactly like the Caffe
+ *     blobs the reference's Python layers see (pylayers.py)
+ */
+#ifndef DSRG_HIP_H
+#define DSRG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#pragma GCC visibility push(default)
+
+#define DSRG_OK 0
+#define DSRG_ERR_INVALID (-1)      /* bad argument */
+#define DSRG_ERR_HIP (-2)          /* HIP runtime error (no device, launch failure, ...) */
+#define DSRG_ERR_UNSUPPORTED (-3)  /* problem does not fit the implemented kernels */
+#define DSRG_ERR_NOMEM (-4)
+
+const char *dsrg_last_error(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+int dsrg_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* 1. Single-image dense-CRF object: mirrors the C++ class DenseCRFWrapper     */
+/*    (CRF/include/densecrf_wrapper.h:3-28) that the Cython class DenseCRF     */
+/*    (CRF/krahenbuhl2013/wrapper.pyx:5-17,20-60) binds.  Host pointers, one   */
+/*    image, synchronous — exactly the reference's calling convention.         */
+/* ------------------------------------------------------------------------ */
+typedef struct dsrg_crf_s *dsrg_crf_t;
+
+/* DenseCRFWrapper::DenseCRFWrapper(int W, int H, int nlabels)  densecrf_wrapper.cpp:5-8 */
+int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out);
+/* DenseCRFWrapper::~DenseCRFWrapper                             densecrf_wrapper.cpp:10-12 */
+int dsrg_crf_destroy(dsrg_crf_t h);
+/* DenseCRFWrapper::set_unary_energy(float*)                     densecrf_wrapper.cpp:32-37
+ * unary_host: [W*H*nlabels], label-fastest (copied). */
+int dsrg_crf_set_unary_energy(dsrg_crf_t h, const float *unary_host);
+/* DenseCRFWrapper::add_pairwise_energy(...)                     densecrf_wrapper.cpp:19-30
+ * Gaussian potential (w2, theta_gamma) first, then bilateral (w1, theta_alpha,
+ * theta_beta), both Potts.  im_host: [W*H*3] uint8, not retained. */
+int dsrg_crf_add_pairwise_energy(dsrg_crf_t h, float w1, float theta_alpha_1, float theta_alpha_2,
+                                 float theta_beta_1, float theta_beta_2, float theta_beta_3,
+                                 float w2, float theta_gamma_1, float theta_gamma_2,
+                                 const unsigned char *im_host);
+/* DenseCRFWrapper::inference(int, float*)                       densecrf_wrapper.cpp:45-50
+ * out_host: [W*H*nlabels] label-fastest marginals. */
+int dsrg_crf_inference(dsrg_crf_t h, int n_iters, float *out_host);
+/* DenseCRFWrapper::map(int, int*)                               densecrf_wrapper.cpp:39-43 */
+int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host);
+/* DenseCRFWrapper::npixels / nlabels                            densecrf_wrapper.cpp:14-15 */
+int dsrg_crf_npixels(dsrg_crf_t h);
+int dsrg_crf_nlabels(dsrg_crf_t h);
+/* introspection (tests): vertex count of lattice k (0 Gaussian, 1 bilateral), -1 if not built */
+int dsrg_crf_lattice_size(dsrg_crf_t h, int k);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Batched device context: workspace for B images of (C,H,W) so that the    */
+/*    per-iteration path runs without allocation or host synchronisation.      */
+/* ------------------------------------------------------------------------ */
+typedef struct dsrg_ctx_s *dsrg_ctx_t;
+
+/* pairwise parameters of krahenbuhl2013.CRF (CRF/krahenbuhl2013/CRF.py:25-35);
+ * the caller evaluates 80/scale_factor etc. in double and rounds to float, as
+ * the Python->Cython call does. */
+typedef struct {
+    float w_bilateral;      /* 10 */
+    float theta_alpha_x;    /* 80 / scale_factor */
+    float theta_alpha_y;
+    float theta_beta_r;     /* color_factor = 13 */
+    float theta_beta_g;
+    float theta_beta_b;
+    float w_gaussian;       /* 3 */
+    float theta_gamma_x;    /* 3 / scale_factor */
+    float theta_gamma_y;
+    int32_t n_iters;        /* maxiter = 10 */
+} dsrg_crf_params;
+
+int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *out);
+int dsrg_ctx_destroy(dsrg_ctx_t ctx);
+
+/* CRFLayer.forward (pylayers/pylayers/pylayers.py:63-88) and, identically,
+ * DSRGLayer.refinement (pylayers.py:310-331):
+ *   probs_dev   (B,C,H,W) f32   clipped IN PLACE to >= 1e-4 (pylayers.py:67,312)
+ *   images_dev  (B,3,Hi,Wi) f32 mean-subtracted BGR (bottom[1]); resampled to
+ *               (H,W) with the align-corners order-1 zoom, + mean pixel
+ *               (104,117,123), round-half-even, cast to uint8 (pylayers.py:70-75)
+ *   refined_dev (B,C,H,W) f64   clip(Q,1e-4)/sum  (pylayers.py:84-86) = self.result
+ *   logq_dev    (B,C,H,W) f32   log(refined)      (pylayers.py:88); may be NULL */
+int dsrg_crf_refine_batch(dsrg_ctx_t ctx, int B, float *probs_dev, const float *images_dev,
+                          int img_h, int img_w, const dsrg_crf_params *params,
+                          double *refined_dev, float *logq_dev, void *stream);
+/* the same mean-field run on caller-prepared inputs (used by krahenbuhl2013.CRF
+ * and by tests): unary_dev (B,C,H,W) f32 holds the NEGATED energies -U (i.e.
+ * the `unary` argument of CRF.py:28), im_u8_dev (B,H*W,3) uint8, q_dev
+ * (B,C,H,W) f32 receives the marginals. */
+int dsrg_crf_meanfield_batch(dsrg_ctx_t ctx, int B, const float *neg_unary_dev,
+                             const unsigned char *im_u8_dev, const dsrg_crf_params *params,
+                             float *q_dev, void *stream);
+/* vertex counts of the lattices built by the last refine/meanfield call:
+ * m_gauss, and m_bilateral[b] for b < B (host arrays; synchronises the stream) */
+int dsrg_ctx_lattice_sizes(dsrg_ctx_t ctx, int B, int32_t *m_gauss_host, int32_t *m_bilateral_host,
+                           void *stream);
+
+/* CRFLayer.backward (pylayers.py:90-92): bottom_diff = (1 - refined) * top_diff */
+int dsrg_crf_layer_backward(size_t n, const double *refined_dev, const float *top_diff_dev,
+                            float *bottom_diff_dev, void *stream);
+
+/* DSRGLayer.forward -> generate_seed -> generate_seed_step (pylayers.py:237-275,
+ * 297-304,333-344) incl. CC_lab (CC_labeling_8.py:112-197), given the refined
+ * marginals:
+ *   labels_dev (B,1,1,C) f32 0/1, cues_dev (B,C,H,W) f32 0/1,
+ *   refined_dev (B,C,H,W) f64, seeds_dev (B,C,H,W) f32 0/1 (output) */
+int dsrg_srg_grow_batch(int B, int C, int H, int W, const float *labels_dev, const float *cues_dev,
+                        const double *refined_dev, double th1, double th2, float *seeds_dev,
+                        void *stream);
+
+/* SoftmaxLayer.forward / backward (pylayers.py:30-51) */
+int dsrg_softmax_forward(int B, int C, int HW, const float *x_dev, float *p_dev, void *stream);
+int dsrg_softmax_backward(int B, int C, int HW, const float *x_dev, const float *top_diff_dev,
+                          float *bottom_diff_dev, void *stream);
+
+/* BalancedSeedLossLayer.forward / backward (pylayers.py:126-152).
+ * loss_dev: one float.  grad_dev may be NULL (forward only). */
+int dsrg_seed_loss(int B, int C, int HW, const float *probs_dev, const float *seeds_dev,
+                   float *loss_dev, float *grad_dev, void *stream);
+/* ConstrainLossLayer.forward / backward (pylayers.py:160-180); grads may be NULL. */
+int dsrg_constrain_loss(int B, int C, int HW, const float *probs_dev, const float *logq_dev,
+                        float *loss_dev, float *grad_probs_dev, float *grad_logq_dev, void *stream);
+
+/* The five Python layers of train-s.prototxt:746-810 as ONE stream-ordered
+ * sequence (Softmax -> CRF -> DSRG -> BalancedSeedLoss + ConstrainLoss, then
+ * the backward pass of A.3 down to d loss / d fc8), computing the CRF once
+ * (SURVEY §0.2).  Outputs:
+ *   losses_dev[2]   = {loss-Seed, loss-Constrain}
+ *   grad_logits_dev = d(loss-Seed + loss-Constrain)/d fc8-SEC      (B,C,H,W)
+ *   probs_dev / seeds_dev / logq_dev: optional (may be NULL) copies of the
+ *   clipped softmax blob, the grown seeds and the CRF log-marginals. */
+int dsrg_supervision_step(dsrg_ctx_t ctx, int B, const float *logits_dev, const float *images_dev,
+                          int img_h, int img_w, const float *labels_dev, const float *cues_dev,
+                          double th1, double th2, const dsrg_crf_params *params,
+                          float *losses_dev, float *grad_logits_dev,
+                          float *probs_dev, float *seeds_dev, float *logq_dev, void *stream);
+
+#pragma GCC visibility pop
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSRG_HIP_H */

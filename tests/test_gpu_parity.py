@@ -1,0 +1,270 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden
+fixtures.  Integer work (SRG) must be bit-exact; floating point within the stated tolerance
+(CRF marginals 1e-4 per BASELINE.json's north_star; observed ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import srg_case, glue_inputs
+from dsrg_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+CRF_TOL = 1e-4          # north_star: "CRF marginals within 1e-4"
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dsrg_amd import ops, _lib
+    _lib.require_gpu()
+    return ops
+
+
+# ---------------------------------------------------------------- SRG: bit-exact
+def test_srg_golden_vectors_bit_exact(ops, golden_srg):
+    for name in golden_srg["names"]:
+        labels, seed, refined, want = srg_case(golden_srg, str(name))
+        got = ops.srg_grow(dev(labels[None]), dev(seed[None]), dev(refined[None], torch.float64), 0.99, 0.85)
+        assert np.array_equal(got.cpu().numpy()[0].astype(np.uint8), want), name
+
+
+def test_srg_random_batches_vs_oracle(ops, O):
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        B, C = 5, 21
+        H, W = (41, 41) if trial < 3 else (int(rng.integers(3, 70)), int(rng.integers(3, 70)))
+        labels, cues = S.make_labels_cues(rng, B, C, max(H, 7), max(W, 7))
+        cues = np.ascontiguousarray(cues[:, :, :H, :W])
+        refined = np.empty((B, C, H, W))
+        for b in range(B):
+            pres = np.where(labels[b, 0, 0] == 1)[0]
+            z = S.make_logits(rng, 1, C, H, W, gain=60.0)[0].astype(np.float64)
+            e = np.exp(z[pres] - z[pres].max(0, keepdims=True))
+            p = np.full((C, H, W), 1e-4)
+            p[pres] = np.maximum(e / e.sum(0, keepdims=True), 1e-4)
+            refined[b] = p / p.sum(0, keepdims=True)
+        want = O.srg_grow_batch(labels, cues, refined)
+        got = ops.srg_grow(dev(labels), dev(cues), dev(refined, torch.float64)).cpu().numpy()
+        assert want.sum() > cues.sum()
+        assert np.array_equal(got, want)
+        # invariants: monotone, absent classes untouched, idempotent
+        assert (got >= cues).all()
+        absent = labels[:, 0, 0] != 1
+        assert np.array_equal(got[absent], cues[absent])
+        again = ops.srg_grow(dev(labels), dev(got), dev(refined, torch.float64)).cpu().numpy()
+        assert np.array_equal(again, got)
+
+
+# ---------------------------------------------------------------- pointwise layers
+def test_softmax_forward_backward(ops, O):
+    b = S.make_batch(1, 4)
+    x = b["logits"]
+    p = ops.softmax_forward(dev(x)).cpu().numpy()
+    assert np.abs(p - O.softmax_forward(x)).max() < 1e-6
+    g = np.random.default_rng(0).standard_normal(x.shape).astype(np.float32)
+    dx = ops.softmax_backward(dev(x), dev(g)).cpu().numpy()
+    want = O.softmax_backward(x, g)
+    assert np.abs(dx - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_losses_forward_backward(ops, O):
+    b = S.make_batch(2, 4)
+    p = O.softmax_forward(b["logits"])
+    seeds = b["cues"]
+    seeds[1] = 0
+    loss, grad = ops.seed_loss(dev(p), dev(seeds))
+    wl, wg = O.seed_loss(p, seeds)
+    assert abs(loss.item() - wl) < 1e-5 * max(1, abs(wl))
+    assert np.abs(grad.cpu().numpy() - wg).max() < 1e-5 * max(1.0, np.abs(wg).max())
+    rng = np.random.default_rng(4)
+    lq = np.log(O.softmax_forward((b["logits"] + rng.standard_normal(p.shape) * 8).astype(np.float32)))
+    loss, gp, gq = ops.constrain_loss(dev(p), dev(lq))
+    wl, wgp, wgq = O.constrain_loss(p, lq)
+    assert abs(loss.item() - wl) < 1e-5 * max(1, abs(wl))
+    # elements whose ratio sits within float rounding of the clip bounds may take the other branch
+    r = np.exp(lq.astype(np.float64)) / p
+    safe = (np.abs(r - 0.05) > 1e-5) & (np.abs(r - 20) > 1e-3)
+    assert np.abs(gp.cpu().numpy() - wgp)[safe].max() < 1e-6
+    assert np.abs(gq.cpu().numpy() - wgq)[safe].max() < 1e-6
+
+
+# ---------------------------------------------------------------- dense CRF
+@pytest.mark.parametrize("kind,scale,HW,C", [("smooth", 12.0, (41, 41), 21), ("noise", 12.0, (41, 41), 21),
+                                             ("dark_corner", 12.0, (41, 41), 21), ("smooth", 12.0, (65, 65), 21),
+                                             ("smooth", 1.0, (24, 31), 7), ("noise", 3.0, (17, 40), 3),
+                                             ("smooth", 12.0, (1, 9), 2)])
+def test_crf_function_vs_oracle(O, kind, scale, HW, C):
+    """krahenbuhl2013.CRF (host API of the reference) — marginals within 1e-4 of the oracle,
+    identical lattice sizes."""
+    import krahenbuhl2013
+    from dsrg_amd.crf import DenseCRF
+    H, W = HW
+    rng = np.random.default_rng(hash((kind, H, W, C)) % 2 ** 31)
+    img = S.make_images(rng, 1, size=max(H, W), kind=kind)[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]
+    im = np.ascontiguousarray(np.transpose(img, (1, 2, 0)))
+    logits = S.make_logits(rng, 1, C, H, W)
+    un = np.ascontiguousarray(np.transpose(np.maximum(O.softmax_forward(logits)[0], 1e-4), (1, 2, 0)))
+    if scale == 1.0:
+        un = np.log(un)                                     # test-time call passes log-probs (test-ms.py:106)
+    want = O.CRF(im, un, scale_factor=scale)
+    got = krahenbuhl2013.CRF(im, un, scale_factor=scale)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.abs(got.sum(-1) - 1).max() < 1e-5
+    assert np.abs(got - want).max() < CRF_TOL
+    oc = O.DenseCRF(W, H, C)
+    oc.add_pairwise_energy(10, 80 / scale, 80 / scale, 13, 13, 13, 3, 3 / scale, 3 / scale, im.astype(np.uint8).ravel())
+    hc = DenseCRF(W, H, C)
+    hc.set_unary_energy(-un.ravel())
+    hc.add_pairwise_energy(10, 80 / scale, 80 / scale, 13, 13, 13, 3, 3 / scale, 3 / scale, im.astype(np.uint8).ravel())
+    lab = hc.map(10)
+    assert hc.lattice_size(0) == oc.lattice_size(0) and hc.lattice_size(1) == oc.lattice_size(1)
+    oc.set_unary_energy(-un.ravel())
+    wl = oc.map(10)
+    assert (lab != wl).mean() < 1e-3                        # argmax ties at ~1e-7 differences only
+
+
+def test_crf_refine_batch_vs_oracle(ops, O):
+    for seed, B, kind in [(3, 4, "smooth"), (4, 2, "noise")]:
+        b = S.make_batch(seed, B, image_kind=kind)
+        probs = O.softmax_forward(b["logits"])
+        assert (probs < 1e-4).any()
+        p_ref = probs.copy()
+        want_ref, want_log = O.crf_refine_batch(p_ref, b["images"], 12.0, 10)
+        p_dev = dev(probs)
+        ctx = ops.get_context(B, 21, 41, 41)
+        refined, logq = ops.crf_refine(p_dev, dev(b["images"]), 12.0, 10, ctx=ctx)
+        assert np.array_equal(p_dev.cpu().numpy(), p_ref)                       # in-place clip
+        assert np.abs(refined.cpu().numpy() - want_ref).max() < CRF_TOL
+        assert np.abs(np.exp(logq.cpu().numpy()) - want_ref).max() < CRF_TOL
+        assert np.abs(refined.cpu().numpy().sum(1) - 1).max() < 1e-12
+        mg, mb = ctx.lattice_sizes(B)
+        print("lattice sizes: gaussian %d bilateral %s (N=1681)" % (mg, mb))
+        assert mg >= 3 * 1681 and all(1681 < m <= 6 * 1684 for m in mb)
+        bd = ops.crf_layer_backward(refined, dev(b["cues"])).cpu().numpy()
+        assert np.abs(bd - O.crf_layer_backward(refined.cpu().numpy(), b["cues"])).max() < 1e-6
+
+
+def test_crf_is_deterministic(ops, O):
+    b = S.make_batch(9, 3)
+    probs = O.softmax_forward(b["logits"])
+    outs = []
+    for _ in range(3):
+        refined, _ = ops.crf_refine(dev(probs), dev(b["images"]), 12.0, 10)
+        outs.append(refined.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+# ---------------------------------------------------------------- Caffe-protocol layers vs golden glue
+class Blob(object):
+    def __init__(self, data):
+        self.data = np.ascontiguousarray(data, dtype=np.float32)
+        self.diff = np.zeros_like(self.data)
+
+    def reshape(self, *shape):
+        if self.data.shape != tuple(shape):
+            self.data = np.zeros(shape, np.float32)
+            self.diff = np.zeros(shape, np.float32)
+
+
+@pytest.mark.parametrize("tag", ["voc", "tiny"])
+def test_pylayers_protocol_vs_reference_glue(golden_glue, tag):
+    """Drive the drop-in `pylayers` classes exactly as Caffe would and compare with what the
+    reference's Python layers produced on the same blobs (tests/golden/layer_glue.npz)."""
+    import pylayers
+    g = golden_glue
+    probs, images = glue_inputs(g, tag)
+    crf = pylayers.CRFLayer()
+    b_probs, b_im, top = Blob(probs), Blob(images), Blob(np.zeros_like(probs))
+    crf.setup([b_probs, b_im], [top])
+    crf.reshape([b_probs, b_im], [top])
+    crf.forward([b_probs, b_im], [top])
+    assert np.array_equal(b_probs.data, g[tag + "_probs_clipped"])
+    assert crf.result.dtype == np.float64
+    assert np.abs(crf.result - g[tag + "_refined"]).max() < CRF_TOL
+    assert np.abs(np.exp(top.data) - g[tag + "_refined"]).max() < CRF_TOL
+    top.diff[...] = g[tag + "_top_diff"]
+    crf.backward([top], [True, False], [b_probs, b_im])
+    assert np.abs(b_probs.diff - g[tag + "_crf_bottom_diff"]).max() < 1e-3 * np.abs(g[tag + "_top_diff"]).max()
+
+    dsrg = pylayers.DSRGLayer()
+    dsrg.param_str = "{'th1': 0.99, 'th2': 0.85}"
+    d_probs = Blob(probs)
+    bottoms = [Blob(g[tag + "_labels"]), d_probs, Blob(g[tag + "_cues"]), Blob(images)]
+    dtop = Blob(np.zeros_like(probs))
+    dsrg.setup(bottoms, [dtop])
+    dsrg.reshape(bottoms, [dtop])
+    dsrg.forward(bottoms, [dtop])
+    assert np.array_equal(d_probs.data, g[tag + "_probs_clipped"])
+    want = g[tag + "_seeds"]
+    diff = (dtop.data.astype(np.uint8) != want)
+    # grown masks are bit-exact GIVEN identical marginals; end to end a marginal within 1e-6 of a
+    # threshold may flip a pixel (SURVEY §7 hard part 4) — report, and require none here
+    print("end-to-end seed pixels differing from the reference glue:", int(diff.sum()))
+    ref = g[tag + "_refined"]
+    borderline = int(((np.abs(ref - 0.85) < 1e-5) | (np.abs(ref - 0.99) < 1e-5)).sum())
+    assert diff.sum() == 0 or borderline > 0
+
+
+# ---------------------------------------------------------------- fused step vs layer-by-layer oracle
+def test_supervision_step_vs_oracle_composition(ops, O):
+    B = 4
+    b = S.make_batch(21, B)
+    losses, grad, blobs = ops.supervision_step(dev(b["logits"]), dev(b["images"]), dev(b["labels"]), dev(b["cues"]),
+                                               want_blobs=True)
+    # oracle, layer by layer, in the order of train-s.prototxt:746-810 / SURVEY A.3
+    probs = O.softmax_forward(b["logits"])
+    refined, logq = O.crf_refine_batch(probs, b["images"], 12.0, 10)           # clips probs in place
+    seeds = O.srg_grow_batch(b["labels"], b["cues"], refined)
+    l_seed, g_seed = O.seed_loss(probs, seeds)
+    l_con, g_p, g_lq = O.constrain_loss(probs, logq)
+    g_total = g_seed + g_p + O.crf_layer_backward(refined, g_lq)
+    want_grad = O.softmax_backward(b["logits"], g_total)
+    assert np.array_equal(blobs["probs"].cpu().numpy(), probs)
+    assert np.abs(np.exp(blobs["logq"].cpu().numpy()) - refined).max() < CRF_TOL
+    got_seeds = blobs["seeds"].cpu().numpy()
+    nflip = int((got_seeds != seeds).sum())
+    print("fused step: seed pixels differing from oracle:", nflip, "grown", int(seeds.sum() - b["cues"].sum()))
+    if nflip == 0:
+        assert abs(losses[0].item() - l_seed) < 1e-4 * max(1, abs(l_seed))
+        assert abs(losses[1].item() - l_con) < 1e-4 * max(1, abs(l_con))
+        scale = np.abs(want_grad).max()
+        assert np.abs(grad.cpu().numpy() - want_grad).max() < 2e-3 * scale
+    else:
+        assert nflip < 50      # threshold-borderline flips only
+
+
+def test_autograd_function(ops):
+    from dsrg_amd.ops import dsrg_supervision_loss
+    b = S.make_batch(22, 2)
+    x = dev(b["logits"]).requires_grad_(True)
+    total, losses = dsrg_supervision_loss(x, dev(b["images"]), dev(b["labels"]), dev(b["cues"]))
+    (2.0 * total).backward()
+    _, grad, _ = ops.supervision_step(dev(b["logits"]), dev(b["images"]), dev(b["labels"]), dev(b["cues"]))
+    assert torch.allclose(x.grad, 2.0 * grad)
+    assert abs(total.item() - losses.sum().item()) < 1e-6
+
+
+# ---------------------------------------------------------------- size-independent properties
+def test_crf_label_permutation_equivariance_on_gpu(ops, O):
+    b = S.make_batch(31, 2)
+    probs = O.softmax_forward(b["logits"])
+    perm = np.random.default_rng(0).permutation(21)
+    r1, _ = ops.crf_refine(dev(probs), dev(b["images"]), 12.0, 10)
+    r2, _ = ops.crf_refine(dev(probs[:, perm]), dev(b["images"]), 12.0, 10)
+    assert np.abs(r1.cpu().numpy()[:, perm] - r2.cpu().numpy()).max() < 1e-6
+
+
+def test_unsupported_sizes_fail_loudly(ops):
+    from dsrg_amd import _lib
+    with pytest.raises(_lib.DsrgError):
+        ops.Context(1, 21, 321, 321)          # full-resolution lattice: not on the LDS-resident path yet
