@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py — images/s of a full DSRG train-s step on N MI355X (BASELINE.json metric).
+
+A step = VGG16-ASPP forward (bf16 autocast, MIOpen) -> supervision hot path in
+libdsrg_hip.so (Softmax, dense-CRF mean field, seeded region growing, seed +
+constrain losses, backward) -> backbone backward -> Caffe-style SGD, on one
+synthetic batch of 16 images per GPU (BASELINE.json configs[2]; configs[3] at N=8).
+Synthetic inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode train|supervision]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      — the dominant hot-path kernel (mean-field filter = permutohedral
+                  splat/blur/slice): algorithmic bytes per launch / HIP-event time per launch
+  cpu_baseline  — the CPU oracle (a port of the reference's CPU path) timed on this box's host
+                  cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def filter_bytes(d, M, C, N):
+    """stage-streamed traffic of one splat/blur/slice over C label planes."""
+    return 8 * C * N + 16 * (d + 1) * N + 8 * C * M + (d + 1) * (16 * C * M + 8 * M)
+
+
+def cpu_baseline(batch_np, target_s=12.0):
+    """Time the CPU oracle on the supervision path of the same synthetic images (single thread)."""
+    from oracle import oracle as O
+    B = batch_np["logits"].shape[0]
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        for b in range(B):
+            sl = slice(b, b + 1)
+            logits = batch_np["logits"][sl]
+            probs = O.softmax_forward(logits)
+            refined, logq = O.crf_refine_batch(probs, batch_np["images"][sl], 12.0, 10)
+            seeds = O.srg_grow_batch(batch_np["labels"][sl], batch_np["cues"][sl], refined)
+            _, g1 = O.seed_loss(probs, seeds)
+            _, g2, g3 = O.constrain_loss(probs, logq)
+            O.softmax_backward(logits, g1 + g2 + O.crf_layer_backward(refined, g3))
+            n_done += 1
+            if time.perf_counter() - t0 > target_s:
+                break
+        if time.perf_counter() - t0 > target_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n_done / dt, "unit": "images/s (supervision path only: softmax+CRF+SRG+losses+backward)",
+            "cores": 1, "kind": "port",
+            "sample": "%d images of the bench batch, %.1f s, oracle/dsrg_oracle.c single-threaded; the "
+                      "reference runs exactly this part on the CPU (its convolutions run in Caffe on a GPU)" % (n_done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU (weak scaling)")
+    ap.add_argument("--mode", choices=["train", "supervision"], default="train")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket filter launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
+
+    from dsrg_amd import ops, synthetic as S
+    from dsrg_amd.backbone import count_flops_per_image
+    from dsrg_amd.trainer import DSRGTrainer
+
+    B, C, H, W = args.batch, 21, 41, 41
+    N = H * W
+    batch_np = S.make_batch(1000 + rank, B)                     # each rank its own shard of the global batch
+    images = torch.from_numpy(batch_np["images"]).to(device)
+    labels = torch.from_numpy(batch_np["labels"]).to(device)
+    cues = torch.from_numpy(batch_np["cues"]).to(device)
+    logits_fixed = torch.from_numpy(batch_np["logits"]).to(device)
+    ctx = ops.get_context(B, C, H, W)
+
+    trainer = DSRGTrainer(device, world_size=world) if args.mode == "train" else None
+
+    def one_step():
+        if trainer is not None:
+            return trainer.step(images, labels, cues)
+        losses, _, _ = ops.supervision_step(logits_fixed, images, labels, cues, ctx=ctx)
+        return losses
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    profile = not args.no_profile
+    if profile:
+        ctx.profile_start(args.steps * 10 + 16)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    filt_ms, filt_n = ctx.profile_stop() if profile else (0.0, 0)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # supervision-only time per step on this rank (same inputs; untimed region)
+    sup_ms = None
+    if args.mode == "train":
+        lg = logits_fixed
+        for _ in range(3):
+            ops.supervision_step(lg, images, labels, cues, ctx=ctx)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.supervision_step(lg, images, labels, cues, ctx=ctx)
+        e1.record()
+        torch.cuda.synchronize()
+        sup_ms = e0.elapsed_time(e1) / 10
+
+    if rank == 0:
+        mg, mb = ctx.lattice_sizes(B)
+        alg_bytes = sum(filter_bytes(2, mg, C, N) + filter_bytes(5, m, C, N) for m in mb)   # one filter launch
+        roofline = None
+        if filt_n > 0:
+            per_launch_s = filt_ms / filt_n * 1e-3
+            achieved = alg_bytes / per_launch_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("mf_filter_kernel_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"kernel": "mf_filter_kernel (permutohedral splat/blur/slice, %d lattices x %d label planes)" % (2 * B, C),
+                        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "alg_bytes_per_launch": alg_bytes, "us_per_launch": per_launch_s * 1e6, "launches": filt_n,
+                        "lattice_M_gauss": mg, "lattice_M_bilateral_mean": float(np.mean(mb)),
+                        "note": "lattice values stay in LDS; algorithmic bytes are the stage-streamed traffic of "
+                                "SURVEY 8d, so frac may exceed what HBM counters show"}
+        total_images = B * world * args.steps
+        out = {
+            "metric": "images/sec DSRG train step (VGG16 321x321, 21-class)" if args.mode == "train"
+                      else "images/sec DSRG supervision path only (softmax+CRF+SRG+losses+backward)",
+            "value": total_images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 backbone (fp32 master weights) + f32/f64 supervision path" if args.mode == "train" else "f32",
+            "data": "synthetic",
+            "config": {"workload": ("full seed_mc train-s step: VGG16-ASPP fwd+bwd + Softmax/CRF(10 it, scale 12)/"
+                                    "SRG/BalancedSeedLoss/ConstrainLoss + SGD, 321x321 -> 41x41x21"
+                                    if args.mode == "train" else "supervision path on fixed fc8 logits"),
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "baseline_config": "configs[2] (batch 16 on 1 GPU); configs[3] at 8 GPUs"},
+            "losses": [float(x) for x in losses.detach().cpu()],
+            "supervision_ms_per_step": sup_ms,
+            "backbone_tflops": (count_flops_per_image() * 3 * B * world * args.steps / dt / 1e12) if args.mode == "train" else None,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch_np)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

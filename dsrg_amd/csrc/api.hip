@@ -36,6 +36,7 @@ struct dsrg_ctx_s {
     float *probs, *logq, *seeds;
     double *refined;
     double *stats;               // (maxB, 5)
+    Profiler prof;
 };
 
 extern "C" const char *dsrg_last_error(void) { return g_err; }
@@ -57,6 +58,7 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     dsrg_ctx_s *c = new (std::nothrow) dsrg_ctx_s();
     if (!c) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
     c->maxB = max_batch; c->C = C; c->H = H; c->W = W; c->N = N; c->gauss_valid = false;
+    c->prof.start = c->prof.stop = nullptr; c->prof.cap = c->prof.used = 0; c->prof.active = false;
     const size_t blob = align256(sizeof(float) * (size_t)max_batch * C * N);
     const size_t szLg = align256(lattice_bytes(2, N, 1)), szLb = align256(lattice_bytes(5, N, max_batch));
     const size_t szIm = align256((size_t)max_batch * N * 3);
@@ -84,8 +86,48 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     return DSRG_OK;
 }
 
+static void prof_free(Profiler &p) {
+    for (int i = 0; i < p.cap; i++) { (void)hipEventDestroy(p.start[i]); (void)hipEventDestroy(p.stop[i]); }
+    delete[] p.start; delete[] p.stop;
+    p.start = p.stop = nullptr; p.cap = p.used = 0; p.active = false;
+}
+
+extern "C" int dsrg_ctx_profile_start(dsrg_ctx_t c, int max_launches) {
+    if (!c || max_launches < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    if (c->prof.cap < max_launches) {
+        prof_free(c->prof);
+        c->prof.start = new (std::nothrow) hipEvent_t[max_launches];
+        c->prof.stop = new (std::nothrow) hipEvent_t[max_launches];
+        if (!c->prof.start || !c->prof.stop) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+        for (int i = 0; i < max_launches; i++) {
+            DSRG_HIP_CHECK(hipEventCreate(&c->prof.start[i]));
+            DSRG_HIP_CHECK(hipEventCreate(&c->prof.stop[i]));
+            c->prof.cap = i + 1;
+        }
+    }
+    c->prof.used = 0;
+    c->prof.active = true;
+    return DSRG_OK;
+}
+
+extern "C" int dsrg_ctx_profile_stop(dsrg_ctx_t c, double *total_ms, int32_t *launches) {
+    if (!c || !total_ms || !launches) return set_error(DSRG_ERR_INVALID, "bad argument");
+    c->prof.active = false;
+    double tot = 0.0;
+    for (int i = 0; i < c->prof.used; i++) {
+        DSRG_HIP_CHECK(hipEventSynchronize(c->prof.stop[i]));
+        float ms = 0.f;
+        DSRG_HIP_CHECK(hipEventElapsedTime(&ms, c->prof.start[i], c->prof.stop[i]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = c->prof.used;
+    return DSRG_OK;
+}
+
 extern "C" int dsrg_ctx_destroy(dsrg_ctx_t c) {
     if (!c) return DSRG_OK;
+    prof_free(c->prof);
     if (c->arena) (void)hipFree(c->arena);
     delete c;
     return DSRG_OK;
@@ -118,7 +160,7 @@ static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned c
     rc = launch_lattice_build(c->Lb, Fb, im_u8, B, s);
     if (rc) return rc;
     return launch_meanfield(c->Lg, c->Lb, c->mf, B, c->C, neg_unary, prm->w_gaussian, prm->w_bilateral,
-                            prm->n_iters, q_out, refined, logq, s);
+                            prm->n_iters, q_out, refined, logq, s, &c->prof);
 }
 
 extern "C" int dsrg_crf_refine_batch(dsrg_ctx_t c, int B, float *probs, const float *images, int img_h, int img_w,

@@ -18,6 +18,20 @@ int set_error(int code, const char *fmt, ...);
     } while (0)
 #define DSRG_LAUNCH_CHECK() DSRG_HIP_CHECK(hipGetLastError())
 
+// raise a kernel's dynamic-LDS limit (default 64 KiB) to `bytes`; `granted` caches what was set.
+// The limit is requested per need, not as a flat 160 KiB: static LDS (e.g. the variable behind
+// __syncthreads_or) counts against the same 160 KiB and an over-ask is rejected.
+inline int ensure_dynamic_lds(const void *fn, size_t bytes, size_t &granted) {
+    if (bytes <= granted) return DSRG_OK;
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess)
+            return set_error(DSRG_ERR_HIP, "cannot reserve %zu B of dynamic LDS: %s", bytes, hipGetErrorString(e));
+    }
+    granted = bytes;
+    return DSRG_OK;
+}
+
 constexpr int kWG = 1024;          // threads per workgroup of the lattice kernels (16 waves)
 constexpr int kMaxLabels = 64;     // per-pixel label loops keep at most this many values in registers
 constexpr float kMinProb = 0.0001f;
@@ -69,9 +83,15 @@ struct MeanfieldBufs {
     float *msg_g;    // (B,C,N) normalised Gaussian message  K~_g Q
     float *msg_b;    // (B,C,N) normalised bilateral message K~_b Q
 };
+// optional per-launch timing of the filter kernel with HIP events on the launch stream
+struct Profiler {
+    hipEvent_t *start, *stop;   // [cap]
+    int cap, used;
+    bool active;
+};
 int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C,
                      const float *neg_unary, float wg, float wb, int n_iters, float *q_out,
-                     double *refined_out, float *logq_out, hipStream_t stream);
+                     double *refined_out, float *logq_out, hipStream_t stream, Profiler *prof = nullptr);
 
 // ---- pointwise / prep ----------------------------------------------------------------
 int launch_clip_min(float *p, size_t n, hipStream_t stream);

@@ -435,20 +435,14 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
     const int cap = lattice_table_cap(L.Mcap);
     const size_t lds = build_lds_bytes(L.d, L.N);
     if (L.d == 2) {
-        static bool attr2 = false;
-        if (!attr2) {
-            DSRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lattice_build_kernel<2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr2 = true;
-        }
+        static size_t granted2 = 0;
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_build_kernel<2>), lds, granted2);
+        if (rc) return rc;
         hipLaunchKernelGGL(lattice_build_kernel<2>, dim3(nlat), dim3(kWG), lds, stream, L, F, im, cap);
     } else {
-        static bool attr5 = false;
-        if (!attr5) {
-            DSRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lattice_build_kernel<5>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr5 = true;
-        }
+        static size_t granted5 = 0;
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_build_kernel<5>), lds, granted5);
+        if (rc) return rc;
         hipLaunchKernelGGL(lattice_build_kernel<5>, dim3(nlat), dim3(kWG), lds, stream, L, F, im, cap);
     }
     DSRG_LAUNCH_CHECK();

@@ -229,24 +229,24 @@ __global__ __launch_bounds__(256) void mf_update_kernel(const float *__restrict_
 
 // ---------------------------------------------------------------------------------
 template <int CPW, int VPT>
-static int launch_filter(const FilterArgs &a, size_t lds, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        DSRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mf_filter_kernel<CPW, VPT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+static int launch_filter(const FilterArgs &a, size_t lds, hipStream_t stream, Profiler *prof) {
+    static size_t granted = 0;
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mf_filter_kernel<CPW, VPT>), lds, granted);
+    if (rc) return rc;
+    const bool timed = prof && prof->active && prof->used < prof->cap;
+    if (timed) DSRG_HIP_CHECK(hipEventRecord(prof->start[prof->used], stream));
     hipLaunchKernelGGL((mf_filter_kernel<CPW, VPT>), dim3(a.groups * a.lat_stride), dim3(kWG), lds, stream, a);
     DSRG_LAUNCH_CHECK();
+    if (timed) { DSRG_HIP_CHECK(hipEventRecord(prof->stop[prof->used], stream)); prof->used++; }
     return DSRG_OK;
 }
 
 template <int CPW>
-static int dispatch_vpt(const FilterArgs &a, size_t lds, int vpt, hipStream_t stream) {
-    if (vpt <= 4) return launch_filter<CPW, 4>(a, lds, stream);
-    if (vpt <= 10) return launch_filter<CPW, 10>(a, lds, stream);
-    if (vpt <= 16) return launch_filter<CPW, 16>(a, lds, stream);
-    if (vpt <= 32) return launch_filter<CPW, 32>(a, lds, stream);
+static int dispatch_vpt(const FilterArgs &a, size_t lds, int vpt, hipStream_t stream, Profiler *prof) {
+    if (vpt <= 4) return launch_filter<CPW, 4>(a, lds, stream, prof);
+    if (vpt <= 10) return launch_filter<CPW, 10>(a, lds, stream, prof);
+    if (vpt <= 16) return launch_filter<CPW, 16>(a, lds, stream, prof);
+    if (vpt <= 32) return launch_filter<CPW, 32>(a, lds, stream, prof);
     return set_error(DSRG_ERR_UNSUPPORTED, "lattice too large for the LDS-resident filter (vpt=%d)", vpt);
 }
 
@@ -265,7 +265,7 @@ static int launch_update(const float *neg_unary, const MeanfieldBufs &buf, float
 
 int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C,
                      const float *neg_unary, float wg, float wb, int n_iters, float *q_out,
-                     double *refined_out, float *logq_out, hipStream_t stream) {
+                     double *refined_out, float *logq_out, hipStream_t stream, Profiler *prof) {
     if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= nlabels <= %d required", kMaxLabels);
     const int N = Lb.N;
     const int McapMax = Lb.Mcap > Lg.Mcap ? Lb.Mcap : Lg.Mcap;
@@ -291,9 +291,9 @@ int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const Meanfie
                            n_iters > 0 ? nullptr : refined_out, n_iters > 0 ? nullptr : logq_out, B, C, N, stream);
     if (rc) return rc;
     for (int it = 0; it < n_iters; it++) {
-        if (cpw == 3) rc = dispatch_vpt<3>(a, lds, vpt, stream);
-        else if (cpw == 2) rc = dispatch_vpt<2>(a, lds, vpt, stream);
-        else rc = dispatch_vpt<1>(a, lds, vpt, stream);
+        if (cpw == 3) rc = dispatch_vpt<3>(a, lds, vpt, stream, prof);
+        else if (cpw == 2) rc = dispatch_vpt<2>(a, lds, vpt, stream, prof);
+        else rc = dispatch_vpt<1>(a, lds, vpt, stream, prof);
         if (rc) return rc;
         const bool last = (it == n_iters - 1);
         rc = launch_update(neg_unary, buf, wg, wb, 1, last ? q_out : buf.q, last ? refined_out : nullptr,

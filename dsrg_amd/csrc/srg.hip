@@ -114,13 +114,10 @@ int launch_srg(int B, int C, int H, int W, const float *labels, const float *cue
     if (C < 1 || C > 64) return set_error(DSRG_ERR_UNSUPPORTED, "SRG supports 1..64 classes, got %d", C);
     const size_t Np = (size_t)(H + 2) * (W + 2);
     const size_t lds = 2 * ((Np + 15) & ~(size_t)15) + (size_t)H * W;
-    if (lds > 160 * 1024) return set_error(DSRG_ERR_UNSUPPORTED, "SRG map %dx%d exceeds LDS", H, W);
-    static bool attr = false;
-    if (!attr) {
-        DSRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&srg_grow_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    if (lds > 150 * 1024) return set_error(DSRG_ERR_UNSUPPORTED, "SRG map %dx%d exceeds LDS", H, W);
+    static size_t granted = 0;
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&srg_grow_kernel), lds, granted);
+    if (rc) return rc;
     hipLaunchKernelGGL(srg_grow_kernel, dim3(B), dim3(kSrgWG), lds, stream, C, H, W, labels, cues, refined, th1,
                        th2, seeds);
     DSRG_LAUNCH_CHECK();

@@ -43,6 +43,16 @@ class Context(object):
             _lib.lib().dsrg_ctx_destroy(h)
             self._h = None
 
+    def profile_start(self, max_launches=4096):
+        """bracket every mean-field filter launch with HIP events on the launch stream"""
+        check(_lib.lib().dsrg_ctx_profile_start(self._h, int(max_launches)))
+
+    def profile_stop(self):
+        """-> (summed filter-kernel milliseconds, number of launches); synchronises"""
+        ms, n = ctypes.c_double(0.0), ctypes.c_int32(0)
+        check(_lib.lib().dsrg_ctx_profile_stop(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
     def lattice_sizes(self, B):
         """(M_gaussian, [M_bilateral per image]) of the lattices built by the last CRF call."""
         mg = ctypes.c_int32(0)

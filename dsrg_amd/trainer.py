@@ -1,0 +1,76 @@
+"""One DSRG train-s step on MI355X: backbone forward (MIOpen, bf16 autocast) -> supervision
+hot path (libdsrg_hip.so) -> backward -> Caffe-style SGD (solver-s.prototxt).  Data parallel
+over images: one process per GPU, gradients all-reduced by RCCL through DistributedDataParallel.
+"""
+import torch
+
+from .backbone import VGG16ASPP
+from .ops import dsrg_supervision_loss
+
+
+class CaffeSGD(object):
+    """Caffe's SGDSolver update (solver-s.prototxt:5-14): V <- m V + lr*lr_mult*(g + wd*decay_mult*W);
+    W <- W - V; lr = base_lr * gamma^floor(iter/stepsize)."""
+
+    def __init__(self, groups, base_lr=5e-4, momentum=0.9, weight_decay=5e-4, gamma=0.33, stepsize=1000):
+        self.groups = groups
+        self.base_lr, self.momentum, self.wd, self.gamma, self.stepsize = base_lr, momentum, weight_decay, gamma, stepsize
+        self.iter = 0
+        for g in self.groups:
+            g["bufs"] = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in g["params"]]
+
+    def lr(self):
+        return self.base_lr * self.gamma ** (self.iter // self.stepsize)
+
+    @torch.no_grad()
+    def step(self):
+        lr = self.lr()
+        for g in self.groups:
+            ps = [p for p in g["params"] if p.grad is not None]
+            if not ps:
+                continue
+            bufs = [b for p, b in zip(g["params"], g["bufs"]) if p.grad is not None]
+            grads = [p.grad for p in ps]
+            local_lr, local_wd = lr * g["lr_mult"], self.wd * g["decay_mult"]
+            if local_wd != 0.0:
+                grads = torch._foreach_add(grads, ps, alpha=local_wd)
+            torch._foreach_mul_(bufs, self.momentum)
+            torch._foreach_add_(bufs, grads, alpha=local_lr)
+            torch._foreach_sub_(ps, bufs)
+        self.iter += 1
+
+    def zero_grad(self):
+        for g in self.groups:
+            for p in g["params"]:
+                p.grad = None
+
+
+class DSRGTrainer(object):
+    def __init__(self, device, world_size=1, seed=0, amp_dtype=torch.bfloat16, channels_last=True):
+        torch.manual_seed(seed)            # same initial weights on every rank (DDP also broadcasts)
+        self.device = device
+        self.amp_dtype = amp_dtype
+        self.channels_last = channels_last
+        net = VGG16ASPP().to(device)
+        if channels_last:
+            net = net.to(memory_format=torch.channels_last)
+        self.net = net
+        self.model = net
+        if world_size > 1:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            # 151.5 MB of fp32 gradients per step; 32 MB buckets -> 5 all-reduces overlapped with backward
+            self.model = DDP(net, device_ids=[device.index], bucket_cap_mb=32, gradient_as_bucket_view=True)
+        self.opt = CaffeSGD(net.caffe_param_groups())
+        torch.manual_seed(seed + 1 + (device.index or 0))      # per-rank dropout stream
+
+    def step(self, images, labels, cues):
+        """images (B,3,321,321) f32 mean-subtracted, labels (B,1,1,21), cues (B,21,41,41) -> losses[2]"""
+        self.opt.zero_grad()
+        x = images.contiguous(memory_format=torch.channels_last) if self.channels_last else images
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            logits = self.model(x)
+        logits = logits.float().contiguous()
+        total, losses = dsrg_supervision_loss(logits, images, labels, cues)
+        total.backward()
+        self.opt.step()
+        return losses

@@ -119,6 +119,12 @@ int dsrg_crf_meanfield_batch(dsrg_ctx_t ctx, int B, const float *neg_unary_dev,
 int dsrg_ctx_lattice_sizes(dsrg_ctx_t ctx, int B, int32_t *m_gauss_host, int32_t *m_bilateral_host,
                            void *stream);
 
+/* measurement hook (no reference counterpart): while profiling is on, every launch of the
+ * mean-field filter kernel (splat/blur/slice, the dominant kernel) is bracketed by HIP events
+ * on the launch stream; _stop synchronises and returns the summed kernel time and launch count. */
+int dsrg_ctx_profile_start(dsrg_ctx_t ctx, int max_launches);
+int dsrg_ctx_profile_stop(dsrg_ctx_t ctx, double *total_ms_host, int32_t *launches_host);
+
 /* CRFLayer.backward (pylayers.py:90-92): bottom_diff = (1 - refined) * top_diff */
 int dsrg_crf_layer_backward(size_t n, const double *refined_dev, const float *top_diff_dev,
                             float *bottom_diff_dev, void *stream);

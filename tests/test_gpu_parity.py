@@ -229,7 +229,9 @@ def test_supervision_step_vs_oracle_composition(ops, O):
     l_con, g_p, g_lq = O.constrain_loss(probs, logq)
     g_total = g_seed + g_p + O.crf_layer_backward(refined, g_lq)
     want_grad = O.softmax_backward(b["logits"], g_total)
-    assert np.array_equal(blobs["probs"].cpu().numpy(), probs)
+    # GPU expf vs libm expf: the softmax blobs agree to rounding; the clip floor is exact
+    gp = blobs["probs"].cpu().numpy()
+    assert np.abs(gp - probs).max() < 1e-6 and gp.min() == np.float32(1e-4)
     assert np.abs(np.exp(blobs["logq"].cpu().numpy()) - refined).max() < CRF_TOL
     got_seeds = blobs["seeds"].cpu().numpy()
     nflip = int((got_seeds != seeds).sum())
@@ -261,7 +263,10 @@ def test_crf_label_permutation_equivariance_on_gpu(ops, O):
     perm = np.random.default_rng(0).permutation(21)
     r1, _ = ops.crf_refine(dev(probs), dev(b["images"]), 12.0, 10)
     r2, _ = ops.crf_refine(dev(probs[:, perm]), dev(b["images"]), 12.0, 10)
-    assert np.abs(r1.cpu().numpy()[:, perm] - r2.cpu().numpy()).max() < 1e-6
+    # the label sum inside expAndNormalize runs in label order, so a permutation reorders float
+    # additions; ten mean-field iterations amplify that to ~2e-5 at undecided pixels (the CPU
+    # oracle shows the same 1.9e-5 on this input)
+    assert np.abs(r1.cpu().numpy()[:, perm] - r2.cpu().numpy()).max() < 1e-4
 
 
 def test_unsupported_sizes_fail_loudly(ops):
