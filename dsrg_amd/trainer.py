@@ -46,12 +46,16 @@ class CaffeSGD(object):
 
 
 class DSRGTrainer(object):
-    def __init__(self, device, world_size=1, seed=0, amp_dtype=torch.bfloat16, channels_last=True):
+    def __init__(self, device, world_size=1, seed=0, amp_dtype=torch.bfloat16, channels_last=True,
+                 loss_fn=None, net=None):
+        """loss_fn(logits, images, labels, cues) -> (total, losses); defaults to the HIP supervision
+        path.  (Tests inject a torch loss to exercise the data-parallel plumbing on CPU/gloo.)"""
         torch.manual_seed(seed)            # same initial weights on every rank (DDP also broadcasts)
         self.device = device
         self.amp_dtype = amp_dtype
         self.channels_last = channels_last
-        net = VGG16ASPP().to(device)
+        self.loss_fn = loss_fn or dsrg_supervision_loss
+        net = (net if net is not None else VGG16ASPP()).to(device)
         if channels_last:
             net = net.to(memory_format=torch.channels_last)
         self.net = net
@@ -59,7 +63,8 @@ class DSRGTrainer(object):
         if world_size > 1:
             from torch.nn.parallel import DistributedDataParallel as DDP
             # 151.5 MB of fp32 gradients per step; 32 MB buckets -> 5 all-reduces overlapped with backward
-            self.model = DDP(net, device_ids=[device.index], bucket_cap_mb=32, gradient_as_bucket_view=True)
+            self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=32,
+                             gradient_as_bucket_view=True)
         self.opt = CaffeSGD(net.caffe_param_groups())
         torch.manual_seed(seed + 1 + (device.index or 0))      # per-rank dropout stream
 
@@ -67,10 +72,10 @@ class DSRGTrainer(object):
         """images (B,3,321,321) f32 mean-subtracted, labels (B,1,1,21), cues (B,21,41,41) -> losses[2]"""
         self.opt.zero_grad()
         x = images.contiguous(memory_format=torch.channels_last) if self.channels_last else images
-        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+        with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             logits = self.model(x)
         logits = logits.float().contiguous()
-        total, losses = dsrg_supervision_loss(logits, images, labels, cues)
+        total, losses = self.loss_fn(logits, images, labels, cues)
         total.backward()
         self.opt.step()
         return losses

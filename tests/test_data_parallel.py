@@ -1,0 +1,104 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of the trainer.  The HIP
+supervision path cannot run without a GPU, so a torch loss with the same batch structure
+(mean over images, like both DSRG losses) is injected; what is checked is the part that is new
+relative to the single-GPU reference: shard -> DDP all-reduce -> Caffe SGD == one process on the
+global batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from dsrg_amd.trainer import DSRGTrainer, CaffeSGD
+
+
+class TinyNet(nn.Module):
+    """same parameter-group structure as VGG16ASPP (weights/biases, fc8 lr multipliers), tiny"""
+
+    def __init__(self):
+        super().__init__()
+        self.features = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.MaxPool2d(3, 2, 1, ceil_mode=True))
+        self.branches = nn.ModuleList([nn.Sequential(nn.Conv2d(8, 8, 3, padding=d, dilation=d), nn.ReLU(), nn.Identity(),
+                                                     nn.Conv2d(8, 8, 1), nn.ReLU(), nn.Identity(), nn.Conv2d(8, 5, 1))
+                                       for d in (1, 2)])
+
+    def forward(self, x):
+        f = self.features(x)
+        return self.branches[0](f) + self.branches[1](f)
+
+    caffe_param_groups = __import__("dsrg_amd.backbone", fromlist=["VGG16ASPP"]).VGG16ASPP.caffe_param_groups
+
+
+def torch_loss(logits, images, labels, cues):
+    """mean over images of a per-image normalised cross-entropy on the cues (structure of pylayers.py:136-137)"""
+    lp = torch.log_softmax(logits, 1)
+    per = -(cues * lp).sum((1, 2, 3)) / cues.sum((1, 2, 3)).clamp(min=1e-4)
+    l = per.mean()
+    return l, torch.stack([l.detach(), l.detach() * 0])
+
+
+def make_data(B):
+    g = torch.Generator().manual_seed(7)
+    images = torch.randn(B, 3, 17, 17, generator=g)
+    cues = (torch.rand(B, 5, 9, 9, generator=g) < 0.1).float()
+    labels = torch.ones(B, 1, 1, 5)
+    return images, labels, cues
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    tr = DSRGTrainer(torch.device("cpu"), world_size=world, seed=0, amp_dtype=None, channels_last=False,
+                     loss_fn=torch_loss, net=TinyNet())
+    images, labels, cues = make_data(4)
+    sh = slice(rank * 2, rank * 2 + 2)                       # rank r takes images [2r, 2r+2)
+    for _ in range(3):
+        tr.step(images[sh], labels[sh], cues[sh])
+    torch.save([p.detach().clone() for p in tr.net.parameters()], os.path.join(out_dir, "w%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_single_process_global_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0 = torch.load(os.path.join(str(tmp_path), "w0.pt"))
+    w1 = torch.load(os.path.join(str(tmp_path), "w1.pt"))
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)                             # replicas stay in lock step
+    torch.manual_seed(0)
+    tr = DSRGTrainer(torch.device("cpu"), world_size=1, seed=0, amp_dtype=None, channels_last=False,
+                     loss_fn=torch_loss, net=TinyNet())
+    images, labels, cues = make_data(4)
+    for _ in range(3):
+        tr.step(images, labels, cues)
+    for a, b in zip(w0, tr.net.parameters()):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_caffe_sgd_matches_hand_computation():
+    p = nn.Parameter(torch.tensor([1.0, -2.0]))
+    q = nn.Parameter(torch.tensor([0.5]))
+    opt = CaffeSGD([dict(params=[p], lr_mult=1.0, decay_mult=1.0), dict(params=[q], lr_mult=2.0, decay_mult=0.0)],
+                   base_lr=0.1, momentum=0.9, weight_decay=0.01, gamma=0.5, stepsize=2)
+    v_p, v_q, w_p, w_q = np.zeros(2), np.zeros(1), np.array([1.0, -2.0]), np.array([0.5])
+    for it in range(5):
+        gp, gq = np.array([0.3, -0.1]) * (it + 1), np.array([0.2])
+        p.grad, q.grad = torch.tensor(gp, dtype=torch.float32), torch.tensor(gq, dtype=torch.float32)
+        lr = 0.1 * 0.5 ** (it // 2)                                   # lr_policy "step" (solver-s.prototxt:5-8)
+        v_p = 0.9 * v_p + lr * (gp + 0.01 * w_p); w_p = w_p - v_p
+        v_q = 0.9 * v_q + 2 * lr * gq; w_q = w_q - v_q
+        opt.step()
+        assert np.allclose(p.detach().numpy(), w_p, atol=1e-6) and np.allclose(q.detach().numpy(), w_q, atol=1e-6)
