@@ -39,6 +39,11 @@ struct dsrg_ctx_s {
     Profiler prof;
 };
 
+namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; }
+extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_build_trace(void *dev_buf) { dsrg::g_build_dbg = dev_buf; }
+// tools only (not in the public header): device buffer of 16 u64 per filter block receiving phase timestamps
+extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_trace(void *dev_buf) { dsrg::g_filter_dbg = dev_buf; }
+
 extern "C" const char *dsrg_last_error(void) { return g_err; }
 
 extern "C" int dsrg_device_count(void) {

@@ -47,6 +47,7 @@ struct LatticeView {
     int nlat;              // number of lattices in this set (1 for the shared Gaussian, B for bilateral)
     // per lattice, strided by the quantities in brackets
     int *M;                // [1]        vertex count
+    int *flags;            // [1]        bit 0: lattice is diagonal (every vertex has one contributor, no blur neighbour)
     uint16_t *vid;         // [(d+1)*N]  vertex id of simplex corner r of pixel i   (r-major)
     float *bary;           // [(d+1)*N]  barycentric weight                         (r-major)
     uint32_t *nb;          // [(d+1)*Mcap] blur neighbours along axis j: n1 | n2<<16 (Mcap = none)
@@ -111,6 +112,32 @@ int launch_sup_loss_backward(int B, int C, int HW, const float *logits, const fl
 int launch_lf_to_planes(int N, int M, const float *in, float *out, int negate, hipStream_t stream);
 int launch_planes_to_lf(int N, int M, const float *in, float *out, hipStream_t stream);
 int launch_argmax_planes(int N, int M, const float *q, int32_t *lab, hipStream_t stream);
+
+#ifdef __HIPCC__
+// SRSRC buffer loads: 32-bit per-lane byte offset + scalar offset against a wave-uniform descriptor
+// (one VGPR of address per load in flight instead of two; out-of-range offsets read 0, so index
+// loads need no clamping).
+using rsrc_t = decltype(__builtin_amdgcn_make_buffer_rsrc((void *)nullptr, (short)0, 0, 0));
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, size_t bytes) {
+    // make wave-uniformity provable to the compiler (else every buffer op gets a waterfall loop)
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t)bytes);
+    void *q = reinterpret_cast<void *>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ uint32_t ld_u32(rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ float ld_f32(rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ uint32_t ld_u16(rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+
+#endif
 
 // ---- seeded region growing ---------------------------------------------------------------
 int launch_srg(int B, int C, int H, int W, const float *labels, const float *cues, const double *refined,

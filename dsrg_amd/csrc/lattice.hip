@@ -18,8 +18,11 @@ template <int D> struct KeyWords { static constexpr int value = (D * 16 + 31) / 
 template <int KW> __device__ __forceinline__ uint32_t hash_key(const uint32_t (&w)[KW]) {
     uint32_t h = 0;
 #pragma unroll
-    for (int i = 0; i < KW; i++) h = (h ^ w[i]) * 0x9E3779B1u;
-    return h ^ (h >> 13);
+    for (int i = 0; i < KW; i++) { h = (h ^ w[i]) * 0x9E3779B1u; h ^= h >> 15; }
+    h *= 0x85EBCA6Bu;                    // avalanche: lattice keys are highly regular
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
 }
 template <int KW> __device__ __forceinline__ void load_key(uint32_t (&w)[KW], const uint32_t *p) {
 #pragma unroll
@@ -31,15 +34,34 @@ template <int KW> __device__ __forceinline__ bool key_eq(const uint32_t (&a)[KW]
     for (int i = 0; i < KW; i++) eq &= (a[i] == p[i]);
     return eq;
 }
+// Keys are `short` coordinates (permutohedral.cpp:168,270) packed two per 32-bit word, each biased
+// by 0x8000 (an injective re-coding: only key EQUALITY matters).  The bias keeps every field away
+// from 0 / 0xFFFF for any realistic lattice, so "all coordinates -1" is one subtraction per word
+// with no borrow between fields; a coordinate that would borrow wraps exactly like the short does
+// only when the neighbouring field is unaffected — guarded by the range flag computed in phase 1.
 template <int D> __device__ __forceinline__ void pack_key(uint32_t (&w)[KeyWords<D>::value], const short (&k)[D]) {
 #pragma unroll
     for (int i = 0; i < KeyWords<D>::value; i++) w[i] = 0;
 #pragma unroll
-    for (int i = 0; i < D; i++) w[i >> 1] |= (uint32_t)(uint16_t)k[i] << ((i & 1) * 16);
+    for (int i = 0; i < D; i++) w[i >> 1] |= (uint32_t)(uint16_t)((int)k[i] + 0x8000) << ((i & 1) * 16);
 }
-template <int D> __device__ __forceinline__ void unpack_key(short (&k)[D], const uint32_t (&w)[KeyWords<D>::value]) {
+// neighbour keys of permutohedral.cpp:307-313 on the packed form:
+//   n1 = key - 1 on every stored coordinate, then coordinate j: key[j] + d   (i.e. -1 + (d+1))
+//   n2 = key + 1 on every stored coordinate, then coordinate j: key[j] - d   (i.e. +1 - (d+1))
+template <int D> __device__ __forceinline__ void neighbour_key(uint32_t (&n)[KeyWords<D>::value],
+                                                               const uint32_t (&w)[KeyWords<D>::value], int j, bool plus) {
+    constexpr int KW = KeyWords<D>::value;
 #pragma unroll
-    for (int i = 0; i < D; i++) k[i] = (short)(uint16_t)(w[i >> 1] >> ((i & 1) * 16));
+    for (int i = 0; i < KW; i++) {
+        const uint32_t ones = (2 * i + 1 < D) ? 0x00010001u : 0x00000001u;      // fields present in word i
+        n[i] = plus ? w[i] + ones : w[i] - ones;
+    }
+    if (j < D) {
+        const uint32_t delta = (uint32_t)(D + 1) << ((j & 1) * 16);
+#pragma unroll
+        for (int i = 0; i < KW; i++)
+            if (i == (j >> 1)) n[i] = plus ? n[i] - delta : n[i] + delta;
+    }
 }
 
 // exclusive scan of one int per thread over the workgroup; `scratch` holds >= 17 ints.
@@ -65,25 +87,54 @@ __device__ __forceinline__ int block_exclusive_scan(int x, int *scratch, int *to
     return scratch[wave] + incl - x;
 }
 
+// hash table: 16-bit slots (entry index, later vertex id; 0xFFFF = empty), capacity >= 2x the
+// worst-case vertex count so linear-probing chains stay short
 __host__ __device__ inline int lattice_table_cap(int Mcap) {
-    int cap = 1024;
-    while (cap < 2 * Mcap && cap < 32768) cap <<= 1;
+    int cap = 2048;
+    while (cap < 2 * Mcap && cap < 65536) cap <<= 1;
     return cap;
 }
 
-constexpr int kBuildVPT = 32;   // register-Jacobi bound of the norm pass: Mcap <= 32*1024
+// compact, exactly comparable form of a vertex key for the LDS-resident key array:
+//   D = 2: the packed word itself;  D = 5: five 12-bit fields (|coordinate| < 2048, checked)
+template <int D> struct CompactKey;
+template <> struct CompactKey<2> {
+    using type = uint32_t;
+    __device__ static __forceinline__ uint32_t make(const uint32_t (&w)[1]) { return w[0]; }
+};
+template <> struct CompactKey<5> {
+    using type = unsigned long long;
+    __device__ static __forceinline__ unsigned long long make(const uint32_t (&w)[3]) {
+        const unsigned long long c0 = (w[0] & 0xFFFFu) - 0x7800u, c1 = (w[0] >> 16) - 0x7800u;
+        const unsigned long long c2 = (w[1] & 0xFFFFu) - 0x7800u, c3 = (w[1] >> 16) - 0x7800u;
+        const unsigned long long c4 = (w[2] & 0xFFFFu) - 0x7800u;
+        return (c0 & 0xFFFu) | ((c1 & 0xFFFu) << 12) | ((c2 & 0xFFFu) << 24) | ((c3 & 0xFFFu) << 36) | ((c4 & 0xFFFu) << 48);
+    }
+};
 
-template <int D>
+constexpr int kBuildVPT = 32;   // largest instantiation: Mcap <= 32*1024 (vertices / entries per thread)
+
+void *g_build_dbg = nullptr;     // tools only: 16 u64 phase timestamps per lattice (dsrg_debug_set_build_trace)
+
+template <int D, int VPT>   // VPT >= ceil(Mcap / 1024): vertices (and entries) per thread
 __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, LatticeFeat F,
-                                                              const unsigned char *__restrict__ im, int cap) {
+                                                              const unsigned char *__restrict__ im, int cap,
+                                                              int wl_in_lds, int lds_keys, unsigned long long *dbg) {
+#define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + (i_)] = wall_clock64(); } while (0)
+    DSRG_STAMP(0);
     constexpr int D1 = D + 1, KW = KeyWords<D>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int N = L.N, Npad = (N + 3) & ~3, E = N * D1, Epad = Npad * D1, Mcap = L.Mcap;
     const uint32_t mask = (uint32_t)cap - 1u;
 
-    int *table = reinterpret_cast<int *>(smem);                   // [cap]
-    int *scan_scratch = reinterpret_cast<int *>(smem + (size_t)cap * 4);   // [32]
+    using ckey_t = typename CompactKey<D>::type;
+    uint16_t *tab = reinterpret_cast<uint16_t *>(smem);                   // [cap] 16-bit slots
+    uint32_t *tabw = reinterpret_cast<uint32_t *>(smem);                  // the same, as words (CAS granularity)
+    int *scan_scratch = reinterpret_cast<int *>(smem + (size_t)cap * 2);  // [32]
+    uint32_t *bm = reinterpret_cast<uint32_t *>(smem + (size_t)cap * 2 + 32 * 4);   // [Epad/32 + 1] first-occurrence bitmap
+    uint32_t *wp = bm + (Epad / 32 + 1);                                  // [Epad/32 + 1] word prefix
+    ckey_t *ckeys = reinterpret_cast<ckey_t *>(smem + (((size_t)cap * 2 + 32 * 4 + 2 * (size_t)(Epad / 32 + 1) * 4 + 7) & ~(size_t)7));   // [Mcap]
 
     uint16_t *vid = L.vid + (size_t)b * D1 * N;
     float *bary = L.bary + (size_t)b * D1 * N;
@@ -93,10 +144,10 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     float *csr_w = L.csr_w + (size_t)b * E;
     float *norm = L.norm + (size_t)b * N;
     uint32_t *key_e = L.key_e + (size_t)b * Epad * KW;
-    uint16_t *slot_e = L.slot_e + (size_t)b * Epad;
     uint32_t *key_v = L.key_v + (size_t)b * Mcap * KW;
 
-    for (int h = tid; h < cap; h += kWG) table[h] = -1;
+    for (int h = tid; h < cap / 2; h += kWG) tabw[h] = 0xFFFFFFFFu;
+    int key_range_bad = 0, key12_bad = 0;
 
     // ---- phase 1: embed every pixel (incl. the SSE zero padding) -> keys + weights
     const float invdplus1 = 1.0f / (float)D1;      // permutohedral.cpp:148
@@ -176,6 +227,8 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
                 int rk = (int)rank[k];
                 int canon = (rk <= D - r) ? r : r - D1;    // canonical[r][rk], :171-176
                 key[k] = (short)(int)(rem0[k] + (float)canon);
+                key_range_bad |= (key[k] > 32000) | (key[k] < -32000);
+                key12_bad |= (key[k] >= 2048) | (key[k] < -2048);
             }
             uint32_t w[KW];
             pack_key<D>(w, key);
@@ -185,77 +238,183 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         }
     }
     __syncthreads();
+    DSRG_STAMP(1);
 
-    // ---- phase 2: deduplicate keys (open addressing, linear probing, LDS CAS)
-    for (int e = tid; e < Epad; e += kWG) {
-        uint32_t w[KW];
-        load_key<KW>(w, key_e + (size_t)e * KW);
-        uint32_t h = hash_key<KW>(w) & mask;
-        for (;;) {
-            int old = atomicCAS(&table[h], -1, e);
-            if (old == -1) break;
-            if (key_eq<KW>(w, key_e + (size_t)old * KW)) break;
-            h = (h + 1) & mask;
-        }
-        slot_e[e] = (uint16_t)h;
-    }
-    __syncthreads();
-
-    // ---- phase 3: dense vertex ids in slot order; table[h] becomes the id
-    const int chunk = cap / kWG;
-    int occupied = 0;
-    for (int q = 0; q < chunk; q++) occupied += (table[tid * chunk + q] >= 0);
-    int M;
-    int base = block_exclusive_scan(occupied, scan_scratch, &M);
-    for (int q = 0; q < chunk; q++) {
-        const int h = tid * chunk + q;
-        const int rep = table[h];
-        if (rep >= 0) {
+    // ---- phase 2: deduplicate keys (open addressing, linear probing, table in LDS).  A slot ends up
+    // holding the SMALLEST entry index of its key = the key's first occurrence in the reference's
+    // visiting order (pixel-major, corner-minor; permutohedral.cpp:261-276).  Slots are 16 bits wide
+    // (two per CAS word).  Thread t owns entries t + k*1024.
+    constexpr uint32_t kEmpty = 0xFFFFu;
+    constexpr int EPT = VPT;                              // entries per thread (Epad <= Mcap)
+    uint16_t hs[EPT];                                     // slot of my k-th entry
 #pragma unroll
-            for (int t = 0; t < KW; t++) key_v[(size_t)base * KW + t] = key_e[(size_t)rep * KW + t];
-            table[h] = base++;
+    for (int k = 0; k < EPT; k++) {
+        const int e = tid + k * kWG;
+        hs[k] = 0;
+        if (e < Epad) {
+            uint32_t w[KW];
+            load_key<KW>(w, key_e + (size_t)e * KW);
+            uint32_t h = hash_key<KW>(w) & mask;
+            for (;;) {
+                const uint32_t sh = (h & 1u) * 16u;
+                const uint32_t cur = *reinterpret_cast<volatile uint32_t *>(&tabw[h >> 1]);
+                const uint32_t half = (cur >> sh) & 0xFFFFu;
+                const uint32_t mine = (cur & ~(0xFFFFu << sh)) | ((uint32_t)e << sh);
+                if (half == kEmpty) {
+                    if (atomicCAS(&tabw[h >> 1], cur, mine) == cur) break;
+                    continue;                              // the word changed under us: look again
+                }
+                if (key_eq<KW>(w, key_e + (size_t)half * KW)) {
+                    if ((uint32_t)e < half && atomicCAS(&tabw[h >> 1], cur, mine) != cur) continue;
+                    break;
+                }
+                h = (h + 1) & mask;
+            }
+            hs[k] = (uint16_t)h;
         }
     }
-    if (tid == 0) L.M[b] = M;
+    const int compact_ok = (D == 2) ? 1 : !__syncthreads_or(key12_bad);    // (also the phase barrier)
+    if (D == 2) __syncthreads();
+    const bool fast_keys = lds_keys && compact_ok;
+    DSRG_STAMP(2);
+
+    // ---- phase 3: vertex ids in first-occurrence order — exactly the ids the reference's hash table
+    // hands out (HashTable::find(create), permutohedral.cpp:98-111).  A bitmap of "first occurrence"
+    // flags over the entries is prefix-summed in LDS.
+    int M;
+    {
+        const int nwords = Epad / 32 + 1;
+        for (int q = tid; q < nwords; q += kWG) bm[q] = 0;
+        __syncthreads();
+        uint32_t isfirst = 0;
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int e = tid + k * kWG;
+            if (e < Epad && (uint32_t)tab[hs[k]] == (uint32_t)e) {
+                isfirst |= 1u << k;
+                atomicOr(&bm[e >> 5], 1u << (e & 31));
+            }
+        }
+        __syncthreads();
+        // exclusive prefix of the per-word popcounts (nwords <= 1024 for Epad <= 32768)
+        const int myc = tid < nwords ? __popc(bm[tid]) : 0;
+        const int pre = block_exclusive_scan(myc, scan_scratch, &M);
+        if (tid < nwords) wp[tid] = (uint32_t)pre;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int e = tid + k * kWG;
+            if ((isfirst >> k) & 1u) {
+                const uint32_t id = wp[e >> 5] + (uint32_t)__popc(bm[e >> 5] & ((1u << (e & 31)) - 1u));
+                uint32_t w[KW];
+                load_key<KW>(w, key_e + (size_t)e * KW);
+#pragma unroll
+                for (int t = 0; t < KW; t++) key_v[(size_t)id * KW + t] = w[t];
+                if (fast_keys) ckeys[id] = CompactKey<D>::make(w);
+                tab[hs[k]] = (uint16_t)id;
+            }
+        }
+        if (tid == 0) L.M[b] = M;
+    }
     __syncthreads();
+    DSRG_STAMP(3);
 
     // ---- phase 4: vertex id of every real (pixel, corner) entry
-    for (int e = tid; e < E; e += kWG) {
-        const int i = e / D1, r = e - i * D1;
-        vid[(size_t)r * N + i] = (uint16_t)table[slot_e[e]];
-    }
-
-    // ---- phase 5: blur neighbours (permutohedral.cpp:303-318)
-    for (int v = tid; v < M; v += kWG) {
-        uint32_t w[KW];
-        load_key<KW>(w, key_v + (size_t)v * KW);
-        short k0[D];
-        unpack_key<D>(k0, w);
 #pragma unroll
-        for (int j = 0; j <= D; j++) {
-            short n1[D], n2[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) { n1[k] = (short)(k0[k] - 1); n2[k] = (short)(k0[k] + 1); }
-            if (j < D) { n1[j < D ? j : 0] = (short)(k0[j < D ? j : 0] + D); n2[j < D ? j : 0] = (short)(k0[j < D ? j : 0] - D); }
-            uint32_t res[2];
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                uint32_t q[KW];
-                if (s == 0) pack_key<D>(q, n1); else pack_key<D>(q, n2);
-                uint32_t h = hash_key<KW>(q) & mask;
-                uint32_t found = (uint32_t)Mcap;
-                for (;;) {
-                    int t = table[h];
-                    if (t < 0) break;
-                    if (key_eq<KW>(q, key_v + (size_t)t * KW)) { found = (uint32_t)t; break; }
-                    h = (h + 1) & mask;
-                }
-                res[s] = found;
-            }
-            nb[(size_t)j * Mcap + v] = res[0] | (res[1] << 16);
+    for (int k = 0; k < EPT; k++) {
+        const int e = tid + k * kWG;
+        if (e < E) {
+            const int i = e / D1, r = e - i * D1;
+            vid[(size_t)r * N + i] = tab[hs[k]];
         }
     }
-    __syncthreads();
+
+    // ---- phase 5: blur neighbours (permutohedral.cpp:303-318): 2(d+1) hash look-ups per vertex,
+    // advanced together one probe per round.  With the compact keys resident in LDS a probe is two
+    // LDS reads (slot, key) and no global traffic; otherwise the candidates of a round are confirmed
+    // by one batch of key fetches from HBM/L2.
+    int has_nb = 0;
+#pragma unroll 1
+    for (int k = 0; k < VPT; k++) {
+        const int v = tid + k * kWG;
+        if (v >= M) break;
+        uint32_t w[KW];
+        load_key<KW>(w, key_v + (size_t)v * KW);
+        uint32_t word[D1];
+#pragma unroll
+        for (int j = 0; j < D1; j++) word[j] = 0;
+        // two halves of D1 look-ups each (keeps the probe state in registers):
+        //   half 0: n1 = all coordinates -1, axis j +d;   half 1: n2 = all +1, axis j -d
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            uint32_t hq[D1], found[D1];
+            ckey_t qc[D1];
+#pragma unroll
+            for (int j = 0; j < D1; j++) {
+                uint32_t q[KW];
+                neighbour_key<D>(q, w, j, half != 0);
+                hq[j] = hash_key<KW>(q) & mask;
+                qc[j] = CompactKey<D>::make(q);
+                found[j] = (uint32_t)Mcap;
+            }
+            uint32_t pend = (1u << D1) - 1u;
+            if (fast_keys) {
+                while (pend) {
+                    uint32_t t[D1];
+#pragma unroll
+                    for (int j = 0; j < D1; j++) t[j] = tab[hq[j]];
+                    ckey_t ck[D1];
+#pragma unroll
+                    for (int j = 0; j < D1; j++) ck[j] = ckeys[min(t[j], (uint32_t)Mcap - 1u)];
+#pragma unroll
+                    for (int j = 0; j < D1; j++) {
+                        if ((pend >> j) & 1u) {
+                            if (t[j] == kEmpty) pend &= ~(1u << j);
+                            else if (ck[j] == qc[j]) { found[j] = t[j]; pend &= ~(1u << j); }
+                            else hq[j] = (hq[j] + 1) & mask;
+                        }
+                    }
+                }
+            } else {
+                while (pend) {
+                    uint32_t t[D1];
+#pragma unroll
+                    for (int j = 0; j < D1; j++) t[j] = tab[hq[j]];
+                    uint32_t kv[D1][KW];
+#pragma unroll
+                    for (int j = 0; j < D1; j++)
+                        load_key<KW>(kv[j], key_v + (size_t)min(t[j], (uint32_t)Mcap - 1u) * KW);
+#pragma unroll
+                    for (int j = 0; j < D1; j++) {
+                        if ((pend >> j) & 1u) {
+                            uint32_t q[KW];
+                            neighbour_key<D>(q, w, j, half != 0);
+                            bool eq = true;
+#pragma unroll
+                            for (int x = 0; x < KW; x++) eq &= (kv[j][x] == q[x]);
+                            if (t[j] == kEmpty) pend &= ~(1u << j);
+                            else if (eq) { found[j] = t[j]; pend &= ~(1u << j); }
+                            else hq[j] = (hq[j] + 1) & mask;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < D1; j++) {
+                word[j] |= found[j] << (half * 16);
+                has_nb |= found[j] != (uint32_t)Mcap;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = word[j];
+    }
+    {   // diagonal lattice: every entry owns its vertex and no vertex has a blur neighbour
+        const int any_nb = __syncthreads_or(has_nb);
+        const int any_bad = __syncthreads_or(key_range_bad);
+        // bit 0: diagonal; bit 1: a key coordinate left the range the packed neighbour arithmetic covers
+        if (tid == 0) L.flags[b] = ((!any_nb && M == E) ? 1 : 0) | (any_bad ? 2 : 0);
+    }
+    DSRG_STAMP(4);
 
     // ---- phase 6: CSR of the splat, contributions in reference order (entry index ascending)
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                       // [Mcap+1]
@@ -284,6 +443,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         if (tid == 0) row_start[M] = (uint32_t)E;
     }
     __syncthreads();
+    DSRG_STAMP(5);
     for (int e = tid; e < E; e += kWG) {
         const int i = e / D1, r = e - i * D1;
         uint32_t pos = atomicAdd(&cnt[vid[(size_t)r * N + i]], 1u);
@@ -300,44 +460,72 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         }
     }
     __syncthreads();
+    DSRG_STAMP(6);
+    // weights of the sorted entries: to HBM for the filter kernel, and (when it fits) to LDS for the
+    // norm pass below
+    float *wl = wl_in_lds ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(scan2) + 32 * 4) : csr_w;
     for (int pos = tid; pos < E; pos += kWG) {
         const int e = csr_e[pos];
         const int i = e / D1, r = e - i * D1;
+        const float w = bary[(size_t)r * N + i];
         csr_pix[pos] = (uint16_t)i;
-        csr_w[pos] = bary[(size_t)r * N + i];
+        csr_w[pos] = w;
+        if (wl_in_lds) wl[pos] = w;
     }
     __syncthreads();
+    DSRG_STAMP(7);
 
     // ---- phase 7: norm = 1/sqrt(K 1 + 1e-20)  (pairwise.cpp:44,54-57), one channel through
     // Permutohedral::seqCompute (permutohedral.cpp:476-527): blur evaluated in double
-    float *val = reinterpret_cast<float *>(smem);                             // [Mcap+1]
-    for (int v = tid; v < M; v += kWG) {
-        float s = 0.0f;
-        const uint32_t a = row_start[v], z = row_start[v + 1];
-        for (uint32_t pos = a; pos < z; pos++) s = s + csr_w[pos] * 1.0f;
-        val[v] = s;
-    }
-    if (tid == 0) val[Mcap] = 0.0f;
-    __syncthreads();
-    for (int j = 0; j <= D; j++) {
-        float nv[kBuildVPT];
+    float *val = reinterpret_cast<float *>(smem);                             // [Mcap+1], aliases cnt
+    {
+        float s0[VPT];
 #pragma unroll
-        for (int k = 0; k < kBuildVPT; k++) {
+        for (int k = 0; k < VPT; k++) {
             const int v = tid + k * kWG;
+            float s = 0.0f;
             if (v < M) {
-                const uint32_t t = nb[(size_t)j * Mcap + v];
-                const float s = val[t & 0xffffu] + val[t >> 16];
-                nv[k] = (float)((double)val[v] + 0.5 * (double)s);
+                const uint32_t a0 = v == 0 ? 0u : cnt[v - 1], z0 = cnt[v];    // cnt[v] = END of row v
+                for (uint32_t pos = a0; pos < z0; pos++) s = s + wl[pos] * 1.0f;
             }
+            s0[k] = s;
         }
-        __syncthreads();
+        __syncthreads();                                                      // cnt is dead from here
 #pragma unroll
-        for (int k = 0; k < kBuildVPT; k++) {
+        for (int k = 0; k < VPT; k++) {
             const int v = tid + k * kWG;
-            if (v < M) val[v] = nv[k];
+            if (v < M) val[v] = s0[k];
         }
-        __syncthreads();
+        if (tid == 0) val[Mcap] = 0.0f;
     }
+    __syncthreads();
+    DSRG_STAMP(8);
+    {
+        const rsrc_t r_nb = make_rsrc(nb, sizeof(uint32_t) * (size_t)D1 * Mcap);
+        for (int j = 0; j <= D; j++) {
+            uint32_t word[VPT];
+#pragma unroll
+            for (int k = 0; k < VPT; k++)      // unconditional, all in flight (past-the-end reads 0)
+                word[k] = (k * kWG < Mcap) ? ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)j * (uint32_t)Mcap * 4u + (uint32_t)k * (kWG * 4u)) : 0u;
+            float nv[VPT];
+#pragma unroll
+            for (int k = 0; k < VPT; k++) {
+                const int v = tid + k * kWG;
+                const bool ok = v < M;
+                const int n1 = ok ? (int)(word[k] & 0xffffu) : Mcap, n2 = ok ? (int)(word[k] >> 16) : Mcap;
+                const float s = val[n1] + val[n2];
+                nv[k] = (float)((double)val[ok ? v : Mcap] + 0.5 * (double)s);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < VPT; k++) {
+                const int v = tid + k * kWG;
+                if (v < M) val[v] = nv[k];
+            }
+            __syncthreads();
+        }
+    }
+    DSRG_STAMP(9);
     const float alpha = 1.0f / (1.0f + exp2f((float)-D));
     for (int i = tid; i < N; i += kWG) {
         float out = 0.0f;
@@ -349,15 +537,17 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         }
         norm[i] = (float)(1.0 / sqrt((double)out + 1e-20));
     }
+    DSRG_STAMP(10);
+#undef DSRG_STAMP
 }
 
 // ---------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static void lattice_layout(int d, int N, int nlat, size_t off[12], size_t &total) {
+static void lattice_layout(int d, int N, int nlat, size_t off[13], size_t &total) {
     const int d1 = d + 1, Npad = (N + 3) / 4 * 4, Mcap = Npad * d1, E = N * d1, Epad = Npad * d1;
     const int KW = (d * 16 + 31) / 32;
-    size_t sz[11] = {
+    size_t sz[12] = {
         sizeof(int) * (size_t)nlat,                          // M
         sizeof(uint16_t) * (size_t)E * nlat,                 // vid
         sizeof(float) * (size_t)E * nlat,                    // bary
@@ -369,20 +559,21 @@ static void lattice_layout(int d, int N, int nlat, size_t off[12], size_t &total
         sizeof(uint32_t) * (size_t)Epad * KW * nlat,         // key_e
         sizeof(uint16_t) * (size_t)Epad * nlat,              // slot_e
         sizeof(uint32_t) * (size_t)Mcap * KW * nlat,         // key_v
+        sizeof(int) * (size_t)nlat,                          // flags
     };
     size_t cur = 0;
-    for (int i = 0; i < 11; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
+    for (int i = 0; i < 12; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
     total = cur;
 }
 
 size_t lattice_bytes(int d, int N, int nlat) {
-    size_t off[12], total;
+    size_t off[13], total;
     lattice_layout(d, N, nlat, off, total);
     return total;
 }
 
 void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
-    size_t off[12], total;
+    size_t off[13], total;
     lattice_layout(d, N, nlat, off, total);
     unsigned char *p = static_cast<unsigned char *>(base);
     L.d = d; L.N = N; L.Mcap = ((N + 3) / 4 * 4) * (d + 1); L.nlat = nlat;
@@ -397,6 +588,7 @@ void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
     L.key_e = reinterpret_cast<uint32_t *>(p + off[8]);
     L.slot_e = reinterpret_cast<uint16_t *>(p + off[9]);
     L.key_v = reinterpret_cast<uint32_t *>(p + off[10]);
+    L.flags = reinterpret_cast<int *>(p + off[11]);
 }
 
 void lattice_feat_init(LatticeFeat &F, int d, int W, int H, float sx, float sy, float sr, float sg, float sb) {
@@ -407,11 +599,13 @@ void lattice_feat_init(LatticeFeat &F, int d, int W, int H, float sx, float sy, 
     for (int i = 0; i < d; i++) F.scale[i] = (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std_dev);
 }
 
-static size_t build_lds_bytes(int d, int N) {
-    const int d1 = d + 1, Npad = (N + 3) / 4 * 4, Mcap = Npad * d1, E = N * d1;
+static size_t build_lds_bytes(int d, int N, bool with_wl = false, bool with_keys = false) {
+    const int d1 = d + 1, Npad = (N + 3) / 4 * 4, Mcap = Npad * d1, E = N * d1, Epad = Npad * d1;
     const int cap = lattice_table_cap(Mcap);
-    size_t a = (size_t)cap * 4 + 32 * 4;
+    size_t a = align_up((size_t)cap * 2 + 32 * 4 + 2 * (size_t)(Epad / 32 + 1) * 4, 8);
+    if (with_keys) a += (size_t)Mcap * (d == 5 ? 8 : 4);
     size_t b = align_up((size_t)(Mcap + 1) * 4, 16) + align_up((size_t)E * 2, 16) + 32 * 4;
+    if (with_wl) b += (size_t)E * 4;
     return a > b ? a : b;
 }
 
@@ -422,8 +616,8 @@ bool lattice_supported(int d, int N) {
     if (Mcap + 1 >= 65536) return false;                         // uint16 ids + sentinel
     if (Mcap > kBuildVPT * kWG) return false;                    // register Jacobi bound
     const int cap = lattice_table_cap(Mcap);
-    if ((double)Mcap > 0.9 * (double)cap) return false;          // linear probing load factor
-    if (build_lds_bytes(d, N) > 160 * 1024) return false;
+    if ((double)Mcap > 0.8 * (double)cap) return false;          // linear probing load factor
+    if (build_lds_bytes(d, N) > 158 * 1024) return false;    // leave room for the static word of __syncthreads_or
     return true;
 }
 
@@ -433,18 +627,27 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
         return set_error(DSRG_ERR_UNSUPPORTED,
                          "lattice with d=%d over %d pixels does not fit the LDS-resident path", L.d, L.N);
     const int cap = lattice_table_cap(L.Mcap);
-    const size_t lds = build_lds_bytes(L.d, L.N);
-    if (L.d == 2) {
-        static size_t granted2 = 0;
-        int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_build_kernel<2>), lds, granted2);
-        if (rc) return rc;
-        hipLaunchKernelGGL(lattice_build_kernel<2>, dim3(nlat), dim3(kWG), lds, stream, L, F, im, cap);
-    } else {
-        static size_t granted5 = 0;
-        int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_build_kernel<5>), lds, granted5);
-        if (rc) return rc;
-        hipLaunchKernelGGL(lattice_build_kernel<5>, dim3(nlat), dim3(kWG), lds, stream, L, F, im, cap);
-    }
+    const bool lds_keys = build_lds_bytes(L.d, L.N, false, true) <= 150 * 1024;
+    const bool wl_in_lds = build_lds_bytes(L.d, L.N, true, lds_keys) <= 150 * 1024;
+    const size_t lds = build_lds_bytes(L.d, L.N, wl_in_lds, lds_keys);
+    const int vpt = (L.Mcap + kWG - 1) / kWG;
+    unsigned long long *dbg = L.d == 5 ? reinterpret_cast<unsigned long long *>(g_build_dbg) : nullptr;
+#define DSRG_BUILD(D_, V_)                                                                                    \
+    do {                                                                                                      \
+        static size_t granted = 0;                                                                            \
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_build_kernel<D_, V_>), lds, granted); \
+        if (rc) return rc;                                                                                    \
+        hipLaunchKernelGGL((lattice_build_kernel<D_, V_>), dim3(nlat), dim3(kWG), lds, stream, L, F, im, cap,  \
+                           (int)wl_in_lds, (int)lds_keys, dbg);                                               \
+    } while (0)
+#define DSRG_BUILD_V(D_)                                                                                      \
+    do {                                                                                                      \
+        if (vpt <= 4) DSRG_BUILD(D_, 4); else if (vpt <= 10) DSRG_BUILD(D_, 10);                              \
+        else if (vpt <= 16) DSRG_BUILD(D_, 16); else if (vpt <= 25) DSRG_BUILD(D_, 25); else DSRG_BUILD(D_, 32); \
+    } while (0)
+    if (L.d == 2) DSRG_BUILD_V(2); else DSRG_BUILD_V(5);
+#undef DSRG_BUILD_V
+#undef DSRG_BUILD
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

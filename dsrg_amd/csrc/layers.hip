@@ -74,16 +74,15 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int C, int HW, 
     float t[CT];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) { t[c] = x[base + (size_t)c * HW]; mx = fmaxf(mx, t[c]); }
+    for (int c = 0; c < CT; c++) t[c] = x[base + (size_t)min(c, C - 1) * HW];    // unconditional: all in flight
+#pragma unroll
+    for (int c = 0; c < CT; c++) { t[c] = (c < C) ? t[c] : -INFINITY; mx = fmaxf(mx, t[c]); }
     float z = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) { t[c] = expf(t[c] - mx); z = z + t[c]; }
+    for (int c = 0; c < CT; c++) { t[c] = expf(t[c] - mx); z = (c < C) ? z + t[c] : z; }
     float z2 = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) { t[c] = t[c] / z + kMinProb; z2 = z2 + t[c]; }
+    for (int c = 0; c < CT; c++) { t[c] = t[c] / z + kMinProb; z2 = (c < C) ? z2 + t[c] : z2; }
 #pragma unroll
     for (int c = 0; c < CT; c++)
         if (c < C) p[base + (size_t)c * HW] = t[c] / z2;
@@ -96,22 +95,28 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, 
     if (idx >= B * HW) return;
     const int b = idx / HW, i = idx - b * HW;
     const size_t base = (size_t)b * C * HW + i;
-    float s[CT];
+    float s[CT], gg[CT];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) { s[c] = x[base + (size_t)c * HW]; mx = fmaxf(mx, s[c]); }
+    for (int c = 0; c < CT; c++) {
+        const size_t o = base + (size_t)min(c, C - 1) * HW;
+        s[c] = x[o];
+        gg[c] = g[o];
+    }
+#pragma unroll
+    for (int c = 0; c < CT; c++) { s[c] = (c < C) ? s[c] : -INFINITY; mx = fmaxf(mx, s[c]); }
     float z = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) { s[c] = expf(s[c] - mx); z += s[c]; }
+    for (int c = 0; c < CT; c++) { s[c] = expf(s[c] - mx); z = (c < C) ? z + s[c] : z; }
     float Z = 0.0f, sg = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) { s[c] = s[c] / z; Z += s[c] + kMinProb; sg += s[c] * g[base + (size_t)c * HW]; }
+    for (int c = 0; c < CT; c++) {
+        s[c] = s[c] / z;
+        if (c < C) { Z += s[c] + kMinProb; sg += s[c] * gg[c]; }
+    }
 #pragma unroll
     for (int c = 0; c < CT; c++)
-        if (c < C) dx[base + (size_t)c * HW] = s[c] * (g[base + (size_t)c * HW] - sg) / Z;
+        if (c < C) dx[base + (size_t)c * HW] = s[c] * (gg[c] - sg) / Z;
 }
 int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream) {
     if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
@@ -336,29 +341,40 @@ __global__ __launch_bounds__(256) void sup_grad_kernel(int B, int C, int HW, con
     const float inv = (float)(1.0 / ((double)B * (double)HW));
     float s[CT], g[CT];
     float mx = -INFINITY;
+    // two passes over the labels, each with its loads issued unconditionally up front
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) { s[c] = logits[base + (size_t)c * HW]; mx = fmaxf(mx, s[c]); }
+    for (int c = 0; c < CT; c++) s[c] = logits[base + (size_t)min(c, C - 1) * HW];
+#pragma unroll
+    for (int c = 0; c < CT; c++) { s[c] = (c < C) ? s[c] : -INFINITY; mx = fmaxf(mx, s[c]); }
     float z = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) { s[c] = expf(s[c] - mx); z += s[c]; }
+    for (int c = 0; c < CT; c++) { s[c] = expf(s[c] - mx); z = (c < C) ? z + s[c] : z; }
+    {
+        float pv[CT], lq[CT], sd[CT];
+        double rf[CT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const size_t o = base + (size_t)min(c, C - 1) * HW;
+            pv[c] = probs[o];
+            lq[c] = logq[o];
+            sd[c] = seeds[o];
+            rf[c] = refined[o];
+        }
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            // BalancedSeedLoss.backward + ConstrainLoss.backward[0] + CRFLayer.backward(ConstrainLoss.backward[1])
+            float dp, dlq;
+            constrain_term(pv[c], lq[c], dp, dlq);
+            const float gseed = -sd[c] / (pv[c] * (c == 0 ? dbg : dfg) * (float)B);
+            const float gcrf = (float)((1.0 - rf[c]) * (double)(dlq * inv));
+            g[c] = gseed + dp * inv + gcrf;
+        }
+    }
     float Z = 0.0f, sg = 0.0f;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-        if (c < C) {
-            const size_t o = base + (size_t)c * HW;
-            const float p = probs[o];
-            // BalancedSeedLoss.backward + ConstrainLoss.backward[0] + CRFLayer.backward(ConstrainLoss.backward[1])
-            float dp, dlq;
-            constrain_term(p, logq[o], dp, dlq);
-            const float gseed = -seeds[o] / (p * (c == 0 ? dbg : dfg) * (float)B);
-            const float gcrf = (float)((1.0 - refined[o]) * (double)(dlq * inv));
-            g[c] = gseed + dp * inv + gcrf;
-            s[c] = s[c] / z;
-            Z += s[c] + kMinProb;
-            sg += s[c] * g[c];
-        }
+        s[c] = s[c] / z;
+        if (c < C) { Z += s[c] + kMinProb; sg += s[c] * g[c]; }
     }
 #pragma unroll
     for (int c = 0; c < CT; c++)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Per-phase timeline of lattice_build_kernel<5> (debug hook dsrg_debug_set_build_trace)."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsrg_amd import ops, synthetic as S, _lib
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+kind = sys.argv[2] if len(sys.argv) > 2 else "smooth"
+b = S.make_batch(1000, B, image_kind=kind)
+d = lambda a: torch.from_numpy(a).cuda()
+logits, images, labels, cues = d(b["logits"]), d(b["images"]), d(b["labels"]), d(b["cues"])
+ctx = ops.get_context(B, 21, 41, 41)
+for _ in range(3):
+    ops.supervision_step(logits, images, labels, cues, ctx=ctx)
+torch.cuda.synchronize()
+buf = torch.zeros(64 * 16, dtype=torch.int64, device="cuda")
+L = _lib.lib()
+L.dsrg_debug_set_build_trace.argtypes = [ctypes.c_void_p]
+L.dsrg_debug_set_build_trace(ctypes.c_void_p(buf.data_ptr()))
+ops.supervision_step(logits, images, labels, cues, ctx=ctx)
+torch.cuda.synchronize()
+L.dsrg_debug_set_build_trace(None)
+t = buf.cpu().numpy().reshape(64, 16)[:B]
+names = ["embed", "insert", "ids", "vid+neigh", "csr count/scan", "csr fill/sort", "csr write", "norm splat", "norm blur", "norm slice"]
+prev = t[:, 0]
+for i, nm in enumerate(names):
+    dt = (t[:, i + 1] - prev) / 100.0
+    print("  %-15s mean %7.2f  max %7.2f us" % (nm, dt.mean(), dt.max()))
+    prev = t[:, i + 1]
+print("  total mean %.2f max %.2f us;  M:" % (((t[:, 10] - t[:, 0]) / 100.0).mean(), ((t[:, 10] - t[:, 0]) / 100.0).max()), ctx.lattice_sizes(B))
+sys.stdout.flush(); os._exit(0)
