@@ -53,6 +53,7 @@ SIGNATURES = {
     "dsrg_ctx_create": (_i, [_i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "dsrg_ctx_destroy": (_i, [_vp]),
     "dsrg_crf_refine_batch": (_i, [_vp, _i, _vp, _vp, _i, _i, ctypes.POINTER(CrfParams), _vp, _vp, _vp]),
+    "dsrg_crf_prepare_batch": (_i, [_vp, _i, _vp, _i, _i, ctypes.POINTER(CrfParams), _vp]),
     "dsrg_crf_meanfield_batch": (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(CrfParams), _vp, _vp]),
     "dsrg_ctx_lattice_sizes": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dsrg_ctx_profile_start": (_i, [_vp, _i]),

@@ -37,6 +37,8 @@ struct dsrg_ctx_s {
     double *refined;
     double *stats;               // (maxB, 5)
     Profiler prof;
+    int prepared_B;              // batch whose lattices dsrg_crf_prepare_batch built (0 = none)
+    dsrg_crf_params prepared_prm;
 };
 
 namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; }
@@ -63,12 +65,12 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     dsrg_ctx_s *c = new (std::nothrow) dsrg_ctx_s();
     if (!c) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
     c->maxB = max_batch; c->C = C; c->H = H; c->W = W; c->N = N; c->gauss_valid = false;
-    c->prof.start = c->prof.stop = nullptr; c->prof.cap = c->prof.used = 0; c->prof.active = false;
+    c->prepared_B = 0; c->prof.start = c->prof.stop = nullptr; c->prof.cap = c->prof.used = 0; c->prof.active = false;
     const size_t blob = align256(sizeof(float) * (size_t)max_batch * C * N);
     const size_t szLg = align256(lattice_bytes(2, N, 1)), szLb = align256(lattice_bytes(5, N, max_batch));
     const size_t szIm = align256((size_t)max_batch * N * 3);
     const size_t szRef = align256(sizeof(double) * (size_t)max_batch * C * N);
-    const size_t szStats = align256(sizeof(double) * (size_t)max_batch * 5);
+    const size_t szStats = align256(sizeof(double) * (size_t)max_batch * 5 * 8);   // [B][kStatSplit][5]
     const size_t total = szLg + szLb + 3 * blob /*mf*/ + szIm + 3 * blob /*probs,logq,seeds*/ + szRef + szStats;
     hipError_t e = hipMalloc(&c->arena, total);
     if (e != hipSuccess) {
@@ -147,9 +149,8 @@ static int check_params(const dsrg_crf_params *p) {
     return DSRG_OK;
 }
 
-// build lattices for B images from im_u8 (B,N,3), then run the mean field
-static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,
-                   const dsrg_crf_params *prm, float *q_out, double *refined, float *logq, hipStream_t s) {
+// build the lattices for B images from im_u8 (B,N,3)
+static int crf_build(dsrg_ctx_t c, int B, const unsigned char *im_u8, const dsrg_crf_params *prm, hipStream_t s) {
     LatticeFeat Fg, Fb;
     lattice_feat_init(Fg, 2, c->W, c->H, prm->theta_gamma_x, prm->theta_gamma_y, 1.f, 1.f, 1.f);
     lattice_feat_init(Fb, 5, c->W, c->H, prm->theta_alpha_x, prm->theta_alpha_y, prm->theta_beta_r,
@@ -162,10 +163,36 @@ static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned c
         c->Fg_built = Fg;
         c->gauss_valid = true;
     }
-    rc = launch_lattice_build(c->Lb, Fb, im_u8, B, s);
-    if (rc) return rc;
+    return launch_lattice_build(c->Lb, Fb, im_u8, B, s);
+}
+
+// build lattices for B images from im_u8 (B,N,3), then run the mean field
+static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,
+                   const dsrg_crf_params *prm, float *q_out, double *refined, float *logq, hipStream_t s,
+                   bool prepared = false) {
+    if (!prepared) {
+        int rc = crf_build(c, B, im_u8, prm, s);
+        if (rc) return rc;
+    }
     return launch_meanfield(c->Lg, c->Lb, c->mf, B, c->C, neg_unary, prm->w_gaussian, prm->w_bilateral,
                             prm->n_iters, q_out, refined, logq, s, &c->prof);
+}
+
+extern "C" int dsrg_crf_prepare_batch(dsrg_ctx_t c, int B, const float *images, int img_h, int img_w,
+                                      const dsrg_crf_params *prm, void *stream) {
+    if (!c || !images) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
+    if (img_h < 1 || img_w < 1) return set_error(DSRG_ERR_INVALID, "bad image size");
+    int rc = check_params(prm);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = launch_prepare_images(images, B, img_h, img_w, c->H, c->W, c->im_u8, s);   // pylayers.py:70-75
+    if (rc) return rc;
+    rc = crf_build(c, B, c->im_u8, prm, s);
+    if (rc) return rc;
+    c->prepared_B = B;
+    c->prepared_prm = *prm;
+    return DSRG_OK;
 }
 
 extern "C" int dsrg_crf_refine_batch(dsrg_ctx_t c, int B, float *probs, const float *images, int img_h, int img_w,
@@ -237,15 +264,29 @@ extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, c
                                      int img_w, const float *labels, const float *cues, double th1, double th2,
                                      const dsrg_crf_params *prm, float *losses, float *grad_logits,
                                      float *probs_out, float *seeds_out, float *logq_out, void *stream) {
-    if (!c || !logits || !images || !labels || !cues || !losses || !grad_logits)
+    if (!c || !logits || !labels || !cues || !losses || !grad_logits)
         return set_error(DSRG_ERR_INVALID, "NULL argument");
     if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
+    const bool prepared = images == nullptr;      // lattices were built by dsrg_crf_prepare_batch
+    if (prepared) {
+        int prc = check_params(prm);
+        if (prc) return prc;
+        if (c->prepared_B != B || memcmp(&c->prepared_prm, prm, offsetof(dsrg_crf_params, n_iters)) != 0)
+            return set_error(DSRG_ERR_INVALID, "images_dev is NULL but dsrg_crf_prepare_batch was not called "
+                                               "for this batch size / these kernel parameters");
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int C = c->C, N = c->N;
     const size_t nb = sizeof(float) * (size_t)B * C * N;
     int rc = launch_softmax_fwd(B, C, N, logits, c->probs, s);                     // Softmax
     if (rc) return rc;
-    rc = dsrg_crf_refine_batch(c, B, c->probs, images, img_h, img_w, prm, c->refined, c->logq, stream);   // CRF (once)
+    if (!prepared) {
+        rc = dsrg_crf_refine_batch(c, B, c->probs, images, img_h, img_w, prm, c->refined, c->logq, stream);   // CRF (once)
+    } else {
+        rc = launch_clip_min(c->probs, (size_t)B * C * N, s);                      // pylayers.py:67
+        if (!rc) rc = crf_run(c, B, c->probs, c->im_u8, prm, nullptr, c->refined, c->logq, s, true);
+        c->prepared_B = 0;                                                         // consumed
+    }
     if (rc) return rc;
     rc = launch_srg(B, C, c->H, c->W, labels, cues, c->refined, th1, th2, c->seeds, s);    // DSRG
     if (rc) return rc;

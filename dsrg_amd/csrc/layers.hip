@@ -287,28 +287,42 @@ int launch_constrain_loss(int B, int C, int HW, const float *p, const float *lq,
 }
 
 // ---- fused loss + backward of the five layers (train-s.prototxt:746-810) ------------------
-// stage 1: per-image statistics {count_bg, count_fg, seed_bg, seed_fg, constrain}
+// stage 1: per-image statistics {count_bg, count_fg, seed_bg, seed_fg, constrain}, computed by
+// kStatSplit workgroups per image (partials combined in a fixed order by stage 2: deterministic)
+constexpr int kStatSplit = 8;
 __global__ __launch_bounds__(1024) void sup_stats_kernel(int C, int HW, const float *__restrict__ probs,
                                                          const float *__restrict__ seeds,
                                                          const float *__restrict__ logq,
-                                                         double *__restrict__ stats /* [B][5] */) {
+                                                         double *__restrict__ stats /* [B][kStatSplit][5] */) {
     __shared__ double scratch[5 * 16];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x / kStatSplit, part = blockIdx.x % kStatSplit;
     const float *pb = probs + (size_t)b * C * HW, *Sb = seeds + (size_t)b * C * HW, *lb = logq + (size_t)b * C * HW;
     double st[5] = {0, 0, 0, 0, 0};
     const int n = C * HW;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float s = Sb[i], p = pb[i];
-        if (s != 0.0f) {
-            const double t = (double)s * (double)logf(p);
-            if (i < HW) { st[0] += s; st[2] += t; } else { st[1] += s; st[3] += t; }
+    constexpr int U = 4;                        // elements per thread per batch of loads
+    for (int i0 = part * 1024 * U + threadIdx.x; i0 < n; i0 += kStatSplit * 1024 * U) {
+        float s[U], p[U], q[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(i0 + u * 1024, n - 1);
+            s[u] = Sb[i]; p[u] = pb[i]; q[u] = lb[i];
         }
-        float dp, dlq;
-        st[4] += (double)constrain_term(p, lb[i], dp, dlq);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 1024;
+            if (i < n) {
+                if (s[u] != 0.0f) {
+                    const double t = (double)s[u] * (double)logf(p[u]);
+                    if (i < HW) { st[0] += s[u]; st[2] += t; } else { st[1] += s[u]; st[3] += t; }
+                }
+                float dp, dlq;
+                st[4] += (double)constrain_term(p[u], q[u], dp, dlq);
+            }
+        }
     }
     block_reduce_sum<5>(st, scratch);
     if (threadIdx.x == 0)
-        for (int q = 0; q < 5; q++) stats[(size_t)b * 5 + q] = st[q];
+        for (int k = 0; k < 5; k++) stats[((size_t)b * kStatSplit + part) * 5 + k] = st[k];
 }
 // stage 2: per pixel: total gradient wrt the (clipped) softmax blob, then SoftmaxLayer.backward;
 // thread 0 of block 0 also finalises the two loss scalars in image order.
@@ -325,7 +339,9 @@ __global__ __launch_bounds__(256) void sup_grad_kernel(int B, int C, int HW, con
     if (idx == 0) {
         double ls = 0.0, lc = 0.0;
         for (int b = 0; b < B; b++) {
-            const double *st = stats + (size_t)b * 5;
+            double st[5] = {0, 0, 0, 0, 0};
+            for (int part = 0; part < kStatSplit; part++)
+                for (int k = 0; k < 5; k++) st[k] += stats[((size_t)b * kStatSplit + part) * 5 + k];
             const double dbg = st[0] > 1e-4 ? st[0] : 1e-4, dfg = st[1] > 1e-4 ? st[1] : 1e-4;
             ls += -(st[2] / dbg) / B - (st[3] / dfg) / B;
             lc += st[4];
@@ -336,8 +352,12 @@ __global__ __launch_bounds__(256) void sup_grad_kernel(int B, int C, int HW, con
     if (idx >= B * HW) return;
     const int b = idx / HW, i = idx - b * HW;
     const size_t base = (size_t)b * C * HW + i;
-    const double *st = stats + (size_t)b * 5;
-    const float dbg = (float)(st[0] > 1e-4 ? st[0] : 1e-4), dfg = (float)(st[1] > 1e-4 ? st[1] : 1e-4);
+    double cnt_bg = 0.0, cnt_fg = 0.0;
+    for (int part = 0; part < kStatSplit; part++) {
+        cnt_bg += stats[((size_t)b * kStatSplit + part) * 5 + 0];
+        cnt_fg += stats[((size_t)b * kStatSplit + part) * 5 + 1];
+    }
+    const float dbg = (float)(cnt_bg > 1e-4 ? cnt_bg : 1e-4), dfg = (float)(cnt_fg > 1e-4 ? cnt_fg : 1e-4);
     const float inv = (float)(1.0 / ((double)B * (double)HW));
     float s[CT], g[CT];
     float mx = -INFINITY;
@@ -384,7 +404,7 @@ int launch_sup_loss_backward(int B, int C, int HW, const float *logits, const fl
                              const float *logq, const double *refined, double *stats, float *grad_logits,
                              float *losses, hipStream_t stream) {
     if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
-    hipLaunchKernelGGL(sup_stats_kernel, dim3(B), dim3(1024), 0, stream, C, HW, probs, seeds, logq, stats);
+    hipLaunchKernelGGL(sup_stats_kernel, dim3(B * kStatSplit), dim3(1024), 0, stream, C, HW, probs, seeds, logq, stats);
     DSRG_LAUNCH_CHECK();
     const int threads = 256, blocks = (B * HW + threads - 1) / threads;
     if (C <= 21)

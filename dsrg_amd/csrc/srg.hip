@@ -15,11 +15,40 @@ namespace dsrg {
 
 constexpr int kSrgWG = 1024;
 
+// 128-bit row masks (maps up to 128 pixels wide): bit x of row y
+struct Mask128 { unsigned long long lo, hi; };
+__device__ __forceinline__ Mask128 m_or(Mask128 a, Mask128 b) { return {a.lo | b.lo, a.hi | b.hi}; }
+__device__ __forceinline__ Mask128 m_and(Mask128 a, Mask128 b) { return {a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ Mask128 m_xor(Mask128 a, Mask128 b) { return {a.lo ^ b.lo, a.hi ^ b.hi}; }
+__device__ __forceinline__ bool m_eq(Mask128 a, Mask128 b) { return a.lo == b.lo && a.hi == b.hi; }
+__device__ __forceinline__ Mask128 m_add(Mask128 a, Mask128 b) {
+    Mask128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
+    return r;
+}
+__device__ __forceinline__ Mask128 m_shl1(Mask128 a) { return {a.lo << 1, (a.hi << 1) | (a.lo >> 63)}; }
+__device__ __forceinline__ Mask128 m_shr1(Mask128 a) { return {(a.lo >> 1) | (a.hi << 63), a.hi >> 1}; }
+__device__ __forceinline__ Mask128 m_rev(Mask128 a) { return {__brevll(a.hi), __brevll(a.lo)}; }
+// all bits of the runs of `m` that contain a bit of `s` (s subset of m): the carry of m + s runs
+// from each seed to the end of its run; the mirrored operation covers the other direction
+__device__ __forceinline__ Mask128 m_fill_up(Mask128 m, Mask128 s) { return m_or(m_and(m_xor(m_add(m, s), m), m), s); }
+__device__ __forceinline__ Mask128 m_fill(Mask128 m, Mask128 s) {
+    return m_or(m_fill_up(m, s), m_rev(m_fill_up(m_rev(m), m_rev(s))));
+}
+__device__ __forceinline__ Mask128 m_dilate3(Mask128 a) { return m_or(a, m_or(m_shl1(a), m_shr1(a))); }
+__device__ __forceinline__ Mask128 m_shfl(Mask128 a, int src_lane) {
+    Mask128 r;
+    r.lo = (unsigned long long)__shfl((long long)a.lo, src_lane, 64);
+    r.hi = (unsigned long long)__shfl((long long)a.hi, src_lane, 64);
+    return r;
+}
+
 __global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W,
                                                           const float *__restrict__ labels,
                                                           const float *__restrict__ cues,
                                                           const double *__restrict__ refined, double th1,
-                                                          double th2, float *__restrict__ seeds) {
+                                                          double th2, float *__restrict__ seeds, int mask_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int N = H * W, Wp = W + 2, Np = (H + 2) * Wp;
@@ -33,78 +62,205 @@ __global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W,
     float *out = seeds + (size_t)b * C * N;
 
     // present classes (labels == 1, pylayers.py:240) as a bit mask; C <= 64
-    unsigned long long present = 0ull;
-    for (int c = 0; c < C; c++)
-        if (lab[c] == 1.0f) present |= 1ull << c;
+    const unsigned long long present = __ballot(lane < C && lab[min(lane, C - 1)] == 1.0f);   // one load per wave
 
     for (int p = tid; p < Np; p += kSrgWG) { lm[p] = 0; grown[p] = 0; }
     __syncthreads();
 
-    for (int p = tid; p < N; p += kSrgWG) {
-        // label map from the cues: highest cued class wins (pylayers.py:248-250)
-        int lmv = 0;
-        float cuesum = 0.0f;
-        for (int c = 0; c < C; c++) {
-            const float s = cu[(size_t)c * N + p];
-            if (s > 0.0f) lmv = c + 1;
-            cuesum += s;
-        }
-        // argmax / max over the present classes, first maximum wins (pylayers.py:241-243)
-        int best = -1;
-        double v = 0.0;
-        for (int c = 0; c < C; c++) {
-            if ((present >> c) & 1ull) {
-                const double t = rf[(size_t)c * N + p];
-                if (best < 0 || t > v) { v = t; best = c; }
+    constexpr int CH = 8;                        // labels per batch of loads (all issued before use)
+    constexpr int PB = 2;                        // pixels per batch
+    for (int p0 = tid; p0 < N; p0 += PB * kSrgWG) {
+        // one sweep over the labels, CH at a time, for PB pixels at once: highest cued class
+        // (pylayers.py:248-250), cue sum, argmax / max over the present classes with the first
+        // maximum winning (pylayers.py:241-243)
+        int lmv[PB], best[PB];
+        float cuesum[PB];
+        double v[PB];
+#pragma unroll
+        for (int u = 0; u < PB; u++) { lmv[u] = 0; best[u] = -1; cuesum[u] = 0.0f; v[u] = 0.0; }
+        for (int c0 = 0; c0 < C; c0 += CH) {
+            float sc[PB][CH];
+            double rc[PB][CH];
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int p = min(p0 + u * kSrgWG, N - 1);
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const size_t o = (size_t)min(c0 + q, C - 1) * N + p;
+                    sc[u][q] = cu[o];
+                    rc[u][q] = rf[o];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int c = c0 + q;
+                    if (c < C) {
+                        if (sc[u][q] > 0.0f) lmv[u] = c + 1;
+                        cuesum[u] += sc[u][q];
+                        if (((present >> c) & 1ull) && (best[u] < 0 || rc[u][q] > v[u])) { v[u] = rc[u][q]; best[u] = c; }
+                    }
+                }
             }
         }
-        if (best >= 0 && v > th2) {            // pylayers.py:253-257, strict float64 compares
-            if (best != 0) lmv = best + 1;
-            else if (v > th1) lmv = 1;
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            const int p = p0 + u * kSrgWG;
+            if (p < N) {
+                if (best[u] >= 0 && v[u] > th2) {      // pylayers.py:253-257, strict float64 compares
+                    if (best[u] != 0) lmv[u] = best[u] + 1;
+                    else if (v[u] > th1) lmv[u] = 1;
+                }
+                const int cls = lmv[u] - 1;
+                const bool active = lmv[u] > 0 && ((present >> cls) & 1ull);   // only present classes are grown (:259)
+                const float own = active ? cu[(size_t)cls * N + p] : 0.0f;
+                const int y = p / W, x = p - y * W;
+                const int pp = (y + 1) * Wp + (x + 1);
+                lm[pp] = active ? (unsigned char)lmv[u] : 0;
+                grown[pp] = (active && own == 1.0f) ? 1 : 0;               // seeds of the component (:266)
+                excl[p] = (active && own != 1.0f && cuesum[u] == 1.0f) ? 1 : 0;   // cued by exactly one OTHER class (:268-269)
+            }
         }
-        const int cls = lmv - 1;
-        const bool active = lmv > 0 && ((present >> cls) & 1ull);   // only present classes are grown (:259)
-        const float own = active ? cu[(size_t)cls * N + p] : 0.0f;
-        const int y = p / W, x = p - y * W;
-        const int pp = (y + 1) * Wp + (x + 1);
-        lm[pp] = active ? (unsigned char)lmv : 0;
-        grown[pp] = (active && own == 1.0f) ? 1 : 0;               // seeds of the component (:266)
-        excl[p] = (active && own != 1.0f && cuesum == 1.0f) ? 1 : 0;   // cued by exactly one OTHER class (:268-269)
     }
     __syncthreads();
 
-    // grow to the fixed point: a pixel joins when an 8-neighbour with the same label is a member
-    for (;;) {
-        int changed = 0;
+    // ---- grow to the fixed point.  A pixel joins when an 8-neighbour with the same label is a member.
+    if (W <= 128 && H <= 128 && (size_t)2 * (C + 1) * H * sizeof(Mask128) <= (size_t)mask_bytes) {
+        // Row-mask formulation: per label l and row y, M[l][y] = pixels carrying l, G[l][y] = members.
+        // Masks are assembled with wave ballots; then ONE lane per label sweeps the rows down and up —
+        // a row step is "dilate the neighbouring row's members by one pixel, intersect with M, close
+        // along the row's runs with a carry chain" — until nothing changes (a handful of sweeps).
+        Mask128 *Mm = reinterpret_cast<Mask128 *>(excl + ((N + 15) & ~15));       // [(C+1)][H]
+        Mask128 *Gm = Mm + (size_t)(C + 1) * H;
+        const int wave = tid >> 6, nwaves = kSrgWG >> 6;
+        for (int y = wave; y < H; y += nwaves) {
+            for (int xh = 0; xh < W; xh += 64) {
+                const int x = xh + lane;
+                const int pp = (y + 1) * Wp + (x + 1);
+                const unsigned char l = (x < W) ? lm[pp] : 0;
+                const unsigned char gr = (x < W) ? grown[pp] : 0;
+                for (int c = 1; c <= C; c++) {
+                    if (!((present >> (c - 1)) & 1ull)) continue;                 // wave-uniform
+                    const unsigned long long mb = __ballot(l == c), gb = __ballot(l == c && gr);
+                    if (lane == 0) {
+                        if (xh == 0) { Mm[c * H + y].lo = mb; Gm[c * H + y].lo = gb; if (W <= 64) { Mm[c * H + y].hi = 0; Gm[c * H + y].hi = 0; } }
+                        else { Mm[c * H + y].hi = mb; Gm[c * H + y].hi = gb; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // one wave per present label, one lane per row (rows y = lane + 64k): every iteration each row
+        // absorbs its two neighbouring rows' members (dilated by one pixel, i.e. incl. diagonals),
+        // restricted to its own label mask and closed along the row's runs; neighbours travel by
+        // lane shuffles, state stays in registers, convergence is a wave vote — no barrier inside.
+        constexpr int RPL = 2;                                                    // rows per lane (H <= 128)
+        if (H <= 64 * RPL) {
+            for (int c = 1 + wave; c <= C; c += nwaves) {
+                if (!((present >> (c - 1)) & 1ull)) continue;                     // wave-uniform
+                Mask128 M[RPL], G[RPL];
+#pragma unroll
+                for (int k = 0; k < RPL; k++) {
+                    const int y = lane + 64 * k;
+                    M[k] = (y < H) ? Mm[(size_t)c * H + y] : Mask128{0ull, 0ull};
+                    G[k] = (y < H) ? m_fill(M[k], Gm[(size_t)c * H + y]) : Mask128{0ull, 0ull};
+                }
+                for (;;) {
+                    bool changed = false;
+                    Mask128 up[RPL], dn[RPL];                                      // members of rows y-1 and y+1
+#pragma unroll
+                    for (int k = 0; k < RPL; k++) {
+                        const Mask128 a = m_shfl(G[k], (lane + 63) & 63);         // from lane-1 (row y-1), wraps
+                        const Mask128 z = m_shfl(G[k], (lane + 1) & 63);          // from lane+1 (row y+1), wraps
+                        up[k] = a;
+                        dn[k] = z;
+                    }
+                    // lane 0's row above is row 64k-1 = lane 63 of chunk k-1; lane 63's row below is lane 0 of chunk k+1
+#pragma unroll
+                    for (int k = RPL - 1; k >= 0; k--) {
+                        if (lane == 0) up[k] = (k > 0) ? up[k - 1] : Mask128{0ull, 0ull};
+                    }
+#pragma unroll
+                    for (int k = 0; k < RPL; k++) {
+                        if (lane == 63) dn[k] = (k + 1 < RPL) ? dn[k + 1] : Mask128{0ull, 0ull};
+                    }
+#pragma unroll
+                    for (int k = 0; k < RPL; k++) {
+                        const Mask128 add = m_and(m_dilate3(m_or(up[k], dn[k])), M[k]);
+                        const Mask128 g1 = m_fill(M[k], m_or(G[k], add));
+                        if (!m_eq(g1, G[k])) { G[k] = g1; changed = true; }
+                    }
+                    if (!__any(changed)) break;
+                }
+#pragma unroll
+                for (int k = 0; k < RPL; k++) {
+                    const int y = lane + 64 * k;
+                    if (y < H) Gm[(size_t)c * H + y] = G[k];
+                }
+            }
+        }
+        __syncthreads();
         for (int p = tid; p < N; p += kSrgWG) {
             const int y = p / W, x = p - y * W;
             const int pp = (y + 1) * Wp + (x + 1);
-            const unsigned char l = lm[pp];
-            if (l != 0 && grown[pp] == 0) {
-                const int up = pp - Wp, dn = pp + Wp;
-                const bool hit = (grown[up - 1] && lm[up - 1] == l) || (grown[up] && lm[up] == l) ||
-                                 (grown[up + 1] && lm[up + 1] == l) || (grown[pp - 1] && lm[pp - 1] == l) ||
-                                 (grown[pp + 1] && lm[pp + 1] == l) || (grown[dn - 1] && lm[dn - 1] == l) ||
-                                 (grown[dn] && lm[dn] == l) || (grown[dn + 1] && lm[dn + 1] == l);
-                if (hit) { grown[pp] = 1; changed = 1; }
+            const int l = lm[pp];
+            if (l != 0) {
+                const Mask128 g = Gm[(size_t)l * H + y];
+                grown[pp] = (unsigned char)(((x < 64 ? g.lo >> x : g.hi >> (x - 64)) & 1ull));
             }
         }
-        // frontier empty?  64-bit wave ballot, then OR across the workgroup's waves
-        const int wave_changed = __ballot(changed) != 0ull;
-        (void)lane;
-        if (!__syncthreads_or(wave_changed)) break;
+        __syncthreads();
+    } else {
+        for (;;) {
+            int changed = 0;
+            for (int p = tid; p < N; p += kSrgWG) {
+                const int y = p / W, x = p - y * W;
+                const int pp = (y + 1) * Wp + (x + 1);
+                const unsigned char l = lm[pp];
+                if (l != 0 && grown[pp] == 0) {
+                    const int up = pp - Wp, dn = pp + Wp;
+                    const bool hit = (grown[up - 1] && lm[up - 1] == l) || (grown[up] && lm[up] == l) ||
+                                     (grown[up + 1] && lm[up + 1] == l) || (grown[pp - 1] && lm[pp - 1] == l) ||
+                                     (grown[pp + 1] && lm[pp + 1] == l) || (grown[dn - 1] && lm[dn - 1] == l) ||
+                                     (grown[dn] && lm[dn] == l) || (grown[dn + 1] && lm[dn + 1] == l);
+                    if (hit) { grown[pp] = 1; changed = 1; }
+                }
+            }
+            // frontier empty?  64-bit wave ballot, then OR across the workgroup's waves
+            const int wave_changed = __ballot(changed) != 0ull;
+            if (!__syncthreads_or(wave_changed)) break;
+        }
     }
 
     // seeds = cues, plus every member pixel of its own class unless excluded (pylayers.py:271-273)
-    for (int p = tid; p < N; p += kSrgWG) {
-        const int y = p / W, x = p - y * W;
-        const int pp = (y + 1) * Wp + (x + 1);
-        const int cls = (int)lm[pp] - 1;
-        const bool add = cls >= 0 && grown[pp] && !excl[p];
-        for (int c = 0; c < C; c++) {
-            float s = cu[(size_t)c * N + p];
-            if (add && c == cls) s = 1.0f;
-            out[(size_t)c * N + p] = s;
+    for (int p0 = tid; p0 < N; p0 += PB * kSrgWG) {
+        int cls[PB];
+        bool add[PB];
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            const int p = min(p0 + u * kSrgWG, N - 1);
+            const int y = p / W, x = p - y * W;
+            const int pp = (y + 1) * Wp + (x + 1);
+            cls[u] = (int)lm[pp] - 1;
+            add[u] = cls[u] >= 0 && grown[pp] && !excl[p];
+        }
+        for (int c0 = 0; c0 < C; c0 += CH) {
+            float sc[PB][CH];
+#pragma unroll
+            for (int u = 0; u < PB; u++)
+#pragma unroll
+                for (int q = 0; q < CH; q++)
+                    sc[u][q] = cu[(size_t)min(c0 + q, C - 1) * N + min(p0 + u * kSrgWG, N - 1)];
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int p = p0 + u * kSrgWG;
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int c = c0 + q;
+                    if (c < C && p < N) out[(size_t)c * N + p] = (add[u] && c == cls[u]) ? 1.0f : sc[u][q];
+                }
+            }
         }
     }
 }
@@ -113,13 +269,17 @@ int launch_srg(int B, int C, int H, int W, const float *labels, const float *cue
                double th1, double th2, float *seeds, hipStream_t stream) {
     if (C < 1 || C > 64) return set_error(DSRG_ERR_UNSUPPORTED, "SRG supports 1..64 classes, got %d", C);
     const size_t Np = (size_t)(H + 2) * (W + 2);
-    const size_t lds = 2 * ((Np + 15) & ~(size_t)15) + (size_t)H * W;
+    size_t lds = 2 * ((Np + 15) & ~(size_t)15) + (((size_t)H * W + 15) & ~(size_t)15);
     if (lds > 150 * 1024) return set_error(DSRG_ERR_UNSUPPORTED, "SRG map %dx%d exceeds LDS", H, W);
+    // row masks for the fast growth path: 2 x (C+1) x H 128-bit masks
+    size_t mask_bytes = (size_t)2 * (C + 1) * H * sizeof(Mask128);
+    if (W > 128 || H > 128 || lds + mask_bytes > 150 * 1024) mask_bytes = 0;
+    lds += mask_bytes;
     static size_t granted = 0;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&srg_grow_kernel), lds, granted);
     if (rc) return rc;
     hipLaunchKernelGGL(srg_grow_kernel, dim3(B), dim3(kSrgWG), lds, stream, C, H, W, labels, cues, refined, th1,
-                       th2, seeds);
+                       th2, seeds, (int)mask_bytes);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

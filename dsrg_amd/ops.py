@@ -109,6 +109,19 @@ def crf_refine(probs, images, scale_factor=12.0, maxiter=10, ctx=None, want_log=
     return refined, logq
 
 
+def crf_prepare(images, C, H, W, scale_factor=12.0, maxiter=10, ctx=None):
+    """Image-dependent half of the CRF (image resampling + bilateral lattice build) on the current
+    stream; a later supervision_step(..., prepared=True) on the same context skips it.  Lets a trainer
+    hide the lattice build under the backbone forward (side stream)."""
+    _f32c(images, "images")
+    B = images.shape[0]
+    ctx = ctx or get_context(B, C, H, W)
+    prm = CrfParams.from_crf_args(maxiter, scale_factor)
+    check(_lib.lib().dsrg_crf_prepare_batch(ctx._h, B, _ptr(images), images.shape[2], images.shape[3],
+                                            ctypes.byref(prm), _stream()))
+    return ctx
+
+
 def crf_meanfield(unary, im_u8, maxiter=10, scale_factor=1.0, color_factor=13, ctx=None):
     """krahenbuhl2013.CRF on device blobs: unary (B,C,H,W) f32 (the `unary` argument of CRF.py:28,
     i.e. minus the energy), im_u8 (B,H,W,3) uint8 -> marginals (B,C,H,W) f32."""
@@ -171,7 +184,7 @@ def constrain_loss(probs, logq, want_grad=True):
 
 
 def supervision_step(logits, images, labels, cues, th1=0.99, th2=0.85, scale_factor=12.0, maxiter=10,
-                     ctx=None, want_blobs=False):
+                     ctx=None, want_blobs=False, prepared=False):
     """The five Python layers of train-s.prototxt:746-810, forward and backward, in one
     stream-ordered launch sequence (CRF computed once).
 
@@ -186,7 +199,8 @@ def supervision_step(logits, images, labels, cues, th1=0.99, th2=0.85, scale_fac
         blobs = dict(probs=torch.empty_like(logits), seeds=torch.empty_like(logits), logq=torch.empty_like(logits))
     prm = CrfParams.from_crf_args(maxiter, scale_factor)
     check(_lib.lib().dsrg_supervision_step(
-        ctx._h, B, _ptr(logits), _ptr(images), images.shape[2], images.shape[3], _ptr(labels), _ptr(cues),
+        ctx._h, B, _ptr(logits), None if prepared else _ptr(images), images.shape[2], images.shape[3],
+        _ptr(labels), _ptr(cues),
         float(th1), float(th2), ctypes.byref(prm), _ptr(losses), _ptr(grad),
         _ptr(blobs["probs"]) if blobs else None, _ptr(blobs["seeds"]) if blobs else None,
         _ptr(blobs["logq"]) if blobs else None, _stream()))
@@ -197,8 +211,9 @@ class DSRGSupervision(torch.autograd.Function):
     """loss-Seed + loss-Constrain as a differentiable function of the fc8 logits."""
 
     @staticmethod
-    def forward(ctx, logits, images, labels, cues, th1, th2, scale_factor, maxiter):
-        losses, grad, _ = supervision_step(logits.contiguous(), images, labels, cues, th1, th2, scale_factor, maxiter)
+    def forward(ctx, logits, images, labels, cues, th1, th2, scale_factor, maxiter, prepared=False):
+        losses, grad, _ = supervision_step(logits.contiguous(), images, labels, cues, th1, th2, scale_factor, maxiter,
+                                           prepared=prepared)
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(losses)
         return losses.sum(), losses
@@ -206,9 +221,10 @@ class DSRGSupervision(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_losses):
         (grad,) = ctx.saved_tensors
-        return grad * g_total, None, None, None, None, None, None, None
+        return grad * g_total, None, None, None, None, None, None, None, None
 
 
-def dsrg_supervision_loss(logits, images, labels, cues, th1=0.99, th2=0.85, scale_factor=12.0, maxiter=10):
+def dsrg_supervision_loss(logits, images, labels, cues, th1=0.99, th2=0.85, scale_factor=12.0, maxiter=10,
+                          prepared=False):
     """-> (total loss (differentiable wrt logits), tensor [loss-Seed, loss-Constrain])."""
-    return DSRGSupervision.apply(logits, images, labels, cues, th1, th2, scale_factor, maxiter)
+    return DSRGSupervision.apply(logits, images, labels, cues, th1, th2, scale_factor, maxiter, prepared)

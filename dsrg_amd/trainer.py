@@ -55,6 +55,10 @@ class DSRGTrainer(object):
         self.amp_dtype = amp_dtype
         self.channels_last = channels_last
         self.loss_fn = loss_fn or dsrg_supervision_loss
+        # the bilateral lattices depend only on the images: build them on a side stream while the
+        # backbone forward runs (HIP path only)
+        self.overlap_build = loss_fn is None and device.type == "cuda"
+        self.side = torch.cuda.Stream(device=device) if self.overlap_build else None
         net = (net if net is not None else VGG16ASPP()).to(device)
         if channels_last:
             net = net.to(memory_format=torch.channels_last)
@@ -72,10 +76,20 @@ class DSRGTrainer(object):
         """images (B,3,321,321) f32 mean-subtracted, labels (B,1,1,21), cues (B,21,41,41) -> losses[2]"""
         self.opt.zero_grad()
         x = images.contiguous(memory_format=torch.channels_last) if self.channels_last else images
+        if self.overlap_build:
+            from .ops import crf_prepare
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)                    # previous step no longer reads the lattices
+            with torch.cuda.stream(self.side):
+                crf_prepare(images, cues.shape[1], cues.shape[2], cues.shape[3])
         with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             logits = self.model(x)
         logits = logits.float().contiguous()
-        total, losses = self.loss_fn(logits, images, labels, cues)
+        if self.overlap_build:
+            torch.cuda.current_stream().wait_stream(self.side)
+            total, losses = self.loss_fn(logits, images, labels, cues, prepared=True)
+        else:
+            total, losses = self.loss_fn(logits, images, labels, cues)
         total.backward()
         self.opt.step()
         return losses

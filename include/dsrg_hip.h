@@ -107,6 +107,13 @@ int dsrg_ctx_destroy(dsrg_ctx_t ctx);
 int dsrg_crf_refine_batch(dsrg_ctx_t ctx, int B, float *probs_dev, const float *images_dev,
                           int img_h, int img_w, const dsrg_crf_params *params,
                           double *refined_dev, float *logq_dev, void *stream);
+/* The image-dependent half of the CRF — resampling the images to (H,W) and building the bilateral
+ * lattices (Permutohedral::init, CRF/src/permutohedral.cpp:140-321) — needs no network output, so a
+ * trainer can run it on a side stream underneath the backbone forward.  After this call (and a
+ * stream dependency set up by the caller) dsrg_supervision_step may be given images_dev = NULL. */
+int dsrg_crf_prepare_batch(dsrg_ctx_t ctx, int B, const float *images_dev, int img_h, int img_w,
+                           const dsrg_crf_params *params, void *stream);
+
 /* the same mean-field run on caller-prepared inputs (used by krahenbuhl2013.CRF
  * and by tests): unary_dev (B,C,H,W) f32 holds the NEGATED energies -U (i.e.
  * the `unary` argument of CRF.py:28), im_u8_dev (B,H*W,3) uint8, q_dev
@@ -158,7 +165,8 @@ int dsrg_constrain_loss(int B, int C, int HW, const float *probs_dev, const floa
  *   losses_dev[2]   = {loss-Seed, loss-Constrain}
  *   grad_logits_dev = d(loss-Seed + loss-Constrain)/d fc8-SEC      (B,C,H,W)
  *   probs_dev / seeds_dev / logq_dev: optional (may be NULL) copies of the
- *   clipped softmax blob, the grown seeds and the CRF log-marginals. */
+ *   clipped softmax blob, the grown seeds and the CRF log-marginals.
+ * images_dev may be NULL when dsrg_crf_prepare_batch has been called for this batch. */
 int dsrg_supervision_step(dsrg_ctx_t ctx, int B, const float *logits_dev, const float *images_dev,
                           int img_h, int img_w, const float *labels_dev, const float *cues_dev,
                           double th1, double th2, const dsrg_crf_params *params,

@@ -245,6 +245,24 @@ def test_supervision_step_vs_oracle_composition(ops, O):
         assert nflip < 50      # threshold-borderline flips only
 
 
+def test_prepared_lattices_on_side_stream(ops):
+    """dsrg_crf_prepare_batch on a side stream + supervision_step(prepared) == the one-call path."""
+    b = S.make_batch(23, 3)
+    args = [dev(b[k]) for k in ("logits", "images", "labels", "cues")]
+    ctx = ops.get_context(3, 21, 41, 41)
+    l0, g0, _ = ops.supervision_step(*args, ctx=ctx)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.crf_prepare(args[1], 21, 41, 41, ctx=ctx)
+    torch.cuda.current_stream().wait_stream(side)
+    l1, g1, _ = ops.supervision_step(*args, ctx=ctx, prepared=True)
+    assert torch.equal(l0, l1) and torch.equal(g0, g1)
+    from dsrg_amd import _lib
+    with pytest.raises(_lib.DsrgError):                      # prepared lattices are single-use
+        ops.supervision_step(*args, ctx=ctx, prepared=True)
+
+
 def test_autograd_function(ops):
     from dsrg_amd.ops import dsrg_supervision_loss
     b = S.make_batch(22, 2)
