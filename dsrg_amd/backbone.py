@@ -9,31 +9,84 @@ outputs, N(0, 0.01) init), summed (Eltwise SUM, train-s.prototxt:737-744).
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 
-def _conv_relu(cin, cout, dilation=1):
-    return [nn.Conv2d(cin, cout, 3, padding=dilation, dilation=dilation), nn.ReLU(inplace=True)]
+class _GemmConvFn(torch.autograd.Function):
+    """3x3 / 1x1 stride-1 'same' convolution forward as an explicit NHWC im2col + one hipBLASLt GEMM.
+    At the 41x41 stages (76 % of the backbone flops) MIOpen's forward kernels reach ~180 TFLOP/s on
+    MI355X, the GEMM route 300-900 (tools/conv_probe.py).  Backward stays with MIOpen/CK, which are fine."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    def forward(ctx, x, weight, bias, dilation):
+        B, C, H, W = x.shape
+        cout, k = weight.shape[0], weight.shape[2]
+        xn = x.permute(0, 2, 3, 1)                                   # free for channels_last tensors
+        if not xn.is_contiguous():
+            xn = xn.contiguous()
+        if k == 1:
+            a = xn.reshape(-1, C)
+        else:
+            p = dilation
+            xp = F.pad(xn, (0, 0, p, p, p, p))
+            a = torch.cat([xp[:, dy * p:dy * p + H, dx * p:dx * p + W, :] for dy in range(3) for dx in range(3)],
+                          dim=-1).reshape(-1, 9 * C)
+        wmat = weight.permute(2, 3, 1, 0).reshape(k * k * C, cout)
+        # write straight into a channels_last (B,cout,H,W) tensor: its NHWC memory is the GEMM's C matrix
+        out = torch.empty((B, cout, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+        torch.addmm(bias, a, wmat, out=out.permute(0, 2, 3, 1).view(-1, cout))
+        ctx.save_for_backward(x, weight)
+        ctx.dilation, ctx.k = dilation, k
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        pad = ctx.dilation * (ctx.k // 2)
+        gx, gw, gb = torch.ops.aten.convolution_backward(
+            g.contiguous(memory_format=torch.channels_last), x, weight, [weight.shape[0]], [1, 1], [pad, pad],
+            [ctx.dilation, ctx.dilation], False, [0, 0], 1, [True, True, True])
+        return gx, gw, gb, None
+
+
+class GemmConv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters, same init, same state_dict) whose CUDA forward is im2col + GEMM."""
+
+    def forward(self, x):
+        if x.is_cuda and self.stride == (1, 1) and self.kernel_size[0] in (1, 3) and \
+                self.padding[0] == self.dilation[0] * (self.kernel_size[0] // 2):
+            return _GemmConvFn.apply(x, self.weight, self.bias, self.dilation[0])
+        return super().forward(x)
+
+
+def _conv_relu(cin, cout, dilation=1, gemm=False):
+    conv = (GemmConv2d if gemm else nn.Conv2d)(cin, cout, 3, padding=dilation, dilation=dilation)
+    return [conv, nn.ReLU(inplace=True)]
 
 
 class VGG16ASPP(nn.Module):
-    def __init__(self, num_classes=21, dropout=0.5):
+    def __init__(self, num_classes=21, dropout=0.5, gemm_convs=True):
         super().__init__()
         L = []
         L += _conv_relu(3, 64) + _conv_relu(64, 64) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
         L += _conv_relu(64, 128) + _conv_relu(128, 128) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
         L += _conv_relu(128, 256) + _conv_relu(256, 256) + _conv_relu(256, 256) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
-        L += _conv_relu(256, 512) + _conv_relu(512, 512) + _conv_relu(512, 512) + [nn.MaxPool2d(3, 1, 1)]
-        L += _conv_relu(512, 512, 2) + _conv_relu(512, 512, 2) + _conv_relu(512, 512, 2) + [nn.MaxPool2d(3, 1, 1)]
+        g = gemm_convs                                                  # the 41x41 stages
+        L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g) + _conv_relu(512, 512, 1, g) + [nn.MaxPool2d(3, 1, 1)]
+        L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + [nn.MaxPool2d(3, 1, 1)]
         L += [nn.AvgPool2d(3, 1, 1)]                                   # pool5a AVE (count_include_pad, as Caffe)
         self.features = nn.Sequential(*L)
         self.branches = nn.ModuleList()
         for d in (6, 12, 18, 24):
-            fc8 = nn.Conv2d(1024, num_classes, 1)
+            Conv = GemmConv2d if gemm_convs else nn.Conv2d
+            fc8 = Conv(1024, num_classes, 1)
             nn.init.normal_(fc8.weight, std=0.01)
             nn.init.zeros_(fc8.bias)
             self.branches.append(nn.Sequential(
-                nn.Conv2d(512, 1024, 3, padding=d, dilation=d), nn.ReLU(inplace=True), nn.Dropout(dropout),
-                nn.Conv2d(1024, 1024, 1), nn.ReLU(inplace=True), nn.Dropout(dropout), fc8))
+                Conv(512, 1024, 3, padding=d, dilation=d), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                Conv(1024, 1024, 1), nn.ReLU(inplace=True), nn.Dropout(dropout), fc8))
 
     def forward(self, x):
         f = self.features(x)

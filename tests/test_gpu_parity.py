@@ -291,3 +291,22 @@ def test_unsupported_sizes_fail_loudly(ops):
     from dsrg_amd import _lib
     with pytest.raises(_lib.DsrgError):
         ops.Context(1, 21, 321, 321)          # full-resolution lattice: not on the LDS-resident path yet
+
+
+def test_gemm_conv_matches_miopen_conv():
+    """backbone plumbing: the im2col+GEMM forward equals nn.Conv2d (bf16 rounding), backward identical path"""
+    from dsrg_amd.backbone import GemmConv2d
+    torch.manual_seed(0)
+    for cin, cout, k, d in [(32, 48, 3, 1), (32, 48, 3, 6), (64, 21, 1, 1)]:
+        a = GemmConv2d(cin, cout, k, padding=d * (k // 2), dilation=d).cuda().to(memory_format=torch.channels_last)
+        b = torch.nn.Conv2d(cin, cout, k, padding=d * (k // 2), dilation=d).cuda().to(memory_format=torch.channels_last)
+        b.load_state_dict(a.state_dict())
+        x = torch.randn(2, cin, 41, 41, device="cuda").contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ya, yb = a(xa), b(xb)
+        assert (ya.float() - yb.float()).abs().max() < 0.05 * yb.float().abs().max()
+        g = torch.randn_like(yb)
+        ya.backward(g.to(ya.dtype)); yb.backward(g)
+        assert (xa.grad - xb.grad).abs().max() < 0.05 * xb.grad.abs().max()
+        assert (a.weight.grad - b.weight.grad).abs().max() < 0.05 * b.weight.grad.abs().max()
