@@ -299,10 +299,26 @@ extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, c
     return DSRG_OK;
 }
 
+namespace dsrg {
+struct LargeCrf;
+int large_crf_create(int W, int H, int C, LargeCrf **out);
+void large_crf_destroy(LargeCrf *c);
+int large_crf_set_unary(LargeCrf *c, const float *unary_host);
+int large_crf_zero_unary(LargeCrf *c);
+int large_crf_set_image(LargeCrf *c, const unsigned char *im_host);
+int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters);
+int large_crf_read_q(LargeCrf *c, float *out_host);
+int large_crf_read_map(LargeCrf *c, int32_t *labels_host);
+int large_crf_lattice_size(LargeCrf *c, int k);
+}  // namespace dsrg
+
 // ---------------------------------------------------------------------------------
-// single-image object (DenseCRFWrapper): host pointers, synchronous
+// single-image object (DenseCRFWrapper): host pointers, synchronous.  Maps that fit the LDS-resident
+// kernels (training sizes) use the batched context with B = 1; larger maps (test-time CRF at image
+// resolution) use the global-memory path of lattice_large.hip.
 struct dsrg_crf_s {
     int W, H, M;
+    dsrg::LargeCrf *large;
     dsrg_ctx_t ctx;
     float *neg_unary;            // device (M,N) planes = -U
     float *q;                    // device (M,N)
@@ -319,6 +335,14 @@ extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) {
     if (!h) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
     memset(h, 0, sizeof(*h));
     h->W = W; h->H = H; h->M = nlabels;
+    if (nlabels > kMaxLabels) { delete h; return set_error(DSRG_ERR_UNSUPPORTED, "at most %d labels", kMaxLabels); }
+    if (dsrg_device_count() < 1) { delete h; return set_error(DSRG_ERR_HIP, "no HIP device visible"); }
+    if (!lattice_supported(2, W * H) || !lattice_supported(5, W * H)) {
+        int rc = large_crf_create(W, H, nlabels, &h->large);
+        if (rc) { delete h; return rc; }
+        *out = h;
+        return DSRG_OK;
+    }
     int rc = dsrg_ctx_create(1, nlabels, H, W, &h->ctx);
     if (rc) { delete h; return rc; }
     const size_t n = (size_t)W * H * nlabels;
@@ -333,6 +357,7 @@ extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) {
 }
 extern "C" int dsrg_crf_destroy(dsrg_crf_t h) {
     if (!h) return DSRG_OK;
+    if (h->large) { large_crf_destroy(h->large); delete h; return DSRG_OK; }
     if (h->neg_unary) (void)hipFree(h->neg_unary);
     if (h->q) (void)hipFree(h->q);
     if (h->stage) (void)hipFree(h->stage);
@@ -347,6 +372,7 @@ extern "C" int dsrg_crf_nlabels(dsrg_crf_t h) { return h ? h->M : 0; }
 
 extern "C" int dsrg_crf_set_unary_energy(dsrg_crf_t h, const float *unary_host) {
     if (!h || !unary_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (h->large) { int rc = large_crf_set_unary(h->large, unary_host); if (!rc) h->have_unary = true; return rc; }
     const int N = h->W * h->H;
     DSRG_HIP_CHECK(hipMemcpy(h->stage, unary_host, sizeof(float) * (size_t)N * h->M, hipMemcpyHostToDevice));
     int rc = launch_lf_to_planes(N, h->M, h->stage, h->neg_unary, 1, nullptr);   // inference uses -unary (densecrf.cpp:120,122)
@@ -364,7 +390,8 @@ extern "C" int dsrg_crf_add_pairwise_energy(dsrg_crf_t h, float w1, float ta1, f
     p.w_gaussian = w2; p.theta_gamma_x = tg1; p.theta_gamma_y = tg2; p.n_iters = 0;
     int rc = check_params(&p);
     if (rc) return rc;
-    DSRG_HIP_CHECK(hipMemcpy(h->im, im_host, (size_t)h->W * h->H * 3, hipMemcpyHostToDevice));
+    if (h->large) { rc = large_crf_set_image(h->large, im_host); if (rc) return rc; }
+    else DSRG_HIP_CHECK(hipMemcpy(h->im, im_host, (size_t)h->W * h->H * 3, hipMemcpyHostToDevice));
     h->prm = p;
     h->have_pairwise = true;
     return DSRG_OK;
@@ -372,20 +399,25 @@ extern "C" int dsrg_crf_add_pairwise_energy(dsrg_crf_t h, float w1, float ta1, f
 static int crf_infer(dsrg_crf_t h, int n_iters) {
     if (n_iters < 0) return set_error(DSRG_ERR_INVALID, "n_iters < 0");
     const int N = h->W * h->H;
-    if (!h->have_unary) {    // DenseCRF::inference starts from a zero unary when none was set (densecrf.cpp:117-119)
-        DSRG_HIP_CHECK(hipMemset(h->neg_unary, 0, sizeof(float) * (size_t)N * h->M));
-        h->have_unary = true;
-    }
     if (!h->have_pairwise)
         return set_error(DSRG_ERR_INVALID, "add_pairwise_energy must be called before inference");
     dsrg_crf_params p = h->prm;
     p.n_iters = n_iters;
+    if (h->large) {
+        if (!h->have_unary) { int rc = large_crf_zero_unary(h->large); if (rc) return rc; h->have_unary = true; }
+        return large_crf_infer(h->large, &p, n_iters);
+    }
+    if (!h->have_unary) {    // DenseCRF::inference starts from a zero unary when none was set (densecrf.cpp:117-119)
+        DSRG_HIP_CHECK(hipMemset(h->neg_unary, 0, sizeof(float) * (size_t)N * h->M));
+        h->have_unary = true;
+    }
     return dsrg_crf_meanfield_batch(h->ctx, 1, h->neg_unary, h->im, &p, h->q, nullptr);
 }
 extern "C" int dsrg_crf_inference(dsrg_crf_t h, int n_iters, float *out_host) {
     if (!h || !out_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
     int rc = crf_infer(h, n_iters);
     if (rc) return rc;
+    if (h->large) return large_crf_read_q(h->large, out_host);
     const int N = h->W * h->H;
     rc = launch_planes_to_lf(N, h->M, h->q, h->stage, nullptr);
     if (rc) return rc;
@@ -396,6 +428,7 @@ extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
     if (!h || !labels_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
     int rc = crf_infer(h, n_iters);
     if (rc) return rc;
+    if (h->large) return large_crf_read_map(h->large, labels_host);
     const int N = h->W * h->H;
     rc = launch_argmax_planes(N, h->M, h->q, h->lab, nullptr);
     if (rc) return rc;
@@ -403,6 +436,7 @@ extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
     return DSRG_OK;
 }
 extern "C" int dsrg_crf_lattice_size(dsrg_crf_t h, int k) {
+    if (h && h->large && k >= 0 && k <= 1) return large_crf_lattice_size(h->large, k);
     if (!h || !h->ctx || k < 0 || k > 1) return -1;
     int32_t m = -1;
     if (hipMemcpy(&m, k == 0 ? h->ctx->Lg.M : h->ctx->Lb.M, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -1,0 +1,491 @@
+// Dense CRF for maps that do not fit the LDS-resident path (test-time CRF at full image resolution,
+// training/tools/test-ms.py:99-106: ~500x375 pixels, scale_factor 1, log-probability unaries).
+//
+// Same arithmetic as lattice.hip / meanfield.hip (shared embedding in embed.h, same accumulation
+// orders), but every structure lives in HBM/L2: a global open-addressing hash table, 32-bit vertex
+// ids, lattice values as [vertex][CP] rows (CP = labels padded to a multiple of 4 — the layout the
+// reference's sseCompute uses, permutohedral.cpp:531-535) moved 16 bytes per lane.  This is the regime
+// where the filter really is bandwidth-bound (values: M x CP x 4 B per buffer, streamed 2(d+1)+2 times).
+//
+// Build-time sorting/scanning uses hipCUB (DeviceRadixSort / DeviceScan): plumbing, once per image.
+#include <math.h>
+#include <hipcub/hipcub.hpp>
+#include "common.h"
+#include "embed.h"
+
+namespace dsrg {
+
+constexpr uint32_t kEmptyL = 0xFFFFFFFFu;
+
+struct LargeLattice {
+    int d, N, Npad, E, Epad, Mcap, cap;
+    int M_host;
+    uint32_t *key_e, *table, *slot_e, *first, *scanned, *key_v, *vid, *nb1, *nb2;
+    uint32_t *ent_vid, *ent_idx, *srt_vid, *srt_idx, *cnt, *row_start, *csr_pix;
+    float *bary, *csr_w, *norm;
+    int *M;
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ void lg_embed_kernel(LargeLattice L, LatticeFeat F, const unsigned char *__restrict__ im) {
+    constexpr int D1 = D + 1, KW = KeyWords<D>::value;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.Npad) return;
+    uint32_t keys[D1][KW];
+    float bc[D1];
+    embed_pixel<D>(F, i, L.N, im, keys, bc);
+#pragma unroll
+    for (int r = 0; r < D1; r++) {
+#pragma unroll
+        for (int q = 0; q < KW; q++) L.key_e[((size_t)i * D1 + r) * KW + q] = keys[r][q];
+        if (i < L.N) L.bary[(size_t)r * L.N + i] = bc[r];
+    }
+}
+
+// open addressing, linear probing; a slot keeps the smallest entry index of its key (= first occurrence
+// in the reference's visiting order, permutohedral.cpp:261-276)
+template <int D>
+__global__ void lg_insert_kernel(LargeLattice L) {
+    constexpr int KW = KeyWords<D>::value;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.Epad) return;
+    uint32_t w[KW];
+    load_key<KW>(w, L.key_e + (size_t)e * KW);
+    const uint32_t mask = (uint32_t)L.cap - 1u;
+    uint32_t h = hash_key<KW>(w) & mask;
+    for (;;) {
+        const uint32_t old = atomicCAS(&L.table[h], kEmptyL, (uint32_t)e);
+        if (old == kEmptyL) break;
+        if (key_eq<KW>(w, L.key_e + (size_t)old * KW)) { atomicMin(&L.table[h], (uint32_t)e); break; }
+        h = (h + 1) & mask;
+    }
+    L.slot_e[e] = h;
+}
+
+__global__ void lg_first_kernel(LargeLattice L) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.Epad) return;
+    L.first[e] = (L.table[L.slot_e[e]] == (uint32_t)e) ? 1u : 0u;
+}
+
+template <int D>
+__global__ void lg_assign_kernel(LargeLattice L) {
+    constexpr int KW = KeyWords<D>::value;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.Epad) return;
+    if (e == L.Epad - 1) *L.M = (int)(L.scanned[e] + L.first[e]);
+    if (L.first[e]) {
+        const uint32_t id = L.scanned[e];           // ids in first-occurrence order = the reference's ids
+#pragma unroll
+        for (int t = 0; t < KW; t++) L.key_v[(size_t)id * KW + t] = L.key_e[(size_t)e * KW + t];
+        L.table[L.slot_e[e]] = id;                  // (all reads of the entry indices finished in lg_first_kernel)
+    }
+}
+
+__global__ void lg_vid_kernel(LargeLattice L, int D1) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.E) return;
+    const int i = e / D1, r = e - i * D1;
+    const uint32_t v = L.table[L.slot_e[e]];
+    L.vid[(size_t)r * L.N + i] = v;
+    L.ent_vid[e] = v;
+    L.ent_idx[e] = (uint32_t)e;
+    atomicAdd(&L.cnt[v], 1u);
+}
+
+// blur neighbours (permutohedral.cpp:303-318); M is the "no neighbour" id (row M of the values is zero)
+template <int D>
+__global__ void lg_neigh_kernel(LargeLattice L) {
+    constexpr int D1 = D + 1, KW = KeyWords<D>::value;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = *L.M;
+    if (v >= M) return;
+    uint32_t w[KW];
+    load_key<KW>(w, L.key_v + (size_t)v * KW);
+    const uint32_t mask = (uint32_t)L.cap - 1u;
+#pragma unroll
+    for (int j = 0; j < D1; j++) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            uint32_t q[KW];
+            neighbour_key<D>(q, w, j, s != 0);
+            uint32_t h = hash_key<KW>(q) & mask;
+            uint32_t found = (uint32_t)M;
+            for (;;) {
+                const uint32_t t = L.table[h];
+                if (t == kEmptyL) break;
+                if (key_eq<KW>(q, L.key_v + (size_t)t * KW)) { found = t; break; }
+                h = (h + 1) & mask;
+            }
+            (s ? L.nb2 : L.nb1)[(size_t)j * L.Mcap + v] = found;
+        }
+    }
+}
+
+__global__ void lg_csr_kernel(LargeLattice L, int D1) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= L.E) return;
+    const uint32_t e = L.srt_idx[pos];              // stable sort by vertex: entries of a vertex in visiting order
+    const uint32_t i = e / (uint32_t)D1, r = e - i * (uint32_t)D1;
+    L.csr_pix[pos] = i;
+    L.csr_w[pos] = L.bary[(size_t)r * L.N + i];
+}
+
+// ---- one-channel filter with Permutohedral::seqCompute semantics (permutohedral.cpp:476-527) for the
+// normalisation vector (pairwise.cpp:44,54-57)
+__global__ void lg_splat1_kernel(LargeLattice L, float *__restrict__ val) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = *L.M;
+    if (v == 0) val[M] = 0.0f;
+    if (v >= M) return;
+    float s = 0.0f;
+    for (uint32_t pos = L.row_start[v]; pos < L.row_start[v + 1]; pos++) s = s + L.csr_w[pos] * 1.0f;
+    val[v] = s;
+}
+__global__ void lg_blur1_kernel(LargeLattice L, int j, const float *__restrict__ a, float *__restrict__ b) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = *L.M;
+    if (v == 0) b[M] = 0.0f;
+    if (v >= M) return;
+    const float s = a[L.nb1[(size_t)j * L.Mcap + v]] + a[L.nb2[(size_t)j * L.Mcap + v]];
+    b[v] = (float)((double)a[v] + 0.5 * (double)s);
+}
+__global__ void lg_norm_kernel(LargeLattice L, int D1, const float *__restrict__ val) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.N) return;
+    const float alpha = 1.0f / (1.0f + exp2f(-(float)(D1 - 1)));
+    float out = 0.0f;
+    for (int r = 0; r < D1; r++) {
+        float t = L.bary[(size_t)r * L.N + i] * val[L.vid[(size_t)r * L.N + i]];
+        t = t * alpha;
+        out = out + t;
+    }
+    L.norm[i] = (float)(1.0 / sqrt((double)out + 1e-20));
+}
+
+// ---- CP-channel filter (Permutohedral::sseCompute, permutohedral.cpp:529-589); in/out are [N][CP]
+// one wave per vertex, lanes = channels: ordered accumulation of the vertex's row of (pixel, weight) entries
+__global__ __launch_bounds__(256) void lg_splat_kernel(LargeLattice L, int CP, const float *__restrict__ in,
+                                                        float *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int M = *L.M;
+    if (v == 0 && lane < CP) val[(size_t)M * CP + lane] = 0.0f;          // zero row = "no neighbour"
+    if (v >= M || lane >= CP) return;
+    const uint32_t p0 = L.row_start[v], p1 = L.row_start[v + 1];
+    float s = 0.0f;
+    uint32_t pos = p0;
+    for (; pos + 4 <= p1; pos += 4) {               // four entries in flight; the sum stays ordered
+        uint32_t px[4];
+        float w[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { px[u] = L.csr_pix[pos + u]; w[u] = L.csr_w[pos + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = in[(size_t)px[u] * CP + lane] * L.norm[px[u]];      // in * norm (pairwise.cpp:66)
+#pragma unroll
+        for (int u = 0; u < 4; u++) s = s + w[u] * x[u];
+    }
+    for (; pos < p1; pos++) {
+        const uint32_t px = L.csr_pix[pos];
+        s = s + L.csr_w[pos] * (in[(size_t)px * CP + lane] * L.norm[px]);
+    }
+    val[(size_t)v * CP + lane] = s;
+}
+// thread per (vertex, 4 channels)
+__global__ void lg_blur_kernel(LargeLattice L, int CP4, int j, const float4 *__restrict__ a, float4 *__restrict__ b) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = *L.M;
+    const size_t v = idx / CP4;
+    const int q = (int)(idx - v * CP4);
+    if (v == 0) b[(size_t)M * CP4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v >= (size_t)M) return;
+    const uint32_t n1 = L.nb1[(size_t)j * L.Mcap + v], n2 = L.nb2[(size_t)j * L.Mcap + v];
+    const float4 x0 = a[v * CP4 + q], x1 = a[(size_t)n1 * CP4 + q], x2 = a[(size_t)n2 * CP4 + q];
+    float4 o;
+    { float s = x1.x + x2.x; s = 0.5f * s; o.x = x0.x + s; }
+    { float s = x1.y + x2.y; s = 0.5f * s; o.y = x0.y + s; }
+    { float s = x1.z + x2.z; s = 0.5f * s; o.z = x0.z + s; }
+    { float s = x1.w + x2.w; s = 0.5f * s; o.w = x0.w + s; }
+    b[v * CP4 + q] = o;
+}
+// thread per (pixel, 4 channels): slice, then * norm and the Potts weight: out = -w * norm * (K ...)
+__global__ void lg_slice_kernel(LargeLattice L, int D1, int CP4, const float4 *__restrict__ val, float neg_w,
+                                float4 *__restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = idx / CP4;
+    const int q = (int)(idx - i * CP4);
+    if (i >= (size_t)L.N) return;
+    const float alpha = 1.0f / (1.0f + exp2f(-(float)(D1 - 1)));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < D1; r++) {
+        const float w = L.bary[(size_t)r * L.N + i] * alpha;
+        const float4 x = val[(size_t)L.vid[(size_t)r * L.N + i] * CP4 + q];
+        acc.x = acc.x + w * x.x; acc.y = acc.y + w * x.y; acc.z = acc.z + w * x.z; acc.w = acc.w + w * x.w;
+    }
+    const float nv = L.norm[i];
+    float4 o;
+    o.x = neg_w * (acc.x * nv); o.y = neg_w * (acc.y * nv); o.z = neg_w * (acc.z * nv); o.w = neg_w * (acc.w * nv);
+    out[i * CP4 + q] = o;
+}
+
+// Q = expAndNormalize(-U - sum_k tmp2_k), pixel-major rows of CP floats (densecrf.cpp:98-106,122-128)
+__global__ void lg_update_kernel(int N, int C, int CP, const float *__restrict__ neg_unary,
+                                 const float *__restrict__ t_g, const float *__restrict__ t_b, int use_msgs,
+                                 float *__restrict__ q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const size_t base = (size_t)i * CP;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; c++) {
+        float v = neg_unary[base + c];
+        if (use_msgs) { v = v - t_g[base + c]; v = v - t_b[base + c]; }
+        q[base + c] = v;
+        mx = fmaxf(mx, v);
+    }
+    float sum = 0.0f;
+    for (int c = 0; c < C; c++) { const float e = expf(q[base + c] - mx); q[base + c] = e; sum = sum + e; }
+    for (int c = 0; c < C; c++) q[base + c] = q[base + c] / sum;
+    for (int c = C; c < CP; c++) q[base + c] = 0.0f;
+}
+// label-fastest [N][C] (host layout of DenseCRFWrapper) <-> padded rows [N][CP]
+__global__ void lg_pad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out, int negate) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * CP) return;
+    const size_t i = idx / CP;
+    const int c = (int)(idx - i * CP);
+    const float v = c < C ? in[i * C + c] : 0.0f;
+    out[idx] = negate ? -v : v;
+}
+__global__ void lg_unpad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * C) return;
+    const size_t i = idx / C;
+    const int c = (int)(idx - i * C);
+    out[idx] = in[i * CP + c];
+}
+__global__ void lg_argmax_rows_kernel(int N, int C, int CP, const float *__restrict__ q, int32_t *__restrict__ lab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int m = 0;
+    float best = q[(size_t)i * CP];
+    for (int c = 1; c < C; c++) { const float v = q[(size_t)i * CP + c]; if (v > best) { best = v; m = c; } }
+    lab[i] = m;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct LargeCrf {
+    int W, H, C, CP, N;
+    LargeLattice Lg, Lb;
+    void *arena;
+    void *cub_tmp; size_t cub_bytes;
+    float *neg_unary, *q, *t_g, *t_b;      // [N][CP]
+    float *val_a, *val_b;                  // [(Mmax+1)][CP], grown on demand
+    size_t val_rows;
+    float *val1_a, *val1_b;                // one-channel buffers for the norm pass [Mcap+1]
+    unsigned char *im;                     // [N][3]
+    int32_t *lab;
+    float *stage;                          // [N][C] host-layout staging
+};
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int blocks_for(size_t n, int t) { return (int)((n + t - 1) / t); }
+
+static size_t large_lattice_carve(LargeLattice &L, unsigned char *p, int d, int N) {
+    const int d1 = d + 1, KW = (d * 16 + 31) / 32;
+    L.d = d; L.N = N; L.Npad = (N + 3) / 4 * 4; L.E = N * d1; L.Epad = L.Npad * d1; L.Mcap = L.Epad;
+    int cap = 1024;
+    while (cap < 2 * L.Epad) cap <<= 1;
+    L.cap = cap; L.M_host = 0;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { unsigned char *r = p ? p + off : nullptr; off += al(bytes); return r; };
+    L.key_e = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Epad * KW);
+    L.table = (uint32_t *)take(sizeof(uint32_t) * (size_t)cap);
+    L.slot_e = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Epad);
+    L.first = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Epad);
+    L.scanned = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Epad);
+    L.key_v = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Mcap * KW);
+    L.vid = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.E);
+    L.nb1 = (uint32_t *)take(sizeof(uint32_t) * (size_t)d1 * L.Mcap);
+    L.nb2 = (uint32_t *)take(sizeof(uint32_t) * (size_t)d1 * L.Mcap);
+    L.ent_vid = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.E);
+    L.ent_idx = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.E);
+    L.srt_vid = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.E);
+    L.srt_idx = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.E);
+    L.cnt = (uint32_t *)take(sizeof(uint32_t) * (size_t)(L.Mcap + 1));
+    L.row_start = (uint32_t *)take(sizeof(uint32_t) * (size_t)(L.Mcap + 1));
+    L.csr_pix = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.E);
+    L.bary = (float *)take(sizeof(float) * (size_t)L.E);
+    L.csr_w = (float *)take(sizeof(float) * (size_t)L.E);
+    L.norm = (float *)take(sizeof(float) * (size_t)N);
+    L.M = (int *)take(sizeof(int));
+    return off;
+}
+
+int large_crf_create(int W, int H, int C, LargeCrf **out) {
+    if ((long long)W * H * 6 >= (1ll << 31) / 4) return set_error(DSRG_ERR_UNSUPPORTED, "map too large");
+    LargeCrf *c = new (std::nothrow) LargeCrf();
+    if (!c) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+    memset(c, 0, sizeof(*c));
+    c->W = W; c->H = H; c->C = C; c->CP = (C + 3) & ~3; c->N = W * H;
+    const int N = c->N;
+    LargeLattice tmp;
+    const size_t sg = large_lattice_carve(tmp, nullptr, 2, N), sb = large_lattice_carve(tmp, nullptr, 5, N);
+    const int Emax = N * 6, Mcap5 = ((N + 3) / 4 * 4) * 6;
+    size_t cb1 = 0, cb2 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cb1, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                       (uint32_t *)nullptr, Emax, 0, 32, (hipStream_t)0);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cb2, (uint32_t *)nullptr, (uint32_t *)nullptr, Mcap5 + 1, (hipStream_t)0);
+    c->cub_bytes = cb1 > cb2 ? cb1 : cb2;
+    const size_t rows = sizeof(float) * (size_t)N * c->CP;
+    const size_t total = sg + sb + al(c->cub_bytes) + 4 * al(rows) + 2 * al(sizeof(float) * (size_t)(Mcap5 + 1)) +
+                         al((size_t)N * 3) + al(sizeof(int32_t) * (size_t)N) + al(sizeof(float) * (size_t)N * C);
+    hipError_t e = hipMalloc(&c->arena, total);
+    if (e != hipSuccess) { delete c; return set_error(DSRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); }
+    unsigned char *p = (unsigned char *)c->arena;
+    p += large_lattice_carve(c->Lg, p, 2, N);
+    p += large_lattice_carve(c->Lb, p, 5, N);
+    c->cub_tmp = p; p += al(c->cub_bytes);
+    c->neg_unary = (float *)p; p += al(rows);
+    c->q = (float *)p; p += al(rows);
+    c->t_g = (float *)p; p += al(rows);
+    c->t_b = (float *)p; p += al(rows);
+    c->val1_a = (float *)p; p += al(sizeof(float) * (size_t)(Mcap5 + 1));
+    c->val1_b = (float *)p; p += al(sizeof(float) * (size_t)(Mcap5 + 1));
+    c->im = p; p += al((size_t)N * 3);
+    c->lab = (int32_t *)p; p += al(sizeof(int32_t) * (size_t)N);
+    c->stage = (float *)p; p += al(sizeof(float) * (size_t)N * C);
+    *out = c;
+    return DSRG_OK;
+}
+
+void large_crf_destroy(LargeCrf *c) {
+    if (!c) return;
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->val_a) (void)hipFree(c->val_a);
+    if (c->val_b) (void)hipFree(c->val_b);
+    delete c;
+}
+
+template <int D>
+static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipStream_t s) {
+    constexpr int D1 = D + 1;
+    const int T = 256;
+    DSRG_HIP_CHECK(hipMemsetAsync(L.table, 0xFF, sizeof(uint32_t) * (size_t)L.cap, s));
+    DSRG_HIP_CHECK(hipMemsetAsync(L.cnt, 0, sizeof(uint32_t) * (size_t)(L.Mcap + 1), s));
+    hipLaunchKernelGGL(lg_embed_kernel<D>, dim3(blocks_for(L.Npad, T)), dim3(T), 0, s, L, F, c->im);
+    hipLaunchKernelGGL(lg_insert_kernel<D>, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
+    hipLaunchKernelGGL(lg_first_kernel, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
+    size_t bytes = c->cub_bytes;
+    DSRG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, bytes, L.first, L.scanned, L.Epad, s));
+    hipLaunchKernelGGL(lg_assign_kernel<D>, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
+    hipLaunchKernelGGL(lg_vid_kernel, dim3(blocks_for(L.E, T)), dim3(T), 0, s, L, D1);
+    DSRG_LAUNCH_CHECK();
+    DSRG_HIP_CHECK(hipMemcpyAsync(&L.M_host, L.M, sizeof(int), hipMemcpyDeviceToHost, s));
+    DSRG_HIP_CHECK(hipStreamSynchronize(s));                      // M sizes the remaining launches
+    const int M = L.M_host;
+    hipLaunchKernelGGL(lg_neigh_kernel<D>, dim3(blocks_for(M, T)), dim3(T), 0, s, L);
+    int bits = 1;
+    while ((1ll << bits) < (long long)M + 1) bits++;
+    bytes = c->cub_bytes;
+    DSRG_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp, bytes, L.ent_vid, L.srt_vid, L.ent_idx, L.srt_idx,
+                                                      L.E, 0, bits, s));
+    bytes = c->cub_bytes;
+    DSRG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, bytes, L.cnt, L.row_start, M + 1, s));
+    hipLaunchKernelGGL(lg_csr_kernel, dim3(blocks_for(L.E, T)), dim3(T), 0, s, L, D1);
+    // norm = 1/sqrt(K 1 + 1e-20)
+    hipLaunchKernelGGL(lg_splat1_kernel, dim3(blocks_for(M, T)), dim3(T), 0, s, L, c->val1_a);
+    float *a = c->val1_a, *b = c->val1_b;
+    for (int j = 0; j < D1; j++) {
+        hipLaunchKernelGGL(lg_blur1_kernel, dim3(blocks_for(M, T)), dim3(T), 0, s, L, j, a, b);
+        float *t = a; a = b; b = t;
+    }
+    hipLaunchKernelGGL(lg_norm_kernel, dim3(blocks_for(L.N, T)), dim3(T), 0, s, L, D1, a);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+static int large_filter(LargeCrf *c, LargeLattice &L, float w, float *out, hipStream_t s) {
+    const int D1 = L.d + 1, CP = c->CP, CP4 = CP / 4, M = L.M_host;
+    hipLaunchKernelGGL(lg_splat_kernel, dim3(blocks_for((size_t)M + 1, 4)), dim3(256), 0, s, L, CP, c->q, c->val_a);
+    float *a = c->val_a, *b = c->val_b;
+    for (int j = 0; j < D1; j++) {
+        hipLaunchKernelGGL(lg_blur_kernel, dim3(blocks_for((size_t)(M + 1) * CP4, 256)), dim3(256), 0, s, L, CP4, j,
+                           (const float4 *)a, (float4 *)b);
+        float *t = a; a = b; b = t;
+    }
+    hipLaunchKernelGGL(lg_slice_kernel, dim3(blocks_for((size_t)L.N * CP4, 256)), dim3(256), 0, s, L, D1, CP4,
+                       (const float4 *)a, -w, (float4 *)out);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+int large_crf_set_unary(LargeCrf *c, const float *unary_host) {
+    DSRG_HIP_CHECK(hipMemcpy(c->stage, unary_host, sizeof(float) * (size_t)c->N * c->C, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(lg_pad_rows_kernel, dim3(blocks_for((size_t)c->N * c->CP, 256)), dim3(256), 0, 0, c->N, c->C,
+                       c->CP, c->stage, c->neg_unary, 1);
+    DSRG_LAUNCH_CHECK();
+    DSRG_HIP_CHECK(hipStreamSynchronize(0));
+    return DSRG_OK;
+}
+int large_crf_zero_unary(LargeCrf *c) {
+    DSRG_HIP_CHECK(hipMemset(c->neg_unary, 0, sizeof(float) * (size_t)c->N * c->CP));
+    return DSRG_OK;
+}
+int large_crf_set_image(LargeCrf *c, const unsigned char *im_host) {
+    DSRG_HIP_CHECK(hipMemcpy(c->im, im_host, (size_t)c->N * 3, hipMemcpyHostToDevice));
+    return DSRG_OK;
+}
+
+// DenseCRF::inference on the large path; q ends up in c->q ([N][CP])
+int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
+    hipStream_t s = 0;
+    LatticeFeat Fg, Fb;
+    lattice_feat_init(Fg, 2, c->W, c->H, prm->theta_gamma_x, prm->theta_gamma_y, 1.f, 1.f, 1.f);
+    lattice_feat_init(Fb, 5, c->W, c->H, prm->theta_alpha_x, prm->theta_alpha_y, prm->theta_beta_r, prm->theta_beta_g,
+                      prm->theta_beta_b);
+    int rc = large_build<2>(c, c->Lg, Fg, s);
+    if (rc) return rc;
+    rc = large_build<5>(c, c->Lb, Fb, s);
+    if (rc) return rc;
+    const size_t need = (size_t)(c->Lg.M_host > c->Lb.M_host ? c->Lg.M_host : c->Lb.M_host) + 1;
+    if (need > c->val_rows) {
+        if (c->val_a) (void)hipFree(c->val_a);
+        if (c->val_b) (void)hipFree(c->val_b);
+        c->val_a = c->val_b = nullptr;
+        hipError_t e = hipMalloc(&c->val_a, sizeof(float) * need * c->CP);
+        if (e == hipSuccess) e = hipMalloc(&c->val_b, sizeof(float) * need * c->CP);
+        if (e != hipSuccess) return set_error(DSRG_ERR_NOMEM, "hipMalloc of lattice values failed: %s", hipGetErrorString(e));
+        c->val_rows = need;
+    }
+    const int T = 256;
+    hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), 0, s, c->N, c->C, c->CP, c->neg_unary,
+                       c->t_g, c->t_b, 0, c->q);
+    for (int it = 0; it < n_iters; it++) {
+        rc = large_filter(c, c->Lg, prm->w_gaussian, c->t_g, s);      // Gaussian first (densecrf_wrapper.cpp:25)
+        if (rc) return rc;
+        rc = large_filter(c, c->Lb, prm->w_bilateral, c->t_b, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), 0, s, c->N, c->C, c->CP,
+                           c->neg_unary, c->t_g, c->t_b, 1, c->q);
+    }
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+int large_crf_read_q(LargeCrf *c, float *out_host) {
+    hipLaunchKernelGGL(lg_unpad_rows_kernel, dim3(blocks_for((size_t)c->N * c->C, 256)), dim3(256), 0, 0, c->N, c->C,
+                       c->CP, c->q, c->stage);
+    DSRG_LAUNCH_CHECK();
+    DSRG_HIP_CHECK(hipMemcpy(out_host, c->stage, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDeviceToHost));
+    return DSRG_OK;
+}
+int large_crf_read_map(LargeCrf *c, int32_t *labels_host) {
+    hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, 0, c->N, c->C, c->CP, c->q, c->lab);
+    DSRG_LAUNCH_CHECK();
+    DSRG_HIP_CHECK(hipMemcpy(labels_host, c->lab, sizeof(int32_t) * (size_t)c->N, hipMemcpyDeviceToHost));
+    return DSRG_OK;
+}
+int large_crf_lattice_size(LargeCrf *c, int k) { return k == 0 ? c->Lg.M_host : c->Lb.M_host; }
+
+}  // namespace dsrg

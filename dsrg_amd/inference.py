@@ -1,0 +1,113 @@
+"""Test-time path of the reference on MI355X ("next" row 1): multi-scale inference,
+full-resolution dense CRF on log-probabilities, pseudo-label generation, and the evaluation metrics.
+
+  preprocess            <-> training/tools/test-ms.py:68-81
+  predict_mask_ms       <-> training/tools/test-ms.py:84-111        (run.sh:6,10: pseudo labels / final test)
+  predict_train_gt      <-> training/tools/generate_train_gt.py:78-106
+  ConfusionMatrix       <-> training/tools/evaluate.py:17-68
+
+The network runs in PyTorch-ROCm; resampling uses align-corners bilinear interpolation, which is the
+sampling scipy.ndimage.zoom(order=1) performs ((in-1)/(out-1) mapping); the CRF is
+krahenbuhl2013.CRF -> libdsrg_hip.so (global-memory lattice path for full-resolution maps).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import krahenbuhl2013
+
+MEAN_PIXEL = (104.0, 117.0, 123.0)
+
+
+def _zoom(x, h, w):
+    """x: (B,C,h0,w0) -> (B,C,h,w), order-1 zoom with scipy's (in-1)/(out-1) coordinate mapping"""
+    if x.shape[2] == h and x.shape[3] == w:
+        return x
+    return F.interpolate(x, size=(h, w), mode="bilinear", align_corners=True)
+
+
+def preprocess(image, size, device="cuda"):
+    """image: (H,W,3) RGB uint8/float -> (1,3,size,size) float32 BGR, mean-subtracted (test-ms.py:68-81)"""
+    x = torch.as_tensor(np.asarray(image), dtype=torch.float32, device=device).permute(2, 0, 1)[None]
+    x = _zoom(x, size, size)
+    x = x[:, [2, 1, 0]]
+    return x - torch.tensor(MEAN_PIXEL, dtype=torch.float32, device=device).view(1, 3, 1, 1)
+
+
+@torch.no_grad()
+def multiscale_scores(net, image, sizes=(241, 321, 401), device="cuda"):
+    """sum over scales of the fc8 scores zoomed to the image resolution (test-ms.py:89-97) -> (C,H,W)"""
+    d1, d2 = image.shape[0], image.shape[1]
+    total = None
+    for size in sizes:
+        scores = net(preprocess(image, size, device)).float()
+        scores = _zoom(scores, d1, d2)
+        total = scores if total is None else total + scores
+    return total[0]
+
+
+def _probs_from_scores(scores, eps=0.00001):
+    probs = torch.softmax(scores, dim=0)
+    return torch.clamp(probs, min=eps)                       # probs[probs < eps] = eps (test-ms.py:102-103)
+
+
+@torch.no_grad()
+def predict_mask_ms(net, image, smooth=True, sizes=(241, 321, 401), device="cuda"):
+    """test-ms.py:84-111 -> (H,W) int64 label mask"""
+    probs = _probs_from_scores(multiscale_scores(net, image, sizes, device))
+    if smooth:
+        unary = torch.log(probs).permute(1, 2, 0).contiguous().cpu().numpy()
+        q = krahenbuhl2013.CRF(np.asarray(image), unary, scale_factor=1.0)
+        return np.argmax(q, axis=2)
+    return probs.argmax(0).cpu().numpy()
+
+
+@torch.no_grad()
+def predict_train_gt(net, image, labels, smooth=True, device="cuda"):
+    """generate_train_gt.py:78-106: single-scale (321) softmax, zoomed to the image, CRF on log-probs,
+    argmax restricted to background + the image-level labels -> (H,W) int64 pseudo-label mask"""
+    d1, d2 = image.shape[0], image.shape[1]
+    scores = net(preprocess(image, 321, device)).float()
+    probs = _zoom(torch.softmax(scores, dim=1), d1, d2)[0]
+    probs = torch.clamp(probs, min=0.00001)
+    if smooth:
+        unary = torch.log(probs).permute(1, 2, 0).contiguous().cpu().numpy()
+        p = krahenbuhl2013.CRF(np.asarray(image), unary, scale_factor=1.0)
+    else:
+        p = probs.permute(1, 2, 0).cpu().numpy()
+    sel = [0] + [int(l) for l in labels]
+    return np.asarray(sel)[np.argmax(p[:, :, sel], axis=2)]
+
+
+class ConfusionMatrix(object):
+    """evaluate.py:17-68 (rows = ground truth, columns = prediction, 255 ignored)."""
+
+    def __init__(self, nclass, classes=None):
+        self.nclass = nclass
+        self.classes = classes
+        self.M = np.zeros((nclass, nclass))
+
+    def add(self, gt, pred):
+        gt, pred = np.asarray(gt).ravel(), np.asarray(pred).ravel()
+        assert np.max(pred) <= self.nclass
+        assert len(gt) == len(pred)
+        keep = gt != 255
+        self.M += np.bincount(gt[keep].astype(np.int64) * self.nclass + pred[keep].astype(np.int64),
+                              minlength=self.nclass ** 2).reshape(self.nclass, self.nclass)
+
+    def addM(self, matrix):
+        assert matrix.shape == self.M.shape
+        self.M += matrix
+
+    def recall(self):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(np.sum(np.diag(self.M) / np.sum(self.M, axis=0)) / self.nclass)
+
+    def accuracy(self):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(np.sum(np.diag(self.M) / np.sum(self.M, axis=1)) / self.nclass)
+
+    def jaccard(self):
+        d = np.diag(self.M)
+        per = [d[i] / (np.sum(self.M[i, :]) + np.sum(self.M[:, i]) - d[i]) for i in range(self.nclass) if d[i] != 0]
+        return np.sum(per) / len(per), per, self.M

@@ -102,7 +102,10 @@ def test_losses_forward_backward(ops, O):
 @pytest.mark.parametrize("kind,scale,HW,C", [("smooth", 12.0, (41, 41), 21), ("noise", 12.0, (41, 41), 21),
                                              ("dark_corner", 12.0, (41, 41), 21), ("smooth", 12.0, (65, 65), 21),
                                              ("smooth", 1.0, (24, 31), 7), ("noise", 3.0, (17, 40), 3),
-                                             ("smooth", 12.0, (1, 9), 2)])
+                                             ("smooth", 12.0, (1, 9), 2),
+                                             # maps beyond the LDS-resident kernels: global-memory path (test-time CRF)
+                                             ("smooth", 1.0, (121, 161), 21), ("noise", 3.0, (100, 150), 5),
+                                             ("smooth", 1.0, (321, 321), 21)])
 def test_crf_function_vs_oracle(O, kind, scale, HW, C):
     """krahenbuhl2013.CRF (host API of the reference) — marginals within 1e-4 of the oracle,
     identical lattice sizes."""

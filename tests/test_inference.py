@@ -1,0 +1,77 @@
+"""Test-time path: evaluation metrics on CPU; multi-scale inference + full-resolution
+CRF on the GPU against a numpy/scipy restatement of training/tools/test-ms.py that uses the oracle CRF."""
+import numpy as np
+import pytest
+import torch
+
+
+def _reference_confusion(gt, pred, n):
+    """evaluate.py:24-29,40-68 as written (loops)"""
+    M = np.zeros((n, n))
+    for g, p in zip(gt, pred):
+        if not g == 255:
+            M[g, p] += 1.0
+    recall = sum(M[i, i] / np.sum(M[:, i]) for i in range(n)) / n
+    acc = sum(M[i, i] / np.sum(M[i, :]) for i in range(n)) / n
+    per = [M[i, i] / (np.sum(M[i, :]) + np.sum(M[:, i]) - M[i, i]) for i in range(n) if not M[i, i] == 0]
+    return M, recall, acc, np.sum(per) / len(per)
+
+
+def test_confusion_matrix_matches_reference_loops():
+    from dsrg_amd.inference import ConfusionMatrix
+    rng = np.random.default_rng(0)
+    n = 21
+    gt = rng.integers(0, n, size=5000)
+    gt[rng.random(5000) < 0.1] = 255
+    pred = np.where(rng.random(5000) < 0.6, np.where(gt == 255, 0, gt), rng.integers(0, n, size=5000))
+    cm = ConfusionMatrix(n)
+    cm.add(gt[:2000], pred[:2000])
+    cm.add(gt[2000:], pred[2000:])
+    M, recall, acc, miou = _reference_confusion(gt, pred, n)
+    assert np.array_equal(cm.M, M)
+    assert abs(cm.recall() - recall) < 1e-12 and abs(cm.accuracy() - acc) < 1e-12
+    assert abs(cm.jaccard()[0] - miou) < 1e-12
+
+
+class TinyNet(torch.nn.Module):
+    """a deterministic stand-in for the deploy net: stride-8 feature map with 21 outputs"""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.w = torch.nn.Parameter(torch.randn(21, 3, 9, 9, generator=g) * 0.02)
+
+    def forward(self, x):
+        return torch.nn.functional.conv2d(x, self.w, stride=8, padding=4)
+
+
+@pytest.mark.gpu
+def test_predict_mask_ms_vs_reference_restatement():
+    import scipy.ndimage as nd
+    from dsrg_amd import inference as I, synthetic as S
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    H, W = 97, 131
+    im = (S.make_images(rng, 1, size=max(H, W))[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]).transpose(1, 2, 0)
+    im = np.ascontiguousarray(im[:, :, ::-1]).astype(np.uint8)            # an "RGB" uint8 image
+    net = TinyNet().cuda().eval()
+    got = I.predict_mask_ms(net, im, smooth=True)
+    # test-ms.py:84-111 in numpy/scipy, network evaluated by the same TinyNet on the CPU in float64
+    netc = TinyNet().double().eval()
+    d1, d2 = float(H), float(W)
+    scores_all = 0
+    for size in [241, 321, 401]:
+        x = nd.zoom(im.astype('float32'), (size / d1, size / d2, 1.0), order=1)[:, :, [2, 1, 0]] - np.array(I.MEAN_PIXEL)
+        with torch.no_grad():
+            sc = netc(torch.tensor(x.transpose(2, 0, 1)[None], dtype=torch.float64))[0].numpy().transpose(1, 2, 0)
+        scores_all = scores_all + nd.zoom(sc, (d1 / sc.shape[0], d2 / sc.shape[1], 1.0), order=1)
+    e = np.exp(scores_all - scores_all.max(2, keepdims=True))
+    probs = e / e.sum(2, keepdims=True)
+    probs[probs < 0.00001] = 0.00001
+    want = np.argmax(O.CRF(im, np.log(probs), scale_factor=1.0), axis=2)
+    agree = (got == want).mean()
+    print("multi-scale + CRF mask agreement with the reference restatement: %.5f" % agree)
+    assert got.shape == (H, W) and agree > 0.995
+    # pseudo-label generation restricted to the image labels (generate_train_gt.py:78-106)
+    mask = I.predict_train_gt(net, im, labels=[3, 7], smooth=True)
+    assert set(np.unique(mask)) <= {0, 3, 7}
