@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <new>
 #include "common.h"
 
@@ -329,8 +330,27 @@ struct dsrg_crf_s {
     dsrg_crf_params prm;
 };
 
+// krahenbuhl2013.CRF() creates and destroys one object per call (CRF.py:25): destroyed objects are
+// parked (device buffers and all) and handed out again for the same shape, so the per-call cost is the
+// inference, not hipMalloc/hipFree of a few hundred MB.
+static constexpr int kCrfCacheSlots = 4;
+static dsrg_crf_s *g_crf_cache[kCrfCacheSlots] = {nullptr, nullptr, nullptr, nullptr};
+static std::mutex g_crf_cache_mutex;
+
 extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) {
     if (!out || W < 1 || H < 1 || nlabels < 1) return set_error(DSRG_ERR_INVALID, "bad CRF shape");
+    {
+        std::lock_guard<std::mutex> lock(g_crf_cache_mutex);
+        for (int i = 0; i < kCrfCacheSlots; i++) {
+            dsrg_crf_s *c = g_crf_cache[i];
+            if (c && c->W == W && c->H == H && c->M == nlabels) {
+                g_crf_cache[i] = nullptr;
+                c->have_unary = c->have_pairwise = false;
+                *out = c;
+                return DSRG_OK;
+            }
+        }
+    }
     dsrg_crf_s *h = new (std::nothrow) dsrg_crf_s();
     if (!h) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
     memset(h, 0, sizeof(*h));
@@ -355,8 +375,20 @@ extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) {
     *out = h;
     return DSRG_OK;
 }
+static int crf_free(dsrg_crf_t h);
 extern "C" int dsrg_crf_destroy(dsrg_crf_t h) {
     if (!h) return DSRG_OK;
+    dsrg_crf_s *evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_crf_cache_mutex);
+        int slot = -1;
+        for (int i = 0; i < kCrfCacheSlots; i++) if (!g_crf_cache[i]) { slot = i; break; }
+        if (slot < 0) { evict = g_crf_cache[0]; for (int i = 0; i + 1 < kCrfCacheSlots; i++) g_crf_cache[i] = g_crf_cache[i + 1]; slot = kCrfCacheSlots - 1; }
+        g_crf_cache[slot] = h;
+    }
+    return evict ? crf_free(evict) : DSRG_OK;
+}
+static int crf_free(dsrg_crf_t h) {
     if (h->large) { large_crf_destroy(h->large); delete h; return DSRG_OK; }
     if (h->neg_unary) (void)hipFree(h->neg_unary);
     if (h->q) (void)hipFree(h->q);

@@ -229,24 +229,37 @@ __global__ void lg_slice_kernel(LargeLattice L, int D1, int CP4, const float4 *_
     out[i * CP4 + q] = o;
 }
 
-// Q = expAndNormalize(-U - sum_k tmp2_k), pixel-major rows of CP floats (densecrf.cpp:98-106,122-128)
-__global__ void lg_update_kernel(int N, int C, int CP, const float *__restrict__ neg_unary,
-                                 const float *__restrict__ t_g, const float *__restrict__ t_b, int use_msgs,
-                                 float *__restrict__ q) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const size_t base = (size_t)i * CP;
-    float mx = -INFINITY;
-    for (int c = 0; c < C; c++) {
-        float v = neg_unary[base + c];
-        if (use_msgs) { v = v - t_g[base + c]; v = v - t_b[base + c]; }
-        q[base + c] = v;
-        mx = fmaxf(mx, v);
+// Q = expAndNormalize(-U - sum_k tmp2_k), pixel-major rows of CP floats (densecrf.cpp:98-106,122-128).
+// A workgroup of 256 threads owns 256 pixels: the rows are combined element-wise with coalesced
+// accesses into LDS (row pitch CP+1: conflict-free column walks), then each thread normalises its
+// pixel's row in label order (the same summation order as the small path), then the rows stream out.
+__global__ __launch_bounds__(256) void lg_update_kernel(int N, int C, int CP, const float *__restrict__ neg_unary,
+                                                        const float *__restrict__ t_g, const float *__restrict__ t_b,
+                                                        int use_msgs, float *__restrict__ q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *row = reinterpret_cast<float *>(smem);            // [256][CP+1]
+    const int P = CP + 1;
+    const size_t i0 = (size_t)blockIdx.x * 256;
+    const int npix = (int)min((size_t)256, (size_t)N - i0);
+    const int nelem = npix * CP;
+    for (int k = threadIdx.x; k < nelem; k += 256) {
+        const size_t o = i0 * CP + k;
+        float v = neg_unary[o];                               // tmp1 = -unary
+        if (use_msgs) { v = v - t_g[o]; v = v - t_b[o]; }     // tmp1 -= tmp2 (Gaussian, then bilateral)
+        row[(k / CP) * P + (k % CP)] = v;
     }
-    float sum = 0.0f;
-    for (int c = 0; c < C; c++) { const float e = expf(q[base + c] - mx); q[base + c] = e; sum = sum + e; }
-    for (int c = 0; c < C; c++) q[base + c] = q[base + c] / sum;
-    for (int c = C; c < CP; c++) q[base + c] = 0.0f;
+    __syncthreads();
+    if ((int)threadIdx.x < npix) {
+        float *r = row + threadIdx.x * P;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; c++) mx = fmaxf(mx, r[c]);
+        float sum = 0.0f;
+        for (int c = 0; c < C; c++) { const float e = expf(r[c] - mx); r[c] = e; sum = sum + e; }
+        for (int c = 0; c < C; c++) r[c] = r[c] / sum;
+        for (int c = C; c < CP; c++) r[c] = 0.0f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nelem; k += 256) q[i0 * CP + k] = row[(k / CP) * P + (k % CP)];
 }
 // label-fastest [N][C] (host layout of DenseCRFWrapper) <-> padded rows [N][CP]
 __global__ void lg_pad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out, int negate) {
@@ -459,14 +472,15 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
         c->val_rows = need;
     }
     const int T = 256;
-    hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), 0, s, c->N, c->C, c->CP, c->neg_unary,
+    const size_t upd_lds = sizeof(float) * 256 * (size_t)(c->CP + 1);
+    hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), upd_lds, s, c->N, c->C, c->CP, c->neg_unary,
                        c->t_g, c->t_b, 0, c->q);
     for (int it = 0; it < n_iters; it++) {
         rc = large_filter(c, c->Lg, prm->w_gaussian, c->t_g, s);      // Gaussian first (densecrf_wrapper.cpp:25)
         if (rc) return rc;
         rc = large_filter(c, c->Lb, prm->w_bilateral, c->t_b, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), 0, s, c->N, c->C, c->CP,
+        hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), upd_lds, s, c->N, c->C, c->CP,
                            c->neg_unary, c->t_g, c->t_b, 1, c->q);
     }
     DSRG_LAUNCH_CHECK();
