@@ -69,7 +69,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (weak scaling)")
-    ap.add_argument("--mode", choices=["train", "supervision"], default="train")
+    ap.add_argument("--mode", choices=["train", "supervision", "train-f"], default="train",
+                    help="train = seed_mc train-s step (the headline metric); supervision = hot path on fixed logits; "
+                         "train-f = stage-2 retrain step (no SRG/CRF inside; BASELINE.json configs[4] with "
+                         "--backbone resnet101 --size 513)")
+    ap.add_argument("--backbone", choices=["vgg16", "resnet101"], default="vgg16")
+    ap.add_argument("--size", type=int, default=321)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket filter launches with HIP events")
     args = ap.parse_args()
@@ -103,8 +108,17 @@ def main():
     ctx = ops.get_context(B, C, H, W)
 
     trainer = DSRGTrainer(device, world_size=world) if args.mode == "train" else None
+    retrainer = None
+    if args.mode == "train-f":
+        from dsrg_amd.retrain import RetrainTrainer
+        retrainer = RetrainTrainer(device, world_size=world, backbone=args.backbone)
+        g = torch.Generator(device="cpu").manual_seed(2000 + rank)
+        f_images = torch.randn(B, 3, args.size, args.size, generator=g).to(device)
+        f_label = torch.randint(0, 21, (B, 1, args.size, args.size), generator=g).float().to(device)
 
     def one_step():
+        if retrainer is not None:
+            return retrainer.step(f_images, f_label).reshape(1)
         if trainer is not None:
             return trainer.step(images, labels, cues)
         losses, _, _ = ops.supervision_step(logits_fixed, images, labels, cues, ctx=ctx)
@@ -118,7 +132,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     barrier()
-    profile = not args.no_profile
+    profile = not args.no_profile and args.mode != "train-f"
     if profile:
         ctx.profile_start(args.steps * 10 + 16)
     t0 = time.perf_counter()
@@ -171,7 +185,9 @@ def main():
         total_images = B * world * args.steps
         out = {
             "metric": "images/sec DSRG train step (VGG16 321x321, 21-class)" if args.mode == "train"
-                      else "images/sec DSRG supervision path only (softmax+CRF+SRG+losses+backward)",
+                      else ("images/sec train-f retrain step (%s %dx%d, softmax loss on pseudo-labels)" % (args.backbone, args.size, args.size)
+                            if args.mode == "train-f" else
+                            "images/sec DSRG supervision path only (softmax+CRF+SRG+losses+backward)"),
             "value": total_images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
