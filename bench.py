@@ -162,7 +162,7 @@ def main():
         sup_ms = e0.elapsed_time(e1) / 10
 
     if rank == 0:
-        mg, mb = ctx.lattice_sizes(B)
+        mg, mb = ctx.lattice_sizes(B) if args.mode != "train-f" else (0, [0])
         alg_bytes = sum(filter_bytes(2, mg, C, N) + filter_bytes(5, m, C, N) for m in mb)   # one filter launch
         roofline = None
         if filt_n > 0:
@@ -195,7 +195,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("full seed_mc train-s step: VGG16-ASPP fwd+bwd + Softmax/CRF(10 it, scale 12)/"
                                     "SRG/BalancedSeedLoss/ConstrainLoss + SGD, 321x321 -> 41x41x21"
-                                    if args.mode == "train" else "supervision path on fixed fc8 logits"),
+                                    if args.mode == "train" else
+                                    ("train-f step: %s fwd+bwd + Interp(1/8) + SoftmaxWithLoss + SGD(poly), %dx%d" % (
+                                        args.backbone, args.size, args.size) if args.mode == "train-f"
+                                     else "supervision path on fixed fc8 logits")),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "baseline_config": "configs[2] (batch 16 on 1 GPU); configs[3] at 8 GPUs"},
             "losses": [float(x) for x in losses.detach().cpu()],
