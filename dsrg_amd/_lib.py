@@ -64,6 +64,7 @@ SIGNATURES = {
     "dsrg_softmax_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dsrg_seed_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dsrg_constrain_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dsrg_im2col3x3_nhwc16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dsrg_supervision_step": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _d, _d, ctypes.POINTER(CrfParams),
                                    _vp, _vp, _vp, _vp, _vp, _vp]),
 }

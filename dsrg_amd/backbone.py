@@ -28,10 +28,14 @@ class _GemmConvFn(torch.autograd.Function):
         if k == 1:
             a = xn.reshape(-1, C)
         else:
-            p = dilation
-            xp = F.pad(xn, (0, 0, p, p, p, p))
-            a = torch.cat([xp[:, dy * p:dy * p + H, dx * p:dx * p + W, :] for dy in range(3) for dx in range(3)],
-                          dim=-1).reshape(-1, 9 * C)
+            if C % 8 == 0:
+                from .ops import im2col3x3_nhwc                       # one bandwidth-bound HIP kernel
+                a = im2col3x3_nhwc(xn, dilation)
+            else:
+                p = dilation
+                xp = F.pad(xn, (0, 0, p, p, p, p))
+                a = torch.cat([xp[:, dy * p:dy * p + H, dx * p:dx * p + W, :] for dy in range(3) for dx in range(3)],
+                              dim=-1).reshape(-1, 9 * C)
         wmat = weight.permute(2, 3, 1, 0).reshape(k * k * C, cout)
         # write straight into a channels_last (B,cout,H,W) tensor: its NHWC memory is the GEMM's C matrix
         out = torch.empty((B, cout, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
@@ -72,7 +76,7 @@ class VGG16ASPP(nn.Module):
         L = []
         L += _conv_relu(3, 64) + _conv_relu(64, 64) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
         L += _conv_relu(64, 128) + _conv_relu(128, 128) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
-        L += _conv_relu(128, 256) + _conv_relu(256, 256) + _conv_relu(256, 256) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
+        L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
         g = gemm_convs                                                  # the 41x41 stages
         L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g) + _conv_relu(512, 512, 1, g) + [nn.MaxPool2d(3, 1, 1)]
         L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + [nn.MaxPool2d(3, 1, 1)]

@@ -261,6 +261,11 @@ extern "C" int dsrg_constrain_loss(int B, int C, int HW, const float *probs, con
     return launch_constrain_loss(B, C, HW, probs, logq, loss, gp, glq, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int dsrg_im2col3x3_nhwc16(const void *in, void *out, int B, int H, int W, int C, int dilation, void *stream) {
+    if (!in || !out || B < 1 || H < 1 || W < 1 || C < 1 || dilation < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return launch_im2col3x3(in, out, B, H, W, C, dilation, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, const float *images, int img_h,
                                      int img_w, const float *labels, const float *cues, double th1, double th2,
                                      const dsrg_crf_params *prm, float *losses, float *grad_logits,

@@ -112,6 +112,7 @@ int launch_sup_loss_backward(int B, int C, int HW, const float *logits, const fl
 int launch_lf_to_planes(int N, int M, const float *in, float *out, int negate, hipStream_t stream);
 int launch_planes_to_lf(int N, int M, const float *in, float *out, hipStream_t stream);
 int launch_argmax_planes(int N, int M, const float *q, int32_t *lab, hipStream_t stream);
+int launch_im2col3x3(const void *in, void *out, int B, int H, int W, int C, int dil, hipStream_t stream);
 
 #ifdef __HIPCC__
 // SRSRC buffer loads: 32-bit per-lane byte offset + scalar offset against a wave-uniform descriptor

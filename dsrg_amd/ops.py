@@ -207,6 +207,16 @@ def supervision_step(logits, images, labels, cues, th1=0.99, th2=0.85, scale_fac
     return losses, grad, blobs
 
 
+def im2col3x3_nhwc(x_nhwc, dilation):
+    """(B,H,W,C) contiguous bf16/fp16 -> (B*H*W, 9*C) im2col matrix of a 3x3 'same' dilated convolution"""
+    if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and x_nhwc.element_size() == 2):
+        raise ValueError("x must be a contiguous 2-byte CUDA tensor in NHWC order")
+    B, H, W, C = x_nhwc.shape
+    out = torch.empty((B * H * W, 9 * C), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    check(_lib.lib().dsrg_im2col3x3_nhwc16(_ptr(x_nhwc), _ptr(out), B, H, W, C, int(dilation), _stream()))
+    return out
+
+
 class DSRGSupervision(torch.autograd.Function):
     """loss-Seed + loss-Constrain as a differentiable function of the fc8 logits."""
 

@@ -158,6 +158,11 @@ int dsrg_seed_loss(int B, int C, int HW, const float *probs_dev, const float *se
 int dsrg_constrain_loss(int B, int C, int HW, const float *probs_dev, const float *logq_dev,
                         float *loss_dev, float *grad_probs_dev, float *grad_logq_dev, void *stream);
 
+/* Backbone plumbing (no reference counterpart; Caffe's im2col lives in the external framework): NHWC im2col
+ * of a 3x3, stride-1, "same"-padded, dilated convolution for 2-byte elements (bf16/fp16), C % 8 == 0:
+ *   out[(b,y,x)][tap][c] = in[b][y+(tap/3-1)*dil][x+(tap%3-1)*dil][c], zero outside the map. */
+int dsrg_im2col3x3_nhwc16(const void *in_dev, void *out_dev, int B, int H, int W, int C, int dilation, void *stream);
+
 /* The five Python layers of train-s.prototxt:746-810 as ONE stream-ordered
  * sequence (Softmax -> CRF -> DSRG -> BalancedSeedLoss + ConstrainLoss, then
  * the backward pass of A.3 down to d loss / d fc8), computing the CRF once
