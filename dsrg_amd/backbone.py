@@ -75,7 +75,7 @@ class VGG16ASPP(nn.Module):
         super().__init__()
         L = []
         L += _conv_relu(3, 64) + _conv_relu(64, 64) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
-        L += _conv_relu(64, 128) + _conv_relu(128, 128) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
+        L += _conv_relu(64, 128, 1, gemm_convs) + _conv_relu(128, 128, 1, gemm_convs) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
         L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
         g = gemm_convs                                                  # the 41x41 stages
         L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g) + _conv_relu(512, 512, 1, g) + [nn.MaxPool2d(3, 1, 1)]
