@@ -66,3 +66,49 @@ def test_layer_protocol_errors_match_reference():
                    (pylayers.BalancedSeedLossLayer, 1), (pylayers.ConstrainLossLayer, 3)]:
         with pytest.raises(Exception):
             cls().setup([None] * n, [None])
+
+
+def test_annotation_layer_cue_pickle_format(tmp_path):
+    """AnnotationLayer (pylayers.py:346-387): '%i_labels' -> class ids, '%i_cues' -> (c,h,w) index triplets,
+    background always on, one flip per image applied to cues and image alike (host-side marshalling)."""
+    import pickle
+    import pylayers
+    rng = np.random.default_rng(0)
+    data = {}
+    for i in (3, 8):
+        data['%i_labels' % i] = np.array(sorted(rng.choice(np.arange(1, 21), size=2, replace=False)))
+        k = 30
+        data['%i_cues' % i] = np.stack([rng.integers(0, 21, k), rng.integers(0, 41, k), rng.integers(0, 41, k)])
+    path = os.path.join(str(tmp_path), "cues.pickle")
+    pickle.dump(data, open(path, "wb"), protocol=2)
+
+    class Blob(object):
+        def __init__(self, a=None):
+            self.data = a if a is not None else np.zeros((0,), np.float32)
+
+        def reshape(self, *s):
+            self.data = np.zeros(s, np.float32)
+    ids = Blob(np.array([3, 8], np.float32).reshape(2, 1, 1, 1))
+    imgs = Blob(rng.standard_normal((2, 3, 321, 321)).astype(np.float32))
+    for mirror in (False, True):
+        lay = pylayers.AnnotationLayer()
+        lay.param_str = "{'cues': %r, 'mirror': %s}" % (path, mirror)
+        tops = [Blob(), Blob(), Blob()]
+        lay.setup([ids, imgs], tops)
+        lay.reshape([ids, imgs], tops)
+        np.random.seed(0)
+        lay.forward([ids, imgs], tops)
+        assert tops[0].data.shape == (2, 1, 1, 21) and tops[1].data.shape == (2, 21, 41, 41)
+        for n, i in enumerate((3, 8)):
+            want = np.zeros(21); want[0] = 1; want[data['%i_labels' % i]] = 1
+            assert np.array_equal(tops[0].data[n, 0, 0], want)
+            cues = np.zeros((21, 41, 41), np.float32)
+            c = data['%i_cues' % i]
+            cues[c[0], c[1], c[2]] = 1
+            if mirror:
+                same = np.array_equal(tops[1].data[n], cues) and np.array_equal(tops[2].data[n], imgs.data[n])
+                flipped = np.array_equal(tops[1].data[n], cues[:, :, ::-1]) and \
+                    np.array_equal(tops[2].data[n], imgs.data[n][:, :, ::-1])
+                assert same or flipped                       # cues and image flip together
+            else:
+                assert np.array_equal(tops[1].data[n], cues) and np.array_equal(tops[2].data[n], imgs.data[n])
