@@ -59,6 +59,8 @@ struct LatticeView {
     uint32_t *key_e;       // [Epad*KW]  packed keys of every (pixel, corner) entry, Epad = Npad*(d+1)
     uint16_t *slot_e;      // [Epad]     hash slot of every entry
     uint32_t *key_v;       // [Mcap*KW]  packed key of every vertex
+    uint32_t *tab_g;       // [cap/2]    hash table (16-bit slots) handed from the build to the neighbour kernel
+    unsigned long long *ckeys_g;   // [Mcap]   compact vertex keys, likewise
 };
 
 struct LatticeFeat {

@@ -46,7 +46,7 @@ void *g_build_dbg = nullptr;     // tools only: 16 u64 phase timestamps per latt
 template <int D, int VPT>   // VPT >= ceil(Mcap / 1024): vertices (and entries) per thread
 __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, LatticeFeat F,
                                                               const unsigned char *__restrict__ im, int cap,
-                                                              int wl_in_lds, int lds_keys, unsigned long long *dbg) {
+                                                              int wl_in_lds, int lds_keys, int split, unsigned long long *dbg) {
 #define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + (i_)] = wall_clock64(); } while (0)
     DSRG_STAMP(0);
     constexpr int D1 = D + 1, KW = KeyWords<D>::value;
@@ -182,90 +182,104 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         }
     }
 
-    // ---- phase 5: blur neighbours (permutohedral.cpp:303-318): 2(d+1) hash look-ups per vertex,
-    // advanced together one probe per round.  With the compact keys resident in LDS a probe is two
-    // LDS reads (slot, key) and no global traffic; otherwise the candidates of a round are confirmed
-    // by one batch of key fetches from HBM/L2.
-    int has_nb = 0;
-#pragma unroll 1
-    for (int k = 0; k < VPT; k++) {
-        const int v = tid + k * kWG;
-        if (v >= M) break;
-        uint32_t w[KW];
-        load_key<KW>(w, key_v + (size_t)v * KW);
-        uint32_t word[D1];
-#pragma unroll
-        for (int j = 0; j < D1; j++) word[j] = 0;
-        // two halves of D1 look-ups each (keeps the probe state in registers):
-        //   half 0: n1 = all coordinates -1, axis j +d;   half 1: n2 = all +1, axis j -d
-#pragma unroll 1
-        for (int half = 0; half < 2; half++) {
-            uint32_t hq[D1], found[D1];
-            ckey_t qc[D1];
-#pragma unroll
-            for (int j = 0; j < D1; j++) {
-                uint32_t q[KW];
-                neighbour_key<D>(q, w, j, half != 0);
-                hq[j] = hash_key<KW>(q) & mask;
-                qc[j] = CompactKey<D>::make(q);
-                found[j] = (uint32_t)Mcap;
-            }
-            uint32_t pend = (1u << D1) - 1u;
-            if (fast_keys) {
-                while (pend) {
-                    uint32_t t[D1];
-#pragma unroll
-                    for (int j = 0; j < D1; j++) t[j] = tab[hq[j]];
-                    ckey_t ck[D1];
-#pragma unroll
-                    for (int j = 0; j < D1; j++) ck[j] = ckeys[min(t[j], (uint32_t)Mcap - 1u)];
-#pragma unroll
-                    for (int j = 0; j < D1; j++) {
-                        if ((pend >> j) & 1u) {
-                            if (t[j] == kEmpty) pend &= ~(1u << j);
-                            else if (ck[j] == qc[j]) { found[j] = t[j]; pend &= ~(1u << j); }
-                            else hq[j] = (hq[j] + 1) & mask;
-                        }
-                    }
-                }
-            } else {
-                while (pend) {
-                    uint32_t t[D1];
-#pragma unroll
-                    for (int j = 0; j < D1; j++) t[j] = tab[hq[j]];
-                    uint32_t kv[D1][KW];
-#pragma unroll
-                    for (int j = 0; j < D1; j++)
-                        load_key<KW>(kv[j], key_v + (size_t)min(t[j], (uint32_t)Mcap - 1u) * KW);
-#pragma unroll
-                    for (int j = 0; j < D1; j++) {
-                        if ((pend >> j) & 1u) {
-                            uint32_t q[KW];
-                            neighbour_key<D>(q, w, j, half != 0);
-                            bool eq = true;
-#pragma unroll
-                            for (int x = 0; x < KW; x++) eq &= (kv[j][x] == q[x]);
-                            if (t[j] == kEmpty) pend &= ~(1u << j);
-                            else if (eq) { found[j] = t[j]; pend &= ~(1u << j); }
-                            else hq[j] = (hq[j] + 1) & mask;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < D1; j++) {
-                word[j] |= found[j] << (half * 16);
-                has_nb |= found[j] != (uint32_t)Mcap;
-            }
+    if (split) {
+        // the neighbour search and the normalisation run in follow-up kernels spread over more workgroups
+        // (lattice_neigh_kernel / lattice_norm_kernel): hand them the hash table and the compact keys
+        __syncthreads();
+        uint32_t *tg = L.tab_g + (size_t)b * (cap / 2);
+        for (int q = tid; q < cap / 2; q += kWG) tg[q] = tabw[q];
+        if (fast_keys) {
+            ckey_t *kg = reinterpret_cast<ckey_t *>(L.ckeys_g) + (size_t)b * Mcap;
+            for (int q = tid; q < M; q += kWG) kg[q] = ckeys[q];
         }
-#pragma unroll
-        for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = word[j];
-    }
-    {   // diagonal lattice: every entry owns its vertex and no vertex has a blur neighbour
-        const int any_nb = __syncthreads_or(has_nb);
         const int any_bad = __syncthreads_or(key_range_bad);
-        // bit 0: diagonal; bit 1: a key coordinate left the range the packed neighbour arithmetic covers
-        if (tid == 0) L.flags[b] = ((!any_nb && M == E) ? 1 : 0) | (any_bad ? 2 : 0);
+        if (tid == 0) L.flags[b] = (any_bad ? 2 : 0) | (fast_keys ? 8 : 0);
+    } else {
+    // ---- phase 5: blur neighbours (permutohedral.cpp:303-318): 2(d+1) hash look-ups per vertex,
+        // advanced together one probe per round.  With the compact keys resident in LDS a probe is two
+        // LDS reads (slot, key) and no global traffic; otherwise the candidates of a round are confirmed
+        // by one batch of key fetches from HBM/L2.
+        int has_nb = 0;
+#pragma unroll 1
+        for (int k = 0; k < VPT; k++) {
+            const int v = tid + k * kWG;
+            if (v >= M) break;
+            uint32_t w[KW];
+            load_key<KW>(w, key_v + (size_t)v * KW);
+            uint32_t word[D1];
+#pragma unroll
+            for (int j = 0; j < D1; j++) word[j] = 0;
+            // two halves of D1 look-ups each (keeps the probe state in registers):
+            //   half 0: n1 = all coordinates -1, axis j +d;   half 1: n2 = all +1, axis j -d
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                uint32_t hq[D1], found[D1];
+                ckey_t qc[D1];
+#pragma unroll
+                for (int j = 0; j < D1; j++) {
+                    uint32_t q[KW];
+                    neighbour_key<D>(q, w, j, half != 0);
+                    hq[j] = hash_key<KW>(q) & mask;
+                    qc[j] = CompactKey<D>::make(q);
+                    found[j] = (uint32_t)Mcap;
+                }
+                uint32_t pend = (1u << D1) - 1u;
+                if (fast_keys) {
+                    while (pend) {
+                        uint32_t t[D1];
+#pragma unroll
+                        for (int j = 0; j < D1; j++) t[j] = tab[hq[j]];
+                        ckey_t ck[D1];
+#pragma unroll
+                        for (int j = 0; j < D1; j++) ck[j] = ckeys[min(t[j], (uint32_t)Mcap - 1u)];
+#pragma unroll
+                        for (int j = 0; j < D1; j++) {
+                            if ((pend >> j) & 1u) {
+                                if (t[j] == kEmpty) pend &= ~(1u << j);
+                                else if (ck[j] == qc[j]) { found[j] = t[j]; pend &= ~(1u << j); }
+                                else hq[j] = (hq[j] + 1) & mask;
+                            }
+                        }
+                    }
+                } else {
+                    while (pend) {
+                        uint32_t t[D1];
+#pragma unroll
+                        for (int j = 0; j < D1; j++) t[j] = tab[hq[j]];
+                        uint32_t kv[D1][KW];
+#pragma unroll
+                        for (int j = 0; j < D1; j++)
+                            load_key<KW>(kv[j], key_v + (size_t)min(t[j], (uint32_t)Mcap - 1u) * KW);
+#pragma unroll
+                        for (int j = 0; j < D1; j++) {
+                            if ((pend >> j) & 1u) {
+                                uint32_t q[KW];
+                                neighbour_key<D>(q, w, j, half != 0);
+                                bool eq = true;
+#pragma unroll
+                                for (int x = 0; x < KW; x++) eq &= (kv[j][x] == q[x]);
+                                if (t[j] == kEmpty) pend &= ~(1u << j);
+                                else if (eq) { found[j] = t[j]; pend &= ~(1u << j); }
+                                else hq[j] = (hq[j] + 1) & mask;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < D1; j++) {
+                    word[j] |= found[j] << (half * 16);
+                    has_nb |= found[j] != (uint32_t)Mcap;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = word[j];
+        }
+        {   // diagonal lattice: every entry owns its vertex and no vertex has a blur neighbour
+            const int any_nb = __syncthreads_or(has_nb);
+            const int any_bad = __syncthreads_or(key_range_bad);
+            // bit 0: diagonal; bit 1: a key coordinate left the range the packed neighbour arithmetic covers
+            if (tid == 0) L.flags[b] = ((!any_nb && M == E) ? 1 : 0) | (any_bad ? 2 : 0);
+        }
     }
     DSRG_STAMP(4);
 
@@ -328,58 +342,229 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     __syncthreads();
     DSRG_STAMP(7);
 
+    if (!split) {
     // ---- phase 7: norm = 1/sqrt(K 1 + 1e-20)  (pairwise.cpp:44,54-57), one channel through
-    // Permutohedral::seqCompute (permutohedral.cpp:476-527): blur evaluated in double
-    float *val = reinterpret_cast<float *>(smem);                             // [Mcap+1], aliases cnt
-    {
-        float s0[VPT];
+        // Permutohedral::seqCompute (permutohedral.cpp:476-527): blur evaluated in double
+        float *val = reinterpret_cast<float *>(smem);                             // [Mcap+1], aliases cnt
+        {
+            float s0[VPT];
 #pragma unroll
-        for (int k = 0; k < VPT; k++) {
-            const int v = tid + k * kWG;
-            float s = 0.0f;
-            if (v < M) {
-                const uint32_t a0 = v == 0 ? 0u : cnt[v - 1], z0 = cnt[v];    // cnt[v] = END of row v
-                for (uint32_t pos = a0; pos < z0; pos++) s = s + wl[pos] * 1.0f;
+            for (int k = 0; k < VPT; k++) {
+                const int v = tid + k * kWG;
+                float s = 0.0f;
+                if (v < M) {
+                    const uint32_t a0 = v == 0 ? 0u : cnt[v - 1], z0 = cnt[v];    // cnt[v] = END of row v
+                    for (uint32_t pos = a0; pos < z0; pos++) s = s + wl[pos] * 1.0f;
+                }
+                s0[k] = s;
             }
-            s0[k] = s;
-        }
-        __syncthreads();                                                      // cnt is dead from here
+            __syncthreads();                                                      // cnt is dead from here
 #pragma unroll
-        for (int k = 0; k < VPT; k++) {
-            const int v = tid + k * kWG;
-            if (v < M) val[v] = s0[k];
+            for (int k = 0; k < VPT; k++) {
+                const int v = tid + k * kWG;
+                if (v < M) val[v] = s0[k];
+            }
+            if (tid == 0) val[Mcap] = 0.0f;
         }
-        if (tid == 0) val[Mcap] = 0.0f;
+        __syncthreads();
+        DSRG_STAMP(8);
+        {
+            const rsrc_t r_nb = make_rsrc(nb, sizeof(uint32_t) * (size_t)D1 * Mcap);
+            for (int j = 0; j <= D; j++) {
+                uint32_t word[VPT];
+#pragma unroll
+                for (int k = 0; k < VPT; k++)      // unconditional, all in flight (past-the-end reads 0)
+                    word[k] = (k * kWG < Mcap) ? ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)j * (uint32_t)Mcap * 4u + (uint32_t)k * (kWG * 4u)) : 0u;
+                float nv[VPT];
+#pragma unroll
+                for (int k = 0; k < VPT; k++) {
+                    const int v = tid + k * kWG;
+                    const bool ok = v < M;
+                    const int n1 = ok ? (int)(word[k] & 0xffffu) : Mcap, n2 = ok ? (int)(word[k] >> 16) : Mcap;
+                    const float s = val[n1] + val[n2];
+                    nv[k] = (float)((double)val[ok ? v : Mcap] + 0.5 * (double)s);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < VPT; k++) {
+                    const int v = tid + k * kWG;
+                    if (v < M) val[v] = nv[k];
+                }
+                __syncthreads();
+            }
+        }
+        DSRG_STAMP(9);
+        const float alpha = 1.0f / (1.0f + exp2f((float)-D));
+        for (int i = tid; i < N; i += kWG) {
+            float out = 0.0f;
+#pragma unroll
+            for (int r = 0; r <= D; r++) {
+                float t = bary[(size_t)r * N + i] * val[vid[(size_t)r * N + i]];
+                t = t * alpha;
+                out = out + t;
+            }
+            norm[i] = (float)(1.0 / sqrt((double)out + 1e-20));
+        }
+    }
+    DSRG_STAMP(10);
+#undef DSRG_STAMP
+}
+
+// ---------------------------------------------------------------------------------
+// Split build, stage 2: blur neighbours (permutohedral.cpp:303-318) with kNeighSplit workgroups per
+// lattice.  Each workgroup reloads the hash table (and the compact keys) into LDS and resolves the
+// 2(d+1) look-ups of its share of the vertices; probes never leave LDS when the compact keys exist.
+constexpr int kNeighSplit = 8;
+
+template <int D>
+__global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int cap, int lds_keys) {
+    constexpr int D1 = D + 1, KW = KeyWords<D>::value;
+    using ckey_t = typename CompactKey<D>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x / kNeighSplit, part = blockIdx.x % kNeighSplit, tid = threadIdx.x;
+    const int Mcap = L.Mcap, M = L.M[b];
+    const uint32_t mask = (uint32_t)cap - 1u;
+    constexpr uint32_t kEmpty = 0xFFFFu;
+    uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *tabw = reinterpret_cast<uint32_t *>(smem);
+    ckey_t *ckeys = reinterpret_cast<ckey_t *>(smem + (size_t)cap * 2);
+    const bool fast_keys = lds_keys && (L.flags[b] & 8);
+    const uint32_t *tg = L.tab_g + (size_t)b * (cap / 2);
+    for (int q = tid; q < cap / 2; q += kWG) tabw[q] = tg[q];
+    if (fast_keys) {
+        const ckey_t *kg = reinterpret_cast<const ckey_t *>(L.ckeys_g) + (size_t)b * Mcap;
+        for (int q = tid; q < M; q += kWG) ckeys[q] = kg[q];
     }
     __syncthreads();
-    DSRG_STAMP(8);
-    {
-        const rsrc_t r_nb = make_rsrc(nb, sizeof(uint32_t) * (size_t)D1 * Mcap);
-        for (int j = 0; j <= D; j++) {
-            uint32_t word[VPT];
+    const uint32_t *key_v = L.key_v + (size_t)b * Mcap * KW;
+    uint32_t *nb = L.nb + (size_t)b * D1 * Mcap;
+    const int chunk = (M + kNeighSplit - 1) / kNeighSplit;
+    const int v_end = min(M, (part + 1) * chunk);
+    for (int v = part * chunk + tid; v < v_end; v += kWG) {
+        uint32_t w[KW];
+        load_key<KW>(w, key_v + (size_t)v * KW);
+        uint32_t word[D1];
 #pragma unroll
-            for (int k = 0; k < VPT; k++)      // unconditional, all in flight (past-the-end reads 0)
-                word[k] = (k * kWG < Mcap) ? ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)j * (uint32_t)Mcap * 4u + (uint32_t)k * (kWG * 4u)) : 0u;
-            float nv[VPT];
+        for (int j = 0; j < D1; j++) word[j] = 0;
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {          // half 0: n1 (all -1, axis j +d); half 1: n2 (all +1, axis j -d)
+            uint32_t hq[D1], found[D1];
+            ckey_t qc[D1];
 #pragma unroll
-            for (int k = 0; k < VPT; k++) {
-                const int v = tid + k * kWG;
-                const bool ok = v < M;
-                const int n1 = ok ? (int)(word[k] & 0xffffu) : Mcap, n2 = ok ? (int)(word[k] >> 16) : Mcap;
-                const float s = val[n1] + val[n2];
-                nv[k] = (float)((double)val[ok ? v : Mcap] + 0.5 * (double)s);
+            for (int j = 0; j < D1; j++) {
+                uint32_t q[KW];
+                neighbour_key<D>(q, w, j, half != 0);
+                hq[j] = hash_key<KW>(q) & mask;
+                qc[j] = CompactKey<D>::make(q);
+                found[j] = (uint32_t)Mcap;
             }
-            __syncthreads();
+            uint32_t pend = (1u << D1) - 1u;
+            if (fast_keys) {
+                while (pend) {
+                    uint32_t t[D1];
 #pragma unroll
-            for (int k = 0; k < VPT; k++) {
-                const int v = tid + k * kWG;
-                if (v < M) val[v] = nv[k];
+                    for (int j = 0; j < D1; j++) t[j] = tab[hq[j]];
+                    ckey_t ck[D1];
+#pragma unroll
+                    for (int j = 0; j < D1; j++) ck[j] = ckeys[min(t[j], (uint32_t)Mcap - 1u)];
+#pragma unroll
+                    for (int j = 0; j < D1; j++) {
+                        if ((pend >> j) & 1u) {
+                            if (t[j] == kEmpty) pend &= ~(1u << j);
+                            else if (ck[j] == qc[j]) { found[j] = t[j]; pend &= ~(1u << j); }
+                            else hq[j] = (hq[j] + 1) & mask;
+                        }
+                    }
+                }
+            } else {
+                while (pend) {
+                    uint32_t t[D1];
+#pragma unroll
+                    for (int j = 0; j < D1; j++) t[j] = tab[hq[j]];
+                    uint32_t kv[D1][KW];
+#pragma unroll
+                    for (int j = 0; j < D1; j++)
+                        load_key<KW>(kv[j], key_v + (size_t)min(t[j], (uint32_t)Mcap - 1u) * KW);
+#pragma unroll
+                    for (int j = 0; j < D1; j++) {
+                        if ((pend >> j) & 1u) {
+                            uint32_t q[KW];
+                            neighbour_key<D>(q, w, j, half != 0);
+                            bool eq = true;
+#pragma unroll
+                            for (int x = 0; x < KW; x++) eq &= (kv[j][x] == q[x]);
+                            if (t[j] == kEmpty) pend &= ~(1u << j);
+                            else if (eq) { found[j] = t[j]; pend &= ~(1u << j); }
+                            else hq[j] = (hq[j] + 1) & mask;
+                        }
+                    }
+                }
             }
-            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < D1; j++) word[j] |= found[j] << (half * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = word[j];
+    }
+}
+
+// Split build, stage 3: norm = 1/sqrt(K 1 + 1e-20) (pairwise.cpp:44,54-57) through
+// Permutohedral::seqCompute (permutohedral.cpp:476-527, blur in double), and the "diagonal" flag.
+template <int D, int VPT>
+__global__ __launch_bounds__(kWG) void lattice_norm_kernel(LatticeView L) {
+    constexpr int D1 = D + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = L.N, Mcap = L.Mcap, E = N * D1, M = L.M[b];
+    float *val = reinterpret_cast<float *>(smem);                             // [Mcap+1]
+    const uint16_t *vid = L.vid + (size_t)b * D1 * N;
+    const float *bary = L.bary + (size_t)b * D1 * N;
+    const rsrc_t r_nb = make_rsrc(L.nb + (size_t)b * D1 * Mcap, sizeof(uint32_t) * (size_t)D1 * Mcap);
+    const rsrc_t r_rs = make_rsrc(L.row_start + (size_t)b * (Mcap + 1), sizeof(uint32_t) * (size_t)(Mcap + 1));
+    const rsrc_t r_cw = make_rsrc(L.csr_w + (size_t)b * E, sizeof(float) * (size_t)E);
+    uint32_t rs0[VPT], rs1[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+        rs0[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
+        rs1[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u) + 4u);
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+        const int v = tid + k * kWG;
+        if (v < M) {
+            float s = 0.0f;
+            for (uint32_t pos = rs0[k]; pos < rs1[k]; pos++) s = s + ld_f32(r_cw, pos * 4u) * 1.0f;
+            val[v] = s;
         }
     }
-    DSRG_STAMP(9);
+    if (tid == 0) val[Mcap] = 0.0f;
+    __syncthreads();
+    int has_nb = 0;
+    for (int j = 0; j <= D; j++) {
+        uint32_t word[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k++)
+            word[k] = ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)j * (uint32_t)Mcap * 4u + (uint32_t)k * (kWG * 4u));
+        float nv[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const int v = tid + k * kWG;
+            const bool ok = v < M;
+            const int n1 = ok ? (int)(word[k] & 0xffffu) : Mcap, n2 = ok ? (int)(word[k] >> 16) : Mcap;
+            has_nb |= (n1 != Mcap) | (n2 != Mcap);
+            const float s = val[n1] + val[n2];
+            nv[k] = (float)((double)val[ok ? v : Mcap] + 0.5 * (double)s);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const int v = tid + k * kWG;
+            if (v < M) val[v] = nv[k];
+        }
+        __syncthreads();
+    }
     const float alpha = 1.0f / (1.0f + exp2f((float)-D));
+    float *norm = L.norm + (size_t)b * N;
     for (int i = tid; i < N; i += kWG) {
         float out = 0.0f;
 #pragma unroll
@@ -390,17 +575,17 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         }
         norm[i] = (float)(1.0 / sqrt((double)out + 1e-20));
     }
-    DSRG_STAMP(10);
-#undef DSRG_STAMP
+    const int any_nb = __syncthreads_or(has_nb);
+    if (tid == 0) L.flags[b] = (L.flags[b] & ~1) | ((!any_nb && M == E) ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static void lattice_layout(int d, int N, int nlat, size_t off[13], size_t &total) {
+static void lattice_layout(int d, int N, int nlat, size_t off[15], size_t &total) {
     const int d1 = d + 1, Npad = (N + 3) / 4 * 4, Mcap = Npad * d1, E = N * d1, Epad = Npad * d1;
     const int KW = (d * 16 + 31) / 32;
-    size_t sz[12] = {
+    size_t sz[14] = {
         sizeof(int) * (size_t)nlat,                          // M
         sizeof(uint16_t) * (size_t)E * nlat,                 // vid
         sizeof(float) * (size_t)E * nlat,                    // bary
@@ -413,20 +598,22 @@ static void lattice_layout(int d, int N, int nlat, size_t off[13], size_t &total
         sizeof(uint16_t) * (size_t)Epad * nlat,              // slot_e
         sizeof(uint32_t) * (size_t)Mcap * KW * nlat,         // key_v
         sizeof(int) * (size_t)nlat,                          // flags
+        sizeof(uint16_t) * (size_t)lattice_table_cap(Mcap) * nlat,     // tab_g
+        sizeof(unsigned long long) * (size_t)Mcap * nlat,     // ckeys_g
     };
     size_t cur = 0;
-    for (int i = 0; i < 12; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
+    for (int i = 0; i < 14; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
     total = cur;
 }
 
 size_t lattice_bytes(int d, int N, int nlat) {
-    size_t off[13], total;
+    size_t off[15], total;
     lattice_layout(d, N, nlat, off, total);
     return total;
 }
 
 void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
-    size_t off[13], total;
+    size_t off[15], total;
     lattice_layout(d, N, nlat, off, total);
     unsigned char *p = static_cast<unsigned char *>(base);
     L.d = d; L.N = N; L.Mcap = ((N + 3) / 4 * 4) * (d + 1); L.nlat = nlat;
@@ -442,6 +629,8 @@ void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
     L.slot_e = reinterpret_cast<uint16_t *>(p + off[9]);
     L.key_v = reinterpret_cast<uint32_t *>(p + off[10]);
     L.flags = reinterpret_cast<int *>(p + off[11]);
+    L.tab_g = reinterpret_cast<uint32_t *>(p + off[12]);
+    L.ckeys_g = reinterpret_cast<unsigned long long *>(p + off[13]);
 }
 
 void lattice_feat_init(LatticeFeat &F, int d, int W, int H, float sx, float sy, float sr, float sg, float sb) {
@@ -485,13 +674,27 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
     const size_t lds = build_lds_bytes(L.d, L.N, wl_in_lds, lds_keys);
     const int vpt = (L.Mcap + kWG - 1) / kWG;
     unsigned long long *dbg = L.d == 5 ? reinterpret_cast<unsigned long long *>(g_build_dbg) : nullptr;
+    // split the build over more workgroups (neighbour search x8 per lattice) when the hash table and the
+    // compact keys fit one workgroup's LDS next to each other
+    const size_t neigh_lds = (size_t)cap * 2 + (lds_keys ? (size_t)L.Mcap * (L.d == 5 ? 8 : 4) : 0);
+    const int split = (neigh_lds <= 150 * 1024 && L.Mcap <= 16 * kWG) ? 1 : 0;
 #define DSRG_BUILD(D_, V_)                                                                                    \
     do {                                                                                                      \
-        static size_t granted = 0;                                                                            \
+        static size_t granted = 0, granted_n = 0, granted_m = 0;                                              \
         int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_build_kernel<D_, V_>), lds, granted); \
         if (rc) return rc;                                                                                    \
         hipLaunchKernelGGL((lattice_build_kernel<D_, V_>), dim3(nlat), dim3(kWG), lds, stream, L, F, im, cap,  \
-                           (int)wl_in_lds, (int)lds_keys, dbg);                                               \
+                           (int)wl_in_lds, (int)lds_keys, split, dbg);                                        \
+        if (split) {                                                                                          \
+            rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_neigh_kernel<D_>), neigh_lds, granted_n); \
+            if (rc) return rc;                                                                                \
+            hipLaunchKernelGGL((lattice_neigh_kernel<D_>), dim3(nlat * kNeighSplit), dim3(kWG), neigh_lds, stream, L, \
+                               cap, (int)lds_keys);                                                           \
+            const size_t norm_lds = (size_t)(L.Mcap + 1) * 4;                                                 \
+            rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_norm_kernel<D_, V_>), norm_lds, granted_m); \
+            if (rc) return rc;                                                                                \
+            hipLaunchKernelGGL((lattice_norm_kernel<D_, V_>), dim3(nlat), dim3(kWG), norm_lds, stream, L);     \
+        }                                                                                                     \
     } while (0)
 #define DSRG_BUILD_V(D_)                                                                                      \
     do {                                                                                                      \
