@@ -89,7 +89,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group and DDP are used even for one rank, so the
+    # single-GPU run of the driver's launch line exercises the same RCCL/DDP path as the 8-GPU run
+    use_dist = world > 1 or (os.environ.get("RANK") is not None and os.environ.get("DSRG_BENCH_NO_DDP") is None)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
@@ -107,11 +110,11 @@ def main():
     logits_fixed = torch.from_numpy(batch_np["logits"]).to(device)
     ctx = ops.get_context(B, C, H, W)
 
-    trainer = DSRGTrainer(device, world_size=world) if args.mode == "train" else None
+    trainer = DSRGTrainer(device, world_size=world, ddp=use_dist) if args.mode == "train" else None
     retrainer = None
     if args.mode == "train-f":
         from dsrg_amd.retrain import RetrainTrainer
-        retrainer = RetrainTrainer(device, world_size=world, backbone=args.backbone)
+        retrainer = RetrainTrainer(device, world_size=2 if use_dist else 1, backbone=args.backbone)
         g = torch.Generator(device="cpu").manual_seed(2000 + rank)
         f_images = torch.randn(B, 3, args.size, args.size, generator=g).to(device)
         f_label = torch.randint(0, 21, (B, 1, args.size, args.size), generator=g).float().to(device)

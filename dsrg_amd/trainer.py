@@ -47,7 +47,7 @@ class CaffeSGD(object):
 
 class DSRGTrainer(object):
     def __init__(self, device, world_size=1, seed=0, amp_dtype=torch.bfloat16, channels_last=True,
-                 loss_fn=None, net=None):
+                 loss_fn=None, net=None, ddp=None):
         """loss_fn(logits, images, labels, cues) -> (total, losses); defaults to the HIP supervision
         path.  (Tests inject a torch loss to exercise the data-parallel plumbing on CPU/gloo.)"""
         torch.manual_seed(seed)            # same initial weights on every rank (DDP also broadcasts)
@@ -64,7 +64,7 @@ class DSRGTrainer(object):
             net = net.to(memory_format=torch.channels_last)
         self.net = net
         self.model = net
-        if world_size > 1:
+        if (world_size > 1) if ddp is None else ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             # 151.5 MB of fp32 gradients per step; 32 MB buckets -> 5 all-reduces overlapped with backward
             self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=32,

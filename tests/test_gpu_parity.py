@@ -313,3 +313,30 @@ def test_gemm_conv_matches_miopen_conv():
         ya.backward(g.to(ya.dtype)); yb.backward(g)
         assert (xa.grad - xb.grad).abs().max() < 0.05 * xb.grad.abs().max()
         assert (a.weight.grad - b.weight.grad).abs().max() < 0.05 * b.weight.grad.abs().max()
+
+
+@pytest.mark.parametrize("B,C,HW", [(20, 21, (41, 41)), (2, 30, (33, 29)), (2, 21, (65, 65)), (1, 21, (41, 41))])
+def test_fused_step_other_shapes_vs_oracle(ops, O, B, C, HW):
+    """reference batch size 20, more than 21 labels (generic-width kernels), the 65x65 map of a 513x513 input,
+    and a lone image (one label plane per workgroup) through the fused step, against the oracle layer by layer"""
+    H, W = HW
+    rng = np.random.default_rng(B * 1000 + C)
+    size = 8 * (H - 1) + 1
+    images = S.make_images(rng, B, size=size)
+    logits = S.make_logits(rng, B, C, H, W)
+    labels, cues = S.make_labels_cues(rng, B, C, H, W)
+    losses, grad, blobs = ops.supervision_step(dev(logits), dev(images), dev(labels), dev(cues), want_blobs=True)
+    probs = O.softmax_forward(logits)
+    refined, logq = O.crf_refine_batch(probs, images, 12.0, 10)
+    seeds = O.srg_grow_batch(labels, cues, refined)
+    assert np.abs(np.exp(blobs["logq"].cpu().numpy()) - refined).max() < CRF_TOL
+    got_seeds = blobs["seeds"].cpu().numpy()
+    nflip = int((got_seeds != seeds).sum())
+    assert nflip < 20, nflip
+    if nflip == 0:
+        l_seed, g_seed = O.seed_loss(probs, seeds)
+        l_con, g_p, g_lq = O.constrain_loss(probs, logq)
+        want = O.softmax_backward(logits, g_seed + g_p + O.crf_layer_backward(refined, g_lq))
+        assert abs(losses[0].item() - l_seed) < 1e-4 * max(1, abs(l_seed))
+        assert abs(losses[1].item() - l_con) < 1e-4 * max(1, abs(l_con))
+        assert np.abs(grad.cpu().numpy() - want).max() < 2e-3 * np.abs(want).max()
