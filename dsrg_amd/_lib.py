@@ -65,6 +65,9 @@ SIGNATURES = {
     "dsrg_seed_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dsrg_constrain_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsrg_im2col3x3_nhwc16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dsrg_relu_bwd_bias_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, ctypes.c_long, _i, _vp]),
+    "dsrg_maxpool3x3_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dsrg_maxpool3x3_bwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_supervision_step": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _d, _d, ctypes.POINTER(CrfParams),
                                    _vp, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -12,85 +12,151 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-class _GemmConvFn(torch.autograd.Function):
-    """3x3 / 1x1 stride-1 'same' convolution forward as an explicit NHWC im2col + one hipBLASLt GEMM.
-    At the 41x41 stages (76 % of the backbone flops) MIOpen's forward kernels reach ~180 TFLOP/s on
-    MI355X, the GEMM route 300-900 (tools/conv_probe.py).  Backward stays with MIOpen/CK, which are fine."""
+def _im2col_gemm(x, weight, bias, dilation, relu):
+    """(B,C,H,W) bf16 -> conv(+ReLU) output as a channels_last tensor: NHWC im2col (HIP) + one hipBLASLt GEMM whose
+    epilogue adds the bias (and applies the ReLU)."""
+    B, C, H, W = x.shape
+    cout, k = weight.shape[0], weight.shape[2]
+    xn = x.permute(0, 2, 3, 1)                                       # free for channels_last tensors
+    if not xn.is_contiguous():
+        xn = xn.contiguous()
+    if k == 1:
+        a = xn.reshape(-1, C)
+    elif C % 8 == 0 and x.element_size() == 2:
+        from .ops import im2col3x3_nhwc                               # one bandwidth-bound HIP kernel
+        a = im2col3x3_nhwc(xn, dilation)
+    else:
+        p = dilation
+        xp = F.pad(xn, (0, 0, p, p, p, p))
+        a = torch.cat([xp[:, dy * p:dy * p + H, dx * p:dx * p + W, :] for dy in range(3) for dx in range(3)],
+                      dim=-1).reshape(-1, 9 * C)
+    wmat = weight.permute(2, 3, 1, 0).reshape(k * k * C, cout)
+    # write straight into a channels_last (B,cout,H,W) tensor: its NHWC memory is the GEMM's C matrix
+    out = torch.empty((B, cout, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+    o2 = out.permute(0, 2, 3, 1).view(-1, cout)
+    if relu:
+        torch._addmm_activation(bias, a, wmat, out=o2)
+    else:
+        torch.addmm(bias, a, wmat, out=o2)
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    """3x3 / 1x1 stride-1 'same' convolution (+ ReLU).  Forward: explicit NHWC im2col + one hipBLASLt GEMM when
+    `gemm` (at the 41x41 stages, 76 % of the backbone flops, MIOpen's forward kernels reach ~180 TFLOP/s on MI355X,
+    the GEMM route 300-900: tools/conv_probe.py), MIOpen otherwise.  Backward: the ReLU mask and the bias gradient
+    come from one fused HIP pass (ops.relu_bwd_bias); data and weight gradients stay with MIOpen/CK."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
-    def forward(ctx, x, weight, bias, dilation):
-        B, C, H, W = x.shape
-        cout, k = weight.shape[0], weight.shape[2]
-        xn = x.permute(0, 2, 3, 1)                                   # free for channels_last tensors
-        if not xn.is_contiguous():
-            xn = xn.contiguous()
-        if k == 1:
-            a = xn.reshape(-1, C)
+    def forward(ctx, x, weight, bias, dilation, relu, gemm):
+        k = weight.shape[2]
+        if gemm:
+            out = _im2col_gemm(x, weight, bias, dilation, relu)
         else:
-            if C % 8 == 0:
-                from .ops import im2col3x3_nhwc                       # one bandwidth-bound HIP kernel
-                a = im2col3x3_nhwc(xn, dilation)
-            else:
-                p = dilation
-                xp = F.pad(xn, (0, 0, p, p, p, p))
-                a = torch.cat([xp[:, dy * p:dy * p + H, dx * p:dx * p + W, :] for dy in range(3) for dx in range(3)],
-                              dim=-1).reshape(-1, 9 * C)
-        wmat = weight.permute(2, 3, 1, 0).reshape(k * k * C, cout)
-        # write straight into a channels_last (B,cout,H,W) tensor: its NHWC memory is the GEMM's C matrix
-        out = torch.empty((B, cout, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
-        torch.addmm(bias, a, wmat, out=out.permute(0, 2, 3, 1).view(-1, cout))
-        ctx.save_for_backward(x, weight)
-        ctx.dilation, ctx.k = dilation, k
+            out = F.conv2d(x.contiguous(memory_format=torch.channels_last), weight, bias, 1, dilation * (k // 2), dilation)
+            if relu:
+                out.relu_()
+        ctx.save_for_backward(x, weight, out if relu else None)
+        ctx.dilation, ctx.k, ctx.relu = dilation, k, relu
         return out
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
         pad = ctx.dilation * (ctx.k // 2)
-        gx, gw, gb = torch.ops.aten.convolution_backward(
-            g.contiguous(memory_format=torch.channels_last), x, weight, [weight.shape[0]], [1, 1], [pad, pad],
-            [ctx.dilation, ctx.dilation], False, [0, 0], 1, [True, True, True])
-        return gx, gw, gb, None
+        fused = ctx.relu and weight.shape[0] % 8 == 0 and g.dtype == torch.bfloat16
+        if fused:
+            from .ops import relu_bwd_bias
+            g, gb = relu_bwd_bias(g, y)
+        else:
+            if ctx.relu:
+                g = g * (y > 0)
+            g = g.contiguous(memory_format=torch.channels_last)
+        gx, gw, gb2 = torch.ops.aten.convolution_backward(
+            g, x, weight, None if fused else [weight.shape[0]], [1, 1], [pad, pad],
+            [ctx.dilation, ctx.dilation], False, [0, 0], 1, [ctx.needs_input_grad[0], True, not fused])
+        return gx, gw, (gb if fused else gb2), None, None, None
 
 
 class GemmConv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters, same init, same state_dict) whose CUDA forward is im2col + GEMM."""
+    """nn.Conv2d (same parameters, same init, same state_dict) whose CUDA forward is im2col + GEMM, optionally
+    with the following ReLU fused (`fuse_relu`); on the CPU it is the plain convolution (+ ReLU)."""
+
+    def __init__(self, *args, fuse_relu=False, gemm=True, **kw):
+        super().__init__(*args, **kw)
+        self.fuse_relu, self.gemm = fuse_relu, gemm
 
     def forward(self, x):
         if x.is_cuda and self.stride == (1, 1) and self.kernel_size[0] in (1, 3) and \
                 self.padding[0] == self.dilation[0] * (self.kernel_size[0] // 2):
-            return _GemmConvFn.apply(x, self.weight, self.bias, self.dilation[0])
+            return _ConvFn.apply(x, self.weight, self.bias, self.dilation[0], self.fuse_relu, self.gemm)
+        out = super().forward(x)
+        return F.relu(out) if self.fuse_relu else out
+
+
+class FusedReLU(nn.Identity):
+    """placeholder that keeps the Sequential indices (and state_dict keys) of the conv/ReLU pairs: the ReLU itself
+    runs inside the GemmConv2d in front of it"""
+
+
+class _MaxPool3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride, ceil_mode):
+        from .ops import maxpool3x3_fwd
+        out, code = maxpool3x3_fwd(x, stride, ceil_mode)
+        ctx.save_for_backward(code)
+        ctx.in_shape, ctx.stride = x.shape, stride
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import maxpool3x3_bwd
+        (code,) = ctx.saved_tensors
+        return maxpool3x3_bwd(g, code, ctx.in_shape, ctx.stride), None, None
+
+
+class MaxPool3x3(nn.MaxPool2d):
+    """3x3 / pad 1 max pooling (stride 1 or 2): one HIP pass each way over bf16 channels_last activations with
+    1-byte window codes instead of torch's int64 indices; anything else takes nn.MaxPool2d's path."""
+
+    def __init__(self, stride, ceil_mode=False):
+        super().__init__(3, stride, 1, ceil_mode=ceil_mode)
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and \
+                x.is_contiguous(memory_format=torch.channels_last):
+            return _MaxPool3x3Fn.apply(x, self.stride, self.ceil_mode)
         return super().forward(x)
 
 
 def _conv_relu(cin, cout, dilation=1, gemm=False):
-    conv = (GemmConv2d if gemm else nn.Conv2d)(cin, cout, 3, padding=dilation, dilation=dilation)
-    return [conv, nn.ReLU(inplace=True)]
+    conv = GemmConv2d(cin, cout, 3, padding=dilation, dilation=dilation, fuse_relu=True, gemm=gemm)
+    return [conv, FusedReLU()]
 
 
 class VGG16ASPP(nn.Module):
     def __init__(self, num_classes=21, dropout=0.5, gemm_convs=True):
         super().__init__()
         L = []
-        L += _conv_relu(3, 64) + _conv_relu(64, 64) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
-        L += _conv_relu(64, 128, 1, gemm_convs) + _conv_relu(128, 128, 1, gemm_convs) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
-        L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + [nn.MaxPool2d(3, 2, 1, ceil_mode=True)]
+        L += _conv_relu(3, 64) + _conv_relu(64, 64) + [MaxPool3x3(2, ceil_mode=True)]
+        L += _conv_relu(64, 128, 1, gemm_convs) + _conv_relu(128, 128, 1, gemm_convs) + [MaxPool3x3(2, ceil_mode=True)]
+        L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + [MaxPool3x3(2, ceil_mode=True)]
         g = gemm_convs                                                  # the 41x41 stages
-        L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g) + _conv_relu(512, 512, 1, g) + [nn.MaxPool2d(3, 1, 1)]
-        L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + [nn.MaxPool2d(3, 1, 1)]
+        L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g) + _conv_relu(512, 512, 1, g) + [MaxPool3x3(1)]
+        L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + [MaxPool3x3(1)]
         L += [nn.AvgPool2d(3, 1, 1)]                                   # pool5a AVE (count_include_pad, as Caffe)
         self.features = nn.Sequential(*L)
         self.branches = nn.ModuleList()
         for d in (6, 12, 18, 24):
-            Conv = GemmConv2d if gemm_convs else nn.Conv2d
-            fc8 = Conv(1024, num_classes, 1)
+            g = gemm_convs
+            fc8 = GemmConv2d(1024, num_classes, 1, gemm=g)
             nn.init.normal_(fc8.weight, std=0.01)
             nn.init.zeros_(fc8.bias)
             self.branches.append(nn.Sequential(
-                Conv(512, 1024, 3, padding=d, dilation=d), nn.ReLU(inplace=True), nn.Dropout(dropout),
-                Conv(1024, 1024, 1), nn.ReLU(inplace=True), nn.Dropout(dropout), fc8))
+                GemmConv2d(512, 1024, 3, padding=d, dilation=d, fuse_relu=True, gemm=g), FusedReLU(), nn.Dropout(dropout),
+                GemmConv2d(1024, 1024, 1, fuse_relu=True, gemm=g), FusedReLU(), nn.Dropout(dropout), fc8))
 
     def forward(self, x):
         f = self.features(x)

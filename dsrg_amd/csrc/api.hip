@@ -265,6 +265,21 @@ extern "C" int dsrg_im2col3x3_nhwc16(const void *in, void *out, int B, int H, in
     if (!in || !out || B < 1 || H < 1 || W < 1 || C < 1 || dilation < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
     return launch_im2col3x3(in, out, B, H, W, C, dilation, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_relu_bwd_bias_bf16(const void *g, const void *y, void *gm, float *bias_grad, float *partials,
+                                       int partial_blocks, long rows, int C, void *stream) {
+    if (!g || !y || !gm || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_relu_bwd_bias(g, y, gm, bias_grad, partials, partial_blocks, rows, C, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_maxpool3x3_fwd_bf16(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C,
+                                        int stride, void *stream) {
+    if (!in || !out || !code) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_maxpool3x3_fwd(in, out, code, B, H, W, OH, OW, C, stride, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_maxpool3x3_bwd_bf16(const void *gout, const void *code, void *gin, int B, int H, int W, int OH, int OW,
+                                        int C, int stride, void *stream) {
+    if (!gout || !code || !gin) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_maxpool3x3_bwd(gout, code, gin, B, H, W, OH, OW, C, stride, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, const float *images, int img_h,
                                      int img_w, const float *labels, const float *cues, double th1, double th2,

@@ -1,0 +1,223 @@
+// Backbone plumbing around the hipBLASLt / MIOpen convolutions of the VGG16-ASPP net (no reference
+// counterpart: the reference's ReLU / Pooling layers live in the external Caffe framework, train-s.prototxt:41-744).
+// All three are HBM-bound elementwise passes over NHWC bf16 activations, 16 bytes (8 channels) per lane:
+//   relu_bwd_bias : ReLU backward fused with the per-channel bias-gradient reduction of the preceding convolution
+//   maxpool3x3    : 3x3 max pooling (stride 1 or 2, pad 1, optional ceil mode) forward with a 1-byte window code,
+//                   and the gather-form backward that reads the codes (no atomics, deterministic)
+#include "common.h"
+
+namespace dsrg {
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16); }
+
+constexpr int kRbThreads = 256;
+
+// gm = g * (y > 0); part[blockIdx][c] = sum over this block's rows of gm[:, c]   (rows x C, C % 8 == 0, C/8 <= 256)
+__global__ __launch_bounds__(kRbThreads) void relu_bwd_bias_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ y,
+                                                                    uint4 *__restrict__ gm, float *__restrict__ part,
+                                                                    int rows, int C8, int rows_per_block) {
+    __shared__ float red[kRbThreads][9];                                 // +1 pad: column reads hit distinct banks
+    const int lanes_r = kRbThreads / C8;                                 // row lanes per block
+    const int cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rl < lanes_r) {
+        const int r0 = blockIdx.x * rows_per_block;
+        const int r1 = min(rows, r0 + rows_per_block);
+        for (int r = r0 + rl; r < r1; r += lanes_r) {
+            const size_t i = (size_t)r * C8 + cg;
+            const uint4 gv = g[i], yv = y[i];
+            const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // y is a ReLU output: positive <=> non-zero magnitude with a clear sign bit (NaN passes the gradient, as torch)
+                const bool plo = (yw[k] & 0x8000u) == 0 && (yw[k] & 0x7fffu) != 0;
+                const bool phi = (yw[k] & 0x80000000u) == 0 && (yw[k] & 0x7fff0000u) != 0;
+                const uint32_t m = (plo ? 0xffffu : 0u) | (phi ? 0xffff0000u : 0u);
+                ow[k] = gw[k] & m;
+                acc[2 * k] += bf16_lo(ow[k]);
+                acc[2 * k + 1] += bf16_hi(ow[k]);
+            }
+            gm[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    // thread t < C sums channel t over the row lanes in a fixed order
+    for (int c = threadIdx.x; c < C8 * 8; c += kRbThreads) {
+        const int g8 = c >> 3, k = c & 7;
+        float s = 0.f;
+        for (int l = 0; l < lanes_r; ++l) s += red[l * C8 + g8][k];
+        part[(size_t)blockIdx.x * (C8 * 8) + c] = s;
+    }
+}
+
+// 32 channels x 8 slices of the partial rows per block; slice sums are combined in slice order (fixed order => deterministic)
+__global__ __launch_bounds__(256) void bias_finalize_kernel(const float *__restrict__ part, float *__restrict__ bias_grad,
+                                                            int nblk, int C) {
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int b = sl;
+        for (; b + 24 < nblk; b += 32) {
+            s0 += part[(size_t)b * C + c];
+            s1 += part[(size_t)(b + 8) * C + c];
+            s2 += part[(size_t)(b + 16) * C + c];
+            s3 += part[(size_t)(b + 24) * C + c];
+        }
+        for (; b < nblk; b += 8) s0 += part[(size_t)b * C + c];
+    }
+    red[sl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        bias_grad[c] = s;
+    }
+}
+
+int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_grad, float *part, int part_blocks,
+                         long rows, int C, hipStream_t stream) {
+    if (C % 8 != 0 || C / 8 > kRbThreads || C < 8) return set_error(DSRG_ERR_UNSUPPORTED, "relu_bwd_bias: channels must be a multiple of 8, at most 2048");
+    if (rows <= 0 || rows > 0x7fffffffL) return set_error(DSRG_ERR_INVALID, "relu_bwd_bias: bad row count");
+    if (part_blocks < 1) return set_error(DSRG_ERR_INVALID, "relu_bwd_bias: no partial-sum blocks");
+    const int C8 = C / 8;
+    int nblk = part_blocks;
+    int rpb = (int)((rows + nblk - 1) / nblk);
+    const int lanes_r = kRbThreads / C8;
+    rpb = ((rpb + lanes_r - 1) / lanes_r) * lanes_r;
+    nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(nblk), dim3(kRbThreads), 0, stream, (const uint4 *)g, (const uint4 *)y,
+                       (uint4 *)gm, part, (int)rows, C8, rpb);
+    DSRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// ---- 3x3 max pooling, NHWC bf16 ----------------------------------------------------------------------------------
+// forward: out[b,oy,ox,c] = max over the window clipped to the image; code = 3*dy+dx of the FIRST maximum in row-major
+// window order (the rule of Caffe's PoolingLayer and of torch's max_pool2d); NaN propagates as in torch.
+__global__ void maxpool3x3_fwd_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, uint2 *__restrict__ code,
+                                      int B, int H, int W, int OH, int OW, int C8, int stride) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * OH * OW * C8;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8);
+    size_t r = idx / C8;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    float best[8];
+    uint32_t bc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { best[k] = -__builtin_inff(); bc[k] = 0xffu; }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = oy * stride - 1 + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = ox * stride - 1 + dx;
+            if (xx < 0 || xx >= W) continue;
+            const uint4 v = in[(((size_t)b * H + yy) * W + xx) * C8 + c];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = bf16_lo(w[k]), hi = bf16_hi(w[k]);
+                if (lo > best[2 * k] || lo != lo || bc[2 * k] == 0xffu) { best[2 * k] = lo; bc[2 * k] = 3 * dy + dx; }
+                if (hi > best[2 * k + 1] || hi != hi || bc[2 * k + 1] == 0xffu) { best[2 * k + 1] = hi; bc[2 * k + 1] = 3 * dy + dx; }
+            }
+        }
+    }
+    out[idx] = make_uint4(pack_bf16(best[0], best[1]), pack_bf16(best[2], best[3]), pack_bf16(best[4], best[5]),
+                          pack_bf16(best[6], best[7]));
+    code[idx] = make_uint2(bc[0] | (bc[1] << 8) | (bc[2] << 16) | (bc[3] << 24), bc[4] | (bc[5] << 8) | (bc[6] << 16) | (bc[7] << 24));
+}
+
+// backward, gather form: every input pixel visits the <= 9 (stride 1) or <= 4 (stride 2) windows that contain it and
+// takes the window's gradient where the window's code names this pixel.  Sums in f32 in a fixed order.
+__global__ void maxpool3x3_bwd_kernel(const uint4 *__restrict__ gout, const uint2 *__restrict__ code, uint4 *__restrict__ gin,
+                                      int B, int H, int W, int OH, int OW, int C8, int stride) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * W * C8;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8);
+    size_t r = idx / C8;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int ty = y + 1 - dy;                                        // oy*stride - 1 + dy == y
+        if (ty < 0 || ty % stride != 0) continue;
+        const int oy = ty / stride;
+        if (oy >= OH) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int tx = x + 1 - dx;
+            if (tx < 0 || tx % stride != 0) continue;
+            const int ox = tx / stride;
+            if (ox >= OW) continue;
+            const size_t o = (((size_t)b * OH + oy) * OW + ox) * C8 + c;
+            const uint2 cd = code[o];
+            const uint4 gv = gout[o];
+            const uint32_t want = 3 * dy + dx;
+            const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t cw = k < 2 ? cd.x : cd.y;
+                const uint32_t c0 = (cw >> (16 * (k & 1))) & 0xffu, c1 = (cw >> (16 * (k & 1) + 8)) & 0xffu;
+                if (c0 == want) acc[2 * k] += bf16_lo(gw[k]);
+                if (c1 == want) acc[2 * k + 1] += bf16_hi(gw[k]);
+            }
+        }
+    }
+    gin[idx] = make_uint4(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]), pack_bf16(acc[6], acc[7]));
+}
+
+static int pool_check(int B, int H, int W, int OH, int OW, int C, int stride) {
+    if (C % 8 != 0) return set_error(DSRG_ERR_UNSUPPORTED, "maxpool3x3: channels must be a multiple of 8");
+    if (stride != 1 && stride != 2) return set_error(DSRG_ERR_UNSUPPORTED, "maxpool3x3: stride must be 1 or 2");
+    if (B <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return set_error(DSRG_ERR_INVALID, "maxpool3x3: bad shape");
+    if ((OH - 1) * stride - 1 >= H || (OW - 1) * stride - 1 >= W) return set_error(DSRG_ERR_INVALID, "maxpool3x3: a window starts outside the image");
+    return DSRG_OK;
+}
+
+int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,
+                          hipStream_t stream) {
+    int rc = pool_check(B, H, W, OH, OW, C, stride);
+    if (rc) return rc;
+    const size_t total = (size_t)B * OH * OW * (C / 8);
+    hipLaunchKernelGGL(maxpool3x3_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint4 *)in,
+                       (uint4 *)out, (uint2 *)code, B, H, W, OH, OW, C / 8, stride);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, int H, int W, int OH, int OW, int C,
+                          int stride, hipStream_t stream) {
+    int rc = pool_check(B, H, W, OH, OW, C, stride);
+    if (rc) return rc;
+    const size_t total = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(maxpool3x3_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint4 *)gout,
+                       (const uint2 *)code, (uint4 *)gin, B, H, W, OH, OW, C / 8, stride);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+}  // namespace dsrg

@@ -115,6 +115,12 @@ int launch_lf_to_planes(int N, int M, const float *in, float *out, int negate, h
 int launch_planes_to_lf(int N, int M, const float *in, float *out, hipStream_t stream);
 int launch_argmax_planes(int N, int M, const float *q, int32_t *lab, hipStream_t stream);
 int launch_im2col3x3(const void *in, void *out, int B, int H, int W, int C, int dil, hipStream_t stream);
+int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_grad, float *part, int part_blocks,
+                         long rows, int C, hipStream_t stream);
+int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,
+                          hipStream_t stream);
+int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, int H, int W, int OH, int OW, int C,
+                          int stride, hipStream_t stream);
 
 #ifdef __HIPCC__
 // SRSRC buffer loads: 32-bit per-lane byte offset + scalar offset against a wave-uniform descriptor

@@ -217,6 +217,57 @@ def im2col3x3_nhwc(x_nhwc, dilation):
     return out
 
 
+_PARTIAL_BLOCKS = 512
+_partials = {}
+
+
+def relu_bwd_bias(g, y):
+    """ReLU backward fused with the bias-gradient reduction of the convolution before it.
+    g, y: (B,C,H,W) bf16 channels_last (y = the ReLU output).  Returns (g * (y > 0), sum over B,H,W as f32 (C,))."""
+    B, C, H, W = y.shape
+    cl = torch.channels_last
+    if not (g.is_cuda and g.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=cl)):
+        raise ValueError("relu_bwd_bias needs bf16 channels_last CUDA tensors")
+    g = g.contiguous(memory_format=cl)
+    gm = torch.empty_like(y)
+    gb = torch.empty(C, dtype=torch.float32, device=y.device)
+    key = (y.device, C)
+    part = _partials.get(key)
+    if part is None:
+        part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=y.device)
+    check(_lib.lib().dsrg_relu_bwd_bias_bf16(_ptr(g), _ptr(y), _ptr(gm), _ptr(gb), _ptr(part), _PARTIAL_BLOCKS,
+                                             B * H * W, C, _stream()))
+    return gm, gb
+
+
+def maxpool3x3_out_size(n, stride, ceil_mode):
+    """output extent of a 3x3 / pad 1 pooling window walk over n pixels (Caffe's ceil rule, torch's with ceil_mode)"""
+    num = n + 2 - 3
+    o = (-(-num // stride) if ceil_mode else num // stride) + 1
+    if (o - 1) * stride >= n + 1:                       # the last window must start inside the image or its left pad
+        o -= 1
+    return o
+
+
+def maxpool3x3_fwd(x, stride, ceil_mode):
+    """x (B,C,H,W) bf16 channels_last -> (pooled (B,C,OH,OW) channels_last, window codes (B,OH,OW,C) uint8)"""
+    B, C, H, W = x.shape
+    OH, OW = maxpool3x3_out_size(H, stride, ceil_mode), maxpool3x3_out_size(W, stride, ceil_mode)
+    out = torch.empty((B, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    code = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().dsrg_maxpool3x3_fwd_bf16(_ptr(x), _ptr(out), _ptr(code), B, H, W, OH, OW, C, stride, _stream()))
+    return out, code
+
+
+def maxpool3x3_bwd(gout, code, in_shape, stride):
+    B, C, H, W = in_shape
+    OH, OW = gout.shape[2], gout.shape[3]
+    gout = gout.contiguous(memory_format=torch.channels_last)
+    gin = torch.empty((B, C, H, W), dtype=gout.dtype, device=gout.device, memory_format=torch.channels_last)
+    check(_lib.lib().dsrg_maxpool3x3_bwd_bf16(_ptr(gout), _ptr(code), _ptr(gin), B, H, W, OH, OW, C, stride, _stream()))
+    return gin
+
+
 class DSRGSupervision(torch.autograd.Function):
     """loss-Seed + loss-Constrain as a differentiable function of the fc8 logits."""
 

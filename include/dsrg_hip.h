@@ -162,6 +162,17 @@ int dsrg_constrain_loss(int B, int C, int HW, const float *probs_dev, const floa
  * of a 3x3, stride-1, "same"-padded, dilated convolution for 2-byte elements (bf16/fp16), C % 8 == 0:
  *   out[(b,y,x)][tap][c] = in[b][y+(tap/3-1)*dil][x+(tap%3-1)*dil][c], zero outside the map. */
 int dsrg_im2col3x3_nhwc16(const void *in_dev, void *out_dev, int B, int H, int W, int C, int dilation, void *stream);
+/* ReLU backward fused with the bias-gradient reduction of the convolution in front of it: g, y (the ReLU output) and
+ * gm are (rows, C) bf16 row-major (NHWC activations), C % 8 == 0; gm = g where y > 0 else 0; bias_grad[c] = sum_r gm[r,c]
+ * (f32, summed in a fixed order).  partials: device scratch of partial_blocks * C floats. */
+int dsrg_relu_bwd_bias_bf16(const void *g_dev, const void *y_dev, void *gm_dev, float *bias_grad_dev, float *partials_dev,
+                            int partial_blocks, long rows, int C, void *stream);
+/* 3x3 max pooling, pad 1, stride 1 or 2, NHWC bf16 (the Pooling layers of train-s.prototxt:69-80 etc.; OH/OW chosen by
+ * the caller, ceil mode included).  code_dev: B*OH*OW*C bytes, the window position (3*dy+dx) of the first maximum. */
+int dsrg_maxpool3x3_fwd_bf16(const void *in_dev, void *out_dev, void *code_dev, int B, int H, int W, int OH, int OW, int C,
+                             int stride, void *stream);
+int dsrg_maxpool3x3_bwd_bf16(const void *gout_dev, const void *code_dev, void *gin_dev, int B, int H, int W, int OH, int OW,
+                             int C, int stride, void *stream);
 
 /* The five Python layers of train-s.prototxt:746-810 as ONE stream-ordered
  * sequence (Softmax -> CRF -> DSRG -> BalancedSeedLoss + ConstrainLoss, then
