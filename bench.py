@@ -175,6 +175,20 @@ def main():
         torch.cuda.synchronize()
         sup_ms = e0.elapsed_time(e1) / 10
 
+    # the region-growing kernel on its own (north_star asks for its HBM rate too): one bracket around 20 launches
+    srg_us = None
+    if args.mode != "train-f" and rank == 0:
+        refined, _ = ops.crf_refine(ops.softmax_forward(logits_fixed), images, ctx=ctx, want_log=False)
+        for _ in range(3):
+            ops.srg_grow(labels, cues, refined)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.srg_grow(labels, cues, refined)
+        e1.record()
+        torch.cuda.synchronize()
+        srg_us = e0.elapsed_time(e1) / 20 * 1e3
+
     if rank == 0:
         mg, mb = ctx.lattice_sizes(B) if args.mode != "train-f" else (0, [0])
         alg_bytes = sum(filter_bytes(2, mg, C, N) + filter_bytes(5, m, C, N) for m in mb)   # one filter launch
@@ -199,6 +213,26 @@ def main():
                         "note": "lattice values stay in LDS; algorithmic bytes are the stage-streamed traffic of "
                                 "SURVEY 8d, so frac may exceed what HBM counters show"}
         total_images = B * world * args.steps
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("kernels", {})
+        except Exception:
+            pass
+        other = []
+        if srg_us:
+            srg_bytes = 16 * C * N * B                  # cues + fp64 marginals in, seeds out, per image
+            other.append({"kernel": "srg_grow_kernel (seeded region growing, %d images)" % B, "bound": "hbm",
+                          "achieved": srg_bytes / (srg_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": srg_bytes / (srg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "traffic": pmc.get("dsrg::srg_grow_kernel", {}).get("hbm_bytes_per_launch"),
+                          "alg_bytes_per_launch": srg_bytes, "us_per_launch": srg_us,
+                          "note": "one workgroup per image; bounded by three dependent memory round trips, not bandwidth"})
+        if args.mode == "train":
+            tf = count_flops_per_image() * 3 * B * world * args.steps / dt / 1e12 / world
+            other.append({"kernel": "backbone convolutions (hipBLASLt / MIOpen / CK, MFMA bf16), whole step per GPU",
+                          "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                          "traffic": None, "note": "3 x forward flops of the conv stack / step time (supervision, "
+                                                   "pooling, optimizer included in the time)"})
         out = {
             "metric": "images/sec DSRG train step (VGG16 321x321, 21-class)" if args.mode == "train"
                       else ("images/sec train-f retrain step (%s %dx%d, softmax loss on pseudo-labels)" % (args.backbone, args.size, args.size)
@@ -221,6 +255,7 @@ def main():
             "supervision_ms_per_step": sup_ms,
             "backbone_tflops": (count_flops_per_image() * 3 * B * world * args.steps / dt / 1e12) if args.mode == "train" else None,
             "roofline": roofline,
+            "other_rooflines": other,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch_np)
