@@ -64,6 +64,9 @@ SIGNATURES = {
     "dsrg_softmax_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dsrg_seed_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dsrg_constrain_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dsrg_seed_loss_plain": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dsrg_expand_loss": (_i, [_i, _i, _i, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp]),
+    "dsrg_confusion_matrix": (_i, [_sz, _vp, _vp, _i, _i, _vp, _vp]),
     "dsrg_im2col3x3_nhwc16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dsrg_relu_bwd_bias_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, ctypes.c_long, _i, _vp]),
     "dsrg_maxpool3x3_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -261,6 +261,24 @@ extern "C" int dsrg_constrain_loss(int B, int C, int HW, const float *probs, con
     return launch_constrain_loss(B, C, HW, probs, logq, loss, gp, glq, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int dsrg_seed_loss_plain(int B, int C, int HW, const float *probs, const float *seeds, float *loss, float *grad,
+                                    void *stream) {
+    if (!probs || !seeds || (!loss && !grad)) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (B <= 0 || C <= 0 || HW <= 0) return set_error(DSRG_ERR_INVALID, "bad shape");
+    return launch_seed_loss_plain(B, C, HW, probs, seeds, loss, grad, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_expand_loss(int B, int C, int HW, const float *probs, const float *stat, double q_fg, double q_bg,
+                                float *loss, float *grad, void *scratch, void *stream) {
+    if (!probs || !stat || (!loss && !grad)) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (B <= 0 || C <= 0 || HW <= 0) return set_error(DSRG_ERR_INVALID, "bad shape");
+    return launch_expand_loss(B, C, HW, probs, stat, q_fg, q_bg, loss, grad, static_cast<double *>(scratch),
+                              static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_confusion_matrix(size_t n, const unsigned char *gt, const unsigned char *pred, int nclass, int rule_lt,
+                                     unsigned long long *hist, void *stream) {
+    if ((n && (!gt || !pred)) || !hist) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_confusion(n, gt, pred, nclass, rule_lt, hist, static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_im2col3x3_nhwc16(const void *in, void *out, int B, int H, int W, int C, int dilation, void *stream) {
     if (!in || !out || B < 1 || H < 1 || W < 1 || C < 1 || dilation < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
     return launch_im2col3x3(in, out, B, H, W, C, dilation, static_cast<hipStream_t>(stream));

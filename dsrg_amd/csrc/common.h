@@ -114,6 +114,11 @@ int launch_sup_loss_backward(int B, int C, int HW, const float *logits, const fl
 int launch_lf_to_planes(int N, int M, const float *in, float *out, int negate, hipStream_t stream);
 int launch_planes_to_lf(int N, int M, const float *in, float *out, hipStream_t stream);
 int launch_argmax_planes(int N, int M, const float *q, int32_t *lab, hipStream_t stream);
+int launch_seed_loss_plain(int B, int C, int HW, const float *p, const float *S, float *loss, float *grad, hipStream_t stream);
+int launch_expand_loss(int B, int C, int HW, const float *p, const float *stat, double q_fg, double q_bg, float *loss,
+                       float *grad, double *terms, hipStream_t stream);
+int launch_confusion(size_t n, const unsigned char *gt, const unsigned char *pred, int nclass, int rule_lt,
+                     unsigned long long *hist, hipStream_t stream);
 int launch_im2col3x3(const void *in, void *out, int B, int H, int W, int C, int dil, hipStream_t stream);
 int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_grad, float *part, int part_blocks,
                          long rows, int C, hipStream_t stream);

@@ -95,6 +95,21 @@ class ConfusionMatrix(object):
         self.M += np.bincount(gt[keep].astype(np.int64) * self.nclass + pred[keep].astype(np.int64),
                               minlength=self.nclass ** 2).reshape(self.nclass, self.nclass)
 
+    def add_device(self, gt, pred):
+        """`add` for uint8 CUDA tensors: the histogram runs on the GPU (dsrg_confusion_matrix), M is updated on the host"""
+        from . import ops
+        h = ops.confusion_matrix(gt.reshape(-1), pred.reshape(-1), self.nclass).cpu().numpy()
+        assert h[-1] == 0, "labels or predictions outside [0, nclass)"
+        self.M += h[:-1].reshape(self.nclass, self.nclass).astype(np.float64)
+
+    def generateM(self, item):
+        """evaluate.py:61-68: the matrix of one (gt, pred) pair, keeping ground truth < nclass"""
+        gt, pred = np.asarray(item[0]).ravel(), np.asarray(item[1]).ravel()
+        assert len(gt) == len(pred)
+        keep = gt < self.nclass
+        return np.bincount(gt[keep].astype(np.int64) * self.nclass + pred[keep].astype(np.int64),
+                           minlength=self.nclass ** 2).reshape(self.nclass, self.nclass).astype(np.float64)
+
     def addM(self, matrix):
         assert matrix.shape == self.M.shape
         self.M += matrix

@@ -92,6 +92,45 @@ class BalancedSeedLossLayer(_Base):
         bottom[0].diff[...] = grad.cpu().numpy()
 
 
+class SeedLossLayer(_Base):
+    """pylayers.py:94-118 (the unbalanced seeding loss of SEC; no seed_mc prototxt uses it).  bottom = [probs, seeds]."""
+
+    def setup(self, bottom, top):
+        if len(bottom) != 2:
+            raise Exception("The layer needs two inputs!")
+
+    def reshape(self, bottom, top):
+        top[0].reshape(1)
+
+    def forward(self, bottom, top):
+        loss, _ = ops.seed_loss_plain(_dev(bottom[0].data), _dev(bottom[1].data), want_grad=False)
+        top[0].data[...] = loss.cpu().numpy()
+
+    def backward(self, top, prop_down, bottom):
+        _, grad = ops.seed_loss_plain(_dev(bottom[0].data), _dev(bottom[1].data), want_grad=True)
+        bottom[0].diff[...] = grad.cpu().numpy()
+
+
+class ExpandLossLayer(_Base):
+    """pylayers.py:183-233 (SEC's expansion loss: global weighted rank pooling with q = 0.996 / 0.999, one sort per
+    label plane).  bottom = [probs (B,21,41,41), image-level labels (B,1,1,21)]."""
+
+    def setup(self, bottom, top):
+        if len(bottom) != 2:
+            raise Exception("The layer needs two inputs!")
+
+    def reshape(self, bottom, top):
+        top[0].reshape(1)
+
+    def forward(self, bottom, top):
+        loss, _ = ops.expand_loss(_dev(bottom[0].data), _dev(bottom[1].data), want_grad=False)
+        top[0].data[...] = loss.cpu().numpy()
+
+    def backward(self, top, prop_down, bottom):
+        _, grad = ops.expand_loss(_dev(bottom[0].data), _dev(bottom[1].data), want_grad=True)
+        bottom[0].diff[...] = grad.cpu().numpy()
+
+
 class ConstrainLossLayer(_Base):
     """pylayers.py:154-180.  bottom = [probs, crf_log]."""
 
@@ -198,3 +237,78 @@ class AnnotationLayer(_Base):
 
     def backward(self, top, prop_down, bottom):
         pass
+
+
+class AnnotationLayerCOCO(_Base):
+    """pylayers.py:387-507: a self-feeding data layer for the 81-class COCO variant.  `source` lists
+    `image_path label_path` pairs under `root`; every forward loads `batch_size` pairs, resizes the image to
+    `new_size` (bilinear, scipy zoom order 1 as the reference), RGB, mean-subtracted, CHW; the label PNG becomes
+    81 one-hot cue planes (ignore_label skipped) and the image-level label vector (1,1,81); one random horizontal
+    flip for image and cues alike; the list is reshuffled at every epoch end.  Host-side marshalling only.
+    Differences forced by the image: PIL instead of the absent OpenCV; `param_str` parsed with ast.literal_eval
+    instead of eval; the per-pixel Python loop over the label is one vectorised scatter."""
+
+    num_classes = 81
+
+    def setup(self, bottom, top):
+        import ast
+        layer_params = ast.literal_eval(self.param_str)
+        self.source = layer_params['source']
+        self.root_folder = layer_params['root']
+        self.batch_size = layer_params['batch_size']
+        self.is_mirror = layer_params.get('mirror', False)
+        self.mean = layer_params['mean']
+        self.new_h, self.new_w = layer_params['new_size']
+        self.ignore_label = layer_params.get('ignore_label', 255)
+        with open(self.source) as f:
+            self.indexlist = [line.strip().split() for line in f if line.strip()]
+        self._cur = 0
+        top[0].reshape(self.batch_size, 1, 1, self.num_classes)
+        top[1].reshape(self.batch_size, self.num_classes, self.new_h // 8 + 1, self.new_w // 8 + 1)
+        top[2].reshape(self.batch_size, 3, self.new_h, self.new_w)
+
+    def reshape(self, bottom, top):
+        pass
+
+    def backward(self, top, propagate_down, bottom):
+        pass
+
+    def forward(self, bottom, top):
+        for itt in range(self.batch_size):
+            im, label, image_label = self.load_next_image()
+            top[0].data[itt, ...] = image_label
+            top[1].data[itt, ...] = label
+            top[2].data[itt, ...] = im
+
+    def load_next_image(self):
+        from random import shuffle
+        from .data import _imread_bgr, _imread_gray
+        if self._cur == len(self.indexlist):
+            self._cur = 0
+            shuffle(self.indexlist)
+        image_file_path, label_file_path = self.indexlist[self._cur]
+        image = _imread_bgr(self.root_folder + image_file_path)
+        label = _imread_gray(self.root_folder + label_file_path)
+        self._cur += 1
+        return self.preprocess(image, label)
+
+    def preprocess(self, image, label):
+        from scipy.ndimage import zoom
+        image = zoom(np.asarray(image).astype('float32'),
+                     (self.new_h / float(image.shape[0]), self.new_w / float(image.shape[1]), 1.0), order=1)
+        image = image[:, :, [2, 1, 0]]
+        image = image - self.mean
+        image = image.transpose([2, 0, 1])
+        h, w = label.shape
+        cues = np.zeros((self.num_classes, h, w), dtype=np.uint8)
+        ys, xs = np.nonzero(label != self.ignore_label)
+        cues[label[ys, xs], ys, xs] = 1
+        if self.is_mirror:
+            flip = np.random.choice(2) * 2 - 1
+            image = image[:, :, ::flip]
+            cues = cues[:, :, ::flip]
+        unique_inst = np.unique(label)
+        unique_inst = unique_inst[unique_inst != self.ignore_label]
+        image_label = np.zeros((1, 1, self.num_classes))
+        image_label[0, 0, unique_inst] = 1
+        return image, cues, image_label

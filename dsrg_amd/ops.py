@@ -183,6 +183,45 @@ def constrain_loss(probs, logq, want_grad=True):
     return loss, gp, gq
 
 
+def seed_loss_plain(probs, seeds, want_grad=True):
+    """SeedLossLayer forward/backward (pylayers.py:94-118) -> (loss (1,), grad or None)."""
+    _f32c(probs, "probs"), _f32c(seeds, "seeds")
+    B, C, H, W = probs.shape
+    loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+    grad = torch.empty_like(probs) if want_grad else None
+    check(_lib.lib().dsrg_seed_loss_plain(B, C, H * W, _ptr(probs), _ptr(seeds), _ptr(loss), _ptr(grad), _stream()))
+    return loss, grad
+
+
+def expand_loss(probs, stat, want_grad=True, q_fg=0.996, q_bg=0.999):
+    """ExpandLossLayer forward/backward (pylayers.py:183-233): probs (B,C,H,W), stat (B,1,1,C) image-level labels."""
+    _f32c(probs, "probs"), _f32c(stat, "stat")
+    B, C, H, W = probs.shape
+    if stat.numel() != B * C:
+        raise ValueError("stat must hold B*C values")
+    loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+    grad = torch.empty_like(probs) if want_grad else None
+    scratch = torch.empty(B * C, dtype=torch.float64, device=probs.device)
+    check(_lib.lib().dsrg_expand_loss(B, C, H * W, _ptr(probs), _ptr(stat), float(q_fg), float(q_bg), _ptr(loss), _ptr(grad),
+                                      _ptr(scratch), _stream()))
+    return loss, grad
+
+
+def confusion_matrix(gt, pred, nclass, rule_lt=False, hist=None):
+    """evaluate.py:25-30 (`add`: gt != 255) / :61-68 (`generateM`: gt < nclass) on uint8 CUDA tensors.
+    Returns the (nclass*nclass + 1) int64 counters (added to `hist` when given); the last counts out-of-range labels."""
+    if not (gt.is_cuda and pred.is_cuda and gt.dtype == torch.uint8 and pred.dtype == torch.uint8):
+        raise ValueError("gt and pred must be uint8 CUDA tensors")
+    gt, pred = gt.contiguous(), pred.contiguous()
+    if gt.numel() != pred.numel():
+        raise ValueError("gt and pred differ in size")
+    if hist is None:
+        hist = torch.zeros(nclass * nclass + 1, dtype=torch.int64, device=gt.device)
+    check(_lib.lib().dsrg_confusion_matrix(gt.numel(), _ptr(gt), _ptr(pred), int(nclass), int(bool(rule_lt)), _ptr(hist),
+                                           _stream()))
+    return hist
+
+
 def supervision_step(logits, images, labels, cues, th1=0.99, th2=0.85, scale_factor=12.0, maxiter=10,
                      ctx=None, want_blobs=False, prepared=False):
     """The five Python layers of train-s.prototxt:746-810, forward and backward, in one

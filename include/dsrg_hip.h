@@ -158,6 +158,22 @@ int dsrg_seed_loss(int B, int C, int HW, const float *probs_dev, const float *se
 int dsrg_constrain_loss(int B, int C, int HW, const float *probs_dev, const float *logq_dev,
                         float *loss_dev, float *grad_probs_dev, float *grad_logq_dev, void *stream);
 
+/* ---- the pylayers classes no seed_mc prototxt references, and the evaluation histogram ---------------- */
+/* SeedLossLayer (pylayers/pylayers/pylayers.py:94-118): L = -mean_b[ sum S log p / sum S ]; loss and/or grad may be NULL. */
+int dsrg_seed_loss_plain(int B, int C, int HW, const float *probs_dev, const float *seeds_dev, float *loss_dev,
+                         float *grad_dev, void *stream);
+/* ExpandLossLayer (pylayers.py:183-233): probs (B,C,HW), class 0 = background; stat (B,C) image-level labels (> 0.5 =
+ * present; stat[:,0] ignored); q_fg / q_bg = 0.996 / 0.999 in the reference.  HW <= 8192.  scratch_dev: B*C doubles
+ * (needed when loss_dev != NULL).  loss and/or grad may be NULL. */
+int dsrg_expand_loss(int B, int C, int HW, const float *probs_dev, const float *stat_dev, double q_fg, double q_bg,
+                     float *loss_dev, float *grad_dev, void *scratch_dev, void *stream);
+/* ConfusionMatrix.add (rule_lt = 0: pixels with gt != 255) / generateM (rule_lt = 1: gt < nclass) of
+ * training/tools/evaluate.py:25-30,61-68.  hist_dev: nclass*nclass + 1 unsigned 64-bit counters that are ADDED to
+ * (row = ground truth, column = prediction); the last one counts kept pixels whose gt or prediction is >= nclass.
+ * nclass <= 127. */
+int dsrg_confusion_matrix(size_t n, const unsigned char *gt_dev, const unsigned char *pred_dev, int nclass, int rule_lt,
+                          unsigned long long *hist_dev, void *stream);
+
 /* Backbone plumbing (no reference counterpart; Caffe's im2col lives in the external framework): NHWC im2col
  * of a 3x3, stride-1, "same"-padded, dilated convolution for 2-byte elements (bf16/fp16), C % 8 == 0:
  *   out[(b,y,x)][tap][c] = in[b][y+(tap/3-1)*dil][x+(tap%3-1)*dil][c], zero outside the map. */

@@ -718,6 +718,84 @@ ORC_API double orc_seed_loss(int B, int C, int HW, const float *p, const float *
     return loss;
 }
 
+/* SeedLossLayer (pylayers.py:94-118; not referenced by the seed_mc prototxts).
+ *   L = -mean_n[ sum_{c,hw} S log p / sum_{c,hw} S ]       (no 1e-4 floor: an empty seed map divides by zero, as Theano does) */
+ORC_API double orc_seed_loss_plain(int B, int C, int HW, const float *p, const float *S, float *grad) {
+    double loss = 0.0;
+    for (int b = 0; b < B; b++) {
+        const float *pb = p + (size_t)b * C * HW, *Sb = S + (size_t)b * C * HW;
+        double cnt = 0.0, l = 0.0;
+        for (size_t i = 0; i < (size_t)C * HW; i++) { cnt += Sb[i]; l += (double)Sb[i] * log((double)pb[i]); }
+        loss += -(l / cnt) / B;
+        if (grad) {
+            float *gb = grad + (size_t)b * C * HW;
+            for (size_t i = 0; i < (size_t)C * HW; i++) gb[i] = (float)(-(double)Sb[i] / ((double)pb[i] * cnt * B));
+        }
+    }
+    return loss;
+}
+
+/* ExpandLossLayer (pylayers.py:183-233; SEC's global weighted rank pooling, unused by seed_mc).
+ *   probs (B,C,HW) with class 0 = background; stat (B,C) image-level labels (stat[:,0] is ignored: pylayers.py:193).
+ *   For every plane: sort ascending, weights w_k = q^(HW-1-k) (largest value gets weight 1), pooled = sum_k sort_k w_k / Z;
+ *   q = 0.996 for the C-1 foreground planes, 0.999 for the background plane.  present = stat > 0.5.
+ *   L1 = -mean_b sum_{c present} log pooled_bc / n_present;  L2 = -mean_b sum_{c absent} log(1 - max_bc) / n_absent;
+ *   L3 = -mean_b log pooled_b0.  Ties: the sort is stable in the pixel index (lower index = lower rank); the max passes
+ *   its gradient to every tied pixel (Theano's eq-mask rule). */
+typedef struct { float v; int i; } orc_vi;
+static int orc_vi_cmp(const void *a, const void *b) {
+    const orc_vi *x = (const orc_vi *)a, *y = (const orc_vi *)b;
+    if (x->v < y->v) return -1;
+    if (x->v > y->v) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+ORC_API double orc_expand_loss(int B, int C, int HW, const float *p, const float *stat, double q_fg, double q_bg,
+                               float *grad) {
+    double *w_fg = (double *)malloc(sizeof(double) * HW), *w_bg = (double *)malloc(sizeof(double) * HW);
+    orc_vi *tmp = (orc_vi *)malloc(sizeof(orc_vi) * HW);
+    double z_fg = 0.0, z_bg = 0.0, loss = 0.0;
+    for (int k = 0; k < HW; k++) { w_fg[k] = pow(q_fg, (double)(HW - 1 - k)); w_bg[k] = pow(q_bg, (double)(HW - 1 - k)); }
+    for (int k = 0; k < HW; k++) { z_fg += w_fg[k]; z_bg += w_bg[k]; }
+    if (grad) memset(grad, 0, sizeof(float) * (size_t)B * C * HW);
+    for (int b = 0; b < B; b++) {
+        double n_pres = 0.0, n_abs = 0.0;
+        for (int c = 1; c < C; c++) { if (stat[(size_t)b * C + c] > 0.5f) n_pres += 1.0; else n_abs += 1.0; }
+        for (int c = 0; c < C; c++) {
+            const float *pl = p + ((size_t)b * C + c) * HW;
+            float *gl = grad ? grad + ((size_t)b * C + c) * HW : 0;
+            const double *w = c == 0 ? w_bg : w_fg;
+            const double z = c == 0 ? z_bg : z_fg;
+            const int present = c > 0 && stat[(size_t)b * C + c] > 0.5f;
+            if (c == 0 || present) {
+                for (int i = 0; i < HW; i++) { tmp[i].v = pl[i]; tmp[i].i = i; }
+                qsort(tmp, HW, sizeof(orc_vi), orc_vi_cmp);
+                double pooled = 0.0;
+                for (int k = 0; k < HW; k++) pooled += ((double)tmp[k].v * w[k]) / z;
+                const double coef = c == 0 ? 1.0 / B : 1.0 / (n_pres * B);
+                loss += -log(pooled) * coef;
+                if (gl) for (int k = 0; k < HW; k++) gl[tmp[k].i] = (float)(-coef / pooled * (w[k] / z));
+            } else {
+                float mx = pl[0];
+                for (int i = 1; i < HW; i++) if (pl[i] > mx) mx = pl[i];
+                const double coef = 1.0 / (n_abs * B);
+                loss += -log(1.0 - (double)mx) * coef;
+                if (gl) for (int i = 0; i < HW; i++) if (pl[i] == mx) gl[i] = (float)(coef / (1.0 - (double)mx));
+            }
+        }
+    }
+    free(w_fg); free(w_bg); free(tmp);
+    return loss;
+}
+
+/* ConfusionMatrix.add / generateM (training/tools/evaluate.py:25-30,61-68): M[gt, pred] += 1 over the pixels whose ground
+ * truth passes the rule (add: gt != 255; generateM: gt < nclass). */
+ORC_API void orc_confusion_matrix(size_t n, const unsigned char *gt, const unsigned char *pred, int nclass, int rule_lt,
+                                  double *M) {
+    for (size_t i = 0; i < n; i++) {
+        if (rule_lt ? gt[i] < nclass : gt[i] != 255) M[(size_t)gt[i] * nclass + pred[i]] += 1.0;
+    }
+}
+
 /* ConstrainLossLayer (pylayers.py:160-180).
  *   q = exp(lq);  L = mean_{n,hw} sum_c q log clip(q/p, 0.05, 20)
  *   dL/dp  = -(q/p) 1[0.05 <= q/p <= 20] / (B HW)

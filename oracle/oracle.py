@@ -58,6 +58,13 @@ def lib():
         L.orc_softmax_backward.argtypes = [ctypes.c_int] * 3 + [c_float_p, c_float_p, c_float_p]
         L.orc_seed_loss.argtypes = [ctypes.c_int] * 3 + [c_float_p, c_float_p, c_float_p]
         L.orc_seed_loss.restype = ctypes.c_double
+        L.orc_seed_loss_plain.argtypes = [ctypes.c_int] * 3 + [c_float_p, c_float_p, c_float_p]
+        L.orc_seed_loss_plain.restype = ctypes.c_double
+        L.orc_expand_loss.argtypes = [ctypes.c_int] * 3 + [c_float_p, c_float_p, ctypes.c_double, ctypes.c_double, c_float_p]
+        L.orc_expand_loss.restype = ctypes.c_double
+        L.orc_confusion_matrix.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_ubyte),
+                                           ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.orc_confusion_matrix.restype = None
         L.orc_constrain_loss.argtypes = [ctypes.c_int] * 3 + [c_float_p, c_float_p, c_float_p, c_float_p]
         L.orc_constrain_loss.restype = ctypes.c_double
         _LIB = L
@@ -216,6 +223,37 @@ def seed_loss(p, S, want_grad=True):
     loss = lib().orc_seed_loss(B, C, H * W, _p(p, c_float_p), _p(S, c_float_p),
                                _p(g, c_float_p) if want_grad else None)
     return loss, g
+
+
+def seed_loss_plain(p, S, want_grad=True):
+    """SeedLossLayer (pylayers.py:94-118)"""
+    p, S = _f32(p), _f32(S)
+    B, C, H, W = p.shape
+    g = np.empty_like(p) if want_grad else None
+    loss = lib().orc_seed_loss_plain(B, C, H * W, _p(p, c_float_p), _p(S, c_float_p),
+                                     _p(g, c_float_p) if want_grad else None)
+    return loss, g
+
+
+def expand_loss(p, stat, want_grad=True, q_fg=0.996, q_bg=0.999):
+    """ExpandLossLayer (pylayers.py:183-233): p (B,C,H,W), stat (B,1,1,C)"""
+    p, stat = _f32(p), _f32(stat)
+    B, C, H, W = p.shape
+    assert stat.size == B * C
+    g = np.empty_like(p) if want_grad else None
+    loss = lib().orc_expand_loss(B, C, H * W, _p(p, c_float_p), _p(stat, c_float_p), q_fg, q_bg,
+                                 _p(g, c_float_p) if want_grad else None)
+    return loss, g
+
+
+def confusion_matrix(gt, pred, nclass, rule_lt=False):
+    """evaluate.py:25-30 (rule gt != 255) / :61-68 (rule gt < nclass)"""
+    gt = np.ascontiguousarray(gt, dtype=np.uint8).ravel()
+    pred = np.ascontiguousarray(pred, dtype=np.uint8).ravel()
+    M = np.zeros((nclass, nclass), dtype=np.float64)
+    lib().orc_confusion_matrix(gt.size, _p(gt, ctypes.POINTER(ctypes.c_ubyte)), _p(pred, ctypes.POINTER(ctypes.c_ubyte)),
+                               nclass, int(rule_lt), _p(M, ctypes.POINTER(ctypes.c_double)))
+    return M
 
 
 def constrain_loss(p, lq, want_grad=True):

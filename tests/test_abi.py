@@ -112,3 +112,77 @@ def test_annotation_layer_cue_pickle_format(tmp_path):
                 assert same or flipped                       # cues and image flip together
             else:
                 assert np.array_equal(tops[1].data[n], cues) and np.array_equal(tops[2].data[n], imgs.data[n])
+
+
+def test_annotation_layer_coco(tmp_path):
+    """AnnotationLayerCOCO (pylayers.py:387-507): list of image/label pairs -> image-level labels (B,1,1,81), one-hot
+    cue planes (B,81,h,w), resized mean-subtracted RGB image; epoch wrap with reshuffle.  Checked against the reference's
+    per-pixel loop restated literally."""
+    from PIL import Image
+    from scipy.ndimage import zoom
+    import pylayers
+    rng = np.random.default_rng(1)
+    root = str(tmp_path) + "/"
+    new_h = new_w = 64
+    lh = lw = new_h // 8 + 1
+    names = []
+    for k in range(3):
+        img = rng.integers(0, 256, size=(40 + k, 50, 3), dtype=np.uint8)
+        lab = rng.integers(0, 81, size=(lh, lw)).astype(np.uint8)
+        lab[rng.random((lh, lw)) < 0.2] = 255
+        Image.fromarray(img).save(root + "im%d.png" % k)
+        Image.fromarray(lab).save(root + "lb%d.png" % k)
+        names.append(("im%d.png" % k, "lb%d.png" % k, img, lab))
+    with open(root + "list.txt", "w") as f:
+        for n in names:
+            f.write("%s %s\n" % (n[0], n[1]))
+    mean = (104.0, 117.0, 123.0)
+
+    class Blob(object):
+        def __init__(self):
+            self.data = np.zeros((0,), np.float32)
+
+        def reshape(self, *s):
+            self.data = np.zeros(s, np.float32)
+    lay = pylayers.AnnotationLayerCOCO()
+    lay.param_str = repr({'source': root + "list.txt", 'root': root, 'batch_size': 2, 'mean': mean,
+                          'new_size': (new_h, new_w), 'mirror': False})
+    tops = [Blob(), Blob(), Blob()]
+    lay.setup([], tops)
+    assert tops[0].data.shape == (2, 1, 1, 81) and tops[1].data.shape == (2, 81, lh, lw) and tops[2].data.shape == (2, 3, new_h, new_w)
+    lay.forward([], tops)
+    for n in range(2):
+        _, _, img, lab = names[n]
+        want_im = zoom(img.astype('float32'), (new_h / float(img.shape[0]), new_w / float(img.shape[1]), 1.0), order=1)
+        want_im = (want_im - mean).transpose(2, 0, 1)               # the file is RGB; BGR read then [2,1,0] gives RGB again
+        assert np.allclose(tops[2].data[n], want_im, atol=1e-4)
+        cues = np.zeros((81, lh, lw), np.uint8)
+        for (x, y), v in np.ndenumerate(lab):                        # pylayers.py:489-492
+            if not v == 255:
+                cues[v, x, y] = 1
+        assert np.array_equal(tops[1].data[n], cues)
+        want_lab = np.zeros(81)
+        want_lab[np.unique(lab[lab != 255])] = 1
+        assert np.array_equal(tops[0].data[n, 0, 0], want_lab)
+    lay.forward([], tops)                                            # third pair, then the epoch wraps and reshuffles
+    assert lay._cur == 1
+    lay2 = pylayers.AnnotationLayerCOCO()
+    lay2.param_str = lay.param_str.replace("'mirror': False", "'mirror': True")
+    lay2.setup([], tops)
+    np.random.seed(3)
+    im, cues, _ = lay2.load_next_image()
+    _, _, img, lab = names[0]
+    plain = np.zeros((81, lh, lw), np.uint8)
+    ys, xs = np.nonzero(lab != 255)
+    plain[lab[ys, xs], ys, xs] = 1
+    assert np.array_equal(cues, plain) or np.array_equal(cues, plain[:, :, ::-1])
+
+
+def test_pylayers_exports_every_reference_class():
+    """every layer class of pylayers/pylayers/pylayers.py is importable from the drop-in package"""
+    import pylayers
+    for name in ("SoftmaxLayer", "CRFLayer", "SeedLossLayer", "BalancedSeedLossLayer", "ConstrainLossLayer",
+                 "ExpandLossLayer", "DSRGLayer", "AnnotationLayer", "AnnotationLayerCOCO"):
+        cls = getattr(pylayers, name)
+        for m in ("setup", "reshape", "forward", "backward"):
+            assert callable(getattr(cls, m))

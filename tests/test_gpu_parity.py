@@ -377,3 +377,45 @@ def test_fused_step_other_shapes_vs_oracle(ops, O, B, C, HW):
         assert abs(losses[0].item() - l_seed) < 1e-4 * max(1, abs(l_seed))
         assert abs(losses[1].item() - l_con) < 1e-4 * max(1, abs(l_con))
         assert np.abs(grad.cpu().numpy() - want).max() < 2e-3 * np.abs(want).max()
+
+
+def test_unused_pylayers_vs_oracle(ops, O):
+    """SeedLossLayer, ExpandLossLayer (sort-weighted pooling) and the evaluation histogram on the GPU"""
+    rng = np.random.default_rng(11)
+    for B, C, H, W in [(3, 21, 41, 41), (2, 21, 65, 65), (2, 5, 9, 11)]:
+        logits = S.make_logits(rng, B, C, H, W, gain=6.0, sigma=2.0)
+        _, cues = S.make_labels_cues(rng, B, C, H, W)
+        p = O.softmax_forward(logits)
+        want_l, want_g = O.seed_loss_plain(p, cues)
+        loss, grad = ops.seed_loss_plain(dev(p), dev(cues))
+        assert abs(loss.item() - want_l) < 1e-5 * max(1, abs(want_l))
+        assert np.abs(grad.cpu().numpy() - want_g).max() < 1e-5 * max(1.0, np.abs(want_g).max())
+        stat = (rng.random((B, 1, 1, C)) < 0.3).astype(np.float32)
+        stat[:, 0, 0, 1] = 1.0                                           # at least one present and one absent class
+        stat[:, 0, 0, 2] = 0.0
+        want_l, want_g = O.expand_loss(p, stat)
+        loss, grad = ops.expand_loss(dev(p), dev(stat))
+        assert abs(loss.item() - want_l) < 1e-5 * max(1, abs(want_l)), (loss.item(), want_l)
+        assert np.abs(grad.cpu().numpy() - want_g).max() < 1e-5 * max(1.0, np.abs(want_g).max())
+        l2, g2 = ops.expand_loss(dev(p), dev(stat))                       # deterministic
+        assert l2.item() == loss.item() and torch.equal(g2, grad)
+    # ties: a constant plane keeps the stable pixel order of the oracle's sort
+    p = np.full((1, 3, 4, 4), 1.0 / 3, np.float32)
+    stat = np.array([1, 1, 0], np.float32).reshape(1, 1, 1, 3)
+    want_l, want_g = O.expand_loss(p, stat)
+    loss, grad = ops.expand_loss(dev(p), dev(stat))
+    assert abs(loss.item() - want_l) < 1e-6 and np.abs(grad.cpu().numpy() - want_g).max() < 1e-7
+    n = 21
+    gt = rng.integers(0, n, size=200000).astype(np.uint8)
+    gt[rng.random(gt.size) < 0.1] = 255
+    pred = rng.integers(0, n, size=gt.size).astype(np.uint8)
+    h = ops.confusion_matrix(dev(gt, torch.uint8), dev(pred, torch.uint8), n).cpu().numpy()
+    assert h[-1] == 0 and np.array_equal(h[:-1].reshape(n, n).astype(np.float64), O.confusion_matrix(gt, pred, n))
+    from dsrg_amd.inference import ConfusionMatrix
+    cm = ConfusionMatrix(n)
+    cm.add_device(dev(gt[:1000], torch.uint8), dev(pred[:1000], torch.uint8))
+    cm.add_device(dev(gt[1000:], torch.uint8), dev(pred[1000:], torch.uint8))
+    assert np.array_equal(cm.M, O.confusion_matrix(gt, pred, n))
+    gt2 = gt.copy(); gt2[:50] = 60
+    h = ops.confusion_matrix(dev(gt2, torch.uint8), dev(pred, torch.uint8), n, rule_lt=True).cpu().numpy()
+    assert np.array_equal(h[:-1].reshape(n, n).astype(np.float64), O.confusion_matrix(gt2, pred, n, rule_lt=True))

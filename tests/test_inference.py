@@ -75,3 +75,16 @@ def test_predict_mask_ms_vs_reference_restatement():
     # pseudo-label generation restricted to the image labels (generate_train_gt.py:78-106)
     mask = I.predict_train_gt(net, im, labels=[3, 7], smooth=True)
     assert set(np.unique(mask)) <= {0, 3, 7}
+
+
+def test_generate_m_rule():
+    """evaluate.py:61-68 keeps ground truth < nclass (not only != 255)"""
+    from dsrg_amd.inference import ConfusionMatrix
+    from oracle import oracle as O
+    rng = np.random.default_rng(2)
+    gt = rng.integers(0, 21, size=3000).astype(np.uint8)
+    gt[rng.random(3000) < 0.1] = 255
+    gt[rng.random(3000) < 0.05] = 60
+    pred = rng.integers(0, 21, size=3000).astype(np.uint8)
+    cm = ConfusionMatrix(21)
+    assert np.array_equal(cm.generateM((gt, pred)), O.confusion_matrix(gt, pred, 21, rule_lt=True))
