@@ -14,6 +14,10 @@ from . import _lib
 from ._lib import check
 
 
+def _is_cuda_tensor(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
 class DenseCRF(object):
     def __init__(self, W, H, nlabels):
         _lib.require_gpu()
@@ -24,7 +28,10 @@ class DenseCRF(object):
 
     def __del__(self):
         if getattr(self, "_h", None):
-            _lib.lib().dsrg_crf_destroy(self._h)
+            try:
+                _lib.lib().dsrg_crf_destroy(self._h)
+            except Exception:                # interpreter teardown: the module globals may already be gone
+                pass
             self._h = None
 
     def npixels(self):
@@ -33,27 +40,52 @@ class DenseCRF(object):
     def nlabels(self):
         return _lib.lib().dsrg_crf_nlabels(self._h)
 
+    # numpy in / numpy out as the Cython class; CUDA tensors in (and `out=` CUDA tensors) stay on the device.
+
     def set_unary_energy(self, unary_costs):
-        u = np.ascontiguousarray(unary_costs, dtype=np.float32).ravel()
-        if u.size != self.npixels() * self.nlabels():
+        if _is_cuda_tensor(unary_costs):
+            import torch
+            u = unary_costs.reshape(-1).to(torch.float32).contiguous()
+            ptr, n = ctypes.c_void_p(u.data_ptr()), u.numel()
+        else:
+            u = np.ascontiguousarray(unary_costs, dtype=np.float32).ravel()
+            ptr, n = u.ctypes.data_as(ctypes.c_void_p), u.size
+        if n != self.npixels() * self.nlabels():
             raise ValueError("unary_costs must hold npixels*nlabels floats")
-        check(_lib.lib().dsrg_crf_set_unary_energy(self._h, u.ctypes.data_as(ctypes.c_void_p)))
+        check(_lib.lib().dsrg_crf_set_unary_energy(self._h, ptr))
 
     def add_pairwise_energy(self, w1, theta_alpha_1, theta_alpha_2, theta_betta_1, theta_betta_2, theta_betta_3,
                             w2, theta_gamma_1, theta_gamma_2, im):
-        im = np.ascontiguousarray(im, dtype=np.uint8).ravel()
-        if im.size != self.npixels() * 3:
+        if _is_cuda_tensor(im):
+            import torch
+            im = im.reshape(-1).to(torch.uint8).contiguous()
+            ptr, n = ctypes.c_void_p(im.data_ptr()), im.numel()
+        else:
+            im = np.ascontiguousarray(im, dtype=np.uint8).ravel()
+            ptr, n = im.ctypes.data_as(ctypes.c_void_p), im.size
+        if n != self.npixels() * 3:
             raise ValueError("im must hold npixels*3 bytes")
         check(_lib.lib().dsrg_crf_add_pairwise_energy(self._h, w1, theta_alpha_1, theta_alpha_2, theta_betta_1,
                                                       theta_betta_2, theta_betta_3, w2, theta_gamma_1,
-                                                      theta_gamma_2, im.ctypes.data_as(ctypes.c_void_p)))
+                                                      theta_gamma_2, ptr))
 
-    def inference(self, n_iters=10):
+    def inference(self, n_iters=10, out=None):
+        if out is not None:
+            if not (_is_cuda_tensor(out) and out.is_contiguous() and out.numel() == self.npixels() * self.nlabels()
+                    and out.element_size() == 4):
+                raise ValueError("out must be a contiguous float32 CUDA tensor of npixels*nlabels values")
+            check(_lib.lib().dsrg_crf_inference(self._h, int(n_iters), ctypes.c_void_p(out.data_ptr())))
+            return out
         probs = np.empty(self.npixels() * self.nlabels(), dtype=np.float32)
         check(_lib.lib().dsrg_crf_inference(self._h, int(n_iters), probs.ctypes.data_as(ctypes.c_void_p)))
         return probs
 
-    def map(self, n_iters=10):
+    def map(self, n_iters=10, out=None):
+        if out is not None:
+            if not (_is_cuda_tensor(out) and out.is_contiguous() and out.numel() == self.npixels() and out.element_size() == 4):
+                raise ValueError("out must be a contiguous int32 CUDA tensor of npixels values")
+            check(_lib.lib().dsrg_crf_map(self._h, int(n_iters), ctypes.c_void_p(out.data_ptr())))
+            return out
         labels = np.empty(self.npixels(), dtype=np.int32)
         check(_lib.lib().dsrg_crf_map(self._h, int(n_iters), labels.ctypes.data_as(ctypes.c_void_p)))
         return labels
@@ -76,3 +108,22 @@ def CRF(image, unary, maxiter=10, scale_factor=1.0, color_factor=13):
                             3, 3 / scale_factor, 3 / scale_factor, image.ravel().astype('ubyte'))
     prediction = crf.inference(maxiter).reshape((H, W, nlables))
     return prediction
+
+
+def CRF_device(image, unary, maxiter=10, scale_factor=1.0, color_factor=13, want="marginals"):
+    """`CRF()` for a device-resident caller: image (H,W,3) uint8 and unary (H,W,M) float32 CUDA tensors in, a CUDA tensor
+    out — (H,W,M) float32 marginals, or with want="map" the (H,W) int32 arg-max labels — without a PCIe round trip.
+    Same statements as CRF() (CRF.py:19-37)."""
+    import torch
+    assert image.shape[:2] == unary.shape[:2]
+    H, W = image.shape[:2]
+    nlables = unary.shape[2]
+    if torch.cuda.current_stream(unary.device) != torch.cuda.default_stream(unary.device):
+        torch.cuda.current_stream(unary.device).synchronize()     # the object API works on the null stream
+    crf = DenseCRF(W, H, nlables)
+    crf.set_unary_energy(-unary.to(torch.float32))
+    crf.add_pairwise_energy(10, 80 / scale_factor, 80 / scale_factor, color_factor, color_factor, color_factor,
+                            3, 3 / scale_factor, 3 / scale_factor, image)
+    if want == "map":
+        return crf.map(maxiter, out=torch.empty((H, W), dtype=torch.int32, device=unary.device))
+    return crf.inference(maxiter, out=torch.empty((H, W, nlables), dtype=torch.float32, device=unary.device))

@@ -444,7 +444,7 @@ extern "C" int dsrg_crf_set_unary_energy(dsrg_crf_t h, const float *unary_host) 
     if (!h || !unary_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
     if (h->large) { int rc = large_crf_set_unary(h->large, unary_host); if (!rc) h->have_unary = true; return rc; }
     const int N = h->W * h->H;
-    DSRG_HIP_CHECK(hipMemcpy(h->stage, unary_host, sizeof(float) * (size_t)N * h->M, hipMemcpyHostToDevice));
+    DSRG_HIP_CHECK(hipMemcpy(h->stage, unary_host, sizeof(float) * (size_t)N * h->M, hipMemcpyDefault));
     int rc = launch_lf_to_planes(N, h->M, h->stage, h->neg_unary, 1, nullptr);   // inference uses -unary (densecrf.cpp:120,122)
     if (rc) return rc;
     DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -461,7 +461,7 @@ extern "C" int dsrg_crf_add_pairwise_energy(dsrg_crf_t h, float w1, float ta1, f
     int rc = check_params(&p);
     if (rc) return rc;
     if (h->large) { rc = large_crf_set_image(h->large, im_host); if (rc) return rc; }
-    else DSRG_HIP_CHECK(hipMemcpy(h->im, im_host, (size_t)h->W * h->H * 3, hipMemcpyHostToDevice));
+    else DSRG_HIP_CHECK(hipMemcpy(h->im, im_host, (size_t)h->W * h->H * 3, hipMemcpyDefault));
     h->prm = p;
     h->have_pairwise = true;
     return DSRG_OK;
@@ -491,7 +491,7 @@ extern "C" int dsrg_crf_inference(dsrg_crf_t h, int n_iters, float *out_host) {
     const int N = h->W * h->H;
     rc = launch_planes_to_lf(N, h->M, h->q, h->stage, nullptr);
     if (rc) return rc;
-    DSRG_HIP_CHECK(hipMemcpy(out_host, h->stage, sizeof(float) * (size_t)N * h->M, hipMemcpyDeviceToHost));
+    DSRG_HIP_CHECK(hipMemcpy(out_host, h->stage, sizeof(float) * (size_t)N * h->M, hipMemcpyDefault));
     return DSRG_OK;
 }
 extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
@@ -502,7 +502,7 @@ extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
     const int N = h->W * h->H;
     rc = launch_argmax_planes(N, h->M, h->q, h->lab, nullptr);
     if (rc) return rc;
-    DSRG_HIP_CHECK(hipMemcpy(labels_host, h->lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+    DSRG_HIP_CHECK(hipMemcpy(labels_host, h->lab, sizeof(int32_t) * (size_t)N, hipMemcpyDefault));
     return DSRG_OK;
 }
 extern "C" int dsrg_crf_lattice_size(dsrg_crf_t h, int k) {

@@ -166,10 +166,12 @@ __global__ void lg_norm_kernel(LargeLattice L, int D1, const float *__restrict__
 
 // ---- CP-channel filter (Permutohedral::sseCompute, permutohedral.cpp:529-589); in/out are [N][CP]
 // one wave per vertex, lanes = channels: ordered accumulation of the vertex's row of (pixel, weight) entries
-__global__ __launch_bounds__(256) void lg_splat_kernel(LargeLattice L, int CP, const float *__restrict__ in,
+// One group of LPV lanes (the power of two >= CP, at most a wave) per vertex: with 21 labels padded to 24 a whole wave
+// per vertex would idle 40 of its 64 lanes.  No cross-lane traffic, so the groups of a wave are independent.
+__global__ __launch_bounds__(256) void lg_splat_kernel(LargeLattice L, int CP, int lpv_shift, const float *__restrict__ in,
                                                         float *__restrict__ val) {
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & ((1 << lpv_shift) - 1);
+    const int v = blockIdx.x * (blockDim.x >> lpv_shift) + (threadIdx.x >> lpv_shift);
     const int M = *L.M;
     if (v == 0 && lane < CP) val[(size_t)M * CP + lane] = 0.0f;          // zero row = "no neighbour"
     if (v >= M || lane >= CP) return;
@@ -192,7 +194,6 @@ __global__ __launch_bounds__(256) void lg_splat_kernel(LargeLattice L, int CP, c
     }
     val[(size_t)v * CP + lane] = s;
 }
-// thread per (vertex, 4 channels)
 __global__ void lg_blur_kernel(LargeLattice L, int CP4, int j, const float4 *__restrict__ a, float4 *__restrict__ b) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int M = *L.M;
@@ -299,6 +300,8 @@ struct LargeCrf {
     unsigned char *im;                     // [N][3]
     int32_t *lab;
     float *stage;                          // [N][C] host-layout staging
+    bool lattices_valid;                   // Lg/Lb were built for the current image and kernel widths
+    dsrg_crf_params built_for;
 };
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -420,7 +423,10 @@ static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipSt
 
 static int large_filter(LargeCrf *c, LargeLattice &L, float w, float *out, hipStream_t s) {
     const int D1 = L.d + 1, CP = c->CP, CP4 = CP / 4, M = L.M_host;
-    hipLaunchKernelGGL(lg_splat_kernel, dim3(blocks_for((size_t)M + 1, 4)), dim3(256), 0, s, L, CP, c->q, c->val_a);
+    int lpv_shift = 3;
+    while ((1 << lpv_shift) < CP && lpv_shift < 6) lpv_shift++;
+    hipLaunchKernelGGL(lg_splat_kernel, dim3(blocks_for((size_t)M + 1, 256 >> lpv_shift)), dim3(256), 0, s, L, CP, lpv_shift,
+                       c->q, c->val_a);
     float *a = c->val_a, *b = c->val_b;
     for (int j = 0; j < D1; j++) {
         hipLaunchKernelGGL(lg_blur_kernel, dim3(blocks_for((size_t)(M + 1) * CP4, 256)), dim3(256), 0, s, L, CP4, j,
@@ -433,8 +439,10 @@ static int large_filter(LargeCrf *c, LargeLattice &L, float w, float *out, hipSt
     return DSRG_OK;
 }
 
-int large_crf_set_unary(LargeCrf *c, const float *unary_host) {
-    DSRG_HIP_CHECK(hipMemcpy(c->stage, unary_host, sizeof(float) * (size_t)c->N * c->C, hipMemcpyHostToDevice));
+// `unary` / `im` / outputs may be host or device pointers (hipMemcpyDefault resolves the kind): the test-time pipeline
+// keeps its scores on the GPU, the Cython-style callers pass numpy memory.
+int large_crf_set_unary(LargeCrf *c, const float *unary) {
+    DSRG_HIP_CHECK(hipMemcpy(c->stage, unary, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault));
     hipLaunchKernelGGL(lg_pad_rows_kernel, dim3(blocks_for((size_t)c->N * c->CP, 256)), dim3(256), 0, 0, c->N, c->C,
                        c->CP, c->stage, c->neg_unary, 1);
     DSRG_LAUNCH_CHECK();
@@ -445,8 +453,9 @@ int large_crf_zero_unary(LargeCrf *c) {
     DSRG_HIP_CHECK(hipMemset(c->neg_unary, 0, sizeof(float) * (size_t)c->N * c->CP));
     return DSRG_OK;
 }
-int large_crf_set_image(LargeCrf *c, const unsigned char *im_host) {
-    DSRG_HIP_CHECK(hipMemcpy(c->im, im_host, (size_t)c->N * 3, hipMemcpyHostToDevice));
+int large_crf_set_image(LargeCrf *c, const unsigned char *im) {
+    DSRG_HIP_CHECK(hipMemcpy(c->im, im, (size_t)c->N * 3, hipMemcpyDefault));
+    c->lattices_valid = false;
     return DSRG_OK;
 }
 
@@ -457,10 +466,18 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
     lattice_feat_init(Fg, 2, c->W, c->H, prm->theta_gamma_x, prm->theta_gamma_y, 1.f, 1.f, 1.f);
     lattice_feat_init(Fb, 5, c->W, c->H, prm->theta_alpha_x, prm->theta_alpha_y, prm->theta_beta_r, prm->theta_beta_g,
                       prm->theta_beta_b);
-    int rc = large_build<2>(c, c->Lg, Fg, s);
-    if (rc) return rc;
-    rc = large_build<5>(c, c->Lb, Fb, s);
-    if (rc) return rc;
+    int rc = DSRG_OK;
+    // the lattices belong to addPairwiseEnergy (densecrf.cpp:61-81): repeated inference() calls reuse them
+    const bool same_kernels = c->lattices_valid && memcmp(&c->built_for, prm, offsetof(dsrg_crf_params, n_iters)) == 0;
+    if (!same_kernels) {
+        c->lattices_valid = false;
+        rc = large_build<2>(c, c->Lg, Fg, s);
+        if (rc) return rc;
+        rc = large_build<5>(c, c->Lb, Fb, s);
+        if (rc) return rc;
+        c->built_for = *prm;
+        c->lattices_valid = true;
+    }
     const size_t need = (size_t)(c->Lg.M_host > c->Lb.M_host ? c->Lg.M_host : c->Lb.M_host) + 1;
     if (need > c->val_rows) {
         if (c->val_a) (void)hipFree(c->val_a);
@@ -491,13 +508,13 @@ int large_crf_read_q(LargeCrf *c, float *out_host) {
     hipLaunchKernelGGL(lg_unpad_rows_kernel, dim3(blocks_for((size_t)c->N * c->C, 256)), dim3(256), 0, 0, c->N, c->C,
                        c->CP, c->q, c->stage);
     DSRG_LAUNCH_CHECK();
-    DSRG_HIP_CHECK(hipMemcpy(out_host, c->stage, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDeviceToHost));
+    DSRG_HIP_CHECK(hipMemcpy(out_host, c->stage, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault));
     return DSRG_OK;
 }
 int large_crf_read_map(LargeCrf *c, int32_t *labels_host) {
     hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, 0, c->N, c->C, c->CP, c->q, c->lab);
     DSRG_LAUNCH_CHECK();
-    DSRG_HIP_CHECK(hipMemcpy(labels_host, c->lab, sizeof(int32_t) * (size_t)c->N, hipMemcpyDeviceToHost));
+    DSRG_HIP_CHECK(hipMemcpy(labels_host, c->lab, sizeof(int32_t) * (size_t)c->N, hipMemcpyDefault));
     return DSRG_OK;
 }
 int large_crf_lattice_size(LargeCrf *c, int k) { return k == 0 ? c->Lg.M_host : c->Lb.M_host; }

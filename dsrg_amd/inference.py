@@ -8,13 +8,13 @@ full-resolution dense CRF on log-probabilities, pseudo-label generation, and the
 
 The network runs in PyTorch-ROCm; resampling uses align-corners bilinear interpolation, which is the
 sampling scipy.ndimage.zoom(order=1) performs ((in-1)/(out-1) mapping); the CRF is
-krahenbuhl2013.CRF -> libdsrg_hip.so (global-memory lattice path for full-resolution maps).
+krahenbuhl2013.CRF (device-resident form crf.CRF_device) -> libdsrg_hip.so (global-memory lattice path for full-resolution maps).
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-import krahenbuhl2013
+from .crf import CRF_device
 
 MEAN_PIXEL = (104.0, 117.0, 123.0)
 
@@ -56,9 +56,10 @@ def predict_mask_ms(net, image, smooth=True, sizes=(241, 321, 401), device="cuda
     """test-ms.py:84-111 -> (H,W) int64 label mask"""
     probs = _probs_from_scores(multiscale_scores(net, image, sizes, device))
     if smooth:
-        unary = torch.log(probs).permute(1, 2, 0).contiguous().cpu().numpy()
-        q = krahenbuhl2013.CRF(np.asarray(image), unary, scale_factor=1.0)
-        return np.argmax(q, axis=2)
+        # scores, log-probabilities, CRF and arg-max all stay on the GPU; only the (H,W) mask crosses PCIe
+        unary = torch.log(probs).permute(1, 2, 0).contiguous()
+        img = torch.as_tensor(np.asarray(image).astype('ubyte'), device=unary.device)
+        return CRF_device(img, unary, scale_factor=1.0, want="map").cpu().numpy().astype(np.int64)
     return probs.argmax(0).cpu().numpy()
 
 
@@ -71,12 +72,13 @@ def predict_train_gt(net, image, labels, smooth=True, device="cuda"):
     probs = _zoom(torch.softmax(scores, dim=1), d1, d2)[0]
     probs = torch.clamp(probs, min=0.00001)
     if smooth:
-        unary = torch.log(probs).permute(1, 2, 0).contiguous().cpu().numpy()
-        p = krahenbuhl2013.CRF(np.asarray(image), unary, scale_factor=1.0)
+        unary = torch.log(probs).permute(1, 2, 0).contiguous()
+        img = torch.as_tensor(np.asarray(image).astype('ubyte'), device=unary.device)
+        p = CRF_device(img, unary, scale_factor=1.0)
     else:
-        p = probs.permute(1, 2, 0).cpu().numpy()
-    sel = [0] + [int(l) for l in labels]
-    return np.asarray(sel)[np.argmax(p[:, :, sel], axis=2)]
+        p = probs.permute(1, 2, 0)
+    sel = torch.as_tensor([0] + [int(l) for l in labels], device=p.device)
+    return sel[p[:, :, sel].argmax(2)].cpu().numpy()
 
 
 class ConfusionMatrix(object):

@@ -50,7 +50,9 @@ typedef struct dsrg_crf_s *dsrg_crf_t;
 int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out);
 /* DenseCRFWrapper::~DenseCRFWrapper                             densecrf_wrapper.cpp:10-12 */
 int dsrg_crf_destroy(dsrg_crf_t h);
-/* DenseCRFWrapper::set_unary_energy(float*)                     densecrf_wrapper.cpp:32-37
+/* The four data pointers of this object API (`unary_host`, `im_host`, `out_host`, `labels_host`) may be host OR device
+ * pointers — the copies use hipMemcpyDefault — so a device-resident caller (dsrg_amd/inference.py) skips the PCIe trips.
+ * DenseCRFWrapper::set_unary_energy(float*)                     densecrf_wrapper.cpp:32-37
  * unary_host: [W*H*nlabels], label-fastest (copied). */
 int dsrg_crf_set_unary_energy(dsrg_crf_t h, const float *unary_host);
 /* DenseCRFWrapper::add_pairwise_energy(...)                     densecrf_wrapper.cpp:19-30

@@ -22,6 +22,14 @@ for (H, W) in [(321, 321), (375, 500)]:
     t = time.perf_counter()
     for _ in range(5): c.inference(10)
     inf_ms = (time.perf_counter() - t) / 5 * 1e3
+    imd, und = torch.from_numpy(im).cuda(), torch.from_numpy(un.astype(np.float32)).cuda()
+    qd = krahenbuhl2013.CRF_device(imd, und, scale_factor=1.0)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): qd = krahenbuhl2013.CRF_device(imd, und, scale_factor=1.0)
+    torch.cuda.synchronize(); dev_ms = (time.perf_counter() - t) / 5 * 1e3
+    assert np.array_equal(qd.cpu().numpy(), q), "device-pointer path differs from the host-pointer path"
+    lab = krahenbuhl2013.CRF_device(imd, und, scale_factor=1.0, want="map")
+    assert np.array_equal(lab.cpu().numpy(), q.argmax(2))
     t = time.perf_counter(); qo = O.CRF(im, un, scale_factor=1.0); cpu_ms = (time.perf_counter() - t) * 1e3
-    print("%dx%d: GPU CRF() %.2f ms (inference only %.2f ms), CPU oracle %.1f ms, M_gauss %d M_bil %d, max|dQ| %.2e, argmax agree %.5f" % (
-        H, W, gpu_ms, inf_ms, cpu_ms, c.lattice_size(0), c.lattice_size(1), np.abs(q - qo).max(), (q.argmax(2) == qo.argmax(2)).mean()), flush=True)
+    print("%dx%d: GPU CRF() %.2f ms from numpy, %.2f ms device-resident (inference only %.2f ms), CPU oracle %.1f ms, M_gauss %d M_bil %d, max|dQ| %.2e, argmax agree %.5f" % (
+        H, W, gpu_ms, dev_ms, inf_ms, cpu_ms, c.lattice_size(0), c.lattice_size(1), np.abs(q - qo).max(), (q.argmax(2) == qo.argmax(2)).mean()), flush=True)
