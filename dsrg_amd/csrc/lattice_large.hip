@@ -166,74 +166,6 @@ __global__ void lg_norm_kernel(LargeLattice L, int D1, const float *__restrict__
 
 // ---- CP-channel filter (Permutohedral::sseCompute, permutohedral.cpp:529-589); in/out are [N][CP]
 // one wave per vertex, lanes = channels: ordered accumulation of the vertex's row of (pixel, weight) entries
-// One group of LPV lanes (the power of two >= CP, at most a wave) per vertex: with 21 labels padded to 24 a whole wave
-// per vertex would idle 40 of its 64 lanes.  No cross-lane traffic, so the groups of a wave are independent.
-__global__ __launch_bounds__(256) void lg_splat_kernel(LargeLattice L, int CP, int lpv_shift, const float *__restrict__ in,
-                                                        float *__restrict__ val) {
-    const int lane = threadIdx.x & ((1 << lpv_shift) - 1);
-    const int v = blockIdx.x * (blockDim.x >> lpv_shift) + (threadIdx.x >> lpv_shift);
-    const int M = *L.M;
-    if (v == 0 && lane < CP) val[(size_t)M * CP + lane] = 0.0f;          // zero row = "no neighbour"
-    if (v >= M || lane >= CP) return;
-    const uint32_t p0 = L.row_start[v], p1 = L.row_start[v + 1];
-    float s = 0.0f;
-    uint32_t pos = p0;
-    for (; pos + 4 <= p1; pos += 4) {               // four entries in flight; the sum stays ordered
-        uint32_t px[4];
-        float w[4], x[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { px[u] = L.csr_pix[pos + u]; w[u] = L.csr_w[pos + u]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) x[u] = in[(size_t)px[u] * CP + lane] * L.norm[px[u]];      // in * norm (pairwise.cpp:66)
-#pragma unroll
-        for (int u = 0; u < 4; u++) s = s + w[u] * x[u];
-    }
-    for (; pos < p1; pos++) {
-        const uint32_t px = L.csr_pix[pos];
-        s = s + L.csr_w[pos] * (in[(size_t)px * CP + lane] * L.norm[px]);
-    }
-    val[(size_t)v * CP + lane] = s;
-}
-__global__ void lg_blur_kernel(LargeLattice L, int CP4, int j, const float4 *__restrict__ a, float4 *__restrict__ b) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int M = *L.M;
-    const size_t v = idx / CP4;
-    const int q = (int)(idx - v * CP4);
-    if (v == 0) b[(size_t)M * CP4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v >= (size_t)M) return;
-    const uint32_t n1 = L.nb1[(size_t)j * L.Mcap + v], n2 = L.nb2[(size_t)j * L.Mcap + v];
-    const float4 x0 = a[v * CP4 + q], x1 = a[(size_t)n1 * CP4 + q], x2 = a[(size_t)n2 * CP4 + q];
-    float4 o;
-    { float s = x1.x + x2.x; s = 0.5f * s; o.x = x0.x + s; }
-    { float s = x1.y + x2.y; s = 0.5f * s; o.y = x0.y + s; }
-    { float s = x1.z + x2.z; s = 0.5f * s; o.z = x0.z + s; }
-    { float s = x1.w + x2.w; s = 0.5f * s; o.w = x0.w + s; }
-    b[v * CP4 + q] = o;
-}
-// thread per (pixel, 4 channels): slice, then * norm and the Potts weight: out = -w * norm * (K ...)
-__global__ void lg_slice_kernel(LargeLattice L, int D1, int CP4, const float4 *__restrict__ val, float neg_w,
-                                float4 *__restrict__ out) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t i = idx / CP4;
-    const int q = (int)(idx - i * CP4);
-    if (i >= (size_t)L.N) return;
-    const float alpha = 1.0f / (1.0f + exp2f(-(float)(D1 - 1)));
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < D1; r++) {
-        const float w = L.bary[(size_t)r * L.N + i] * alpha;
-        const float4 x = val[(size_t)L.vid[(size_t)r * L.N + i] * CP4 + q];
-        acc.x = acc.x + w * x.x; acc.y = acc.y + w * x.y; acc.z = acc.z + w * x.z; acc.w = acc.w + w * x.w;
-    }
-    const float nv = L.norm[i];
-    float4 o;
-    o.x = neg_w * (acc.x * nv); o.y = neg_w * (acc.y * nv); o.z = neg_w * (acc.z * nv); o.w = neg_w * (acc.w * nv);
-    out[i * CP4 + q] = o;
-}
-
-// Q = expAndNormalize(-U - sum_k tmp2_k), pixel-major rows of CP floats (densecrf.cpp:98-106,122-128).
-// A workgroup of 256 threads owns 256 pixels: the rows are combined element-wise with coalesced
-// accesses into LDS (row pitch CP+1: conflict-free column walks), then each thread normalises its
-// pixel's row in label order (the same summation order as the small path), then the rows stream out.
 __global__ __launch_bounds__(256) void lg_update_kernel(int N, int C, int CP, const float *__restrict__ neg_unary,
                                                         const float *__restrict__ t_g, const float *__restrict__ t_b,
                                                         int use_msgs, float *__restrict__ q) {
@@ -263,6 +195,122 @@ __global__ __launch_bounds__(256) void lg_update_kernel(int N, int C, int CP, co
     for (int k = threadIdx.x; k < nelem; k += 256) q[i0 * CP + k] = row[(k / CP) * P + (k % CP)];
 }
 // label-fastest [N][C] (host layout of DenseCRFWrapper) <-> padded rows [N][CP]
+// ---- both lattices in one launch (the mean-field loop is a chain of short dependent launches: 14 -> 8 per iteration) ----
+// Splat: ordered sum of weight * (in * norm) over the vertex's entry list (pairwise.cpp:66, permutohedral.cpp:529-545);
+// blur: x + 0.5 (n1 + n2) per axis, Jacobi (:547-565); slice: barycentric gather * alpha, * norm, * -w (:567-589,
+// pairwise.cpp:72-79); update: -unary - gaussian - bilateral, expAndNormalize (densecrf.cpp:98-131).
+__device__ __forceinline__ void lg_splat_row(const LargeLattice &L, int v, int lane, int CP, const float *__restrict__ in,
+                                             float *__restrict__ val) {
+    const uint32_t p0 = L.row_start[v], p1 = L.row_start[v + 1];
+    float s = 0.0f;
+    uint32_t pos = p0;
+    for (; pos + 4 <= p1; pos += 4) {
+        uint32_t px[4];
+        float w[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { px[u] = L.csr_pix[pos + u]; w[u] = L.csr_w[pos + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = in[(size_t)px[u] * CP + lane] * L.norm[px[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) s = s + w[u] * x[u];
+    }
+    for (; pos < p1; pos++) {
+        const uint32_t px = L.csr_pix[pos];
+        s = s + L.csr_w[pos] * (in[(size_t)px * CP + lane] * L.norm[px]);
+    }
+    val[(size_t)v * CP + lane] = s;
+}
+// One group of LPV lanes (the power of two >= CP, at most a wave) per vertex: with 21 labels padded to 24 a whole wave
+// per vertex would idle 40 of its 64 lanes.  No cross-lane traffic, so the groups of a wave are independent.
+// vertex groups [0, Mb] belong to the bilateral lattice (row Mb = its zero row), the following Mg+1 to the Gaussian one
+__global__ __launch_bounds__(256) void lg_splat2_kernel(LargeLattice Lb, LargeLattice Lg, int CP, int lpv_shift,
+                                                         const float *__restrict__ in, float *__restrict__ val_b,
+                                                         float *__restrict__ val_g) {
+    const int lane = threadIdx.x & ((1 << lpv_shift) - 1);
+    int v = blockIdx.x * (blockDim.x >> lpv_shift) + (threadIdx.x >> lpv_shift);
+    if (lane >= CP) return;
+    const int Mb = *Lb.M, Mg = *Lg.M;
+    if (v <= Mb) {
+        if (v == Mb) val_b[(size_t)Mb * CP + lane] = 0.0f; else lg_splat_row(Lb, v, lane, CP, in, val_b);
+        return;
+    }
+    v -= Mb + 1;
+    if (v > Mg) return;
+    if (v == Mg) val_g[(size_t)Mg * CP + lane] = 0.0f; else lg_splat_row(Lg, v, lane, CP, in, val_g);
+}
+__device__ __forceinline__ void lg_blur_elem(const LargeLattice &L, int M, size_t v, int q, int CP4, int j,
+                                             const float4 *__restrict__ a, float4 *__restrict__ b) {
+    if (v == (size_t)M) { b[(size_t)M * CP4 + q] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const uint32_t n1 = L.nb1[(size_t)j * L.Mcap + v], n2 = L.nb2[(size_t)j * L.Mcap + v];
+    const float4 x0 = a[v * CP4 + q], x1 = a[(size_t)n1 * CP4 + q], x2 = a[(size_t)n2 * CP4 + q];
+    float4 o;
+    { float s = x1.x + x2.x; s = 0.5f * s; o.x = x0.x + s; }
+    { float s = x1.y + x2.y; s = 0.5f * s; o.y = x0.y + s; }
+    { float s = x1.z + x2.z; s = 0.5f * s; o.z = x0.z + s; }
+    { float s = x1.w + x2.w; s = 0.5f * s; o.w = x0.w + s; }
+    b[v * CP4 + q] = o;
+}
+// axis j of the bilateral lattice and, while j < 3, of the Gaussian lattice
+__global__ void lg_blur2_kernel(LargeLattice Lb, LargeLattice Lg, int CP4, int j, const float4 *__restrict__ ab,
+                                float4 *__restrict__ bb, const float4 *__restrict__ ag, float4 *__restrict__ bg) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Mb = *Lb.M, Mg = *Lg.M;
+    size_t v = idx / CP4;
+    const int q = (int)(idx - v * CP4);
+    if (v <= (size_t)Mb) { lg_blur_elem(Lb, Mb, v, q, CP4, j, ab, bb); return; }
+    v -= (size_t)Mb + 1;
+    if (j < 3 && v <= (size_t)Mg) lg_blur_elem(Lg, Mg, v, q, CP4, j, ag, bg);
+}
+__device__ __forceinline__ float4 lg_slice_elem(const LargeLattice &L, int D1, size_t i, int q, int CP4,
+                                                const float4 *__restrict__ val, float neg_w) {
+    const float alpha = 1.0f / (1.0f + exp2f(-(float)(D1 - 1)));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < D1; r++) {
+        const float w = L.bary[(size_t)r * L.N + i] * alpha;
+        const float4 x = val[(size_t)L.vid[(size_t)r * L.N + i] * CP4 + q];
+        acc.x = acc.x + w * x.x; acc.y = acc.y + w * x.y; acc.z = acc.z + w * x.z; acc.w = acc.w + w * x.w;
+    }
+    const float nv = L.norm[i];
+    float4 o;
+    o.x = neg_w * (acc.x * nv); o.y = neg_w * (acc.y * nv); o.z = neg_w * (acc.z * nv); o.w = neg_w * (acc.w * nv);
+    return o;
+}
+// slice both lattices, subtract the messages from -unary (Gaussian first) and renormalise: 256 pixels per workgroup
+__global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, LargeLattice Lg, int C, int CP,
+                                                              const float4 *__restrict__ val_b, const float4 *__restrict__ val_g,
+                                                              float neg_wb, float neg_wg, const float *__restrict__ neg_unary,
+                                                              float *__restrict__ q_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *row = reinterpret_cast<float *>(smem);            // [256][CP+1]
+    const int P = CP + 1, CP4 = CP / 4, N = Lb.N;
+    const size_t i0 = (size_t)blockIdx.x * 256;
+    const int npix = (int)min((size_t)256, (size_t)N - i0);
+    for (int k = threadIdx.x; k < npix * CP4; k += 256) {
+        const int pl = k / CP4, q4 = k - pl * CP4;
+        const size_t i = i0 + pl;
+        const float4 tg = lg_slice_elem(Lg, 3, i, q4, CP4, val_g, neg_wg);
+        const float4 tb = lg_slice_elem(Lb, 6, i, q4, CP4, val_b, neg_wb);
+        const float4 nu = reinterpret_cast<const float4 *>(neg_unary)[i * CP4 + q4];
+        float *r = row + pl * P + q4 * 4;
+        { float v = nu.x; v = v - tg.x; v = v - tb.x; r[0] = v; }
+        { float v = nu.y; v = v - tg.y; v = v - tb.y; r[1] = v; }
+        { float v = nu.z; v = v - tg.z; v = v - tb.z; r[2] = v; }
+        { float v = nu.w; v = v - tg.w; v = v - tb.w; r[3] = v; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < npix) {
+        float *r = row + threadIdx.x * P;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; c++) mx = fmaxf(mx, r[c]);
+        float sum = 0.0f;
+        for (int c = 0; c < C; c++) { const float e = expf(r[c] - mx); r[c] = e; sum = sum + e; }
+        for (int c = 0; c < C; c++) r[c] = r[c] / sum;
+        for (int c = C; c < CP; c++) r[c] = 0.0f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < npix * CP; k += 256) q_out[i0 * CP + k] = row[(k / CP) * P + (k % CP)];
+}
+
 __global__ void lg_pad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out, int negate) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * CP) return;
@@ -293,8 +341,8 @@ struct LargeCrf {
     LargeLattice Lg, Lb;
     void *arena;
     void *cub_tmp; size_t cub_bytes;
-    float *neg_unary, *q, *t_g, *t_b;      // [N][CP]
-    float *val_a, *val_b;                  // [(Mmax+1)][CP], grown on demand
+    float *neg_unary, *q;                  // [N][CP]
+    float *val_a, *val_b;                  // ping-pong [(Mb+1) + (Mg+1)][CP], grown on demand: bilateral rows first
     size_t val_rows;
     float *val1_a, *val1_b;                // one-channel buffers for the norm pass [Mcap+1]
     unsigned char *im;                     // [N][3]
@@ -354,7 +402,7 @@ int large_crf_create(int W, int H, int C, LargeCrf **out) {
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cb2, (uint32_t *)nullptr, (uint32_t *)nullptr, Mcap5 + 1, (hipStream_t)0);
     c->cub_bytes = cb1 > cb2 ? cb1 : cb2;
     const size_t rows = sizeof(float) * (size_t)N * c->CP;
-    const size_t total = sg + sb + al(c->cub_bytes) + 4 * al(rows) + 2 * al(sizeof(float) * (size_t)(Mcap5 + 1)) +
+    const size_t total = sg + sb + al(c->cub_bytes) + 2 * al(rows) + 2 * al(sizeof(float) * (size_t)(Mcap5 + 1)) +
                          al((size_t)N * 3) + al(sizeof(int32_t) * (size_t)N) + al(sizeof(float) * (size_t)N * C);
     hipError_t e = hipMalloc(&c->arena, total);
     if (e != hipSuccess) { delete c; return set_error(DSRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); }
@@ -364,8 +412,6 @@ int large_crf_create(int W, int H, int C, LargeCrf **out) {
     c->cub_tmp = p; p += al(c->cub_bytes);
     c->neg_unary = (float *)p; p += al(rows);
     c->q = (float *)p; p += al(rows);
-    c->t_g = (float *)p; p += al(rows);
-    c->t_b = (float *)p; p += al(rows);
     c->val1_a = (float *)p; p += al(sizeof(float) * (size_t)(Mcap5 + 1));
     c->val1_b = (float *)p; p += al(sizeof(float) * (size_t)(Mcap5 + 1));
     c->im = p; p += al((size_t)N * 3);
@@ -421,24 +467,6 @@ static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipSt
     return DSRG_OK;
 }
 
-static int large_filter(LargeCrf *c, LargeLattice &L, float w, float *out, hipStream_t s) {
-    const int D1 = L.d + 1, CP = c->CP, CP4 = CP / 4, M = L.M_host;
-    int lpv_shift = 3;
-    while ((1 << lpv_shift) < CP && lpv_shift < 6) lpv_shift++;
-    hipLaunchKernelGGL(lg_splat_kernel, dim3(blocks_for((size_t)M + 1, 256 >> lpv_shift)), dim3(256), 0, s, L, CP, lpv_shift,
-                       c->q, c->val_a);
-    float *a = c->val_a, *b = c->val_b;
-    for (int j = 0; j < D1; j++) {
-        hipLaunchKernelGGL(lg_blur_kernel, dim3(blocks_for((size_t)(M + 1) * CP4, 256)), dim3(256), 0, s, L, CP4, j,
-                           (const float4 *)a, (float4 *)b);
-        float *t = a; a = b; b = t;
-    }
-    hipLaunchKernelGGL(lg_slice_kernel, dim3(blocks_for((size_t)L.N * CP4, 256)), dim3(256), 0, s, L, D1, CP4,
-                       (const float4 *)a, -w, (float4 *)out);
-    DSRG_LAUNCH_CHECK();
-    return DSRG_OK;
-}
-
 // `unary` / `im` / outputs may be host or device pointers (hipMemcpyDefault resolves the kind): the test-time pipeline
 // keeps its scores on the GPU, the Cython-style callers pass numpy memory.
 int large_crf_set_unary(LargeCrf *c, const float *unary) {
@@ -478,27 +506,39 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
         c->built_for = *prm;
         c->lattices_valid = true;
     }
-    const size_t need = (size_t)(c->Lg.M_host > c->Lb.M_host ? c->Lg.M_host : c->Lb.M_host) + 1;
+    const int Mb = c->Lb.M_host, Mg = c->Lg.M_host, CP = c->CP, CP4 = CP / 4;
+    const size_t need = (size_t)Mb + 1 + (size_t)Mg + 1;
     if (need > c->val_rows) {
         if (c->val_a) (void)hipFree(c->val_a);
         if (c->val_b) (void)hipFree(c->val_b);
         c->val_a = c->val_b = nullptr;
-        hipError_t e = hipMalloc(&c->val_a, sizeof(float) * need * c->CP);
-        if (e == hipSuccess) e = hipMalloc(&c->val_b, sizeof(float) * need * c->CP);
+        c->val_rows = 0;
+        hipError_t e = hipMalloc(&c->val_a, sizeof(float) * need * CP);
+        if (e == hipSuccess) e = hipMalloc(&c->val_b, sizeof(float) * need * CP);
         if (e != hipSuccess) return set_error(DSRG_ERR_NOMEM, "hipMalloc of lattice values failed: %s", hipGetErrorString(e));
         c->val_rows = need;
     }
     const int T = 256;
-    const size_t upd_lds = sizeof(float) * 256 * (size_t)(c->CP + 1);
-    hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), upd_lds, s, c->N, c->C, c->CP, c->neg_unary,
-                       c->t_g, c->t_b, 0, c->q);
+    const size_t upd_lds = sizeof(float) * 256 * (size_t)(CP + 1);
+    hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), upd_lds, s, c->N, c->C, CP, c->neg_unary,
+                       nullptr, nullptr, 0, c->q);
+    int lpv_shift = 3;
+    while ((1 << lpv_shift) < CP && lpv_shift < 6) lpv_shift++;
+    const size_t g_off = ((size_t)Mb + 1) * CP;                          // Gaussian rows follow the bilateral ones
     for (int it = 0; it < n_iters; it++) {
-        rc = large_filter(c, c->Lg, prm->w_gaussian, c->t_g, s);      // Gaussian first (densecrf_wrapper.cpp:25)
-        if (rc) return rc;
-        rc = large_filter(c, c->Lb, prm->w_bilateral, c->t_b, s);
-        if (rc) return rc;
-        hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), upd_lds, s, c->N, c->C, c->CP,
-                           c->neg_unary, c->t_g, c->t_b, 1, c->q);
+        hipLaunchKernelGGL(lg_splat2_kernel, dim3(blocks_for(need, 256 >> lpv_shift)), dim3(256), 0, s, c->Lb, c->Lg, CP,
+                           lpv_shift, c->q, c->val_a, c->val_a + g_off);
+        float *a = c->val_a, *b = c->val_b;
+        for (int j = 0; j < 6; j++) {
+            const size_t rows = j < 3 ? need : (size_t)Mb + 1;
+            hipLaunchKernelGGL(lg_blur2_kernel, dim3(blocks_for(rows * CP4, 256)), dim3(256), 0, s, c->Lb, c->Lg, CP4, j,
+                               (const float4 *)a, (float4 *)b, (const float4 *)(a + g_off), (float4 *)(b + g_off));
+            float *t = a; a = b; b = t;
+        }
+        // after 6 swaps the bilateral result is back in val_a; the Gaussian one stopped after 3 swaps, in val_b
+        hipLaunchKernelGGL(lg_slice_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), upd_lds, s, c->Lb, c->Lg, c->C, CP,
+                           (const float4 *)c->val_a, (const float4 *)(c->val_b + g_off), -prm->w_bilateral,
+                           -prm->w_gaussian, c->neg_unary, c->q);
     }
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
