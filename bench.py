@@ -241,7 +241,8 @@ def main():
             "value": total_images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 backbone (fp32 master weights) + f32/f64 supervision path" if args.mode == "train" else "f32",
+            "dtype": ("bf16 backbone (fp32 master weights) + f32/f64 supervision path" if args.mode == "train" else
+                      ("bf16 backbone (fp32 master weights), f32 loss" if args.mode == "train-f" else "f32 (thresholds and marginals f64)")),
             "data": "synthetic",
             "config": {"workload": ("full seed_mc train-s step: VGG16-ASPP fwd+bwd + Softmax/CRF(10 it, scale 12)/"
                                     "SRG/BalancedSeedLoss/ConstrainLoss + SGD, 321x321 -> 41x41x21"
