@@ -230,6 +230,10 @@ def supervision_step(logits, images, labels, cues, th1=0.99, th2=0.85, scale_fac
     Returns (losses[2] = {loss-Seed, loss-Constrain}, d(sum)/d logits, blobs or None)."""
     _f32c(logits, "logits"), _f32c(images, "images"), _f32c(labels, "labels"), _f32c(cues, "cues")
     B, C, H, W = logits.shape
+    if images.dim() != 4 or images.shape[0] != B or images.shape[1] != 3:
+        raise ValueError("images must be (B,3,Hi,Wi) with the batch size of logits")
+    if labels.numel() != B * C or tuple(cues.shape) != (B, C, H, W):
+        raise ValueError("labels must hold B*C values and cues must have the shape of logits")
     ctx = ctx or get_context(B, C, H, W)
     losses = torch.empty(2, dtype=torch.float32, device=logits.device)
     grad = torch.empty_like(logits)

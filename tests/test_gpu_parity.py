@@ -102,7 +102,10 @@ def test_losses_forward_backward(ops, O):
 @pytest.mark.parametrize("kind,scale,HW,C", [("smooth", 12.0, (41, 41), 21), ("noise", 12.0, (41, 41), 21),
                                              ("dark_corner", 12.0, (41, 41), 21), ("smooth", 12.0, (65, 65), 21),
                                              ("smooth", 1.0, (24, 31), 7), ("noise", 3.0, (17, 40), 3),
-                                             ("smooth", 12.0, (1, 9), 2),
+                                             ("smooth", 12.0, (1, 9), 2), ("noise", 12.0, (1, 1), 2),
+                                             ("noise", 1.0, (2, 3), 4), ("smooth", 3.0, (5, 1), 21),
+                                             ("noise", 12.0, (70, 70), 3),      # largest LDS-resident map
+                                             ("noise", 12.0, (71, 71), 3),      # smallest map on the global-memory path
                                              # maps beyond the LDS-resident kernels: global-memory path (test-time CRF)
                                              ("smooth", 1.0, (121, 161), 21), ("noise", 3.0, (100, 150), 5),
                                              ("smooth", 1.0, (321, 321), 21)])
@@ -419,3 +422,44 @@ def test_unused_pylayers_vs_oracle(ops, O):
     gt2 = gt.copy(); gt2[:50] = 60
     h = ops.confusion_matrix(dev(gt2, torch.uint8), dev(pred, torch.uint8), n, rule_lt=True).cpu().numpy()
     assert np.array_equal(h[:-1].reshape(n, n).astype(np.float64), O.confusion_matrix(gt2, pred, n, rule_lt=True))
+
+
+def test_object_api_accepts_device_pointers(O):
+    """the DenseCRF object with CUDA tensors in and out equals the numpy form bit for bit (small and large path)"""
+    import krahenbuhl2013
+    for (H, W, C, scale) in [(41, 41, 21, 12.0), (90, 110, 6, 1.0)]:
+        rng = np.random.default_rng(H)
+        img = S.make_images(rng, 1, size=max(H, W))[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]
+        im = np.ascontiguousarray(np.transpose(img, (1, 2, 0))).astype(np.uint8)
+        un = np.log(np.ascontiguousarray(np.transpose(np.maximum(O.softmax_forward(S.make_logits(rng, 1, C, H, W))[0], 1e-4), (1, 2, 0))))
+        q = krahenbuhl2013.CRF(im, un, scale_factor=scale)
+        qd = krahenbuhl2013.CRF_device(torch.from_numpy(im).cuda(), torch.from_numpy(un).cuda(), scale_factor=scale)
+        assert qd.is_cuda and np.array_equal(qd.cpu().numpy(), q)
+        lab = krahenbuhl2013.CRF_device(torch.from_numpy(im).cuda(), torch.from_numpy(un).cuda(), scale_factor=scale, want="map")
+        assert lab.dtype == torch.int32 and np.array_equal(lab.cpu().numpy(), q.argmax(2))
+
+
+def test_error_paths_return_codes(ops):
+    """wrong shapes / NULL pointers / unsupported sizes come back as DsrgError with a message, never as a crash"""
+    import ctypes
+    from dsrg_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(2, 21, 41, 41, device="cuda")
+    assert L.dsrg_softmax_forward(2, 21, 1681, None, ctypes.c_void_p(x.data_ptr()), None) != 0
+    assert b"" != L.dsrg_last_error()
+    h = ctypes.c_void_p()
+    assert L.dsrg_crf_create(0, 5, 3, ctypes.byref(h)) != 0
+    assert L.dsrg_crf_create(5, 5, 100, ctypes.byref(h)) != 0                 # more than 64 labels
+    with pytest.raises(ValueError):
+        ops.supervision_step(x, torch.zeros(1, 3, 321, 321, device="cuda"), torch.zeros(2, 1, 1, 21, device="cuda"),
+                             torch.zeros(2, 21, 41, 41, device="cuda"))            # batch mismatch images vs logits
+    with pytest.raises(ValueError):
+        ops.srg_grow(torch.zeros(2, 1, 1, 21, device="cuda"), x, torch.zeros(2, 21, 41, 41, device="cuda"))  # refined must be f64
+    with pytest.raises(_lib.DsrgError):
+        ops.expand_loss(torch.rand(1, 3, 100, 100, device="cuda"), torch.ones(1, 1, 1, 3, device="cuda"))   # plane > 8192 px
+    from dsrg_amd.crf import DenseCRF
+    c = DenseCRF(4, 4, 3)
+    with pytest.raises(_lib.DsrgError):
+        c.inference(5)                                                             # no pairwise energy yet
+    with pytest.raises(ValueError):
+        c.set_unary_energy(np.zeros(7, np.float32))
