@@ -366,7 +366,7 @@ ORC_API void orc_crf_add_pairwise_energy(orc_crf *c, float w1, float ta1, float 
                                          float tg1, float tg2, const unsigned char *im) {
     const int W = c->W, H = c->H, N = W * H;
     for (int k = 0; k < c->nkern; k++) orc_kernel_free(&c->kern[k]);
-    float *f2 = (float *)malloc(sizeof(float) * 2 * N);
+    float *f2 = (float *)calloc((size_t)2 * N, sizeof(float));
     for (int j = 0; j < H; j++)
         for (int i = 0; i < W; i++) {
             f2[(size_t)(j * W + i) * 2 + 0] = (float)i / tg1;
