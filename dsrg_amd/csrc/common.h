@@ -128,6 +128,12 @@ int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, 
                           int stride, hipStream_t stream);
 
 #ifdef __HIPCC__
+// exp for the softmax-type normalisations (expAndNormalize densecrf.cpp:98-106, SoftmaxLayer pylayers.py:30-41): the fp64
+// exp rounded once to fp32, i.e. the correctly rounded fp32 result (up to double rounding) that a good host libm returns.
+// Mean-field amplifies last-bit differences of this exp at pixels where two labels compete, so the device's 1-ulp expf
+// would be the largest source of divergence from the CPU path.
+__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
+
 // SRSRC buffer loads: 32-bit per-lane byte offset + scalar offset against a wave-uniform descriptor
 // (one VGPR of address per load in flight instead of two; out-of-range offsets read 0, so index
 // loads need no clamping).

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void lg_update_kernel(int N, int C, int CP, co
         float mx = -INFINITY;
         for (int c = 0; c < C; c++) mx = fmaxf(mx, r[c]);
         float sum = 0.0f;
-        for (int c = 0; c < C; c++) { const float e = expf(r[c] - mx); r[c] = e; sum = sum + e; }
+        for (int c = 0; c < C; c++) { const float e = exp_cr(r[c] - mx); r[c] = e; sum = sum + e; }
         for (int c = 0; c < C; c++) r[c] = r[c] / sum;
         for (int c = C; c < CP; c++) r[c] = 0.0f;
     }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, L
         float mx = -INFINITY;
         for (int c = 0; c < C; c++) mx = fmaxf(mx, r[c]);
         float sum = 0.0f;
-        for (int c = 0; c < C; c++) { const float e = expf(r[c] - mx); r[c] = e; sum = sum + e; }
+        for (int c = 0; c < C; c++) { const float e = exp_cr(r[c] - mx); r[c] = e; sum = sum + e; }
         for (int c = 0; c < C; c++) r[c] = r[c] / sum;
         for (int c = C; c < CP; c++) r[c] = 0.0f;
     }

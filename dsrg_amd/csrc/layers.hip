@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int C, int HW, 
     for (int c = 0; c < CT; c++) { t[c] = (c < C) ? t[c] : -INFINITY; mx = fmaxf(mx, t[c]); }
     float z = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++) { t[c] = expf(t[c] - mx); z = (c < C) ? z + t[c] : z; }
+    for (int c = 0; c < CT; c++) { t[c] = exp_cr(t[c] - mx); z = (c < C) ? z + t[c] : z; }
     float z2 = 0.0f;
 #pragma unroll
     for (int c = 0; c < CT; c++) { t[c] = t[c] / z + kMinProb; z2 = (c < C) ? z2 + t[c] : z2; }
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, 
     for (int c = 0; c < CT; c++) { s[c] = (c < C) ? s[c] : -INFINITY; mx = fmaxf(mx, s[c]); }
     float z = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++) { s[c] = expf(s[c] - mx); z = (c < C) ? z + s[c] : z; }
+    for (int c = 0; c < CT; c++) { s[c] = exp_cr(s[c] - mx); z = (c < C) ? z + s[c] : z; }
     float Z = 0.0f, sg = 0.0f;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void sup_grad_kernel(int B, int C, int HW, con
     for (int c = 0; c < CT; c++) { s[c] = (c < C) ? s[c] : -INFINITY; mx = fmaxf(mx, s[c]); }
     float z = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++) { s[c] = expf(s[c] - mx); z = (c < C) ? z + s[c] : z; }
+    for (int c = 0; c < CT; c++) { s[c] = exp_cr(s[c] - mx); z = (c < C) ? z + s[c] : z; }
     {
         float pv[CT], lq[CT], sd[CT];
         double rf[CT];

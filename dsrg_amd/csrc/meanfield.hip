@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void mf_update_kernel(const float *__restrict_
     float sum = 0.0f;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-        const float e = expf(t[c] - mx);
+        const float e = exp_cr(t[c] - mx);
         t[c] = e;
         sum = (c < C) ? sum + e : sum;
     }

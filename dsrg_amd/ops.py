@@ -40,7 +40,10 @@ class Context(object):
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().dsrg_ctx_destroy(h)
+            try:
+                _lib.lib().dsrg_ctx_destroy(h)
+            except Exception:                # interpreter teardown: the module globals may already be gone
+                pass
             self._h = None
 
     def profile_start(self, max_launches=4096):
