@@ -66,10 +66,15 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         pad = ctx.dilation * (ctx.k // 2)
-        fused = ctx.relu and weight.shape[0] % 8 == 0 and g.dtype == torch.bfloat16
-        if fused:
+        fused = g.dtype == torch.bfloat16 and ((ctx.relu and weight.shape[0] % 8 == 0) or
+                                               (not ctx.relu and weight.shape[0] <= 256))
+        if fused and ctx.relu:
             from .ops import relu_bwd_bias
             g, gb = relu_bwd_bias(g, y)
+        elif fused:
+            from .ops import bias_grad                                  # e.g. the 21-channel fc8 outputs
+            g = g.contiguous(memory_format=torch.channels_last)
+            gb = bias_grad(g)
         else:
             if ctx.relu:
                 g = g * (y > 0)
@@ -117,6 +122,36 @@ class _MaxPool3x3Fn(torch.autograd.Function):
         return maxpool3x3_bwd(g, code, ctx.in_shape, ctx.stride), None, None
 
 
+class _AvgPool3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        from .ops import avgpool3x3_s1
+        return avgpool3x3_s1(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import avgpool3x3_s1
+        return avgpool3x3_s1(g)                                          # symmetric stencil: its own adjoint
+
+
+class AvgPool3x3(nn.AvgPool2d):
+    """pool5a: 3x3 / stride 1 / pad 1 average over padded windows (Caffe AVE); one HIP pass each way for bf16
+    channels_last activations, nn.AvgPool2d otherwise.  Not only a speed matter: PyTorch-ROCm 2.10's avg_pool2d
+    backward returns wrong gradients for channels_last inputs (tests/test_gpu_parity.py checks ours against the fp32
+    NCHW adjoint), so any other channels_last input is made contiguous first."""
+
+    def __init__(self):
+        super().__init__(3, 1, 1)
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and \
+                x.is_contiguous(memory_format=torch.channels_last):
+            return _AvgPool3x3Fn.apply(x)
+        if x.is_cuda and x.dim() == 4 and not x.is_contiguous():
+            x = x.contiguous()                                            # keep torch's kernel on its correct (NCHW) path
+        return super().forward(x)
+
+
 class MaxPool3x3(nn.MaxPool2d):
     """3x3 / pad 1 max pooling (stride 1 or 2): one HIP pass each way over bf16 channels_last activations with
     1-byte window codes instead of torch's int64 indices; anything else takes nn.MaxPool2d's path."""
@@ -146,7 +181,7 @@ class VGG16ASPP(nn.Module):
         g = gemm_convs                                                  # the 41x41 stages
         L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g) + _conv_relu(512, 512, 1, g) + [MaxPool3x3(1)]
         L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + [MaxPool3x3(1)]
-        L += [nn.AvgPool2d(3, 1, 1)]                                   # pool5a AVE (count_include_pad, as Caffe)
+        L += [AvgPool3x3()]                                   # pool5a AVE (count_include_pad, as Caffe)
         self.features = nn.Sequential(*L)
         self.branches = nn.ModuleList()
         for d in (6, 12, 18, 24):

@@ -288,6 +288,15 @@ extern "C" int dsrg_relu_bwd_bias_bf16(const void *g, const void *y, void *gm, f
     if (!g || !y || !gm || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_relu_bwd_bias(g, y, gm, bias_grad, partials, partial_blocks, rows, C, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_avgpool3x3_s1_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream) {
+    if (!in || !out) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_avgpool3x3_s1(in, out, B, H, W, C, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_bias_grad_bf16(const void *g, float *bias_grad, float *partials, int partial_blocks, long rows, int C,
+                                   void *stream) {
+    if (!g || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_bias_grad(g, bias_grad, partials, partial_blocks, rows, C, static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_maxpool3x3_fwd_bf16(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C,
                                         int stride, void *stream) {
     if (!in || !out || !code) return set_error(DSRG_ERR_INVALID, "NULL argument");

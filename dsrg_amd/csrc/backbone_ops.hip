@@ -190,6 +190,82 @@ __global__ void maxpool3x3_bwd_kernel(const uint4 *__restrict__ gout, const uint
     gin[idx] = make_uint4(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]), pack_bf16(acc[6], acc[7]));
 }
 
+// ---- 3x3 / stride 1 / pad 1 average pooling over padded windows (Caffe AVE pooling = count_include_pad), NHWC bf16 --------
+// out = (sum of the in-image taps) / 9.  The stencil is symmetric, so the backward pass is the same kernel on the gradient.
+__global__ void avgpool3x3_s1_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, int B, int H, int W, int C8) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * W * C8;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8);
+    size_t r = idx / C8;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const uint4 v = in[(((size_t)b * H + yy) * W + xx) * C8 + c];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[2 * k] += bf16_lo(w[k]); acc[2 * k + 1] += bf16_hi(w[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = acc[k] / 9.0f;
+    out[idx] = make_uint4(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]), pack_bf16(acc[6], acc[7]));
+}
+int launch_avgpool3x3_s1(const void *in, void *out, int B, int H, int W, int C, hipStream_t stream) {
+    if (C % 8 != 0) return set_error(DSRG_ERR_UNSUPPORTED, "avgpool3x3: channels must be a multiple of 8");
+    if (B <= 0 || H <= 0 || W <= 0) return set_error(DSRG_ERR_INVALID, "avgpool3x3: bad shape");
+    const size_t total = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(avgpool3x3_s1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint4 *)in,
+                       (uint4 *)out, B, H, W, C / 8);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// ---- bias gradient of a (rows, C) bf16 matrix for any C <= 256 (the 21-channel fc8 outputs): column sums in f32 -------------
+// lanes walk the flat array, so a wave reads 128 contiguous bytes; thread t always meets channel (t % C) because the row
+// group a block advances by is a whole number of rows.  Partials per block, then bias_finalize_kernel.
+__global__ __launch_bounds__(kRbThreads) void bias_grad_kernel(const unsigned short *__restrict__ g, float *__restrict__ part,
+                                                               int rows, int C, int rows_per_block) {
+    __shared__ float red[kRbThreads];
+    const int R = kRbThreads / C;                                        // rows covered by one sweep of the block
+    const int rl = threadIdx.x / C, c = threadIdx.x - rl * C;
+    float acc = 0.f;
+    if (rl < R) {
+        const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+        for (int r = r0 + rl; r < r1; r += R) acc += __uint_as_float((uint32_t)g[(size_t)r * C + c] << 16);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float s = 0.f;
+        for (int l = 0; l < R; ++l) s += red[l * C + threadIdx.x];
+        part[(size_t)blockIdx.x * C + threadIdx.x] = s;
+    }
+}
+int launch_bias_grad(const void *g, float *bias_grad, float *part, int part_blocks, long rows, int C, hipStream_t stream) {
+    if (C < 1 || C > kRbThreads) return set_error(DSRG_ERR_UNSUPPORTED, "bias_grad: 1..256 channels");
+    if (rows <= 0 || rows > 0x7fffffffL || part_blocks < 1) return set_error(DSRG_ERR_INVALID, "bias_grad: bad arguments");
+    const int R = kRbThreads / C;
+    int rpb = (int)((rows + part_blocks - 1) / part_blocks);
+    rpb = ((rpb + R - 1) / R) * R;
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(nblk), dim3(kRbThreads), 0, stream, (const unsigned short *)g, part, (int)rows, C, rpb);
+    DSRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
 static int pool_check(int B, int H, int W, int OH, int OW, int C, int stride) {
     if (C % 8 != 0) return set_error(DSRG_ERR_UNSUPPORTED, "maxpool3x3: channels must be a multiple of 8");
     if (stride != 1 && stride != 2) return set_error(DSRG_ERR_UNSUPPORTED, "maxpool3x3: stride must be 1 or 2");

@@ -286,6 +286,30 @@ def relu_bwd_bias(g, y):
     return gm, gb
 
 
+def bias_grad(g):
+    """(B,C,H,W) bf16 channels_last -> per-channel sums over B,H,W as f32 (C,), any C <= 256"""
+    B, C, H, W = g.shape
+    if not (g.is_cuda and g.dtype == torch.bfloat16):
+        raise ValueError("bias_grad needs a bf16 CUDA tensor")
+    g = g.contiguous(memory_format=torch.channels_last)
+    gb = torch.empty(C, dtype=torch.float32, device=g.device)
+    key = (g.device, C)
+    part = _partials.get(key)
+    if part is None:
+        part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=g.device)
+    check(_lib.lib().dsrg_bias_grad_bf16(_ptr(g), _ptr(gb), _ptr(part), _PARTIAL_BLOCKS, B * H * W, C, _stream()))
+    return gb
+
+
+def avgpool3x3_s1(x):
+    """3x3 / stride 1 / pad 1 average over padded windows of a (B,C,H,W) bf16 channels_last tensor (also its own backward)"""
+    B, C, H, W = x.shape
+    x = x.contiguous(memory_format=torch.channels_last)
+    out = torch.empty_like(x)
+    check(_lib.lib().dsrg_avgpool3x3_s1_bf16(_ptr(x), _ptr(out), B, H, W, C, _stream()))
+    return out
+
+
 def maxpool3x3_out_size(n, stride, ceil_mode):
     """output extent of a 3x3 / pad 1 pooling window walk over n pixels (Caffe's ceil rule, torch's with ceil_mode)"""
     num = n + 2 - 3

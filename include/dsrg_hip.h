@@ -185,6 +185,13 @@ int dsrg_im2col3x3_nhwc16(const void *in_dev, void *out_dev, int B, int H, int W
  * (f32, summed in a fixed order).  partials: device scratch of partial_blocks * C floats. */
 int dsrg_relu_bwd_bias_bf16(const void *g_dev, const void *y_dev, void *gm_dev, float *bias_grad_dev, float *partials_dev,
                             int partial_blocks, long rows, int C, void *stream);
+/* Column sums of a (rows, C) bf16 matrix in f32, any C <= 256 (bias gradient of a convolution without a ReLU behind it,
+ * e.g. the 21-channel fc8 outputs).  partials: device scratch of partial_blocks * C floats. */
+int dsrg_bias_grad_bf16(const void *g_dev, float *bias_grad_dev, float *partials_dev, int partial_blocks, long rows, int C,
+                        void *stream);
+/* 3x3 / stride 1 / pad 1 average pooling over padded windows (Caffe AVE pooling, pool5a of train-s.prototxt), NHWC bf16,
+ * C % 8 == 0.  The stencil is symmetric: the backward pass is the same call on the output gradient. */
+int dsrg_avgpool3x3_s1_bf16(const void *in_dev, void *out_dev, int B, int H, int W, int C, void *stream);
 /* 3x3 max pooling, pad 1, stride 1 or 2, NHWC bf16 (the Pooling layers of train-s.prototxt:69-80 etc.; OH/OW chosen by
  * the caller, ceil mode included).  code_dev: B*OH*OW*C bytes, the window position (3*dy+dx) of the first maximum. */
 int dsrg_maxpool3x3_fwd_bf16(const void *in_dev, void *out_dev, void *code_dev, int B, int H, int W, int OH, int OW, int C,

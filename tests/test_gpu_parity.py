@@ -340,6 +340,24 @@ def test_relu_bwd_bias_and_maxpool_match_torch(ops):
         assert torch.equal(gm, want)
         ref = want.float().sum((0, 2, 3))
         assert (gb - ref).abs().max() <= 1e-4 * want.float().abs().sum((0, 2, 3)).max()
+    for B, C, H, W in [(2, 21, 41, 41), (1, 5, 3, 7), (3, 256, 9, 9), (16, 21, 41, 41)]:
+        g = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        gb = ops.bias_grad(g)
+        ref = g.float().sum((0, 2, 3))
+        assert (gb - ref).abs().max() <= 1e-4 * g.float().abs().sum((0, 2, 3)).max()
+        assert torch.equal(gb, ops.bias_grad(g))                           # fixed summation order
+    for B, C, H, W in [(2, 512, 41, 41), (1, 8, 1, 1), (2, 16, 2, 5), (1, 64, 7, 3)]:
+        # reference in fp32 NCHW: PyTorch-ROCm 2.10's avg_pool2d BACKWARD is wrong for channels_last tensors (O(1) errors
+        # against the CPU, f32 and bf16 alike), which is one more reason pool5a has its own kernel
+        x = torch.randn(B, C, H, W, device="cuda").bfloat16()
+        xr = x.float().requires_grad_(True)
+        ref = F.avg_pool2d(xr, 3, 1, 1)
+        out = ops.avgpool3x3_s1(x.contiguous(memory_format=cl))
+        assert (out.float() - ref).abs().max() <= 0.01 * ref.abs().max() + 1e-6
+        go = torch.randn_like(ref).bfloat16()
+        ref.backward(go.float())
+        gin = ops.avgpool3x3_s1(go.contiguous(memory_format=cl))
+        assert (gin.float() - xr.grad).abs().max() <= 0.01 * xr.grad.abs().max() + 1e-6
     for B, C, H, W, stride, ceil in [(2, 64, 33, 29, 2, True), (2, 64, 321, 321, 2, True), (1, 8, 6, 6, 2, False),
                                      (2, 512, 41, 41, 1, False), (1, 16, 1, 1, 1, False), (1, 16, 2, 3, 2, True)]:
         x = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
