@@ -10,7 +10,11 @@ from .ops import dsrg_supervision_loss
 
 class CaffeSGD(object):
     """Caffe's SGDSolver update (solver-s.prototxt:5-14): V <- m V + lr*lr_mult*(g + wd*decay_mult*W);
-    W <- W - V; lr = base_lr * gamma^floor(iter/stepsize)."""
+    W <- W - V; lr = base_lr * gamma^floor(iter/stepsize).
+
+    Kept in the equivalent form B = V / lr (B <- m B + (g + wd W); W <- W - lr B), which is what the one-pass fused
+    multi-tensor kernel `torch._fused_sgd_` computes; when the learning rate steps, B is rescaled by lr_old / lr_new so
+    that the trajectory stays exactly Caffe's (V carries the old rate in its history)."""
 
     def __init__(self, groups, base_lr=5e-4, momentum=0.9, weight_decay=5e-4, gamma=0.33, stepsize=1000):
         self.groups = groups
@@ -18,6 +22,7 @@ class CaffeSGD(object):
         self.iter = 0
         for g in self.groups:
             g["bufs"] = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in g["params"]]
+            g["buf_lr"] = None
 
     def lr(self):
         return self.base_lr * self.gamma ** (self.iter // self.stepsize)
@@ -32,11 +37,18 @@ class CaffeSGD(object):
             bufs = [b for p, b in zip(g["params"], g["bufs"]) if p.grad is not None]
             grads = [p.grad for p in ps]
             local_lr, local_wd = lr * g["lr_mult"], self.wd * g["decay_mult"]
-            if local_wd != 0.0:
-                grads = torch._foreach_add(grads, ps, alpha=local_wd)
-            torch._foreach_mul_(bufs, self.momentum)
-            torch._foreach_add_(bufs, grads, alpha=local_lr)
-            torch._foreach_sub_(ps, bufs)
+            if g["buf_lr"] is not None and g["buf_lr"] != local_lr:
+                torch._foreach_mul_(g["bufs"], g["buf_lr"] / local_lr)
+            g["buf_lr"] = local_lr
+            try:
+                torch._fused_sgd_(ps, grads, bufs, weight_decay=local_wd, momentum=self.momentum, lr=local_lr,
+                                  dampening=0.0, nesterov=False, maximize=False, is_first_step=False)
+            except (RuntimeError, NotImplementedError):          # no fused kernel for this device / dtype mix
+                if local_wd != 0.0:
+                    grads = torch._foreach_add(grads, ps, alpha=local_wd)
+                torch._foreach_mul_(bufs, self.momentum)
+                torch._foreach_add_(bufs, grads)
+                torch._foreach_add_(ps, bufs, alpha=-local_lr)
         self.iter += 1
 
     def zero_grad(self):
