@@ -3,12 +3,13 @@
 (`rocprofv3 --kernel-trace --stats -d DIR -o NAME -- cmd` writes DIR/NAME_results.db).
 Usage: python tools/rocpd_stats.py gpurun_out/prof/x_results.db [top [steps marker]] > profiles/rNN_x_kernel_stats.txt
 With `steps marker` only the last `steps` steady-state steps are summarised (per step): a step is the span between two
-consecutive dispatches of the kernel whose name contains `marker` (one that runs once per step, e.g. sup_grad_kernel)."""
+consecutive dispatches of the kernel whose name contains `marker` (one that runs once per step, e.g. sup_grad_kernel;
+a fifth argument gives the number of dispatches of the marker per step when it is not 1)."""
 import sqlite3
 import sys
 
 
-def main(path, top=40, steps=0, marker=None):
+def main(path, top=40, steps=0, marker=None, occ=1):
     c = sqlite3.connect(path)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
@@ -20,9 +21,9 @@ def main(path, top=40, steps=0, marker=None):
     div = 1
     if steps and marker:
         marks = sorted(st for name, st, en in rows if marker in name)
-        if len(marks) < steps + 1:
+        if len(marks) < steps * occ + 1:
             raise SystemExit("only %d dispatches of %s" % (len(marks), marker))
-        lo, hi = marks[-steps - 1], marks[-1]
+        lo, hi = marks[-steps * occ - 1], marks[-1]
         rows = [r for r in rows if lo <= r[1] < hi]
         div = steps
         print("# last %d steps between dispatches of *%s*: wall %.3f ms per step; figures below are PER STEP" % (
@@ -46,4 +47,5 @@ def main(path, top=40, steps=0, marker=None):
 
 if __name__ == "__main__":
     main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40,
-         int(sys.argv[3]) if len(sys.argv) > 4 else 0, sys.argv[4] if len(sys.argv) > 4 else None)
+         int(sys.argv[3]) if len(sys.argv) > 4 else 0, sys.argv[4] if len(sys.argv) > 4 else None,
+         int(sys.argv[5]) if len(sys.argv) > 5 else 1)
