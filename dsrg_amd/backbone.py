@@ -42,14 +42,15 @@ def _im2col_gemm(x, weight, bias, dilation, relu):
 
 
 class _ConvFn(torch.autograd.Function):
-    """3x3 / 1x1 stride-1 'same' convolution (+ ReLU).  Forward: explicit NHWC im2col + one hipBLASLt GEMM when
-    `gemm` (at the 41x41 stages, 76 % of the backbone flops, MIOpen's forward kernels reach ~180 TFLOP/s on MI355X,
-    the GEMM route 300-900: tools/conv_probe.py), MIOpen otherwise.  Backward: the ReLU mask and the bias gradient
-    come from one fused HIP pass (ops.relu_bwd_bias); data and weight gradients stay with MIOpen/CK."""
+    """3x3 / 1x1 stride-1 'same' convolution (+ ReLU (+ Dropout)).  Forward: explicit NHWC im2col + one hipBLASLt GEMM
+    when `gemm` (at the 41x41 stages, 76 % of the backbone flops, MIOpen's forward kernels reach ~180 TFLOP/s on MI355X,
+    the GEMM route 300-1200: tools/conv_probe.py), MIOpen otherwise.  Backward: the ReLU mask, the dropout mask and scale
+    and the bias gradient come from one fused HIP pass (ops.relu_bwd_bias: the output of ReLU + Dropout is positive
+    exactly where both masks pass); data and weight gradients stay with MIOpen/CK."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
-    def forward(ctx, x, weight, bias, dilation, relu, gemm):
+    def forward(ctx, x, weight, bias, dilation, relu, gemm, drop_p):
         k = weight.shape[2]
         if gemm:
             out = _im2col_gemm(x, weight, bias, dilation, relu)
@@ -57,8 +58,10 @@ class _ConvFn(torch.autograd.Function):
             out = F.conv2d(x.contiguous(memory_format=torch.channels_last), weight, bias, 1, dilation * (k // 2), dilation)
             if relu:
                 out.relu_()
+        if drop_p > 0.0:
+            out = torch.ops.aten.native_dropout(out, drop_p, True)[0]    # out = relu * mask / (1 - p)
         ctx.save_for_backward(x, weight, out if relu else None)
-        ctx.dilation, ctx.k, ctx.relu = dilation, k, relu
+        ctx.dilation, ctx.k, ctx.relu, ctx.scale = dilation, k, relu, 1.0 / (1.0 - drop_p)
         return out
 
     @staticmethod
@@ -70,40 +73,49 @@ class _ConvFn(torch.autograd.Function):
                                                (not ctx.relu and weight.shape[0] <= 256))
         if fused and ctx.relu:
             from .ops import relu_bwd_bias
-            g, gb = relu_bwd_bias(g, y)
+            g, gb = relu_bwd_bias(g, y, ctx.scale)
         elif fused:
             from .ops import bias_grad                                  # e.g. the 21-channel fc8 outputs
             g = g.contiguous(memory_format=torch.channels_last)
             gb = bias_grad(g)
         else:
             if ctx.relu:
-                g = g * (y > 0)
+                g = g * (y > 0) * ctx.scale
             g = g.contiguous(memory_format=torch.channels_last)
         gx, gw, gb2 = torch.ops.aten.convolution_backward(
             g, x, weight, None if fused else [weight.shape[0]], [1, 1], [pad, pad],
             [ctx.dilation, ctx.dilation], False, [0, 0], 1, [ctx.needs_input_grad[0], True, not fused])
-        return gx, gw, (gb if fused else gb2), None, None, None
+        return gx, gw, (gb if fused else gb2), None, None, None, None
 
 
 class GemmConv2d(nn.Conv2d):
     """nn.Conv2d (same parameters, same init, same state_dict) whose CUDA forward is im2col + GEMM, optionally
-    with the following ReLU fused (`fuse_relu`); on the CPU it is the plain convolution (+ ReLU)."""
+    with the following ReLU (`fuse_relu`) and Dropout (`fuse_dropout` = p, needs fuse_relu) fused; on the CPU it is the
+    plain convolution (+ ReLU (+ Dropout))."""
 
-    def __init__(self, *args, fuse_relu=False, gemm=True, **kw):
+    def __init__(self, *args, fuse_relu=False, gemm=True, fuse_dropout=0.0, **kw):
         super().__init__(*args, **kw)
-        self.fuse_relu, self.gemm = fuse_relu, gemm
+        if fuse_dropout and not fuse_relu:
+            raise ValueError("fuse_dropout needs fuse_relu (the fused backward reads both masks from the output sign)")
+        self.fuse_relu, self.gemm, self.fuse_dropout = fuse_relu, gemm, float(fuse_dropout)
 
     def forward(self, x):
+        p = self.fuse_dropout if self.training else 0.0
         if x.is_cuda and self.stride == (1, 1) and self.kernel_size[0] in (1, 3) and \
                 self.padding[0] == self.dilation[0] * (self.kernel_size[0] // 2):
-            return _ConvFn.apply(x, self.weight, self.bias, self.dilation[0], self.fuse_relu, self.gemm)
+            return _ConvFn.apply(x, self.weight, self.bias, self.dilation[0], self.fuse_relu, self.gemm, p)
         out = super().forward(x)
-        return F.relu(out) if self.fuse_relu else out
+        out = F.relu(out) if self.fuse_relu else out
+        return F.dropout(out, p, True) if p > 0.0 else out
 
 
 class FusedReLU(nn.Identity):
     """placeholder that keeps the Sequential indices (and state_dict keys) of the conv/ReLU pairs: the ReLU itself
     runs inside the GemmConv2d in front of it"""
+
+
+class FusedDropout(nn.Identity):
+    """placeholder for the Dropout layer that runs inside the GemmConv2d two slots in front of it (`fuse_dropout`)"""
 
 
 class _MaxPool3x3Fn(torch.autograd.Function):
@@ -190,8 +202,9 @@ class VGG16ASPP(nn.Module):
             nn.init.normal_(fc8.weight, std=0.01)
             nn.init.zeros_(fc8.bias)
             self.branches.append(nn.Sequential(
-                GemmConv2d(512, 1024, 3, padding=d, dilation=d, fuse_relu=True, gemm=g), FusedReLU(), nn.Dropout(dropout),
-                GemmConv2d(1024, 1024, 1, fuse_relu=True, gemm=g), FusedReLU(), nn.Dropout(dropout), fc8))
+                GemmConv2d(512, 1024, 3, padding=d, dilation=d, fuse_relu=True, gemm=g, fuse_dropout=dropout), FusedReLU(),
+                FusedDropout(),
+                GemmConv2d(1024, 1024, 1, fuse_relu=True, gemm=g, fuse_dropout=dropout), FusedReLU(), FusedDropout(), fc8))
 
     def forward(self, x):
         f = self.features(x)

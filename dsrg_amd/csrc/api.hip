@@ -284,9 +284,9 @@ extern "C" int dsrg_im2col3x3_nhwc16(const void *in, void *out, int B, int H, in
     return launch_im2col3x3(in, out, B, H, W, C, dilation, static_cast<hipStream_t>(stream));
 }
 extern "C" int dsrg_relu_bwd_bias_bf16(const void *g, const void *y, void *gm, float *bias_grad, float *partials,
-                                       int partial_blocks, long rows, int C, void *stream) {
+                                       int partial_blocks, long rows, int C, float scale, void *stream) {
     if (!g || !y || !gm || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
-    return launch_relu_bwd_bias(g, y, gm, bias_grad, partials, partial_blocks, rows, C, static_cast<hipStream_t>(stream));
+    return launch_relu_bwd_bias(g, y, gm, bias_grad, partials, partial_blocks, rows, C, scale, static_cast<hipStream_t>(stream));
 }
 extern "C" int dsrg_avgpool3x3_s1_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream) {
     if (!in || !out) return set_error(DSRG_ERR_INVALID, "NULL argument");

@@ -19,10 +19,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return f32_t
 
 constexpr int kRbThreads = 256;
 
-// gm = g * (y > 0); part[blockIdx][c] = sum over this block's rows of gm[:, c]   (rows x C, C % 8 == 0, C/8 <= 256)
+// gm = scale * g * (y > 0); part[blockIdx][c] = sum over this block's rows of gm[:, c]   (rows x C, C % 8 == 0, C/8 <= 256)
+// scale = 1 for a plain ReLU; 1/(1-p) when y is the output of ReLU followed by dropout (then y > 0 is both masks at once)
 __global__ __launch_bounds__(kRbThreads) void relu_bwd_bias_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ y,
                                                                     uint4 *__restrict__ gm, float *__restrict__ part,
-                                                                    int rows, int C8, int rows_per_block) {
+                                                                    int rows, int C8, int rows_per_block, float scale) {
     __shared__ float red[kRbThreads][9];                                 // +1 pad: column reads hit distinct banks
     const int lanes_r = kRbThreads / C8;                                 // row lanes per block
     const int cg = threadIdx.x % C8, rl = threadIdx.x / C8;
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(kRbThreads) void relu_bwd_bias_kernel(const uint4 *
                 const bool phi = (yw[k] & 0x80000000u) == 0 && (yw[k] & 0x7fff0000u) != 0;
                 const uint32_t m = (plo ? 0xffffu : 0u) | (phi ? 0xffff0000u : 0u);
                 ow[k] = gw[k] & m;
+                if (scale != 1.0f) ow[k] = pack_bf16(bf16_lo(ow[k]) * scale, bf16_hi(ow[k]) * scale);
                 acc[2 * k] += bf16_lo(ow[k]);
                 acc[2 * k + 1] += bf16_hi(ow[k]);
             }
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void bias_finalize_kernel(const float *__restr
 }
 
 int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_grad, float *part, int part_blocks,
-                         long rows, int C, hipStream_t stream) {
+                         long rows, int C, float scale, hipStream_t stream) {
     if (C % 8 != 0 || C / 8 > kRbThreads || C < 8) return set_error(DSRG_ERR_UNSUPPORTED, "relu_bwd_bias: channels must be a multiple of 8, at most 2048");
     if (rows <= 0 || rows > 0x7fffffffL) return set_error(DSRG_ERR_INVALID, "relu_bwd_bias: bad row count");
     if (part_blocks < 1) return set_error(DSRG_ERR_INVALID, "relu_bwd_bias: no partial-sum blocks");
@@ -99,7 +101,7 @@ int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_gra
     rpb = ((rpb + lanes_r - 1) / lanes_r) * lanes_r;
     nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(nblk), dim3(kRbThreads), 0, stream, (const uint4 *)g, (const uint4 *)y,
-                       (uint4 *)gm, part, (int)rows, C8, rpb);
+                       (uint4 *)gm, part, (int)rows, C8, rpb, scale);
     DSRG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
     DSRG_LAUNCH_CHECK();

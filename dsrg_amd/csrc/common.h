@@ -121,7 +121,7 @@ int launch_confusion(size_t n, const unsigned char *gt, const unsigned char *pre
                      unsigned long long *hist, hipStream_t stream);
 int launch_im2col3x3(const void *in, void *out, int B, int H, int W, int C, int dil, hipStream_t stream);
 int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_grad, float *part, int part_blocks,
-                         long rows, int C, hipStream_t stream);
+                         long rows, int C, float scale, hipStream_t stream);
 int launch_avgpool3x3_s1(const void *in, void *out, int B, int H, int W, int C, hipStream_t stream);
 int launch_bias_grad(const void *g, float *bias_grad, float *part, int part_blocks, long rows, int C, hipStream_t stream);
 int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,

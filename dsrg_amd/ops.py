@@ -267,9 +267,10 @@ _PARTIAL_BLOCKS = 512
 _partials = {}
 
 
-def relu_bwd_bias(g, y):
+def relu_bwd_bias(g, y, scale=1.0):
     """ReLU backward fused with the bias-gradient reduction of the convolution before it.
-    g, y: (B,C,H,W) bf16 channels_last (y = the ReLU output).  Returns (g * (y > 0), sum over B,H,W as f32 (C,))."""
+    g, y: (B,C,H,W) bf16 channels_last (y = the ReLU output, or the output of ReLU + Dropout with scale = 1/(1-p)).
+    Returns (scale * g * (y > 0), its sum over B,H,W as f32 (C,))."""
     B, C, H, W = y.shape
     cl = torch.channels_last
     if not (g.is_cuda and g.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=cl)):
@@ -282,7 +283,7 @@ def relu_bwd_bias(g, y):
     if part is None:
         part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=y.device)
     check(_lib.lib().dsrg_relu_bwd_bias_bf16(_ptr(g), _ptr(y), _ptr(gm), _ptr(gb), _ptr(part), _PARTIAL_BLOCKS,
-                                             B * H * W, C, _stream()))
+                                             B * H * W, C, float(scale), _stream()))
     return gm, gb
 
 

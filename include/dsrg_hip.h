@@ -181,10 +181,12 @@ int dsrg_confusion_matrix(size_t n, const unsigned char *gt_dev, const unsigned 
  *   out[(b,y,x)][tap][c] = in[b][y+(tap/3-1)*dil][x+(tap%3-1)*dil][c], zero outside the map. */
 int dsrg_im2col3x3_nhwc16(const void *in_dev, void *out_dev, int B, int H, int W, int C, int dilation, void *stream);
 /* ReLU backward fused with the bias-gradient reduction of the convolution in front of it: g, y (the ReLU output) and
- * gm are (rows, C) bf16 row-major (NHWC activations), C % 8 == 0; gm = g where y > 0 else 0; bias_grad[c] = sum_r gm[r,c]
- * (f32, summed in a fixed order).  partials: device scratch of partial_blocks * C floats. */
+ * gm are (rows, C) bf16 row-major (NHWC activations), C % 8 == 0; gm = scale * g where y > 0 else 0; bias_grad[c] =
+ * sum_r gm[r,c] (f32, summed in a fixed order).  scale = 1 for a plain ReLU; with y = dropout(relu(.)) and
+ * scale = 1/(1-p) the same pass is the backward of ReLU + Dropout (y > 0 is both masks at once).
+ * partials: device scratch of partial_blocks * C floats. */
 int dsrg_relu_bwd_bias_bf16(const void *g_dev, const void *y_dev, void *gm_dev, float *bias_grad_dev, float *partials_dev,
-                            int partial_blocks, long rows, int C, void *stream);
+                            int partial_blocks, long rows, int C, float scale, void *stream);
 /* Column sums of a (rows, C) bf16 matrix in f32, any C <= 256 (bias gradient of a convolution without a ReLU behind it,
  * e.g. the 21-channel fc8 outputs).  partials: device scratch of partial_blocks * C floats. */
 int dsrg_bias_grad_bf16(const void *g_dev, float *bias_grad_dev, float *partials_dev, int partial_blocks, long rows, int C,

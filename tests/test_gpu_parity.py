@@ -502,14 +502,12 @@ def test_backbone_runs_with_and_without_autocast():
     assert (y32 - yr).abs().max() < 1e-3 * scale
     assert (y16 - yr).abs().max() < 0.05 * scale
     # training mode: gradients reach the first convolution through the fused backward kernels
+    from dsrg_amd.backbone import GemmConv2d
     net.train()
-    for m in net.modules():
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
     ref.train()
-    for m in ref.modules():
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
+    for m in list(net.modules()) + list(ref.modules()):
+        if isinstance(m, GemmConv2d):
+            m.fuse_dropout = 0.0                         # dropout off: the two nets must see the same function
     g = torch.randn(2, 21, 13, 13, device="cuda")
     with torch.autocast("cuda", dtype=torch.bfloat16):
         la = (net(x.contiguous(memory_format=torch.channels_last)).float() * g).sum()
@@ -520,3 +518,33 @@ def test_backbone_runs_with_and_without_autocast():
                       ("features.28.weight", 0.15), ("features.17.weight", 0.4)]:
         ga, gb = dict(net.named_parameters())[name].grad, dict(ref.named_parameters())[name].grad
         assert torch.isfinite(ga).all() and (ga - gb).norm() < tol * gb.norm(), (name, float((ga - gb).norm() / gb.norm()))
+
+
+def test_fused_relu_dropout_backward_matches_unfused_sequence():
+    """conv + ReLU + Dropout in one autograd function: same dropout mask as F.dropout under the same seed, and the fused
+    backward (one pass reading the sign of the dropped output) equals conv -> relu -> dropout differentiated by torch"""
+    import torch.nn.functional as F
+    from dsrg_amd.backbone import GemmConv2d
+    for k, d in [(3, 6), (1, 1)]:
+        torch.manual_seed(3)
+        a = GemmConv2d(64, 128, k, padding=d * (k // 2), dilation=d, fuse_relu=True, fuse_dropout=0.5).cuda().to(
+            memory_format=torch.channels_last).train()
+        b = torch.nn.Conv2d(64, 128, k, padding=d * (k // 2), dilation=d).cuda().to(memory_format=torch.channels_last)
+        b.load_state_dict(a.state_dict())
+        x = torch.randn(2, 64, 41, 41, device="cuda").contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            torch.manual_seed(11)
+            ya = a(xa)
+            torch.manual_seed(11)
+            yb = F.dropout(torch.relu(b(xb)), 0.5, True)
+        zero_a, zero_b = ya == 0, yb == 0
+        assert (zero_a != zero_b).float().mean() < 0.01            # same mask (the two convs may disagree on a few signs)
+        g = torch.randn_like(yb)
+        ya.backward(g.to(ya.dtype)); yb.backward(g)
+        for u, v in [(xa.grad, xb.grad), (a.weight.grad, b.weight.grad), (a.bias.grad, b.bias.grad)]:
+            assert (u.float() - v.float()).norm() <= 0.03 * v.float().norm()
+    a.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y1, y2 = a(x), a(x)
+    assert torch.equal(y1, y2)                                      # no dropout in eval mode
