@@ -209,6 +209,7 @@ def main():
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "alg_bytes_per_launch": alg_bytes, "us_per_launch": per_launch_s * 1e6, "launches": filt_n,
                         "us_per_launch_event_bracket": raw_launch_us, "event_bracket_overhead_us": ev_overhead_ms * 1e3,
+                        "hbm_gbs_from_pmc_traffic": (traffic / per_launch_s / 1e9) if traffic else None,
                         "lattice_M_gauss": mg, "lattice_M_bilateral_mean": float(np.mean(mb)),
                         "note": "lattice values stay in LDS; algorithmic bytes are the stage-streamed traffic of "
                                 "SURVEY 8d, so frac may exceed what HBM counters show"}
@@ -225,6 +226,8 @@ def main():
                           "achieved": srg_bytes / (srg_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": srg_bytes / (srg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                           "traffic": pmc.get("dsrg::srg_grow_kernel", {}).get("hbm_bytes_per_launch"),
+                          "hbm_gbs_from_pmc_traffic": (pmc["dsrg::srg_grow_kernel"]["hbm_bytes_per_launch"] / (srg_us * 1e-6) / 1e9)
+                          if "dsrg::srg_grow_kernel" in pmc else None,
                           "alg_bytes_per_launch": srg_bytes, "us_per_launch": srg_us,
                           "note": "one workgroup per image; bounded by three dependent memory round trips, not bandwidth"})
         if args.mode == "train":
