@@ -25,8 +25,10 @@ struct FilterArgs {
     const float *q;          // (B,C,N)
     float *msg_g, *msg_b;    // (B,C,N)
     int B, C, N;
-    int nblk_b;              // bilateral blocks: ceil(C / CPW_B) * lat_stride
-    int lat_stride;          // round_up(B, 8): blocks of one image share blockIdx % 8 (one XCD)
+    int nblk_b;              // bilateral blocks: nblk_xcd + groups_b * (B - lat_stride) when B > lat_stride
+    int nblk_xcd;            // the first groups_b * lat_stride blocks: index = group * lat_stride + image
+    int lat_stride;          // a multiple of 8, so that the blocks of one image share blockIdx % 8 (one XCD and its L2)
+    int groups_b;            // ceil(C / CPW_B)
     int gau_stride;          // Gaussian blocks per plane group: ceil(B / ipb)
     int ipb;                 // images per Gaussian block
     int lds_val_stride;      // bilateral: vertices in the LDS value array (Mcap_b + 1, padded to 4)
@@ -336,8 +338,12 @@ __global__ __launch_bounds__(kWG) void mf_filter_kernel(FilterArgs a) {
     unsigned long long *dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr;
     if ((int)blockIdx.x < a.nblk_b) {
         using vec_t = typename PlaneVec<CPW_B>::type;
-        // blocks of one image share blockIdx % 8, i.e. one XCD and its L2
-        const int g = blockIdx.x / a.lat_stride, b = blockIdx.x % a.lat_stride;
+        // blocks of one image share blockIdx % 8, i.e. one XCD and its L2; the images beyond the last multiple of 8
+        // (B = 20: images 16..19) are laid out image-major so that they spread evenly over the XCDs — with the
+        // XCD-aware order alone 3 images x 11 blocks would land on a 32-CU XCD and force a second round there
+        int g, b;
+        if ((int)blockIdx.x < a.nblk_xcd) { g = blockIdx.x / a.lat_stride; b = blockIdx.x % a.lat_stride; }
+        else { const int rel = blockIdx.x - a.nblk_xcd; b = a.lat_stride + rel / a.groups_b; g = rel % a.groups_b; }
         if (b >= a.B) return;
         const int c0 = g * CPW_B, nc = min(CPW_B, a.C - c0);
         vec_t *val = reinterpret_cast<vec_t *>(smem);                      // [Mcap + 1] label-interleaved
@@ -527,13 +533,16 @@ int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const Meanfie
     FilterArgs a;
     a.Lg = Lg; a.Lb = Lb; a.q = buf.q; a.msg_g = buf.msg_g; a.msg_b = buf.msg_b;
     a.B = B; a.C = C; a.N = N;
-    a.lat_stride = (B + 7) & ~7;
-    a.nblk_b = ((C + cpw_b - 1) / cpw_b) * a.lat_stride;
-    // Gaussian blocks take two images each when the launch would otherwise exceed one round of 256 CUs (one workgroup
-    // per CU): a Gaussian pass costs half a bilateral block (9 vs 18 us), so two images balance the two kinds.  More
-    // images per block only stretch the critical path (measured at B = 20: 4 images per block 56 us, 2 images 36 us).
+    a.groups_b = (C + cpw_b - 1) / cpw_b;
+    // one workgroup per CU (LDS), 32 CUs per XCD, blockIdx % 8 picks the XCD: keep whole images on one XCD for the largest
+    // multiple of 8 images (small batches are padded up to 8), spread the remaining images' blocks over all XCDs
+    a.lat_stride = B < 8 ? 8 : (B & ~7);
+    a.nblk_xcd = a.groups_b * a.lat_stride;
+    a.nblk_b = a.nblk_xcd + (B > a.lat_stride ? a.groups_b * (B - a.lat_stride) : 0);
+    // Gaussian blocks come last in the grid and fill CUs as bilateral blocks (twice as long) drain; one image each
+    // balances best up to B = 24, two images each beyond (measured: B = 16 20.0 vs 20.8 us, B = 32 39.2 vs 38.1 us)
     const int groups_g = (C + cpw_g - 1) / cpw_g;
-    a.ipb = (a.nblk_b + groups_g * B > 256 && B > 1) ? 2 : 1;
+    a.ipb = B > 24 ? 2 : 1;
     a.gau_stride = (B + a.ipb - 1) / a.ipb;
     a.lds_val_stride = vs_b;
     a.lds_val_stride_g = vs_g;
