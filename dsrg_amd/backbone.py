@@ -69,8 +69,8 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         pad = ctx.dilation * (ctx.k // 2)
-        fused = g.dtype == torch.bfloat16 and ((ctx.relu and weight.shape[0] % 8 == 0) or
-                                               (not ctx.relu and weight.shape[0] <= 256))
+        cout = weight.shape[0]
+        fused = g.dtype == torch.bfloat16 and ((cout % 8 == 0 and cout <= 2048) or (not ctx.relu and cout <= 256))
         if fused and ctx.relu:
             from .ops import relu_bwd_bias
             g, gb = relu_bwd_bias(g, y, ctx.scale)

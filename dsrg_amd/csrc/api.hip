@@ -285,7 +285,7 @@ extern "C" int dsrg_im2col3x3_nhwc16(const void *in, void *out, int B, int H, in
 }
 extern "C" int dsrg_relu_bwd_bias_bf16(const void *g, const void *y, void *gm, float *bias_grad, float *partials,
                                        int partial_blocks, long rows, int C, float scale, void *stream) {
-    if (!g || !y || !gm || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (!g || !bias_grad || !partials || (y && !gm)) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_relu_bwd_bias(g, y, gm, bias_grad, partials, partial_blocks, rows, C, scale, static_cast<hipStream_t>(stream));
 }
 extern "C" int dsrg_avgpool3x3_s1_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream) {

@@ -33,7 +33,9 @@ __global__ __launch_bounds__(kRbThreads) void relu_bwd_bias_kernel(const uint4 *
         const int r1 = min(rows, r0 + rows_per_block);
         for (int r = r0 + rl; r < r1; r += lanes_r) {
             const size_t i = (size_t)r * C8 + cg;
-            const uint4 gv = g[i], yv = y[i];
+            const uint4 gv = g[i];
+            // y == nullptr: no ReLU in front (plain column sums of g, nothing stored); 0x3f80 = bf16 1.0 passes the mask
+            const uint4 yv = y ? y[i] : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
             const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
             uint32_t ow[4];
 #pragma unroll
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(kRbThreads) void relu_bwd_bias_kernel(const uint4 *
                 acc[2 * k] += bf16_lo(ow[k]);
                 acc[2 * k + 1] += bf16_hi(ow[k]);
             }
-            gm[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            if (gm) gm[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
     }
 #pragma unroll

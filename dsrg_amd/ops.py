@@ -288,7 +288,7 @@ def relu_bwd_bias(g, y, scale=1.0):
 
 
 def bias_grad(g):
-    """(B,C,H,W) bf16 channels_last -> per-channel sums over B,H,W as f32 (C,), any C <= 256"""
+    """(B,C,H,W) bf16 channels_last -> per-channel sums over B,H,W as f32 (C,); C <= 256, or a multiple of 8 up to 2048"""
     B, C, H, W = g.shape
     if not (g.is_cuda and g.dtype == torch.bfloat16):
         raise ValueError("bias_grad needs a bf16 CUDA tensor")
@@ -298,7 +298,11 @@ def bias_grad(g):
     part = _partials.get(key)
     if part is None:
         part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=g.device)
-    check(_lib.lib().dsrg_bias_grad_bf16(_ptr(g), _ptr(gb), _ptr(part), _PARTIAL_BLOCKS, B * H * W, C, _stream()))
+    if C % 8 == 0:                                   # 16-byte lanes, no mask, nothing stored
+        check(_lib.lib().dsrg_relu_bwd_bias_bf16(_ptr(g), None, None, _ptr(gb), _ptr(part), _PARTIAL_BLOCKS,
+                                                 B * H * W, C, 1.0, _stream()))
+    else:
+        check(_lib.lib().dsrg_bias_grad_bf16(_ptr(g), _ptr(gb), _ptr(part), _PARTIAL_BLOCKS, B * H * W, C, _stream()))
     return gb
 
 

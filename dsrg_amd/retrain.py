@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .backbone import VGG16ASPP, GemmConv2d
+from .backbone import VGG16ASPP, GemmConv2d, _ConvFn
 from .trainer import CaffeSGD
 
 
@@ -58,6 +58,20 @@ class _FrozenBN(nn.Module):
         return x * scale.view(1, -1, 1, 1).to(x.dtype) + shift.view(1, -1, 1, 1).to(x.dtype)
 
 
+def _conv_bn(x, conv, bn, relu):
+    """conv -> frozen-statistics BN (-> ReLU).  On the GPU, for stride-1 convolutions, the BN affine is folded into the
+    weights (W * scale per output channel, bias = shift) and the whole thing is one im2col + GEMM with the bias (and ReLU)
+    in the epilogue (backbone._ConvFn; 1x1 convolutions need no im2col at all).  gamma / beta still train: their
+    gradients flow through the weight-sized products instead of activation-sized reductions."""
+    if x.is_cuda and conv.stride == (1, 1) and conv.kernel_size[0] in (1, 3) and conv.in_channels % 8 == 0 and \
+            conv.padding[0] == conv.dilation[0] * (conv.kernel_size[0] // 2):
+        scale = bn.weight * torch.rsqrt(bn.running_var + 1e-5)
+        shift = bn.bias - bn.running_mean * scale
+        return _ConvFn.apply(x, conv.weight * scale.view(-1, 1, 1, 1), shift, conv.dilation[0], relu, True, 0.0)
+    y = bn(conv(x))
+    return F.relu(y) if relu else y
+
+
 class _Bottleneck(nn.Module):
     def __init__(self, cin, mid, stride, dilation, down):
         super().__init__()
@@ -68,10 +82,11 @@ class _Bottleneck(nn.Module):
         self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), _FrozenBN(cout)) if down else None
 
     def forward(self, x):
-        y = F.relu(self.b1(self.c1(x)))
-        y = F.relu(self.b2(self.c2(y)))
-        y = self.b3(self.c3(y))
-        return F.relu(y + (self.down(x) if self.down is not None else x))
+        y = _conv_bn(x, self.c1, self.b1, True)
+        y = _conv_bn(y, self.c2, self.b2, True)
+        y = _conv_bn(y, self.c3, self.b3, False)
+        idn = _conv_bn(x, self.down[0], self.down[1], False) if self.down is not None else x
+        return F.relu(y + idn)
 
 
 class ResNet101DeepLab(nn.Module):

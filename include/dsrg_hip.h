@@ -183,7 +183,8 @@ int dsrg_im2col3x3_nhwc16(const void *in_dev, void *out_dev, int B, int H, int W
 /* ReLU backward fused with the bias-gradient reduction of the convolution in front of it: g, y (the ReLU output) and
  * gm are (rows, C) bf16 row-major (NHWC activations), C % 8 == 0; gm = scale * g where y > 0 else 0; bias_grad[c] =
  * sum_r gm[r,c] (f32, summed in a fixed order).  scale = 1 for a plain ReLU; with y = dropout(relu(.)) and
- * scale = 1/(1-p) the same pass is the backward of ReLU + Dropout (y > 0 is both masks at once).
+ * scale = 1/(1-p) the same pass is the backward of ReLU + Dropout (y > 0 is both masks at once).  y_dev = gm_dev = NULL:
+ * no ReLU, only the column sums of g (any C % 8 == 0 up to 2048; dsrg_bias_grad_bf16 covers the other widths).
  * partials: device scratch of partial_blocks * C floats. */
 int dsrg_relu_bwd_bias_bf16(const void *g_dev, const void *y_dev, void *gm_dev, float *bias_grad_dev, float *partials_dev,
                             int partial_blocks, long rows, int C, float scale, void *stream);

@@ -548,3 +548,33 @@ def test_fused_relu_dropout_backward_matches_unfused_sequence():
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         y1, y2 = a(x), a(x)
     assert torch.equal(y1, y2)                                      # no dropout in eval mode
+
+
+def test_resnet_folded_bn_path_matches_unfused_reference():
+    """train-f's ResNet-101: conv + frozen BN (+ ReLU) folded into one GEMM on the GPU against the plain
+    conv -> affine -> relu sequence in fp32 on the CPU, forward and the gradients of conv weights, gamma and beta"""
+    from dsrg_amd import retrain as R
+    torch.manual_seed(0)
+    ref = R.ResNet101DeepLab(blocks=(1, 1, 1, 1))
+    with torch.no_grad():
+        for m in ref.modules():                      # non-trivial statistics and affine parameters
+            if isinstance(m, R._FrozenBN):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    net = R.ResNet101DeepLab(blocks=(1, 1, 1, 1))
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(2, 3, 65, 65)
+    g = torch.randn(2, 21, 9, 9)
+    yr = ref(x)
+    (yr * g).sum().backward()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yg = net(x.cuda().contiguous(memory_format=torch.channels_last)).float()
+    (yg * g.cuda()).sum().backward()
+    assert yg.shape == yr.shape
+    assert (yg.cpu() - yr).norm() < 0.05 * yr.norm()
+    pr, pg = dict(ref.named_parameters()), dict(net.named_parameters())
+    for name in ["layers.3.c3.weight", "layers.3.b3.weight", "layers.3.b3.bias", "layers.2.c2.weight", "layers.2.b2.weight",
+                 "layers.1.c1.weight", "layers.1.b1.bias", "layers.0.down.0.weight", "layers.0.b2.weight", "aspp.2.weight"]:
+        a, b = pg[name].grad.float().cpu(), pr[name].grad
+        assert torch.isfinite(a).all() and (a - b).norm() < 0.15 * b.norm(), (name, float((a - b).norm() / b.norm()))
