@@ -34,7 +34,9 @@ def _im2col_gemm(x, weight, bias, dilation, relu):
     # write straight into a channels_last (B,cout,H,W) tensor: its NHWC memory is the GEMM's C matrix
     out = torch.empty((B, cout, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
     o2 = out.permute(0, 2, 3, 1).view(-1, cout)
-    if relu:
+    if bias is None:
+        torch.mm(a, wmat, out=o2)
+    elif relu:
         torch._addmm_activation(bias, a, wmat, out=o2)
     else:
         torch.addmm(bias, a, wmat, out=o2)
@@ -61,7 +63,7 @@ class _ConvFn(torch.autograd.Function):
         if drop_p > 0.0:
             out = torch.ops.aten.native_dropout(out, drop_p, True)[0]    # out = relu * mask / (1 - p)
         ctx.save_for_backward(x, weight, out if relu else None)
-        ctx.dilation, ctx.k, ctx.relu, ctx.scale = dilation, k, relu, 1.0 / (1.0 - drop_p)
+        ctx.dilation, ctx.k, ctx.relu, ctx.scale, ctx.gemm = dilation, k, relu, 1.0 / (1.0 - drop_p), gemm
         return out
 
     @staticmethod
@@ -82,10 +84,29 @@ class _ConvFn(torch.autograd.Function):
             if ctx.relu:
                 g = g * (y > 0) * ctx.scale
             g = g.contiguous(memory_format=torch.channels_last)
-        gx, gw, gb2 = torch.ops.aten.convolution_backward(
+        # data gradient of a 3x3 'same' convolution = the forward convolution of g with the flipped, transposed kernel:
+        # the im2col + hipBLASLt route again (~1.2 PFLOP/s at the 41x41 stages against 550-630 TFLOP/s for CK's dgrad)
+        gemm_dgrad = ctx.gemm and ctx.k == 3 and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and cout % 8 == 0 \
+            and x.shape[2] * x.shape[3] <= 2048                # larger maps: the im2col of g costs more than it saves
+        gx = None
+        if gemm_dgrad:
+            gx = _im2col_gemm(g, weight.flip(2, 3).transpose(0, 1), None, ctx.dilation, False)
+        # weight gradient = im2col(x)^T @ g, again one hipBLASLt GEMM (K = B*H*W).  Only where MIOpen's wrw is slow: the
+        # 512 -> 1024 dilated fc6 layers (650 TFLOP/s; measured 883 -> 902 images/s); at 512 -> 512 MIOpen already runs
+        # at ~1 PFLOP/s and the GEMM route loses (864 images/s with it everywhere)
+        gemm_wgrad = gemm_dgrad and fused and x.shape[1] % 8 == 0 and cout >= 1024
+        gw = None
+        if gemm_wgrad:
+            from .ops import im2col3x3_nhwc
+            cin = x.shape[1]
+            cols = im2col3x3_nhwc(x.permute(0, 2, 3, 1), ctx.dilation)                  # (M, 9*Cin)
+            g2d = g.permute(0, 2, 3, 1).reshape(-1, cout)                                # (M, Cout), NHWC memory
+            gw = torch.mm(cols.t(), g2d).view(3, 3, cin, cout).permute(3, 2, 0, 1)
+        gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
             g, x, weight, None if fused else [weight.shape[0]], [1, 1], [pad, pad],
-            [ctx.dilation, ctx.dilation], False, [0, 0], 1, [ctx.needs_input_grad[0], True, not fused])
-        return gx, gw, (gb if fused else gb2), None, None, None, None
+            [ctx.dilation, ctx.dilation], False, [0, 0], 1,
+            [ctx.needs_input_grad[0] and not gemm_dgrad, not gemm_wgrad, not fused])
+        return (gx if gemm_dgrad else gx2), (gw if gemm_wgrad else gw2), (gb if fused else gb2), None, None, None, None
 
 
 class GemmConv2d(nn.Conv2d):

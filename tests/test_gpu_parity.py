@@ -304,7 +304,8 @@ def test_gemm_conv_matches_miopen_conv():
     from dsrg_amd.backbone import GemmConv2d
     torch.manual_seed(0)
     for cin, cout, k, d, relu, gemm in [(32, 48, 3, 1, False, True), (32, 48, 3, 6, True, True), (64, 21, 1, 1, False, True),
-                                        (64, 64, 1, 1, True, True), (3, 64, 3, 1, True, False), (16, 24, 3, 2, True, True)]:
+                                        (64, 64, 1, 1, True, True), (3, 64, 3, 1, True, False), (16, 24, 3, 2, True, True),
+                                        (64, 1024, 3, 12, True, True)]:      # wide output: GEMM data AND weight gradients
         a = GemmConv2d(cin, cout, k, padding=d * (k // 2), dilation=d, fuse_relu=relu, gemm=gemm).cuda().to(memory_format=torch.channels_last)
         b = torch.nn.Conv2d(cin, cout, k, padding=d * (k // 2), dilation=d).cuda().to(memory_format=torch.channels_last)
         b.load_state_dict(a.state_dict())
