@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-def _im2col_gemm(x, weight, bias, dilation, relu):
+def _im2col_gemm(x, weight, bias, dilation, relu, want_cols=False):
     """(B,C,H,W) bf16 -> conv(+ReLU) output as a channels_last tensor: NHWC im2col (HIP) + one hipBLASLt GEMM whose
     epilogue adds the bias (and applies the ReLU)."""
     B, C, H, W = x.shape
@@ -40,7 +40,7 @@ def _im2col_gemm(x, weight, bias, dilation, relu):
         torch._addmm_activation(bias, a, wmat, out=o2)
     else:
         torch.addmm(bias, a, wmat, out=o2)
-    return out
+    return (out, a) if want_cols else out
 
 
 class _ConvFn(torch.autograd.Function):
@@ -54,22 +54,27 @@ class _ConvFn(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
     def forward(ctx, x, weight, bias, dilation, relu, gemm, drop_p):
         k = weight.shape[2]
+        cols = None
         if gemm:
-            out = _im2col_gemm(x, weight, bias, dilation, relu)
+            # the im2col matrix is kept for the layers whose weight gradient is a GEMM too (see backward)
+            keep = k == 3 and weight.shape[0] >= 1024 and x.shape[1] % 8 == 0 and x.shape[2] * x.shape[3] <= 2048
+            out = _im2col_gemm(x, weight, bias, dilation, relu, want_cols=keep)
+            if keep:
+                out, cols = out
         else:
             out = F.conv2d(x.contiguous(memory_format=torch.channels_last), weight, bias, 1, dilation * (k // 2), dilation)
             if relu:
                 out.relu_()
         if drop_p > 0.0:
             out = torch.ops.aten.native_dropout(out, drop_p, True)[0]    # out = relu * mask / (1 - p)
-        ctx.save_for_backward(x, weight, out if relu else None)
+        ctx.save_for_backward(x, weight, out if relu else None, cols)
         ctx.dilation, ctx.k, ctx.relu, ctx.scale, ctx.gemm = dilation, k, relu, 1.0 / (1.0 - drop_p), gemm
         return out
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        x, weight, y = ctx.saved_tensors
+        x, weight, y, cols = ctx.saved_tensors
         pad = ctx.dilation * (ctx.k // 2)
         cout = weight.shape[0]
         fused = g.dtype == torch.bfloat16 and ((cout % 8 == 0 and cout <= 2048) or (not ctx.relu and cout <= 256))
@@ -97,9 +102,10 @@ class _ConvFn(torch.autograd.Function):
         gemm_wgrad = gemm_dgrad and fused and x.shape[1] % 8 == 0 and cout >= 1024
         gw = None
         if gemm_wgrad:
-            from .ops import im2col3x3_nhwc
             cin = x.shape[1]
-            cols = im2col3x3_nhwc(x.permute(0, 2, 3, 1), ctx.dilation)                  # (M, 9*Cin)
+            if cols is None or cols.dtype != g.dtype:
+                from .ops import im2col3x3_nhwc
+                cols = im2col3x3_nhwc(x.permute(0, 2, 3, 1).contiguous(), ctx.dilation)  # (M, 9*Cin)
             g2d = g.permute(0, 2, 3, 1).reshape(-1, cout)                                # (M, Cout), NHWC memory
             gw = torch.mm(cols.t(), g2d).view(3, 3, cin, cout).permute(3, 2, 0, 1)
         gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
