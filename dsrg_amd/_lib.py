@@ -69,6 +69,7 @@ SIGNATURES = {
     "dsrg_confusion_matrix": (_i, [_sz, _vp, _vp, _i, _i, _vp, _vp]),
     "dsrg_im2col3x3_nhwc16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dsrg_relu_bwd_bias_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, ctypes.c_long, _i, ctypes.c_float, _vp]),
+    "dsrg_col2im3x3_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dsrg_avgpool3x3_s1_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dsrg_bias_grad_bf16": (_i, [_vp, _vp, _vp, _i, ctypes.c_long, _i, _vp]),
     "dsrg_maxpool3x3_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -94,7 +94,14 @@ class _ConvFn(torch.autograd.Function):
         gemm_dgrad = ctx.gemm and ctx.k == 3 and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and cout % 8 == 0 \
             and x.shape[2] * x.shape[3] <= 2048    # larger maps: the im2col of g costs more than it saves (measured at 81x81)
         gx = None
-        if gemm_dgrad:
+        if gemm_dgrad and cout > x.shape[1] and x.shape[1] % 8 == 0:
+            # more output than input channels (fc6: 1024 vs 512): g @ W^T first, then gather the nine taps (col2im) —
+            # half the traffic of an im2col of the wide g
+            from .ops import col2im3x3_nhwc
+            B_, cin, H_, W_ = x.shape
+            wmat = weight.permute(2, 3, 1, 0).reshape(9 * cin, cout)
+            gx = col2im3x3_nhwc(torch.mm(g.permute(0, 2, 3, 1).reshape(-1, cout), wmat.t()), B_, H_, W_, cin, ctx.dilation)
+        elif gemm_dgrad:
             gx = _im2col_gemm(g, weight.flip(2, 3).transpose(0, 1), None, ctx.dilation, False)
         # weight gradient = im2col(x)^T @ g, again one hipBLASLt GEMM (K = B*H*W).  Only where MIOpen's wrw is slow: the
         # 512 -> 1024 dilated fc6 layers (650 TFLOP/s; measured 883 -> 902 images/s); at 512 -> 512 MIOpen already runs

@@ -288,6 +288,10 @@ extern "C" int dsrg_relu_bwd_bias_bf16(const void *g, const void *y, void *gm, f
     if (!g || !bias_grad || !partials || (y && !gm)) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_relu_bwd_bias(g, y, gm, bias_grad, partials, partial_blocks, rows, C, scale, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_col2im3x3_nhwc_bf16(const void *cols, void *out, int B, int H, int W, int C, int dilation, void *stream) {
+    if (!cols || !out || B <= 0 || H <= 0 || W <= 0 || dilation < 1) return set_error(DSRG_ERR_INVALID, "bad col2im arguments");
+    return launch_col2im3x3(cols, out, B, H, W, C, dilation, static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_avgpool3x3_s1_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream) {
     if (!in || !out) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_avgpool3x3_s1(in, out, B, H, W, C, static_cast<hipStream_t>(stream));

@@ -120,6 +120,7 @@ int launch_expand_loss(int B, int C, int HW, const float *p, const float *stat, 
 int launch_confusion(size_t n, const unsigned char *gt, const unsigned char *pred, int nclass, int rule_lt,
                      unsigned long long *hist, hipStream_t stream);
 int launch_im2col3x3(const void *in, void *out, int B, int H, int W, int C, int dil, hipStream_t stream);
+int launch_col2im3x3(const void *cols, void *out, int B, int H, int W, int C, int dil, hipStream_t stream);
 int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_grad, float *part, int part_blocks,
                          long rows, int C, float scale, hipStream_t stream);
 int launch_avgpool3x3_s1(const void *in, void *out, int B, int H, int W, int C, hipStream_t stream);

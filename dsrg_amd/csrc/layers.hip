@@ -484,6 +484,52 @@ __global__ void im2col3x3_nhwc16_kernel(const uint4 *__restrict__ in, uint4 *__r
     if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[(((size_t)b * H + yy) * W + xx) * C8 + c];
     out[idx] = v;
 }
+// adjoint of the im2col above: out[b,y,x,:] = sum over the 9 taps of cols[(b, y - dy*dil, x - dx*dil), tap, :] for the source
+// pixels that exist (dy, dx in {-1,0,1}); cols is (B*H*W, 9*C) 2-byte bf16, sums in f32.  Used for the data gradient of a
+// 3x3 convolution with more output than input channels: g @ W^T first (no im2col of the wide g), then this gather.
+__global__ void col2im3x3_nhwc16_kernel(const uint4 *__restrict__ cols, uint4 *__restrict__ out, int B, int H, int W,
+                                        int C8, int dil) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * W * C8;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8);
+    size_t r = idx / C8;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y - (tap / 3 - 1) * dil, xx = x - (tap % 3 - 1) * dil;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const uint4 v = cols[((((size_t)b * H + yy) * W + xx) * 9 + tap) * C8 + c];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[2 * k] += __uint_as_float(w[k] << 16);
+            acc[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t lo = __float_as_uint(acc[2 * k]), hi = __float_as_uint(acc[2 * k + 1]);
+        lo = (lo + 0x7fffu + ((lo >> 16) & 1u)) >> 16;                    // round to nearest even (finite sums)
+        hi = (hi + 0x7fffu + ((hi >> 16) & 1u)) >> 16;
+        o[k] = lo | (hi << 16);
+    }
+    out[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+int launch_col2im3x3(const void *cols, void *out, int B, int H, int W, int C, int dil, hipStream_t stream) {
+    if (C % 8 != 0) return set_error(DSRG_ERR_UNSUPPORTED, "col2im: channels must be a multiple of 8");
+    const size_t total = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(col2im3x3_nhwc16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const uint4 *)cols, (uint4 *)out, B, H, W, C / 8, dil);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
 int launch_im2col3x3(const void *in, void *out, int B, int H, int W, int C, int dil, hipStream_t stream) {
     if (C % 8 != 0) return set_error(DSRG_ERR_UNSUPPORTED, "im2col: channels must be a multiple of 8");
     const size_t total = (size_t)B * H * W * 9 * (C / 8);

@@ -263,6 +263,15 @@ def im2col3x3_nhwc(x_nhwc, dilation):
     return out
 
 
+def col2im3x3_nhwc(cols, B, H, W, C, dilation):
+    """(B*H*W, 9*C) contiguous bf16 -> (B,C,H,W) channels_last bf16: the adjoint of im2col3x3_nhwc"""
+    if not (cols.is_cuda and cols.is_contiguous() and cols.dtype == torch.bfloat16 and cols.shape == (B * H * W, 9 * C)):
+        raise ValueError("cols must be a contiguous (B*H*W, 9*C) bf16 CUDA tensor")
+    out = torch.empty((B, C, H, W), dtype=cols.dtype, device=cols.device, memory_format=torch.channels_last)
+    check(_lib.lib().dsrg_col2im3x3_nhwc_bf16(_ptr(cols), _ptr(out), B, H, W, C, int(dilation), _stream()))
+    return out
+
+
 _PARTIAL_BLOCKS = 512
 _partials = {}
 

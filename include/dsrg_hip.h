@@ -180,6 +180,9 @@ int dsrg_confusion_matrix(size_t n, const unsigned char *gt_dev, const unsigned 
  * of a 3x3, stride-1, "same"-padded, dilated convolution for 2-byte elements (bf16/fp16), C % 8 == 0:
  *   out[(b,y,x)][tap][c] = in[b][y+(tap/3-1)*dil][x+(tap%3-1)*dil][c], zero outside the map. */
 int dsrg_im2col3x3_nhwc16(const void *in_dev, void *out_dev, int B, int H, int W, int C, int dilation, void *stream);
+/* Adjoint of dsrg_im2col3x3_nhwc16 for bf16: out[b,y,x,:] = sum over the 9 taps of cols[(b, y-dy*dil, x-dx*dil), tap, :]
+ * (cols: (B*H*W, 9*C) row-major, f32 accumulation).  With cols = g @ W^T this is the data gradient of the convolution. */
+int dsrg_col2im3x3_nhwc_bf16(const void *cols_dev, void *out_dev, int B, int H, int W, int C, int dilation, void *stream);
 /* ReLU backward fused with the bias-gradient reduction of the convolution in front of it: g, y (the ReLU output) and
  * gm are (rows, C) bf16 row-major (NHWC activations), C % 8 == 0; gm = scale * g where y > 0 else 0; bias_grad[c] =
  * sum_r gm[r,c] (f32, summed in a fixed order).  scale = 1 for a plain ReLU; with y = dropout(relu(.)) and

@@ -579,3 +579,14 @@ def test_resnet_folded_bn_path_matches_unfused_reference():
                  "layers.1.c1.weight", "layers.1.b1.bias", "layers.0.down.0.weight", "layers.0.b2.weight", "aspp.2.weight"]:
         a, b = pg[name].grad.float().cpu(), pr[name].grad
         assert torch.isfinite(a).all() and (a - b).norm() < 0.15 * b.norm(), (name, float((a - b).norm() / b.norm()))
+
+
+def test_col2im_is_the_adjoint_of_im2col(ops):
+    """<col2im(c), x> == <c, im2col(x)> for random bf16 tensors (f32 dot products), several dilations"""
+    torch.manual_seed(5)
+    for B, C, H, W, d in [(2, 16, 9, 7, 1), (1, 64, 41, 41, 12), (2, 8, 5, 5, 6), (1, 24, 13, 11, 2)]:
+        x = torch.randn(B, H, W, C, device="cuda").bfloat16()
+        c = torch.randn(B * H * W, 9 * C, device="cuda").bfloat16()
+        lhs = (ops.col2im3x3_nhwc(c, B, H, W, C, d).permute(0, 2, 3, 1).float() * x.float()).sum()
+        rhs = (c.float() * ops.im2col3x3_nhwc(x, d).float()).sum()
+        assert abs(lhs.item() - rhs.item()) <= 0.01 * max(1.0, abs(rhs.item())) + 0.02 * (c.float().abs().sum() * 2 ** -8).item() ** 0.5
