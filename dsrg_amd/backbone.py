@@ -48,7 +48,8 @@ class _ConvFn(torch.autograd.Function):
     when `gemm` (at the 41x41 stages, 76 % of the backbone flops, MIOpen's forward kernels reach ~180 TFLOP/s on MI355X,
     the GEMM route 300-1200: tools/conv_probe.py), MIOpen otherwise.  Backward: the ReLU mask, the dropout mask and scale
     and the bias gradient come from one fused HIP pass (ops.relu_bwd_bias: the output of ReLU + Dropout is positive
-    exactly where both masks pass); data and weight gradients stay with MIOpen/CK."""
+    exactly where both masks pass); data and weight gradients go to hipBLASLt GEMMs where that beats MIOpen/CK (the 41x41
+    stages, see the comments in backward) and to MIOpen/CK otherwise."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
