@@ -69,6 +69,32 @@ def cpu_baseline(batch_np, target_s=12.0):
                       "reference runs exactly this part on the CPU (its convolutions run in Caffe on a GPU)" % (n_done, dt)}
 
 
+def cpu_baseline_all_cores(seconds=6.0, max_workers=32, timeout_s=90.0):
+    """the same port, image-parallel over the host cores as the reference's multiprocessing.Pool does it: independent
+    `oracle/baseline_worker.py` processes (they never touch the GPU), every wait bounded by a timeout"""
+    import subprocess
+    workers = max(1, min(os.cpu_count() or 1, max_workers))
+    t0 = time.perf_counter()
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "baseline_worker.py"), str(5000 + w), str(seconds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for w in range(workers)]
+    n, span, failed = 0, 0.0, 0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, timeout_s - (time.perf_counter() - t0)))
+            a, b = out.decode().split()[:2]
+            n += int(a)
+            span = max(span, float(b))
+        except Exception:
+            p.kill()
+            failed += 1
+    if n == 0:
+        return {"error": "no worker finished within %.0f s" % timeout_s}
+    return {"value": n / span, "unit": "images/s (supervision path only)", "cores": workers - failed, "kind": "port",
+            "sample": "%d images over %d processes in %.1f s of work each (%.1f s with process start-up), host has %d "
+                      "logical CPUs" % (n, workers - failed, span, time.perf_counter() - t0, os.cpu_count() or 0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +295,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch_np)
+            try:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+            except Exception as e:                       # never let the extra baseline cost the bench line
+                out["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
