@@ -139,3 +139,14 @@ def test_confusion_matrix_oracle():
                 M[g, q] += 1.0
         keep = gt != 100 if not rule_lt else np.ones_like(gt, bool)
         assert np.array_equal(O.confusion_matrix(gt[keep], pred[keep], n, rule_lt), M)
+
+
+def test_baseline_worker_script_runs():
+    """bench.py's image-parallel CPU baseline launches oracle/baseline_worker.py: it must print '<count> <seconds>'"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "oracle", "baseline_worker.py"), "1", "0.3"],
+                         capture_output=True, timeout=120, check=True).stdout.decode().split()
+    assert int(out[0]) >= 1 and float(out[1]) >= 0.3
