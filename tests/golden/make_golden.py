@@ -184,6 +184,24 @@ def srg_case_inputs():
         ref = r / r.sum(0, keepdims=True)
         seed = (rng.random((C, H, W)) < 0.03).astype(np.float32)
         yield "noise%d" % s, labels, seed, ref
+    # (i) larger and oddly shaped noise maps: training sizes, the 128-column limit of the row-mask path and beyond it,
+    #     many present classes, dense and sparse cues (separate generator so that the cases above keep their bytes)
+    rng2 = np.random.default_rng(11)
+    shapes = [(41, 41), (41, 41), (65, 65), (2, 128), (128, 3), (33, 97), (3, 150), (140, 5), (17, 64), (64, 17), (41, 41), (9, 129)]
+    for s, (H, W) in enumerate(shapes):
+        npres = int(rng2.integers(1, 9))
+        pres = [0] + sorted(int(x) for x in rng2.choice(np.arange(1, C), size=npres, replace=False))
+        labels, seed, ref = blank(H, W, pres)
+        r = rng2.random((C, H, W)) ** 4
+        r[[c for c in range(C) if c not in pres]] *= 0.01
+        blocks = max(1, int(rng2.integers(1, 6)))                      # coarse winner map -> larger components
+        win = rng2.integers(0, len(pres), size=((H + blocks - 1) // blocks, (W + blocks - 1) // blocks))
+        win = np.kron(win, np.ones((blocks, blocks), dtype=win.dtype))[:H, :W]
+        for k, c in enumerate(pres):
+            r[c][win == k] += rng2.choice([0.0, 5.0, 50.0], size=int((win == k).sum()), p=[0.15, 0.35, 0.5])
+        ref = r / r.sum(0, keepdims=True)
+        seed = (rng2.random((C, H, W)) < (0.002 if s % 2 else 0.02)).astype(np.float32)
+        yield "wide%d" % s, labels, seed, ref
 
 
 def main():
