@@ -44,8 +44,9 @@ struct FilterArgs {
 //     buffer loads (per-lane offset in one VGPR, strides in the scalar offset, out-of-range reads
 //     return 0) — one exposed round trip per lattice instead of one per phase;
 //   * label planes are interleaved [vertex][CPW] in LDS and moved 8 bytes at a time (CPW = 2);
-//   * one workgroup filters its planes through the bilateral and then the Gaussian lattice of its
-//     image, so every workgroup carries the same load (176 workgroups at B = 16, one round).
+//   * one launch carries both lattices: bilateral blocks (2 label planes of one image, ~18 us) first in the grid,
+//     Gaussian blocks (4 planes, ~9 us per image) after them so that they fill CUs as those drain; one workgroup per
+//     CU (LDS), 176 + 96 blocks at B = 16 (see launch_meanfield for the block -> XCD map).
 template <int CPW> struct PlaneVec;
 template <> struct PlaneVec<1> { using type = float; };
 template <> struct PlaneVec<2> { using type = float2; };
