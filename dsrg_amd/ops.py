@@ -273,6 +273,9 @@ def col2im3x3_nhwc(cols, B, H, W, C, dilation):
 
 
 _PARTIAL_BLOCKS = 512
+# scratch for the per-block partial column sums, one buffer per (device, channel count).  Calls are stream-ordered on
+# torch's current stream (autograd runs a backward pass on one stream), so consecutive users never overlap; code that
+# drives these ops from several streams at once must give each stream its own buffers.
 _partials = {}
 
 
