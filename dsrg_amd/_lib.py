@@ -56,6 +56,8 @@ SIGNATURES = {
     "dsrg_crf_prepare_batch": (_i, [_vp, _i, _vp, _i, _i, ctypes.POINTER(CrfParams), _vp]),
     "dsrg_crf_meanfield_batch": (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(CrfParams), _vp, _vp]),
     "dsrg_ctx_lattice_sizes": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "dsrg_ctx_lattice_dump": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dsrg_ctx_read_refined": (_i, [_vp, _i, _vp, _vp]),
     "dsrg_ctx_profile_start": (_i, [_vp, _i]),
     "dsrg_ctx_profile_stop": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
     "dsrg_crf_layer_backward": (_i, [_sz, _vp, _vp, _vp, _vp]),

@@ -242,10 +242,20 @@ class VGG16ASPP(nn.Module):
                 GemmConv2d(1024, 1024, 1, fuse_relu=True, gemm=g, fuse_dropout=dropout), FusedReLU(), FusedDropout(), fc8))
 
     def forward(self, x):
+        """-> fc8-SEC scores (B,21,h,w) in float32.  Under autocast the trunk and fc6/fc7 run in the autocast dtype, but
+        the four fc8-SEC_k classifiers and their Eltwise SUM (train-s.prototxt:737-744) always run in float32 (fp32
+        weights, fp32 accumulation, fp32 sum): these scores feed hard decisions the reference takes on fp32/fp64 values
+        (Softmax + 1e-4, the CRF, the 0.85 / 0.99 SRG thresholds, the 0.05 / 20 clip of the constrain loss), and a bf16
+        score of magnitude 8-16 has a step of 0.06-0.125."""
         f = self.features(x)
-        out = self.branches[0](f)
-        for br in self.branches[1:]:
-            out = out + br(f)
+        out = None
+        for br in self.branches:
+            h = f
+            for m in list(br)[:-1]:
+                h = m(h)
+            with torch.autocast(device_type=h.device.type, enabled=False):
+                s = br[-1](h.float())
+            out = s if out is None else out + s
         return out
 
     def caffe_param_groups(self):

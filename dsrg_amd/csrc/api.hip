@@ -230,6 +230,79 @@ extern "C" int dsrg_ctx_lattice_sizes(dsrg_ctx_t c, int B, int32_t *m_gauss, int
     return DSRG_OK;
 }
 
+// introspection (tests): the lattice of image b (kind 1, bilateral) or the shared Gaussian lattice (kind 0) in the
+// reference's own form — keys in id order (HashTable::getKeys, permutohedral.cpp:296), per-pixel vertex ids and
+// barycentric weights pixel-major (offset_ / barycentric_, :272-274), blur neighbours per axis with -1 = none (:315-316)
+extern "C" int dsrg_ctx_lattice_dump(dsrg_ctx_t c, int kind, int b, int32_t *m_host, int16_t *keys_host, int32_t *vid_host,
+                                     float *bary_host, int32_t *n1_host, int32_t *n2_host, void *stream) {
+    if (!c || (kind != 0 && kind != 1) || !m_host) return set_error(DSRG_ERR_INVALID, "bad argument");
+    const LatticeView &L = kind == 0 ? c->Lg : c->Lb;
+    if (b < 0 || b >= L.nlat) return set_error(DSRG_ERR_INVALID, "lattice index %d outside 0..%d", b, L.nlat - 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DSRG_HIP_CHECK(hipStreamSynchronize(s));
+    const int d = L.d, d1 = d + 1, N = L.N, Mcap = L.Mcap, KW = (d * 16 + 31) / 32;
+    int32_t M = 0;
+    DSRG_HIP_CHECK(hipMemcpy(&M, L.M + b, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *m_host = M;
+    if (M < 0 || M > Mcap) return set_error(DSRG_ERR_HIP, "lattice %d has not been built", b);
+    if (keys_host) {
+        uint32_t *kv = new (std::nothrow) uint32_t[(size_t)(M > 0 ? M : 1) * KW];
+        if (!kv) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+        hipError_t e = hipMemcpy(kv, L.key_v + (size_t)b * Mcap * KW, sizeof(uint32_t) * (size_t)M * KW, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (int v = 0; v < M; v++)
+                for (int k = 0; k < d; k++)            // embed.h pack_key: (short + 0x8000) in 16-bit fields
+                    keys_host[(size_t)v * d + k] =
+                        (int16_t)(int)(((kv[(size_t)v * KW + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu) - 0x8000u);
+        delete[] kv;
+        DSRG_HIP_CHECK(e);
+    }
+    if (vid_host) {
+        uint16_t *t = new (std::nothrow) uint16_t[(size_t)d1 * N];
+        if (!t) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+        hipError_t e = hipMemcpy(t, L.vid + (size_t)b * d1 * N, sizeof(uint16_t) * (size_t)d1 * N, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (int i = 0; i < N; i++)
+                for (int r = 0; r < d1; r++) vid_host[(size_t)i * d1 + r] = t[(size_t)r * N + i];
+        delete[] t;
+        DSRG_HIP_CHECK(e);
+    }
+    if (bary_host) {
+        float *t = new (std::nothrow) float[(size_t)d1 * N];
+        if (!t) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+        hipError_t e = hipMemcpy(t, L.bary + (size_t)b * d1 * N, sizeof(float) * (size_t)d1 * N, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (int i = 0; i < N; i++)
+                for (int r = 0; r < d1; r++) bary_host[(size_t)i * d1 + r] = t[(size_t)r * N + i];
+        delete[] t;
+        DSRG_HIP_CHECK(e);
+    }
+    if (n1_host || n2_host) {
+        uint32_t *t = new (std::nothrow) uint32_t[(size_t)d1 * Mcap];
+        if (!t) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+        hipError_t e = hipMemcpy(t, L.nb + (size_t)b * d1 * Mcap, sizeof(uint32_t) * (size_t)d1 * Mcap, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (int j = 0; j < d1; j++)
+                for (int v = 0; v < M; v++) {
+                    const uint32_t w = t[(size_t)j * Mcap + v];
+                    const int a = (int)(w & 0xFFFFu), z = (int)(w >> 16);
+                    if (n1_host) n1_host[(size_t)j * M + v] = a == Mcap ? -1 : a;
+                    if (n2_host) n2_host[(size_t)j * M + v] = z == Mcap ? -1 : z;
+                }
+        delete[] t;
+        DSRG_HIP_CHECK(e);
+    }
+    return DSRG_OK;
+}
+
+// introspection (tests): the float64 marginals (pylayers.py:84-86, `self.result`) of the last dsrg_supervision_step
+extern "C" int dsrg_ctx_read_refined(dsrg_ctx_t c, int B, double *refined_dev, void *stream) {
+    if (!c || !refined_dev || B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "bad argument");
+    DSRG_HIP_CHECK(hipMemcpyAsync(refined_dev, c->refined, sizeof(double) * (size_t)B * c->C * c->N, hipMemcpyDeviceToDevice,
+                                  static_cast<hipStream_t>(stream)));
+    return DSRG_OK;
+}
+
 extern "C" int dsrg_crf_layer_backward(size_t n, const double *refined, const float *td, float *bd, void *stream) {
     if (!refined || !td || !bd) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_crf_bwd(n, refined, td, bd, static_cast<hipStream_t>(stream));
@@ -505,6 +578,9 @@ extern "C" int dsrg_crf_inference(dsrg_crf_t h, int n_iters, float *out_host) {
     rc = launch_planes_to_lf(N, h->M, h->q, h->stage, nullptr);
     if (rc) return rc;
     DSRG_HIP_CHECK(hipMemcpy(out_host, h->stage, sizeof(float) * (size_t)N * h->M, hipMemcpyDefault));
+    // a device-to-device hipMemcpy may return before the copy has landed and other (non-blocking) streams do not wait
+    // for the null stream: this synchronous API returns only when `out` is final
+    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));
     return DSRG_OK;
 }
 extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
@@ -516,6 +592,7 @@ extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
     rc = launch_argmax_planes(N, h->M, h->q, h->lab, nullptr);
     if (rc) return rc;
     DSRG_HIP_CHECK(hipMemcpy(labels_host, h->lab, sizeof(int32_t) * (size_t)N, hipMemcpyDefault));
+    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));      // see dsrg_crf_inference
     return DSRG_OK;
 }
 extern "C" int dsrg_crf_lattice_size(dsrg_crf_t h, int k) {

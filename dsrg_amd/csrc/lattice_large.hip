@@ -549,12 +549,14 @@ int large_crf_read_q(LargeCrf *c, float *out_host) {
                        c->CP, c->q, c->stage);
     DSRG_LAUNCH_CHECK();
     DSRG_HIP_CHECK(hipMemcpy(out_host, c->stage, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault));
+    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));      // device-to-device copies may return early (see dsrg_crf_inference)
     return DSRG_OK;
 }
 int large_crf_read_map(LargeCrf *c, int32_t *labels_host) {
     hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, 0, c->N, c->C, c->CP, c->q, c->lab);
     DSRG_LAUNCH_CHECK();
     DSRG_HIP_CHECK(hipMemcpy(labels_host, c->lab, sizeof(int32_t) * (size_t)c->N, hipMemcpyDefault));
+    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));
     return DSRG_OK;
 }
 int large_crf_lattice_size(LargeCrf *c, int k) { return k == 0 ? c->Lg.M_host : c->Lb.M_host; }

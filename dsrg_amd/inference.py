@@ -10,6 +10,8 @@ The network runs in PyTorch-ROCm; resampling uses align-corners bilinear interpo
 sampling scipy.ndimage.zoom(order=1) performs ((in-1)/(out-1) mapping); the CRF is
 krahenbuhl2013.CRF (device-resident form crf.CRF_device) -> libdsrg_hip.so (global-memory lattice path for full-resolution maps).
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -26,6 +28,18 @@ def _zoom(x, h, w):
     return F.interpolate(x, size=(h, w), mode="bilinear", align_corners=True)
 
 
+@contextlib.contextmanager
+def _eval_mode(net):
+    """the reference runs these passes with caffe.TEST, where Dropout is the identity (test-ms.py:56-58): switch a net
+    that comes straight from a trainer to eval mode for the call and restore its mode afterwards"""
+    was_training = net.training
+    net.eval()
+    try:
+        yield net
+    finally:
+        net.train(was_training)
+
+
 def preprocess(image, size, device="cuda"):
     """image: (H,W,3) RGB uint8/float -> (1,3,size,size) float32 BGR, mean-subtracted (test-ms.py:68-81)"""
     x = torch.as_tensor(np.asarray(image), dtype=torch.float32, device=device).permute(2, 0, 1)[None]
@@ -39,10 +53,11 @@ def multiscale_scores(net, image, sizes=(241, 321, 401), device="cuda"):
     """sum over scales of the fc8 scores zoomed to the image resolution (test-ms.py:89-97) -> (C,H,W)"""
     d1, d2 = image.shape[0], image.shape[1]
     total = None
-    for size in sizes:
-        scores = net(preprocess(image, size, device)).float()
-        scores = _zoom(scores, d1, d2)
-        total = scores if total is None else total + scores
+    with _eval_mode(net):
+        for size in sizes:
+            scores = net(preprocess(image, size, device)).float()
+            scores = _zoom(scores, d1, d2)
+            total = scores if total is None else total + scores
     return total[0]
 
 
@@ -68,7 +83,8 @@ def predict_train_gt(net, image, labels, smooth=True, device="cuda"):
     """generate_train_gt.py:78-106: single-scale (321) softmax, zoomed to the image, CRF on log-probs,
     argmax restricted to background + the image-level labels -> (H,W) int64 pseudo-label mask"""
     d1, d2 = image.shape[0], image.shape[1]
-    scores = net(preprocess(image, 321, device)).float()
+    with _eval_mode(net):
+        scores = net(preprocess(image, 321, device)).float()
     probs = _zoom(torch.softmax(scores, dim=1), d1, d2)[0]
     probs = torch.clamp(probs, min=0.00001)
     if smooth:

@@ -63,6 +63,30 @@ class Context(object):
         check(_lib.lib().dsrg_ctx_lattice_sizes(self._h, B, ctypes.byref(mg), mb, _stream()))
         return mg.value, [mb[i] for i in range(B)]
 
+    def lattice_dump(self, kind, b=0):
+        """One lattice in the reference's own form (tests): kind 0 = Gaussian, 1 = bilateral lattice of image b.
+        -> dict(M, keys (M,d) int16, vid (N,d+1) int32, bary (N,d+1) f32, n1 / n2 (d+1,M) int32 with -1 = none)."""
+        import numpy as np
+        d, N = (2, self.H * self.W) if kind == 0 else (5, self.H * self.W)
+        m = ctypes.c_int32(0)
+        L = _lib.lib()
+        check(L.dsrg_ctx_lattice_dump(self._h, kind, b, ctypes.byref(m), None, None, None, None, None, _stream()))
+        M = m.value
+        keys = np.empty((M, d), np.int16)
+        vid = np.empty((N, d + 1), np.int32)
+        bary = np.empty((N, d + 1), np.float32)
+        n1 = np.empty((d + 1, M), np.int32)
+        n2 = np.empty((d + 1, M), np.int32)
+        check(L.dsrg_ctx_lattice_dump(self._h, kind, b, ctypes.byref(m), keys.ctypes.data, vid.ctypes.data, bary.ctypes.data,
+                                      n1.ctypes.data, n2.ctypes.data, _stream()))
+        return dict(M=M, keys=keys, vid=vid, bary=bary, n1=n1, n2=n2)
+
+    def read_refined(self, B):
+        """float64 marginals (B,C,H,W) the last supervision_step on this context thresholded (tests)"""
+        out = torch.empty((B, self.C, self.H, self.W), dtype=torch.float64, device="cuda")
+        check(_lib.lib().dsrg_ctx_read_refined(self._h, B, _ptr(out), _stream()))
+        return out
+
 
 _CTX_CACHE = {}
 

@@ -129,10 +129,15 @@ class RetrainTrainer(object):
     """one train-f step: backbone -> (logits, labels shrunk by 8) -> softmax loss -> SGD with poly LR"""
 
     def __init__(self, device, world_size=1, backbone="vgg16", base_lr=1e-3, max_iter=20000, seed=0,
-                 amp_dtype=torch.bfloat16, net=None):
+                 amp_dtype=torch.bfloat16, net=None, weights=None, snapshot=None):
+        """weights: run.sh:9 `--weights models/model-s_iter_8000.caffemodel` — stage 2 starts from the stage-1 model
+        (copied by layer name: .caffemodel / .npz / torch file); snapshot: a solverstate written by save()."""
         torch.manual_seed(seed)
         self.device, self.amp_dtype, self.max_iter, self.base_lr = device, amp_dtype, max_iter, base_lr
         net = net if net is not None else (VGG16ASPP() if backbone == "vgg16" else ResNet101DeepLab())
+        if weights is not None:
+            from .checkpoint import load_weights
+            self.loaded_layers = load_weights(net, weights)
         net = net.to(device)
         if device.type == "cuda":
             net = net.to(memory_format=torch.channels_last)
@@ -142,6 +147,17 @@ class RetrainTrainer(object):
             self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=32,
                              gradient_as_bucket_view=True)
         self.opt = CaffeSGD(net.caffe_param_groups(), base_lr=base_lr, gamma=1.0, stepsize=1 << 30)
+        if snapshot is not None:
+            self.load(snapshot)
+
+    def save(self, prefix="models/model-f"):
+        """solver-f.prototxt:15-16 `snapshot_prefix`"""
+        from .checkpoint import save_snapshot
+        return save_snapshot(self, prefix)
+
+    def load(self, state_path):
+        from .checkpoint import load_snapshot
+        return load_snapshot(self, state_path)          # the poly rate is recomputed from opt.iter at every step
 
     def step(self, images, label):
         self.opt.zero_grad()

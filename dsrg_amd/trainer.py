@@ -56,12 +56,33 @@ class CaffeSGD(object):
             for p in g["params"]:
                 p.grad = None
 
+    def state_dict(self):
+        """Caffe's .solverstate: iteration + momentum history (here B = V / lr and the rate it is scaled by)"""
+        return {"iter": self.iter, "base_lr": self.base_lr,
+                "groups": [{"lr_mult": g["lr_mult"], "decay_mult": g["decay_mult"], "buf_lr": g["buf_lr"],
+                            "bufs": [b.detach().cpu() for b in g["bufs"]]} for g in self.groups]}
+
+    @torch.no_grad()
+    def load_state_dict(self, st):
+        if len(st["groups"]) != len(self.groups):
+            raise ValueError("solver state has %d parameter groups, the net %d" % (len(st["groups"]), len(self.groups)))
+        for g, sg in zip(self.groups, st["groups"]):
+            if (g["lr_mult"], g["decay_mult"]) != (sg["lr_mult"], sg["decay_mult"]) or len(g["bufs"]) != len(sg["bufs"]):
+                raise ValueError("solver state does not match the parameter groups of this net")
+            for b, sb in zip(g["bufs"], sg["bufs"]):
+                b.copy_(sb.to(b.device, b.dtype))
+            g["buf_lr"] = sg["buf_lr"]
+        self.iter = int(st["iter"])
+        self.base_lr = st.get("base_lr", self.base_lr)
+
 
 class DSRGTrainer(object):
     def __init__(self, device, world_size=1, seed=0, amp_dtype=torch.bfloat16, channels_last=True,
-                 loss_fn=None, net=None, ddp=None):
+                 loss_fn=None, net=None, ddp=None, weights=None, snapshot=None):
         """loss_fn(logits, images, labels, cues) -> (total, losses); defaults to the HIP supervision
-        path.  (Tests inject a torch loss to exercise the data-parallel plumbing on CPU/gloo.)"""
+        path.  (Tests inject a torch loss to exercise the data-parallel plumbing on CPU/gloo.)
+        weights: `train.py --weights` (run.sh:5: ../../vgg16_20M_mc.caffemodel) — a .caffemodel / .npz / torch file
+        copied by layer name before training; snapshot: `train.py --snapshot` — a solverstate written by save()."""
         torch.manual_seed(seed)            # same initial weights on every rank (DDP also broadcasts)
         self.device = device
         self.amp_dtype = amp_dtype
@@ -71,7 +92,11 @@ class DSRGTrainer(object):
         # backbone forward runs (HIP path only)
         self.overlap_build = loss_fn is None and device.type == "cuda"
         self.side = torch.cuda.Stream(device=device) if self.overlap_build else None
-        net = (net if net is not None else VGG16ASPP()).to(device)
+        net = net if net is not None else VGG16ASPP()
+        if weights is not None:
+            from .checkpoint import load_weights
+            self.loaded_layers = load_weights(net, weights)
+        net = net.to(device)
         if channels_last:
             net = net.to(memory_format=torch.channels_last)
         self.net = net
@@ -82,7 +107,18 @@ class DSRGTrainer(object):
             self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=32,
                              gradient_as_bucket_view=True)
         self.opt = CaffeSGD(net.caffe_param_groups())
+        if snapshot is not None:
+            self.load(snapshot)
         torch.manual_seed(seed + 1 + (device.index or 0))      # per-rank dropout stream
+
+    def save(self, prefix="models/model-s"):
+        """solver-s.prototxt:16-17 `snapshot_prefix`: <prefix>_iter_N.caffemodel + .solverstate.pt (rank 0 writes)"""
+        from .checkpoint import save_snapshot
+        return save_snapshot(self, prefix)
+
+    def load(self, state_path):
+        from .checkpoint import load_snapshot
+        return load_snapshot(self, state_path)
 
     def step(self, images, labels, cues):
         """images (B,3,321,321) f32 mean-subtracted, labels (B,1,1,21), cues (B,21,41,41) -> losses[2]"""

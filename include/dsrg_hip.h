@@ -128,6 +128,19 @@ int dsrg_crf_meanfield_batch(dsrg_ctx_t ctx, int B, const float *neg_unary_dev,
 int dsrg_ctx_lattice_sizes(dsrg_ctx_t ctx, int B, int32_t *m_gauss_host, int32_t *m_bilateral_host,
                            void *stream);
 
+/* introspection for the parity tests: one lattice as the reference holds it.  kind 0 = the Gaussian lattice (b = 0),
+ * kind 1 = the bilateral lattice of image b of the last refine / prepare / meanfield / supervision call.
+ *   keys_host [M*d] int16   vertex keys in id order          (HashTable::getKeys, CRF/src/permutohedral.cpp:296-297)
+ *   vid_host  [N*(d+1)]     offset_: vertex id of corner r of pixel i, pixel-major   (permutohedral.cpp:272)
+ *   bary_host [N*(d+1)]     barycentric_                                             (permutohedral.cpp:274)
+ *   n1_host / n2_host [(d+1)*M]  blur_neighbors_[j*M+i].n1 / .n2, -1 = none          (permutohedral.cpp:315-316)
+ * Any array may be NULL; *m_host receives M (size the arrays with dsrg_ctx_lattice_sizes first).  Synchronises. */
+int dsrg_ctx_lattice_dump(dsrg_ctx_t ctx, int kind, int b, int32_t *m_host, int16_t *keys_host, int32_t *vid_host,
+                          float *bary_host, int32_t *n1_host, int32_t *n2_host, void *stream);
+/* introspection for the parity tests: the float64 marginals (`self.result`, pylayers.py:84-86) the last
+ * dsrg_supervision_step thresholded, copied to refined_dev (B,C,H,W) f64 in stream order. */
+int dsrg_ctx_read_refined(dsrg_ctx_t ctx, int B, double *refined_dev, void *stream);
+
 /* measurement hook (no reference counterpart): while profiling is on, every launch of the
  * mean-field filter kernel (splat/blur/slice, the dominant kernel) is bracketed by HIP events
  * on the launch stream; _stop synchronises and returns the summed kernel time and launch count. */

@@ -450,6 +450,13 @@ ORC_API void orc_crf_lattice_dump(const orc_crf *c, int k, short *keys, int *off
     if (offset) memcpy(offset, L->offset, sizeof(int) * (size_t)L->N * (L->d + 1));
     if (bary) memcpy(bary, L->bary, sizeof(float) * (size_t)L->N * (L->d + 1));
 }
+/* blur neighbours [(d+1)*M] each, -1 = none (permutohedral.cpp:303-318) */
+ORC_API void orc_crf_lattice_neighbours(const orc_crf *c, int k, int *n1, int *n2) {
+    const orc_lattice *L = &c->kern[k].lat;
+    const size_t n = (size_t)(L->d + 1) * (size_t)L->M;
+    if (n1) memcpy(n1, L->n1, sizeof(int) * n);
+    if (n2) memcpy(n2, L->n2, sizeof(int) * n);
+}
 /* one application of kernel k's lattice filter (Permutohedral::compute) to a
  * vs x N column-major matrix; for known-answer tests of splat/blur/slice. */
 ORC_API void orc_crf_lattice_filter(const orc_crf *c, int k, const float *in, float *out, int vs) {

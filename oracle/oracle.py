@@ -46,6 +46,7 @@ def lib():
         L.orc_crf_lattice_size.restype = ctypes.c_int
         L.orc_crf_lattice_norm.argtypes = [ctypes.c_void_p, ctypes.c_int, c_float_p]
         L.orc_crf_lattice_dump.argtypes = [ctypes.c_void_p, ctypes.c_int, c_short_p, c_int_p, c_float_p]
+        L.orc_crf_lattice_neighbours.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p]
         L.orc_crf_lattice_filter.argtypes = [ctypes.c_void_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int]
         L.orc_crf_refine_batch.argtypes = [ctypes.c_int] * 4 + [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                                               ctypes.c_double, ctypes.c_int, c_double_p, c_float_p]
@@ -128,6 +129,15 @@ class DenseCRF(object):
         bary = np.empty((N, d + 1), dtype=np.float32)
         lib().orc_crf_lattice_dump(self._h, k, _p(keys, c_short_p), _p(off, c_int_p), _p(bary, c_float_p))
         return keys, off, bary
+
+    def lattice_neighbours(self, k):
+        """blur neighbour ids (d+1, M) x 2, -1 = none (permutohedral.cpp:303-318)"""
+        d = 2 if k == 0 else 5
+        M = self.lattice_size(k)
+        n1 = np.empty((d + 1, M), dtype=np.int32)
+        n2 = np.empty((d + 1, M), dtype=np.int32)
+        lib().orc_crf_lattice_neighbours(self._h, k, _p(n1, c_int_p), _p(n2, c_int_p))
+        return n1, n2
 
     def lattice_filter(self, k, x):
         """x: (N, vs) float32 (label-fastest) -> filtered, same shape."""
