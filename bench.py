@@ -95,19 +95,146 @@ def cpu_baseline_all_cores(seconds=6.0, max_workers=32, timeout_s=90.0):
                       "logical CPUs" % (n, workers - failed, span, time.perf_counter() - t0, os.cpu_count() or 0)}
 
 
+def run_crf_fullres(args, device, rank):
+    """--mode crf-fullres (training/tools/test-ms.py:84-111): the test-time dense CRF at image resolution —
+    log-probability unaries, scale_factor 1, 21 labels, 10 iterations — through krahenbuhl2013's object API with device
+    pointers (dsrg_amd.crf.DenseCRF; what CRF_device does per call).  One step = one image: unary + pairwise set-up
+    (both lattices are built) + inference.  This is the path where HBM/L2 bandwidth is the bound: lattice values live in
+    HBM and one launch streams them per blur axis."""
+    from dsrg_amd import synthetic as S
+    from dsrg_amd.crf import DenseCRF
+    C, out_sizes = 21, []
+    sizes = [(321, 321), (375, 500)] if args.size == 321 else [(args.size, args.size)]
+    for (H, W) in sizes:
+        rng = np.random.default_rng(3000 + H)
+        img = S.make_images(rng, 1, size=max(H, W))[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]
+        im_np = np.ascontiguousarray(np.transpose(img, (1, 2, 0))).astype(np.uint8)
+        logits = S.make_logits(rng, 1, C, H, W, gain=12.0, sigma=12.0)[0]
+        e = np.exp(logits - logits.max(0, keepdims=True))
+        un_np = np.log(np.maximum(e / e.sum(0, keepdims=True), 1e-5)).transpose(1, 2, 0).astype(np.float32)   # test-ms.py:102-106
+        im, neg = torch.from_numpy(im_np).to(device), (-torch.from_numpy(np.ascontiguousarray(un_np)).to(device)).contiguous()
+        out = torch.empty((H, W, C), dtype=torch.float32, device=device)
+        crf = DenseCRF(W, H, C)
+
+        def one():
+            crf.set_unary_energy(neg)
+            crf.add_pairwise_energy(10, 80.0, 80.0, 13, 13, 13, 3, 3.0, 3.0, im)
+            crf.inference(10, out=out)
+        for _ in range(args.warmup):
+            one()
+        torch.cuda.synchronize()
+        crf.profile_start(args.steps * 60 + 8)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        blur_ms, blur_n = crf.profile_stop()
+        mg, mb = crf.lattice_size(0), crf.lattice_size(1)
+        N = H * W
+        # SURVEY 8d per blur axis: read own + two neighbour rows, write one row (4-byte values, C labels) + the (n1, n2) pair;
+        # launches of axes 0-2 carry both lattices, 3-5 the bilateral one only
+        axis_b, axis_g = 16 * C * mb + 8 * mb, 16 * C * mg + 8 * mg
+        alg_per_launch = (6 * axis_b + 3 * axis_g) / 6.0
+        out_sizes.append(dict(H=H, W=W, images_per_s=args.steps / dt, ms_per_image=dt / args.steps * 1e3, M_gauss=mg, M_bil=mb,
+                              blur_us_per_launch_event_bracket=blur_ms / max(blur_n, 1) * 1e3, blur_launches=blur_n,
+                              alg_bytes_per_blur_launch=alg_per_launch,
+                              crf_alg_bytes=10 * (filter_bytes(2, mg, C, N) + filter_bytes(5, mb, C, N) + 8 * C * N),
+                              q=out.cpu().numpy(), im=im_np, un=un_np, dt=dt))
+    if rank != 0:
+        return
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for _ in range(2):
+        for a, b in pairs:
+            a.record(torch.cuda.default_stream())
+            b.record(torch.cuda.default_stream())
+        torch.cuda.synchronize()
+    ev_us = float(np.median([a.elapsed_time(b) for a, b in pairs])) * 1e3
+    head = out_sizes[0]
+    per_launch_s = max(head["blur_us_per_launch_event_bracket"] - ev_us, 1e-3) * 1e-6
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_fullres.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("lg_blur2_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    achieved = head["alg_bytes_per_blur_launch"] / per_launch_s / 1e9
+    roofline = {"kernel": "lg_blur2_kernel (one permutohedral blur axis over both lattices, values in HBM/L2)", "bound": "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "alg_bytes_per_launch": head["alg_bytes_per_blur_launch"], "us_per_launch": per_launch_s * 1e6,
+                "us_per_launch_event_bracket": head["blur_us_per_launch_event_bracket"], "event_bracket_overhead_us": ev_us,
+                "launches": head["blur_launches"], "lattice_M_gauss": head["M_gauss"], "lattice_M_bilateral": head["M_bil"],
+                "hbm_gbs_from_pmc_traffic": (traffic / per_launch_s / 1e9) if traffic else None,
+                "whole_crf_alg_gbs": head["crf_alg_bytes"] / (head["ms_per_image"] * 1e-3) / 1e9,
+                "note": "the lattice values of a 321x321 image (%.1f MB per buffer) fit the L2s / Infinity Cache, so HBM counters "
+                        "may read below the algorithmic bytes" % ((head["M_gauss"] + head["M_bil"] + 2) * 24 * 4 / 1e6)}
+    out = {"metric": "images/sec full-resolution dense CRF (test-ms.py:84-111; %dx%d, 21 labels, 10 iterations, lattices built "
+                     "per image)" % (head["H"], head["W"]),
+           "value": head["images_per_s"], "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": head["ms_per_image"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "krahenbuhl2013.CRF on device tensors, log-prob unaries, scale_factor 1, maxiter 10"},
+           "sizes": [{k: v for k, v in o.items() if k not in ("q", "im", "un", "dt")} for o in out_sizes],
+           "roofline": roofline}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        t0 = time.perf_counter()
+        want = O.CRF(head["im"], head["un"], scale_factor=1.0)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "images/s", "cores": 1, "kind": "port",
+                               "sample": "1 image %dx%d, oracle/dsrg_oracle.c single-threaded, %.2f s" % (head["H"], head["W"], t_cpu)}
+        out["max_abs_dq_vs_oracle"] = float(np.abs(head["q"] - want).max())
+    print(json.dumps(out))
+
+
+def fp32_leg(device, images, labels, cues, steps, warmup=3):
+    """the same train-s step with the backbone in float32 (the reference's Caffe arithmetic, train-s.prototxt:41-744):
+    ms per step at this batch size, timed like the headline (synchronised brackets)"""
+    from dsrg_amd.trainer import DSRGTrainer
+    tr = DSRGTrainer(device, amp_dtype=None)
+    for _ in range(warmup):
+        tr.step(images, labels, cues)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = tr.step(images, labels, cues)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del tr
+    return dt, [float(x) for x in losses]
+
+
+def loss_trajectories(device, images, labels, cues, steps=20):
+    """bf16-autocast backbone vs float32 backbone: same initial weights, same dropout seeds, same batch, `steps` steps;
+    -> (bf16 totals, fp32 totals, max relative gap of the total loss)"""
+    from dsrg_amd.trainer import DSRGTrainer
+    out = []
+    for amp in (torch.bfloat16, None):
+        tr = DSRGTrainer(device, amp_dtype=amp, seed=123)
+        tot = []
+        for _ in range(steps):
+            tot.append(tr.step(images, labels, cues))
+        out.append([float(t.sum()) for t in tot])
+        del tr
+    a, b = np.asarray(out[0]), np.asarray(out[1])
+    return out[0], out[1], float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (weak scaling)")
-    ap.add_argument("--mode", choices=["train", "supervision", "train-f"], default="train",
+    ap.add_argument("--mode", choices=["train", "supervision", "train-f", "crf-fullres"], default="train",
                     help="train = seed_mc train-s step (the headline metric); supervision = hot path on fixed logits; "
                          "train-f = stage-2 retrain step (no SRG/CRF inside; BASELINE.json configs[4] with "
                          "--backbone resnet101 --size 513)")
     ap.add_argument("--backbone", choices=["vgg16", "resnet101"], default="vgg16")
     ap.add_argument("--size", type=int, default=321)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the float32-backbone leg and the bf16/fp32 loss trajectories")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket filter launches with HIP events")
     args = ap.parse_args()
 
@@ -128,6 +255,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
+
+    if args.mode == "crf-fullres":
+        run_crf_fullres(args, device, rank)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from dsrg_amd import ops, synthetic as S
     from dsrg_amd.backbone import count_flops_per_image
@@ -293,6 +427,27 @@ def main():
             "roofline": roofline,
             "other_rooflines": other,
         }
+        if args.mode == "train" and world == 1 and not args.no_fp32:
+            # the reference's backbone arithmetic is Caffe float32: the same step with a float32 backbone, and how far the two
+            # loss trajectories drift apart
+            del trainer
+            torch.cuda.empty_cache()
+            n32 = max(5, args.steps // 4)
+            dt32, l32 = fp32_leg(device, images, labels, cues, n32)
+            tf32 = count_flops_per_image() * 3 * B / dt32 / 1e12
+            out["value_fp32"] = B / dt32
+            out["ms_per_step_fp32"] = dt32 * 1e3
+            out["fp32"] = {"steps": n32, "losses": l32, "backbone_tflops": tf32, "mfma_peak_tflops": 157.3,
+                           "mfma_frac": tf32 / 157.3, "dtype": "f32 backbone + f32/f64 supervision path",
+                           "note": "float32 is the reference's backbone precision; `value` is the bf16-autocast (fp32 master "
+                                   "weights, fp32 classifier heads) figure"}
+            try:
+                t16, t32, gap = loss_trajectories(device, images, labels, cues)
+                out["fp32"]["loss_trajectory_bf16"] = t16
+                out["fp32"]["loss_trajectory_fp32"] = t32
+                out["fp32"]["max_rel_loss_gap_20_steps"] = gap
+            except Exception as e:                       # never let the comparison cost the bench line
+                out["fp32"]["loss_trajectory_error"] = str(e)[:200]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch_np)
             try:

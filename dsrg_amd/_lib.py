@@ -50,6 +50,8 @@ SIGNATURES = {
     "dsrg_crf_npixels": (_i, [_vp]),
     "dsrg_crf_nlabels": (_i, [_vp]),
     "dsrg_crf_lattice_size": (_i, [_vp, _i]),
+    "dsrg_crf_profile_start": (_i, [_vp, _i]),
+    "dsrg_crf_profile_stop": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
     "dsrg_ctx_create": (_i, [_i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "dsrg_ctx_destroy": (_i, [_vp]),
     "dsrg_crf_refine_batch": (_i, [_vp, _i, _vp, _vp, _i, _i, ctypes.POINTER(CrfParams), _vp, _vp, _vp]),
@@ -74,6 +76,7 @@ SIGNATURES = {
     "dsrg_col2im3x3_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dsrg_avgpool3x3_s1_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dsrg_bias_grad_bf16": (_i, [_vp, _vp, _vp, _i, ctypes.c_long, _i, _vp]),
+    "dsrg_heads_forward_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dsrg_maxpool3x3_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_maxpool3x3_bwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_supervision_step": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _d, _d, ctypes.POINTER(CrfParams),

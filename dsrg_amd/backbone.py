@@ -22,8 +22,8 @@ def _im2col_gemm(x, weight, bias, dilation, relu, want_cols=False):
         xn = xn.contiguous()
     if k == 1:
         a = xn.reshape(-1, C)
-    elif C % 8 == 0 and x.element_size() == 2:
-        from .ops import im2col3x3_nhwc                               # one bandwidth-bound HIP kernel
+    elif (C * x.element_size()) % 16 == 0 and x.element_size() in (2, 4):
+        from .ops import im2col3x3_nhwc                               # one bandwidth-bound HIP kernel (16-byte channel groups)
         a = im2col3x3_nhwc(xn, dilation)
     else:
         p = dilation
@@ -92,10 +92,10 @@ class _ConvFn(torch.autograd.Function):
             g = g.contiguous(memory_format=torch.channels_last)
         # data gradient of a 3x3 'same' convolution = the forward convolution of g with the flipped, transposed kernel:
         # the im2col + hipBLASLt route again (~1.2 PFLOP/s at the 41x41 stages against 550-630 TFLOP/s for CK's dgrad)
-        gemm_dgrad = ctx.gemm and ctx.k == 3 and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and cout % 8 == 0 \
-            and x.shape[2] * x.shape[3] <= 2048    # larger maps: the im2col of g costs more than it saves (measured at 81x81)
+        gemm_dgrad = ctx.gemm and ctx.k == 3 and ctx.needs_input_grad[0] and g.dtype in (torch.bfloat16, torch.float32) \
+            and cout % 8 == 0 and x.shape[2] * x.shape[3] <= 2048    # larger maps: the im2col of g costs more than it saves (measured at 81x81)
         gx = None
-        if gemm_dgrad and cout > x.shape[1] and x.shape[1] % 8 == 0:
+        if gemm_dgrad and cout > x.shape[1] and x.shape[1] % 8 == 0 and g.dtype == torch.bfloat16:
             # more output than input channels (fc6: 1024 vs 512): g @ W^T first, then gather the nine taps (col2im) —
             # half the traffic of an im2col of the wide g
             from .ops import col2im3x3_nhwc
@@ -107,7 +107,7 @@ class _ConvFn(torch.autograd.Function):
         # weight gradient = im2col(x)^T @ g, again one hipBLASLt GEMM (K = B*H*W).  Only where MIOpen's wrw is slow: the
         # 512 -> 1024 dilated fc6 layers (650 TFLOP/s; measured 883 -> 902 images/s); at 512 -> 512 MIOpen already runs
         # at ~1 PFLOP/s and the GEMM route loses (864 images/s with it everywhere)
-        gemm_wgrad = gemm_dgrad and fused and x.shape[1] % 8 == 0 and cout >= 1024
+        gemm_wgrad = gemm_dgrad and x.shape[1] % 8 == 0 and cout >= 1024
         gw = None
         if gemm_wgrad:
             cin = x.shape[1]
@@ -218,6 +218,36 @@ def _conv_relu(cin, cout, dilation=1, gemm=False):
     return [conv, FusedReLU()]
 
 
+class _HeadsFn(torch.autograd.Function):
+    """The four fc8-SEC_k classifiers + Eltwise SUM on bf16 activations with fp32 weights, fp32 accumulation and an fp32
+    NCHW result (one HIP pass, ops.heads_forward).  Backward: the gradient that continues into the bf16 trunk and the
+    weight gradients are hipBLASLt GEMMs with fp32 accumulation on the bf16-rounded score gradient — what autocast does
+    for every other layer; the weight and bias gradients come out in fp32."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, *xs):
+        from .ops import heads_forward
+        xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+        ctx.save_for_backward(weight, *xs)
+        return heads_forward(xs, weight.contiguous(), bias.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, *xs = ctx.saved_tensors
+        n, O, K = weight.shape
+        B, _, H, W = g.shape
+        gb1 = g.sum((0, 2, 3))                                            # fp32, the same for every branch
+        g2 = g.permute(0, 2, 3, 1).reshape(-1, O).to(torch.bfloat16)      # (M, O)
+        w16 = weight.to(torch.bfloat16)
+        gxs, gws = [], []
+        for k, x in enumerate(xs):
+            gx = torch.empty((B, K, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+            torch.mm(g2, w16[k], out=gx.permute(0, 2, 3, 1).view(-1, K))
+            gxs.append(gx)
+            gws.append(torch.mm(g2.t(), x.permute(0, 2, 3, 1).reshape(-1, K), out_dtype=torch.float32))
+        return (torch.stack(gws), gb1.unsqueeze(0).expand(n, O).contiguous()) + tuple(gxs)
+
+
 class VGG16ASPP(nn.Module):
     def __init__(self, num_classes=21, dropout=0.5, gemm_convs=True):
         super().__init__()
@@ -248,14 +278,23 @@ class VGG16ASPP(nn.Module):
         (Softmax + 1e-4, the CRF, the 0.85 / 0.99 SRG thresholds, the 0.05 / 20 clip of the constrain loss), and a bf16
         score of magnitude 8-16 has a step of 0.06-0.125."""
         f = self.features(x)
-        out = None
+        hs = []
         for br in self.branches:
             h = f
             for m in list(br)[:-1]:
                 h = m(h)
-            with torch.autocast(device_type=h.device.type, enabled=False):
-                s = br[-1](h.float())
-            out = s if out is None else out + s
+            hs.append(h)
+        heads = [br[-1] for br in self.branches]
+        if hs[0].is_cuda and hs[0].dtype == torch.bfloat16 and len(hs) <= 4 and heads[0].out_channels <= 24 \
+                and heads[0].in_channels % 64 == 0:
+            w = torch.stack([m.weight.reshape(m.out_channels, m.in_channels) for m in heads])
+            b = torch.stack([m.bias for m in heads])
+            return _HeadsFn.apply(w.float(), b.float(), *hs)
+        out = None
+        with torch.autocast(device_type=hs[0].device.type, enabled=False):
+            for m, h in zip(heads, hs):
+                s = m(h.float())
+                out = s if out is None else out + s
         return out
 
     def caffe_param_groups(self):

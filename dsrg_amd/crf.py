@@ -93,6 +93,16 @@ class DenseCRF(object):
     def lattice_size(self, k):
         return _lib.lib().dsrg_crf_lattice_size(self._h, int(k))
 
+    def profile_start(self, max_launches=4096):
+        """bracket every launch of this object's dominant kernel with HIP events (bench.py)"""
+        check(_lib.lib().dsrg_crf_profile_start(self._h, int(max_launches)))
+
+    def profile_stop(self):
+        """-> (summed kernel milliseconds, launches); synchronises"""
+        ms, n = ctypes.c_double(0.0), ctypes.c_int32(0)
+        check(_lib.lib().dsrg_crf_profile_stop(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
 
 def CRF(image, unary, maxiter=10, scale_factor=1.0, color_factor=13):
     """Mean-field inference in a fully connected CRF with Gaussian edge potentials.

@@ -100,37 +100,44 @@ static void prof_free(Profiler &p) {
     p.start = p.stop = nullptr; p.cap = p.used = 0; p.active = false;
 }
 
-extern "C" int dsrg_ctx_profile_start(dsrg_ctx_t c, int max_launches) {
-    if (!c || max_launches < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
-    if (c->prof.cap < max_launches) {
-        prof_free(c->prof);
-        c->prof.start = new (std::nothrow) hipEvent_t[max_launches];
-        c->prof.stop = new (std::nothrow) hipEvent_t[max_launches];
-        if (!c->prof.start || !c->prof.stop) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
+static int prof_start(Profiler &p, int max_launches) {
+    if (p.cap < max_launches) {
+        prof_free(p);
+        p.start = new (std::nothrow) hipEvent_t[max_launches];
+        p.stop = new (std::nothrow) hipEvent_t[max_launches];
+        if (!p.start || !p.stop) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
         for (int i = 0; i < max_launches; i++) {
-            DSRG_HIP_CHECK(hipEventCreate(&c->prof.start[i]));
-            DSRG_HIP_CHECK(hipEventCreate(&c->prof.stop[i]));
-            c->prof.cap = i + 1;
+            DSRG_HIP_CHECK(hipEventCreate(&p.start[i]));
+            DSRG_HIP_CHECK(hipEventCreate(&p.stop[i]));
+            p.cap = i + 1;
         }
     }
-    c->prof.used = 0;
-    c->prof.active = true;
+    p.used = 0;
+    p.active = true;
     return DSRG_OK;
+}
+static int prof_stop(Profiler &p, double *total_ms, int32_t *launches) {
+    p.active = false;
+    double tot = 0.0;
+    for (int i = 0; i < p.used; i++) {
+        DSRG_HIP_CHECK(hipEventSynchronize(p.stop[i]));
+        float ms = 0.f;
+        DSRG_HIP_CHECK(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = p.used;
+    return DSRG_OK;
+}
+
+extern "C" int dsrg_ctx_profile_start(dsrg_ctx_t c, int max_launches) {
+    if (!c || max_launches < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return prof_start(c->prof, max_launches);
 }
 
 extern "C" int dsrg_ctx_profile_stop(dsrg_ctx_t c, double *total_ms, int32_t *launches) {
     if (!c || !total_ms || !launches) return set_error(DSRG_ERR_INVALID, "bad argument");
-    c->prof.active = false;
-    double tot = 0.0;
-    for (int i = 0; i < c->prof.used; i++) {
-        DSRG_HIP_CHECK(hipEventSynchronize(c->prof.stop[i]));
-        float ms = 0.f;
-        DSRG_HIP_CHECK(hipEventElapsedTime(&ms, c->prof.start[i], c->prof.stop[i]));
-        tot += ms;
-    }
-    *total_ms = tot;
-    *launches = c->prof.used;
-    return DSRG_OK;
+    return prof_stop(c->prof, total_ms, launches);
 }
 
 extern "C" int dsrg_ctx_destroy(dsrg_ctx_t c) {
@@ -374,6 +381,13 @@ extern "C" int dsrg_bias_grad_bf16(const void *g, float *bias_grad, float *parti
     if (!g || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_bias_grad(g, bias_grad, partials, partial_blocks, rows, C, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_heads_forward_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *bias_dev,
+                                       float *out_dev, int B, int HW, int K, int O, void *stream) {
+    if (!x_dev || !w_dev || !out_dev || B < 1 || HW < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    for (int k = 0; k < n_branches && k < 4; k++)
+        if (!x_dev[k]) return set_error(DSRG_ERR_INVALID, "NULL branch input");
+    return launch_heads_fwd(x_dev, n_branches, w_dev, bias_dev, out_dev, B, HW, K, O, static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_maxpool3x3_fwd_bf16(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C,
                                         int stride, void *stream) {
     if (!in || !out || !code) return set_error(DSRG_ERR_INVALID, "NULL argument");
@@ -435,6 +449,7 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters);
 int large_crf_read_q(LargeCrf *c, float *out_host);
 int large_crf_read_map(LargeCrf *c, int32_t *labels_host);
 int large_crf_lattice_size(LargeCrf *c, int k);
+Profiler *large_crf_profiler(LargeCrf *c);
 }  // namespace dsrg
 
 // ---------------------------------------------------------------------------------
@@ -594,6 +609,16 @@ extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
     DSRG_HIP_CHECK(hipMemcpy(labels_host, h->lab, sizeof(int32_t) * (size_t)N, hipMemcpyDefault));
     DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));      // see dsrg_crf_inference
     return DSRG_OK;
+}
+// measurement hook of the object API: brackets the dominant kernel of this handle's path with HIP events on its stream —
+// lg_blur2_kernel (one launch per blur axis) on the global-memory path, the mean-field kernel on the LDS-resident path
+extern "C" int dsrg_crf_profile_start(dsrg_crf_t h, int max_launches) {
+    if (!h || max_launches < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return prof_start(h->large ? *large_crf_profiler(h->large) : h->ctx->prof, max_launches);
+}
+extern "C" int dsrg_crf_profile_stop(dsrg_crf_t h, double *total_ms, int32_t *launches) {
+    if (!h || !total_ms || !launches) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return prof_stop(h->large ? *large_crf_profiler(h->large) : h->ctx->prof, total_ms, launches);
 }
 extern "C" int dsrg_crf_lattice_size(dsrg_crf_t h, int k) {
     if (h && h->large && k >= 0 && k <= 1) return large_crf_lattice_size(h->large, k);

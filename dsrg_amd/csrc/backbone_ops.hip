@@ -300,4 +300,91 @@ int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, 
     return DSRG_OK;
 }
 
+
+
+// ---------------------------------------------------------------------------------
+// fc8-SEC heads: out[b][o][hw] = sum over the NBR branches k of ( x_k[(b,hw)][:] . W[k][o][:] + bias[k][o] )
+// (the four 1x1 classifiers fc8-SEC_k and their Eltwise SUM, train-s.prototxt:461-744) with bf16 activations, FLOAT32
+// weights, float32 accumulation and a float32 NCHW result — the scores that feed Softmax + 1e-4, the CRF and the 0.85 / 0.99
+// region-growing thresholds never pass through bf16.  bf16 -> f32 is exact, so this equals the fp32 convolution of the
+// (bf16-valued) fc7 outputs.  A skinny GEMM (N = 21): VALU FMAs, x and W tiles through LDS, each thread one row x 3 outputs.
+namespace {
+constexpr int kHeadRows = 32, kHeadKC = 64, kHeadOutPad = 24, kHeadThreads = 256;
+struct HeadArgs {
+    const uint16_t *x[4];      // NBR activations, (M, K) bf16 row-major (NHWC)
+    const float *w;            // (NBR, O, K)
+    const float *bias;         // (NBR, O) or nullptr
+    float *out;                // (B, O, HW)
+    int nbr, M, K, O, HW;
+};
+}  // namespace
+
+__global__ __launch_bounds__(kHeadThreads) void heads_fwd_kernel(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t xs[kHeadRows][kHeadKC + 4];      // row stride 136 B: 32 rows hit 32 distinct bank pairs
+    __shared__ __attribute__((aligned(16))) float ws[kHeadOutPad][kHeadKC + 4];
+    const int t = threadIdx.x, row = t & 31, og = t >> 5;                            // lanes 0..31 = rows, og = 0..7 -> outputs 3*og..3*og+2
+    const int m0 = blockIdx.x * kHeadRows;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < a.nbr; k++) {
+        const uint16_t *x = a.x[k];
+        const float *w = a.w + (size_t)k * a.O * a.K;
+        for (int c0 = 0; c0 < a.K; c0 += kHeadKC) {
+            {   // x tile: 32 rows x 64 bf16 = 256 x 16 B; W tile: 24 x 64 f32 = 384 x 16 B
+                const int r = t >> 3, q = t & 7;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (m0 + r < a.M) v = *reinterpret_cast<const uint4 *>(x + (size_t)(m0 + r) * a.K + c0 + q * 8);
+                *reinterpret_cast<uint2 *>(&xs[r][q * 8]) = make_uint2(v.x, v.y);
+                *reinterpret_cast<uint2 *>(&xs[r][q * 8 + 4]) = make_uint2(v.z, v.w);
+                for (int e = t; e < kHeadOutPad * (kHeadKC / 4); e += kHeadThreads) {
+                    const int o = e / (kHeadKC / 4), q4 = e % (kHeadKC / 4);
+                    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (o < a.O) wv = *reinterpret_cast<const float4 *>(w + (size_t)o * a.K + c0 + q4 * 4);
+                    *reinterpret_cast<float4 *>(&ws[o][q4 * 4]) = wv;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < kHeadKC; kk += 4) {
+                const uint2 xv = *reinterpret_cast<const uint2 *>(&xs[row][kk]);
+                const float x0 = bf16_lo(xv.x), x1 = bf16_hi(xv.x), x2 = bf16_lo(xv.y), x3 = bf16_hi(xv.y);
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(&ws[og * 3 + j][kk]);
+                    acc[j] = __builtin_fmaf(x0, wv.x, acc[j]);
+                    acc[j] = __builtin_fmaf(x1, wv.y, acc[j]);
+                    acc[j] = __builtin_fmaf(x2, wv.z, acc[j]);
+                    acc[j] = __builtin_fmaf(x3, wv.w, acc[j]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int m = m0 + row;
+    if (m < a.M) {
+        const int b = m / a.HW, hw = m - b * a.HW;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int o = og * 3 + j;
+            if (o < a.O) {
+                float s = acc[j];
+                if (a.bias)
+                    for (int k = 0; k < a.nbr; k++) s += a.bias[k * a.O + o];
+                a.out[((size_t)b * a.O + o) * a.HW + hw] = s;
+            }
+        }
+    }
+}
+
+int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float *bias, float *out, int B, int HW, int K, int O,
+                     hipStream_t stream) {
+    if (nbr < 1 || nbr > 4 || O < 1 || O > kHeadOutPad || K < kHeadKC || K % kHeadKC != 0)
+        return set_error(DSRG_ERR_UNSUPPORTED, "heads: 1..4 branches, <= %d outputs, K a multiple of %d", kHeadOutPad, kHeadKC);
+    HeadArgs a;
+    for (int k = 0; k < 4; k++) a.x[k] = static_cast<const uint16_t *>(x[k < nbr ? k : 0]);
+    a.w = w; a.bias = bias; a.out = out; a.nbr = nbr; a.M = B * HW; a.K = K; a.O = O; a.HW = HW;
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3((a.M + kHeadRows - 1) / kHeadRows), dim3(kHeadThreads), 0, stream, a);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
 }  // namespace dsrg

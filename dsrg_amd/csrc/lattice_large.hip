@@ -350,6 +350,7 @@ struct LargeCrf {
     float *stage;                          // [N][C] host-layout staging
     bool lattices_valid;                   // Lg/Lb were built for the current image and kernel widths
     dsrg_crf_params built_for;
+    Profiler prof;                         // optional HIP-event brackets around the blur launches (dsrg_crf_profile_*)
 };
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -423,6 +424,8 @@ int large_crf_create(int W, int H, int C, LargeCrf **out) {
 
 void large_crf_destroy(LargeCrf *c) {
     if (!c) return;
+    for (int i = 0; i < c->prof.cap; i++) { (void)hipEventDestroy(c->prof.start[i]); (void)hipEventDestroy(c->prof.stop[i]); }
+    delete[] c->prof.start; delete[] c->prof.stop;
     if (c->arena) (void)hipFree(c->arena);
     if (c->val_a) (void)hipFree(c->val_a);
     if (c->val_b) (void)hipFree(c->val_b);
@@ -531,8 +534,11 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
         float *a = c->val_a, *b = c->val_b;
         for (int j = 0; j < 6; j++) {
             const size_t rows = j < 3 ? need : (size_t)Mb + 1;
+            const bool timed = c->prof.active && c->prof.used < c->prof.cap;
+            if (timed) DSRG_HIP_CHECK(hipEventRecord(c->prof.start[c->prof.used], s));
             hipLaunchKernelGGL(lg_blur2_kernel, dim3(blocks_for(rows * CP4, 256)), dim3(256), 0, s, c->Lb, c->Lg, CP4, j,
                                (const float4 *)a, (float4 *)b, (const float4 *)(a + g_off), (float4 *)(b + g_off));
+            if (timed) { DSRG_HIP_CHECK(hipEventRecord(c->prof.stop[c->prof.used], s)); c->prof.used++; }
             float *t = a; a = b; b = t;
         }
         // after 6 swaps the bilateral result is back in val_a; the Gaussian one stopped after 3 swaps, in val_b
@@ -560,5 +566,6 @@ int large_crf_read_map(LargeCrf *c, int32_t *labels_host) {
     return DSRG_OK;
 }
 int large_crf_lattice_size(LargeCrf *c, int k) { return k == 0 ? c->Lg.M_host : c->Lb.M_host; }
+Profiler *large_crf_profiler(LargeCrf *c) { return &c->prof; }
 
 }  // namespace dsrg

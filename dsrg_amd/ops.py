@@ -278,12 +278,14 @@ def supervision_step(logits, images, labels, cues, th1=0.99, th2=0.85, scale_fac
 
 
 def im2col3x3_nhwc(x_nhwc, dilation):
-    """(B,H,W,C) contiguous bf16/fp16 -> (B*H*W, 9*C) im2col matrix of a 3x3 'same' dilated convolution"""
-    if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and x_nhwc.element_size() == 2):
-        raise ValueError("x must be a contiguous 2-byte CUDA tensor in NHWC order")
+    """(B,H,W,C) contiguous bf16/fp16 (C % 8 == 0) or float32 (C % 4 == 0) -> (B*H*W, 9*C) im2col matrix of a 3x3 'same'
+    dilated convolution.  The kernel moves 16-byte channel groups, so a float32 pixel is passed as 2*C two-byte elements."""
+    es = x_nhwc.element_size()
+    if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and es in (2, 4)):
+        raise ValueError("x must be a contiguous 2- or 4-byte CUDA tensor in NHWC order")
     B, H, W, C = x_nhwc.shape
     out = torch.empty((B * H * W, 9 * C), dtype=x_nhwc.dtype, device=x_nhwc.device)
-    check(_lib.lib().dsrg_im2col3x3_nhwc16(_ptr(x_nhwc), _ptr(out), B, H, W, C, int(dilation), _stream()))
+    check(_lib.lib().dsrg_im2col3x3_nhwc16(_ptr(x_nhwc), _ptr(out), B, H, W, C * (es // 2), int(dilation), _stream()))
     return out
 
 
@@ -348,6 +350,24 @@ def avgpool3x3_s1(x):
     x = x.contiguous(memory_format=torch.channels_last)
     out = torch.empty_like(x)
     check(_lib.lib().dsrg_avgpool3x3_s1_bf16(_ptr(x), _ptr(out), B, H, W, C, _stream()))
+    return out
+
+
+def heads_forward(xs, weight, bias):
+    """fc8-SEC_k + Eltwise SUM in float32: xs = list of <= 4 (B,K,H,W) bf16 channels_last activations, weight (n,O,K) f32,
+    bias (n,O) f32 or None -> (B,O,H,W) float32, NCHW-contiguous (what the supervision path reads)."""
+    B, K, H, W = xs[0].shape
+    n, O = weight.shape[0], weight.shape[1]
+    cl = torch.channels_last
+    xs = [x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl) for x in xs]
+    if not all(x.is_cuda and x.dtype == torch.bfloat16 and x.shape == xs[0].shape for x in xs) or len(xs) != n:
+        raise ValueError("heads_forward needs n bf16 CUDA activations of one shape")
+    _f32c(weight, "weight")
+    if bias is not None:
+        _f32c(bias, "bias")
+    out = torch.empty((B, O, H, W), dtype=torch.float32, device=xs[0].device)
+    ptrs = (ctypes.c_void_p * 4)(*([x.data_ptr() for x in xs] + [None] * (4 - n)))
+    check(_lib.lib().dsrg_heads_forward_bf16(ptrs, n, _ptr(weight), _ptr(bias), _ptr(out), B, H * W, K, O, _stream()))
     return out
 
 

@@ -73,6 +73,12 @@ int dsrg_crf_nlabels(dsrg_crf_t h);
 /* introspection (tests): vertex count of lattice k (0 Gaussian, 1 bilateral), -1 if not built */
 int dsrg_crf_lattice_size(dsrg_crf_t h, int k);
 
+/* measurement hook (no reference counterpart): while on, every launch of the dominant kernel of this object's path — the
+ * per-axis blur of the global-memory path (full-resolution maps), the mean-field kernel of the LDS-resident path — is
+ * bracketed by HIP events on its stream; _stop synchronises and returns the summed time and the launch count. */
+int dsrg_crf_profile_start(dsrg_crf_t h, int max_launches);
+int dsrg_crf_profile_stop(dsrg_crf_t h, double *total_ms_host, int32_t *launches_host);
+
 /* ------------------------------------------------------------------------ */
 /* 2. Batched device context: workspace for B images of (C,H,W) so that the    */
 /*    per-iteration path runs without allocation or host synchronisation.      */
@@ -211,6 +217,12 @@ int dsrg_bias_grad_bf16(const void *g_dev, float *bias_grad_dev, float *partials
 /* 3x3 / stride 1 / pad 1 average pooling over padded windows (Caffe AVE pooling, pool5a of train-s.prototxt), NHWC bf16,
  * C % 8 == 0.  The stencil is symmetric: the backward pass is the same call on the output gradient. */
 int dsrg_avgpool3x3_s1_bf16(const void *in_dev, void *out_dev, int B, int H, int W, int C, void *stream);
+/* The four fc8-SEC_k 1x1 classifiers and their Eltwise SUM (train-s.prototxt:461-744) in one pass with float32 weights,
+ * float32 accumulation and a float32 NCHW result: out[b][o][hw] = sum_k ( x_k[(b,hw)][:] . w[k][o][:] + bias[k][o] ).
+ * x_dev: host array of n_branches (<= 4) device pointers to (B*HW, K) bf16 row-major (NHWC) activations; w_dev
+ * (n_branches, O, K) f32; bias_dev (n_branches, O) f32 or NULL; out_dev (B, O, HW) f32.  O <= 24, K % 64 == 0. */
+int dsrg_heads_forward_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *bias_dev,
+                            float *out_dev, int B, int HW, int K, int O, void *stream);
 /* 3x3 max pooling, pad 1, stride 1 or 2, NHWC bf16 (the Pooling layers of train-s.prototxt:69-80 etc.; OH/OW chosen by
  * the caller, ceil mode included).  code_dev: B*OH*OW*C bytes, the window position (3*dy+dx) of the first maximum. */
 int dsrg_maxpool3x3_fwd_bf16(const void *in_dev, void *out_dev, void *code_dev, int B, int H, int W, int OH, int OW, int C,

@@ -4,6 +4,10 @@ import sys
 import numpy as np
 import pytest
 
+# the GPU tests need MIOpen to answer, not to be fast: take its heuristic pick instead of a ~50 s exhaustive search per
+# new convolution shape (bench.py leaves the default, its warm-up absorbs the search)
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -108,7 +108,9 @@ def test_losses_forward_backward(ops, O):
                                              ("noise", 12.0, (71, 71), 3),      # smallest map on the global-memory path
                                              # maps beyond the LDS-resident kernels: global-memory path (test-time CRF)
                                              ("smooth", 1.0, (121, 161), 21), ("noise", 3.0, (100, 150), 5),
-                                             ("smooth", 1.0, (321, 321), 21)])
+                                             ("smooth", 1.0, (321, 321), 21),
+                                             ("smooth", 1.0, (375, 500), 21),   # the largest VOC image shape (test-ms.py)
+                                             ("noise", 1.0, (101, 123), 4)])    # odd width, N % 4 = 3: phantom vertices on the large path
 def test_crf_function_vs_oracle(O, kind, scale, HW, C):
     """krahenbuhl2013.CRF (host API of the reference) — marginals within 1e-4 of the oracle,
     identical lattice sizes."""
@@ -137,6 +139,50 @@ def test_crf_function_vs_oracle(O, kind, scale, HW, C):
     oc.set_unary_energy(-un.ravel())
     wl = oc.map(10)
     assert (lab != wl).mean() < 1e-3                        # argmax ties at ~1e-7 differences only
+
+
+@pytest.mark.parametrize("kind,scale,HW", [("smooth", 12.0, (41, 41)), ("noise", 12.0, (41, 41)), ("dark_corner", 12.0, (41, 41)),
+                                           ("smooth", 12.0, (65, 65)), ("noise", 1.0, (24, 31)), ("smooth", 3.0, (17, 40))])
+def test_lattice_structure_vs_oracle(ops, O, kind, scale, HW):
+    """SURVEY 8c, last row: Permutohedral::init (permutohedral.cpp:140-321) -> M, the keys, the per-pixel (vertex,
+    weight) lists and the blur-neighbour table of BOTH lattices, HIP against the oracle.  Compared id for id (the HIP
+    build hands out the reference's first-occurrence ids) and, so that a future renumbering only has to relax the
+    former, in the id-invariant form too (key multiset, per-pixel sorted (key, weight), neighbour KEYS per vertex key)."""
+    H, W = HW
+    B, C = 2, 3
+    rng = np.random.default_rng(hash((kind, H, W)) % 2 ** 31)
+    img = S.make_images(rng, B, size=max(H, W), kind=kind)[:, :, :H, :W] + S.MEAN_PIXEL[None, :, None, None]
+    im_u8 = np.ascontiguousarray(np.transpose(img, (0, 2, 3, 1))).astype(np.uint8)
+    unary = np.log(np.maximum(O.softmax_forward(S.make_logits(rng, B, C, H, W)), 1e-4))
+    ctx = ops.Context(B, C, H, W)
+    ops.crf_meanfield(dev(unary), dev(im_u8, torch.uint8), 10, scale, ctx=ctx)
+    for b in range(B):
+        oc = O.DenseCRF(W, H, C)
+        oc.add_pairwise_energy(10, 80 / scale, 80 / scale, 13, 13, 13, 3, 3 / scale, 3 / scale, im_u8[b].ravel())
+        for k in (0, 1):
+            if k == 0 and b > 0:
+                continue                                    # one Gaussian lattice shared by the batch
+            keys, off, bary = oc.lattice_dump(k)
+            n1, n2 = oc.lattice_neighbours(k)
+            got = ctx.lattice_dump(k, b if k == 1 else 0)
+            tag = "%s %dx%d scale %g image %d lattice %d" % (kind, H, W, scale, b, k)
+            assert got["M"] == keys.shape[0], tag
+            # id-invariant form
+            gk, ok = [tuple(r) for r in got["keys"]], [tuple(r) for r in keys]
+            assert sorted(gk) == sorted(ok) and len(set(gk)) == len(gk), tag
+            per_px_g = [sorted((gk[v], float(w)) for v, w in zip(got["vid"][i], got["bary"][i])) for i in range(H * W)]
+            per_px_o = [sorted((ok[v], float(w)) for v, w in zip(off[i], bary[i])) for i in range(H * W)]
+            assert per_px_g == per_px_o, tag
+            nb_g = {gk[v]: [(gk[a] if a >= 0 else None, gk[z] if z >= 0 else None) for a, z in zip(got["n1"][:, v], got["n2"][:, v])]
+                    for v in range(got["M"])}
+            nb_o = {ok[v]: [(ok[a] if a >= 0 else None, ok[z] if z >= 0 else None) for a, z in zip(n1[:, v], n2[:, v])]
+                    for v in range(keys.shape[0])}
+            assert nb_g == nb_o, tag
+            # id for id
+            assert np.array_equal(got["keys"], keys) and np.array_equal(got["vid"], off), tag
+            assert np.array_equal(got["bary"].view(np.uint32), bary.view(np.uint32)), tag      # bit-exact weights
+            assert np.array_equal(got["n1"], n1) and np.array_equal(got["n2"], n2), tag
+        print("lattices", kind, HW, "image", b, "M_gauss", oc.lattice_size(0), "M_bil", oc.lattice_size(1))
 
 
 def test_crf_refine_batch_vs_oracle(ops, O):
@@ -508,6 +554,34 @@ def test_backbone_runs_with_and_without_autocast():
                       ("features.28.weight", 0.15), ("features.17.weight", 0.4)]:
         ga, gb = dict(net.named_parameters())[name].grad, dict(ref.named_parameters())[name].grad
         assert torch.isfinite(ga).all() and (ga - gb).norm() < tol * gb.norm(), (name, float((ga - gb).norm() / gb.norm()))
+
+
+def test_fp32_heads_kernel_matches_fp32_convolutions(ops):
+    """fc8-SEC_k + Eltwise SUM in one HIP pass (bf16 activations, fp32 weights/accumulation/result, NCHW) against the fp32
+    1x1 convolutions of the same bf16-valued activations; the backward of the autograd wrapper against torch's"""
+    import torch.nn.functional as F
+    from dsrg_amd.backbone import _HeadsFn
+    torch.manual_seed(7)
+    for B, K, H, W, O, n in [(2, 1024, 41, 41, 21, 4), (1, 128, 5, 7, 24, 2), (3, 64, 9, 9, 3, 1)]:
+        xs = [torch.randn(B, K, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(n)]
+        w = (torch.randn(n, O, K, device="cuda") * 0.05).requires_grad_(True)
+        b = torch.randn(n, O, device="cuda").requires_grad_(True)
+        want = sum(F.conv2d(x.float(), w[k].reshape(O, K, 1, 1), b[k]) for k, x in enumerate(xs))
+        got = ops.heads_forward(xs, w.detach(), b.detach())
+        assert got.dtype == torch.float32 and got.is_contiguous() and got.shape == (B, O, H, W)
+        assert (got - want).abs().max() <= 2e-5 * want.abs().max()
+        assert torch.equal(got, ops.heads_forward(xs, w.detach(), b.detach()))              # deterministic
+        xa = [x.clone().requires_grad_(True) for x in xs]
+        wa, ba = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+        ya = _HeadsFn.apply(wa, ba, *xa)
+        g = torch.randn_like(ya)
+        ya.backward(g)
+        xr = [x.float().requires_grad_(True) for x in xs]
+        want2 = sum(F.conv2d(x, w[k].reshape(O, K, 1, 1), b[k]) for k, x in enumerate(xr))
+        want2.backward(g)
+        assert (wa.grad - w.grad).norm() <= 0.01 * w.grad.norm() and (ba.grad - b.grad).norm() <= 1e-4 * b.grad.norm()
+        for u, v in zip(xa, xr):
+            assert u.grad.dtype == torch.bfloat16 and (u.grad.float() - v.grad).norm() <= 0.01 * v.grad.norm()
 
 
 def test_fused_relu_dropout_backward_matches_unfused_sequence():

@@ -1,0 +1,211 @@
+"""GPU (-m gpu): the configurations BASELINE.json quotes, end to end.
+
+  configs[1]  VGG16 forward + CRF + SRG, batch 1 (inference-only supervision path) on the backbone's own scores
+  configs[2]  full seed_mc train-s step, batch 16: DSRGTrainer.step (side-stream lattice build, autocast, CaffeSGD)
+  configs[3]  the same step under torch.distributed.run with the nccl (= RCCL) backend and DDP, one rank
+  configs[4]  RetrainTrainer.step with the full ResNet-101 DeepLab at 513x513
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from dsrg_amd import synthetic as S
+from test_gpu_parity import dev, _check_fused_step, CRF_TOL
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dsrg_amd import ops, _lib
+    _lib.require_gpu()
+    return ops
+
+
+def _batch(B, seed=41):
+    b = S.make_batch(seed, B)
+    return dev(b["images"]), dev(b["labels"]), dev(b["cues"])
+
+
+def _dropout_off(net):
+    from dsrg_amd.backbone import GemmConv2d
+    for m in net.modules():
+        if isinstance(m, GemmConv2d):
+            m.fuse_dropout = 0.0
+
+
+def test_config2_backbone_forward_then_supervision_b1(ops, O):
+    """BASELINE configs[1]: one 321x321 image through the VGG16-ASPP forward (bf16 autocast, fp32 heads), then
+    Softmax -> CRF -> SRG (+ losses) on the backbone's OWN scores, against the oracle layer by layer"""
+    from dsrg_amd.backbone import VGG16ASPP
+    torch.manual_seed(0)
+    net = VGG16ASPP().cuda().to(memory_format=torch.channels_last).eval()
+    b = S.make_batch(77, 1)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        scores = net(dev(b["images"]).contiguous(memory_format=torch.channels_last))
+    assert scores.dtype == torch.float32 and scores.shape == (1, 21, 41, 41)
+    # a random-init net scores ~1e-2 (fc8-SEC ~ N(0, 0.01)): stretch to the range of a trained net so that the CRF and
+    # the region growing have decisions to take; both sides see the same numbers
+    scores = (scores - scores.mean()) * (8.0 / scores.std().clamp(min=1e-12))
+    # ... and lean towards the cued classes around their cues, as a net a few hundred iterations into training does, so
+    # that the region growing has something to grow
+    from scipy.ndimage import gaussian_filter
+    bump = np.stack([gaussian_filter(c, 3.0) for c in b["cues"][0]])[None].astype(np.float32)
+    logits = np.ascontiguousarray(scores.cpu().numpy() + 40.0 * bump / max(bump.max(), 1e-12))
+    _check_fused_step(ops, O, logits, b["images"], b["labels"], b["cues"], "config 2 (B=1, backbone scores)")
+    probs = O.softmax_forward(logits)
+    refined, _ = O.crf_refine_batch(probs, b["images"], 12.0, 10)
+    grown = int(O.srg_grow_batch(b["labels"], b["cues"], refined).sum() - b["cues"].sum())
+    print("config 2: max refined %.4f, grown %d" % (refined.max(), grown))
+    assert grown > 0
+
+
+def test_config3_train_step_b16(ops):
+    """BASELINE configs[2]: DSRGTrainer.step at batch 16 exactly as bench.py runs it (bf16 autocast, dropout on, lattices
+    built on the side stream): finite losses, every parameter moves, and the first update obeys Caffe's rule with the
+    lr / decay multipliers of train-s.prototxt (weights 1/1, biases 2/0, fc8-SEC 10/1 and 20/0; solver-s.prototxt:5-14)"""
+    from dsrg_amd.trainer import DSRGTrainer
+    device = torch.device("cuda", 0)
+    tr = DSRGTrainer(device, seed=0)
+    assert tr.overlap_build
+    images, labels, cues = _batch(16)
+    before = [p.detach().clone() for g in tr.opt.groups for p in g["params"]]
+    l0 = tr.step(images, labels, cues)
+    torch.cuda.synchronize()
+    assert torch.isfinite(l0).all() and l0.shape == (2,)
+    lr, wd = tr.opt.base_lr, tr.opt.wd
+    seen = set()
+    i = moved = 0
+    for g in tr.opt.groups:
+        seen.add((g["lr_mult"], g["decay_mult"]))
+        for p in g["params"]:
+            w0 = before[i]
+            i += 1
+            assert p.grad is not None and torch.isfinite(p.grad).all()
+            want = w0 - lr * g["lr_mult"] * (p.grad + wd * g["decay_mult"] * w0)      # V0 = 0 (solver-s.prototxt: momentum 0.9)
+            assert torch.allclose(p.detach(), want, rtol=1e-5, atol=1e-8)
+            moved += int(not torch.equal(p.detach(), w0))
+            if g["decay_mult"] == 1.0:
+                assert not torch.equal(p.detach(), w0)          # every weight tensor moves (a bias whose update is below
+    assert moved >= 0.9 * len(before)                           # half an ulp of its value may stay put in fp32)
+    assert seen == {(1.0, 1.0), (2.0, 0.0), (10.0, 1.0), (20.0, 0.0)}
+    l1 = tr.step(images, labels, cues)
+    assert torch.isfinite(l1).all() and tr.opt.iter == 2
+    print("config 3 losses:", [float(x) for x in l0], [float(x) for x in l1])
+
+
+def test_trainer_prepared_lattices_equal_inline_and_fp32_twin(ops):
+    """(a) lattices built on the side stream under the backbone forward == built inline after it (bit-equal losses and
+    weights); (b) the bf16-autocast step against an fp32 twin of the same net on the same batch (dropout off): the fp32
+    heads keep the two loss values close, and the fp32 path itself runs (bench.py's fp32 headline uses it)"""
+    from dsrg_amd.trainer import DSRGTrainer
+    device = torch.device("cuda", 0)
+    images, labels, cues = _batch(4, seed=43)
+
+    def run(amp, overlap, steps=2):
+        tr = DSRGTrainer(device, seed=5, amp_dtype=amp)
+        _dropout_off(tr.net)
+        tr.overlap_build = overlap
+        out = [tr.step(images, labels, cues).clone() for _ in range(steps)]
+        torch.cuda.synchronize()
+        return out, tr
+    la, ta = run(torch.bfloat16, True)
+    lb, tb = run(torch.bfloat16, False)
+    for x, y in zip(la, lb):
+        assert torch.equal(x, y)
+    for pa, pb in zip(ta.net.parameters(), tb.net.parameters()):
+        assert torch.equal(pa, pb)
+    lc, tc = run(None, True)
+    for x, y in zip(la, lc):
+        assert torch.isfinite(y).all()
+        assert torch.allclose(x, y, rtol=0.03, atol=3e-3), (x, y)
+    print("bf16 losses", [[float(v) for v in x] for x in la], "fp32 losses", [[float(v) for v in x] for x in lc])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ta.net.eval()
+        s16 = ta.net(images.contiguous(memory_format=torch.channels_last))
+    assert s16.dtype == torch.float32                                    # heads and their sum stay fp32 under autocast
+
+
+DDP_WORKER = r"""
+import os, sys, json
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from dsrg_amd import synthetic as S
+from dsrg_amd.trainer import DSRGTrainer
+rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+device = torch.device("cuda", local)
+dist.init_process_group("nccl", device_id=device)
+b = S.make_batch(51, 4)
+d = lambda a: torch.from_numpy(a).to(device)
+images, labels, cues = d(b["images"]), d(b["labels"]), d(b["cues"])
+def run(ddp):
+    tr = DSRGTrainer(device, world_size=dist.get_world_size(), seed=9, ddp=ddp)
+    out = [[float(v) for v in tr.step(images, labels, cues)] for _ in range(3)]
+    torch.cuda.synchronize()
+    return out, [p.detach().clone() for p in tr.net.parameters()]
+l_ddp, w_ddp = run(True)
+l_one, w_one = run(False)
+t = torch.ones(1, device=device); dist.all_reduce(t)
+same_w = all(torch.allclose(a, b, rtol=1e-6, atol=1e-9) for a, b in zip(w_ddp, w_one))
+print("DDPRESULT " + json.dumps({"ddp": l_ddp, "one": l_one, "same_weights": bool(same_w), "allreduce": float(t.item()),
+                                 "backend": dist.get_backend()}))
+dist.destroy_process_group()
+"""
+
+
+def test_config4_ddp_rccl_single_rank(tmp_path):
+    """BASELINE configs[3] on the one GPU there is: bench.py's launch line (torch.distributed.run, nccl = RCCL, DDP-wrapped
+    VGG16ASPP with the custom autograd functions, side-stream lattice build, gradient_as_bucket_view with grad = None
+    resets) for 3 steps == the same 3 steps without DDP"""
+    import json
+    import socket
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER % {"root": ROOT})
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MIOPEN_FIND_MODE=os.environ.get("MIOPEN_FIND_MODE", "2"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("DDPRESULT ")][-1]
+    res = json.loads(line[len("DDPRESULT "):])
+    assert res["backend"] == "nccl" and res["allreduce"] == 1.0
+    assert np.allclose(res["ddp"], res["one"], rtol=1e-5, atol=1e-6), res
+    assert res["same_weights"]
+    assert np.isfinite(res["ddp"]).all()
+
+
+def test_config5_retrain_step_resnet101_513():
+    """BASELINE configs[4]: RetrainTrainer.step with the full ResNet-101 DeepLab (3,4,23,3) at 513x513, batch 2: the
+    65x65 score map, a finite SoftmaxWithLoss (ignore 255) on the 1/8-shrunk label map, parameters move, poly rate"""
+    from dsrg_amd.retrain import RetrainTrainer, poly_lr
+    device = torch.device("cuda", 0)
+    tr = RetrainTrainer(device, backbone="resnet101", seed=0)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(2, 3, 513, 513, generator=g).to(device)
+    label = torch.randint(0, 21, (2, 1, 513, 513), generator=g).float()
+    label[:, :, :40] = 255.0
+    label = label.to(device)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        assert tr.net(images.contiguous(memory_format=torch.channels_last)).shape == (2, 21, 65, 65)
+    w0 = [p.detach().clone() for p in tr.net.parameters()]
+    l0 = tr.step(images, label)
+    l1 = tr.step(images, label)
+    torch.cuda.synchronize()
+    assert torch.isfinite(l0) and torch.isfinite(l1) and 2.0 < float(l0) < 4.5          # ~log(21) at initialisation
+    moved = sum(int(not torch.equal(a, b.detach())) for a, b in zip(w0, tr.net.parameters()))
+    assert moved == len(w0), (moved, len(w0))
+    assert tr.opt.iter == 2 and abs(tr.opt.base_lr - poly_lr(tr.base_lr, 1, tr.max_iter)) < 1e-12
+    print("train-f ResNet-101 513x513 losses:", float(l0), float(l1))
