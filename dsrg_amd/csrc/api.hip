@@ -40,9 +40,16 @@ struct dsrg_ctx_s {
     Profiler prof;
     int prepared_B;              // batch whose lattices dsrg_crf_prepare_batch built (0 = none)
     dsrg_crf_params prepared_prm;
+    unsigned int mf_epoch;       // launch counter of the one-launch inference loop (granule tags)
+    unsigned int *mf_status;     // host-mapped: non-zero after a hand-off inside that kernel timed out
 };
 
-namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; }
+namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; extern int g_meanfield_mode; }
+// tests / tools only (not in the public header): 1 = the one-launch inference loop, 0 = one filter + one update launch per
+// iteration, -1 = back to the DSRG_MEANFIELD environment variable
+extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_meanfield_mode(int mode) { dsrg::g_meanfield_mode = mode; }
+// tests only: the hand-off status word of a context (non-zero after a timed-out hand-off)
+extern "C" __attribute__((visibility("default"))) int dsrg_debug_meanfield_status(dsrg_ctx_t c);
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_build_trace(void *dev_buf) { dsrg::g_build_dbg = dev_buf; }
 // tools only (not in the public header): device buffer of 16 u64 per filter block receiving phase timestamps
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_trace(void *dev_buf) { dsrg::g_filter_dbg = dev_buf; }
@@ -72,12 +79,21 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     const size_t szIm = align256((size_t)max_batch * N * 3);
     const size_t szRef = align256(sizeof(double) * (size_t)max_batch * C * N);
     const size_t szStats = align256(sizeof(double) * (size_t)max_batch * 5 * 8);   // [B][kStatSplit][5]
-    const size_t total = szLg + szLb + 3 * blob /*mf*/ + szIm + 3 * blob /*probs,logq,seeds*/ + szRef + szStats;
+    const size_t szGran = align256(sizeof(unsigned long long) * (size_t)max_batch * C * N);
+    const size_t total = szLg + szLb + 3 * blob /*mf*/ + szIm + 3 * blob /*probs,logq,seeds*/ + szRef + szStats + 2 * szGran;
     hipError_t e = hipMalloc(&c->arena, total);
     if (e != hipSuccess) {
         delete c;
         return set_error(DSRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
     }
+    c->mf_epoch = 0; c->mf_status = nullptr;
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->mf_status), sizeof(unsigned int), hipHostMallocMapped);
+    if (e != hipSuccess) {
+        (void)hipFree(c->arena);
+        delete c;
+        return set_error(DSRG_ERR_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    *c->mf_status = 0;
     unsigned char *p = static_cast<unsigned char *>(c->arena);
     lattice_carve(c->Lg, p, 2, N, 1); p += szLg;
     lattice_carve(c->Lb, p, 5, N, max_batch); p += szLb;
@@ -90,6 +106,20 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     c->seeds = reinterpret_cast<float *>(p); p += blob;
     c->refined = reinterpret_cast<double *>(p); p += szRef;
     c->stats = reinterpret_cast<double *>(p); p += szStats;
+    c->mf.qg = reinterpret_cast<unsigned long long *>(p); p += szGran;
+    c->mf.vg = reinterpret_cast<unsigned long long *>(p); p += szGran;
+    c->mf.status_host = c->mf_status;
+    c->mf.epoch = &c->mf_epoch;
+    void *sdev = nullptr;
+    e = hipHostGetDevicePointer(&sdev, c->mf_status, 0);
+    if (e == hipSuccess) e = hipMemset(c->mf.qg, 0, 2 * szGran);          // tag 0 = never written
+    if (e != hipSuccess) {
+        (void)hipHostFree(c->mf_status);
+        (void)hipFree(c->arena);
+        delete c;
+        return set_error(DSRG_ERR_HIP, "context set-up failed: %s", hipGetErrorString(e));
+    }
+    c->mf.status = static_cast<unsigned int *>(sdev);
     *out = c;
     return DSRG_OK;
 }
@@ -140,10 +170,13 @@ extern "C" int dsrg_ctx_profile_stop(dsrg_ctx_t c, double *total_ms, int32_t *la
     return prof_stop(c->prof, total_ms, launches);
 }
 
+extern "C" int dsrg_debug_meanfield_status(dsrg_ctx_t c) { return (c && c->mf_status) ? (int)*c->mf_status : -1; }
+
 extern "C" int dsrg_ctx_destroy(dsrg_ctx_t c) {
     if (!c) return DSRG_OK;
     prof_free(c->prof);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->mf_status) (void)hipHostFree(c->mf_status);
     delete c;
     return DSRG_OK;
 }
@@ -178,6 +211,10 @@ static int crf_build(dsrg_ctx_t c, int B, const unsigned char *im_u8, const dsrg
 static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,
                    const dsrg_crf_params *prm, float *q_out, double *refined, float *logq, hipStream_t s,
                    bool prepared = false) {
+    if (c->mf_status && *c->mf_status)
+        return set_error(DSRG_ERR_HIP, "a hand-off inside the one-launch mean-field kernel timed out in an earlier call on this "
+                                       "context (workgroups of one image not co-resident?); results since then are invalid — "
+                                       "DSRG_MEANFIELD=launches selects the multi-launch loop");
     if (!prepared) {
         int rc = crf_build(c, B, im_u8, prm, s);
         if (rc) return rc;

@@ -21,6 +21,13 @@ int set_error(int code, const char *fmt, ...);
 // raise a kernel's dynamic-LDS limit (default 64 KiB) to `bytes`; `granted` caches what was set.
 // The limit is requested per need, not as a flat 160 KiB: static LDS (e.g. the variable behind
 // __syncthreads_or) counts against the same 160 KiB and an over-ask is rejected.
+struct LdsGrant { size_t bytes[16] = {0}; };       // per device (hipFuncSetAttribute acts on the current device)
+inline int ensure_dynamic_lds(const void *fn, size_t bytes, size_t &granted);
+inline int ensure_dynamic_lds(const void *fn, size_t bytes, LdsGrant &g) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { size_t none = 0; return ensure_dynamic_lds(fn, bytes, none); }
+    return ensure_dynamic_lds(fn, bytes, g.bytes[dev]);
+}
 inline int ensure_dynamic_lds(const void *fn, size_t bytes, size_t &granted) {
     if (bytes <= granted) return DSRG_OK;
     if (bytes > 64 * 1024) {
@@ -85,6 +92,11 @@ struct MeanfieldBufs {
     float *q;        // (B,C,N) current marginals
     float *msg_g;    // (B,C,N) normalised Gaussian message  K~_g Q
     float *msg_b;    // (B,C,N) normalised bilateral message K~_b Q
+    // the one-launch (persistent) inference loop: {tag, value} granules handed between the workgroups of an image
+    unsigned long long *qg, *vg;   // (B,C,N) each, zeroed at creation (tag 0 is never used); null = multi-launch path only
+    unsigned int *status;          // host-mapped word (device address), set by the kernel if a hand-off timed out
+    unsigned int *status_host;     // the same word, host address
+    unsigned int *epoch;           // host counter, advanced once per launch (tag = epoch << 6 | iteration)
 };
 // optional per-launch timing of the filter kernel with HIP events on the launch stream
 struct Profiler {

@@ -7,7 +7,10 @@
 namespace dsrg {
 
 // dynamic LDS next to static arrays: above 48 KB ask for the size explicitly (the default cap is 64 KB for both together)
-static int reserve_lds(const void *fn, size_t bytes, size_t &granted) {
+static int reserve_lds(const void *fn, size_t bytes, LdsGrant &grant) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    size_t &granted = grant.bytes[dev];
     if (bytes <= granted) return DSRG_OK;
     if (bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -176,7 +179,7 @@ int launch_expand_loss(int B, int C, int HW, const float *p, const float *stat, 
     if (loss && !terms) return set_error(DSRG_ERR_INVALID, "expand loss: the loss needs the B*C scratch doubles");
     int NP = 1;
     while (NP < HW) NP <<= 1;
-    static size_t granted = 0;
+    static LdsGrant granted;
     int rc = reserve_lds((const void *)expand_plane_kernel, (size_t)NP * 8, granted);
     if (rc) return rc;
     hipLaunchKernelGGL(expand_plane_kernel, dim3(B * C), dim3(1024), (size_t)NP * 8, stream, B, C, HW, NP, p, stat, q_fg, q_bg,
@@ -216,7 +219,7 @@ int launch_confusion(size_t n, const unsigned char *gt, const unsigned char *pre
     if (nclass < 1 || nclass > 127) return set_error(DSRG_ERR_UNSUPPORTED, "confusion matrix: 1..127 classes");
     if (n == 0) return DSRG_OK;
     const size_t lds = ((size_t)nclass * nclass + 1) * sizeof(unsigned int);
-    static size_t granted = 0;
+    static LdsGrant granted;
     int rc = reserve_lds((const void *)confusion_kernel, lds, granted);
     if (rc) return rc;
     size_t blocks = (n + 256 * 16 - 1) / (256 * 16);

@@ -680,7 +680,7 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
     const int split = (neigh_lds <= 150 * 1024 && L.Mcap <= 16 * kWG) ? 1 : 0;
 #define DSRG_BUILD(D_, V_)                                                                                    \
     do {                                                                                                      \
-        static size_t granted = 0, granted_n = 0, granted_m = 0;                                              \
+        static LdsGrant granted, granted_n, granted_m;                                                         \
         int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_build_kernel<D_, V_>), lds, granted); \
         if (rc) return rc;                                                                                    \
         hipLaunchKernelGGL((lattice_build_kernel<D_, V_>), dim3(nlat), dim3(kWG), lds, stream, L, F, im, cap,  \

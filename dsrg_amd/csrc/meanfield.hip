@@ -12,6 +12,8 @@
 // only the per-pixel messages travel through HBM/L2.  A second, per-pixel kernel
 // combines unary + weighted messages and renormalises over the labels.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace dsrg {
@@ -64,17 +66,27 @@ __device__ __forceinline__ void pv_set(float4 &v, int c, float x) {
 
 // one lattice (dimension D, index li of set L), planes [c0, c0+nc) of image b:
 //   out[c][i] = norm[i] * (K (norm . q[c]))[i]
-template <int CPW, int VPT, int PPT, int D>
+// REG_IO (the persistent kernel): the marginals of this thread's pixels tid + p*kWG arrive in io[p][c] and the filtered
+// values leave in io[p][c]; qb / out are not touched.
+// `mid` runs once right after the lattice's index loads have been issued and before anything is consumed: the persistent
+// kernel waits for the marginals there (and fills io), so the index round trip and the hand-off wait overlap.  M_pre /
+// flags_pre: the lattice size and flags when the caller already holds them (REG_IO; saves a dependent load per call).
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <int CPW, int VPT, int PPT, int D, bool REG_IO = false, typename Mid = NoMid>
 __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, const float *__restrict__ qb,
                                                float *__restrict__ out, int nc, int N,
                                                typename PlaneVec<CPW>::type *val,
-                                               typename PlaneVec<CPW>::type *inq, unsigned long long *dbg) {
+                                               typename PlaneVec<CPW>::type *inq, unsigned long long *dbg,
+                                               float (*io)[CPW] = nullptr, int tid_in = 0, int M_pre = 0, int flags_pre = 0,
+                                               Mid mid = Mid()) {
     using vec_t = typename PlaneVec<CPW>::type;
     constexpr int D1 = D + 1;
     constexpr bool DEEP = VPT <= 10;             // all index words of a thread fit the register file
     constexpr int KC = DEEP ? VPT : 8;           // vertices per chunk of index loads otherwise
     constexpr int NCH = (VPT + KC - 1) / KC;
-    const int tid = threadIdx.x;
+    // inside the persistent kernel's iteration loop the thread index arrives laundered (tid_in): everything derived from
+    // it is then recomputed per iteration instead of being hoisted out of the loop and held in registers across it
+    const int tid = REG_IO ? tid_in : (int)threadIdx.x;
     const int Mcap = L.Mcap, E = N * D1;
     const float *norm = L.norm + (size_t)li * N;
 
@@ -87,26 +99,37 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
     const rsrc_t r_norm = make_rsrc(norm, sizeof(float) * (size_t)N);
     const rsrc_t r_q = make_rsrc(qb, sizeof(float) * (size_t)nc * N);
 
-    const int M = L.M[li];
+    const int M = REG_IO ? M_pre : L.M[li];
+    const int lat_flags = REG_IO ? flags_pre : L.flags[li];
     DSRG_STAMP(0);
 
-    if (L.flags[li] & 1) {
+    if (lat_flags & 1) {
         // Diagonal lattice (e.g. the Gaussian kernel at training scale: sigma = 0.25 px):
         // every simplex corner is private to its pixel and has no blur neighbour, so splat, blur and
         // slice collapse to per-pixel arithmetic — evaluated here in the general path's operation
         // order (products, 0 + p, val + 0.5*(0+0), ordered slice sum), hence bit-identical to it.
         const float alpha = 1.0f / (1.0f + exp2f(-(float)D));
+        float nvs[PPT], bws[PPT][D1];
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            nvs[p] = ld_f32(r_norm, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u));
+#pragma unroll
+            for (int r = 0; r < D1; r++)
+                bws[p][r] = ld_f32(r_bary, (uint32_t)tid * 4u, ((uint32_t)p * kWG + (uint32_t)r * (uint32_t)N) * 4u);
+        }
+        mid();
 #pragma unroll
         for (int p = 0; p < PPT; p++) {
             const int i = tid + p * kWG;
-            const float nv = ld_f32(r_norm, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u));
+            const float nv = nvs[p];
             float bw[D1], qq[CPW];
 #pragma unroll
-            for (int r = 0; r < D1; r++)
-                bw[r] = ld_f32(r_bary, (uint32_t)tid * 4u, ((uint32_t)p * kWG + (uint32_t)r * (uint32_t)N) * 4u);
+            for (int r = 0; r < D1; r++) bw[r] = bws[p][r];
 #pragma unroll
-            for (int c = 0; c < CPW; c++)
-                qq[c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
+            for (int c = 0; c < CPW; c++) {
+                if constexpr (REG_IO) qq[c] = io[p][c];
+                else qq[c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
+            }
             if (i < N) {
 #pragma unroll
                 for (int c = 0; c < CPW; c++) {
@@ -119,7 +142,8 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
                             v = v + 0.5f * (0.0f + 0.0f);        // d+1 blur passes without neighbours
                             acc = acc + (bw[r] * alpha) * v;     // slice
                         }
-                        out[(size_t)c * N + i] = acc * nv;
+                        if constexpr (REG_IO) io[p][c] = acc * nv;
+                        else out[(size_t)c * N + i] = acc * nv;
                     }
                 }
             }
@@ -134,9 +158,11 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #pragma unroll
     for (int p = 0; p < PPT; p++) {
         nrm[p] = ld_f32(r_norm, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u));
+        if constexpr (!REG_IO) {
 #pragma unroll
-        for (int c = 0; c < CPW; c++)
-            qv[p][c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
+            for (int c = 0; c < CPW; c++)
+                qv[p][c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
+        }
     }
     uint32_t epx[KC];
     float ew[KC];
@@ -158,6 +184,13 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
             nbw[j % RING][k] = ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)j * (uint32_t)Mcap * 4u + (uint32_t)k * (kWG * 4u));
     };
     if constexpr (DEEP) load_axis(0);
+    mid();
+    if constexpr (REG_IO) {
+#pragma unroll
+        for (int p = 0; p < PPT; p++)
+#pragma unroll
+            for (int c = 0; c < CPW; c++) qv[p][c] = io[p][c];
+    }
 
     // in = Q * norm   (pairwise.cpp:66)
 #pragma unroll
@@ -320,8 +353,10 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
                 for (int c = 0; c < CPW; c++) acc[c] = acc[c] + w * pv_get(x, c);
             }
 #pragma unroll
-            for (int c = 0; c < CPW; c++)
-                if (c < nc) out[(size_t)c * N + i] = acc[c] * nrm[p];
+            for (int c = 0; c < CPW; c++) {
+                if constexpr (REG_IO) io[p][c] = acc[c] * nrm[p];
+                else if (c < nc) out[(size_t)c * N + i] = acc[c] * nrm[p];
+            }
         }
     }
     DSRG_STAMP(11);
@@ -469,11 +504,257 @@ __global__ __launch_bounds__(256) void mf_update_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------
+// The whole inference loop (densecrf.cpp:115-131) as ONE launch: workgroup (b, g) keeps plane group g of image b for all
+// iterations.  An iteration has a plane-parallel half (the two filters on my planes, for every pixel) and a pixel-parallel
+// half (expAndNormalize needs all labels of a pixel: workgroup g owns the pixel range g of its image), so the marginals
+// are transposed twice per iteration between the G workgroups of an image.  The hand-off is the data itself: 8-byte
+// {tag, value} granules, one relaxed agent-scope (write-through, L1-bypassing) store each, polled by their reader until
+// the tag of the expected phase shows (cdna_hip_programming.md, Guideline 16, form R2) — no flag, no fence, no grid
+// barrier, and images never wait for one another.  tag = launch epoch << 6 | iteration: a granule is written exactly once
+// per (launch, iteration), and the protocol cannot overwrite one before its readers are through (a writer needs every
+// reader's next output first).  All G workgroups of an image must be resident: the host launches at most 256 of them.
+struct PersistArgs {
+    LatticeView Lg, Lb;
+    const float *neg_unary;            // (B,C,N)  -U
+    unsigned long long *qg, *vg;       // (B,C,N) granules: marginals Q, pre-normalisation values V = -U - sum_k (-w_k msg_k)
+    float *q_out;                      // (B,C,N) marginals of the last iteration (may be null)
+    double *refined_out;               // (B,C,N) pylayers.py:84-86 (may be null)
+    float *logq_out;                   // (B,C,N) pylayers.py:88 (may be null)
+    unsigned int *status;              // host-mapped word: set when a hand-off timed out
+    float wg, wb;
+    int b0, B, C, N, n_iters;          // this launch covers images [b0, B)
+    int nblk_xcd, lat_stride, groups;  // block -> (group, image - b0) map, as in FilterArgs
+    int lds_val_stride;                // vertices in the LDS value array (bilateral Mcap + 1, padded to 4)
+    int lp_shift;                      // log2 of the lanes per pixel in the pixel-parallel half (5: C <= 32, 6: C <= 64)
+    unsigned int epoch;
+    unsigned long long *dbg;           // tools: 64 phase timestamps (100 MHz wall clock) per workgroup
+};
+
+constexpr unsigned int kSpinLimit = 1u << 18;
+
+__device__ __forceinline__ void store_granule(unsigned long long *g, unsigned int tag, float v) {
+    __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// every lane polls its K granules (null = nothing to wait for) until all lanes of the wave hold the expected tag
+template <int K>
+__device__ __forceinline__ void poll_granules(const unsigned long long *const (&g)[K], unsigned int tag, float (&v)[K],
+                                              unsigned int *status) {
+    unsigned int need = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) { v[k] = 0.0f; if (g[k]) need |= 1u << k; }
+    for (unsigned int spins = 0;; spins++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if ((need >> k) & 1u) {
+                const unsigned long long x = __hip_atomic_load(g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(x >> 32) == tag) { v[k] = __uint_as_float((unsigned int)x); need &= ~(1u << k); }
+            }
+        }
+        if (__all(need == 0)) return;
+        if (spins >= kSpinLimit || (spins > 64 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // bounded: never hang the GPU
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// pixel-parallel half for my pixel range [px0, px1): LP lanes per pixel, lane = label, kWG / LP pixels per round.  USE_V:
+// values from the V granules of iteration `it`, else from -U (Q0, densecrf.cpp:120).  Not last: Q granules of iteration
+// `it`; last: the layer outputs.  The granules of kUpdBatch rounds are requested together (one memory round trip).
+constexpr int kUpdBatch = 8;
+template <bool USE_V>
+__device__ __forceinline__ void update_phase(const PersistArgs &a, int b, int px0, int px1, int it, bool last, float *scr) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));          // nothing derived from it is hoisted out of the iteration loop (register pressure)
+    const int C = a.C, N = a.N, lp = 1 << a.lp_shift, ppr = kWG >> a.lp_shift;
+    const int c = tid & (lp - 1), grp = tid & ~(lp - 1);
+    const size_t img = (size_t)b * C * N + (size_t)min(c, C - 1) * N;
+    const unsigned int tag = (a.epoch << 6) | (unsigned int)it;
+    for (int base0 = px0; base0 < px1; base0 += kUpdBatch * ppr) {
+        float tv[kUpdBatch];
+        {
+            const unsigned long long *gp[kUpdBatch];
+#pragma unroll
+            for (int r = 0; r < kUpdBatch; r++) {
+                const int i = base0 + r * ppr + (tid >> a.lp_shift);
+                const bool act = i < px1 && c < C;
+                if (USE_V) gp[r] = act ? a.vg + img + i : nullptr;
+                else tv[r] = a.neg_unary[img + min(i, N - 1)];
+            }
+            if (USE_V) poll_granules<kUpdBatch>(gp, tag, tv, a.status);
+        }
+#pragma unroll
+        for (int r = 0; r < kUpdBatch; r++) {
+            if (base0 + r * ppr >= px1) break;                   // workgroup-uniform
+            const int i = base0 + r * ppr + (tid >> a.lp_shift);
+            const bool act = i < px1 && c < C;
+            const size_t o = img + min(i, N - 1);
+            const float t = act ? tv[r] : -INFINITY;
+            float mx = t;                                        // column max (densecrf.cpp:101); fmax is order-independent
+            for (int off = lp >> 1; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            const float e = act ? exp_cr(t - mx) : 0.0f;
+            __builtin_amdgcn_wave_barrier();
+            scr[tid] = e;                                        // read back only by lanes of this wave: no workgroup barrier
+            __builtin_amdgcn_wave_barrier();
+            float sum = 0.0f;                                    // label-order sum, as the reference's column sum
+            for (int cc = 0; cc < C; cc++) sum = sum + scr[grp + cc];
+            const float q = e / sum;
+            if (!last) {
+                if (act) store_granule(a.qg + o, tag, q);
+            } else {
+                if (act && a.q_out) a.q_out[o] = q;
+                if (a.refined_out) {
+                    // pylayers.py:84-88: float64, clip at min_prob, divide by numpy's pairwise label sum, log
+                    __builtin_amdgcn_wave_barrier();
+                    scr[tid] = q;
+                    __builtin_amdgcn_wave_barrier();
+                    auto col = [&](int k) { const double v = (double)scr[grp + k]; return v < 0.0001 ? 0.0001 : v; };
+                    double s;
+                    if (C < 8) {
+                        s = 0.0;
+                        for (int k = 0; k < C; k++) s += col(k);
+                    } else {
+                        const int full = C - (C % 8);
+                        double rs[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) rs[k] = col(k);
+                        for (int k0 = 8; k0 < full; k0 += 8) {
+#pragma unroll
+                            for (int k = 0; k < 8; k++) rs[k] += col(k0 + k);
+                        }
+                        s = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+                        for (int k = full; k < C; k++) s += col(k);
+                    }
+                    if (act) {
+                        const double qd = (double)q;
+                        const double rr = (qd < 0.0001 ? 0.0001 : qd) / s;
+                        a.refined_out[o] = rr;
+                        if (a.logq_out) a.logq_out[o] = (float)log(rr);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int CPW, int VPT_B, int PPT>
+__global__ __launch_bounds__(kWG) void mf_persistent_kernel(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using vec_t = typename PlaneVec<CPW>::type;
+    constexpr int VPT_G = (VPT_B + 1) / 2;                 // Mcap_gauss = Mcap_bilateral / 2
+    int g, b;
+    if ((int)blockIdx.x < a.nblk_xcd) { g = blockIdx.x / a.lat_stride; b = blockIdx.x % a.lat_stride; }
+    else { const int rel = blockIdx.x - a.nblk_xcd; b = a.lat_stride + rel / a.groups; g = rel % a.groups; }
+    b += a.b0;
+    if (b >= a.B) return;
+    const int tid = threadIdx.x, C = a.C, N = a.N;
+    const int c0 = g * CPW, nc = min(CPW, C - c0);
+    vec_t *val = reinterpret_cast<vec_t *>(smem);                      // [Mcap + 1] label-interleaved
+    vec_t *inq = val + a.lds_val_stride;                               // [N]
+    float *scr = reinterpret_cast<float *>(inq + N);                   // [kWG] scratch of the pixel-parallel half
+    const int npx = (N + a.groups - 1) / a.groups, px0 = min(N, g * npx), px1 = min(N, px0 + npx);
+    const size_t img = (size_t)b * C * N;
+
+    float *stash = scr + kWG;                                          // [PPT * CPW][kWG] per-thread values parked in LDS
+    unsigned long long *dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 64 : nullptr;
+#define DSRG_PSTAMP(i_) do { if (dbg && threadIdx.x == 0 && (i_) < 64) dbg[(i_)] = wall_clock64(); } while (0)
+    DSRG_PSTAMP(0);
+    const rsrc_t r_u = make_rsrc(a.neg_unary + img + (size_t)c0 * N, sizeof(float) * (size_t)nc * N);
+    const int Mg = a.Lg.M[0], flags_g = a.Lg.flags[0], Mb = a.Lb.M[b], flags_b = a.Lb.flags[b];   // loop invariants
+    update_phase<false>(a, b, px0, px1, 0, a.n_iters == 0, scr);       // Q0 = expAndNormalize(-U)
+    DSRG_PSTAMP(1);
+    for (int it = 1; it <= a.n_iters; it++) {
+        const unsigned int tag_q = (a.epoch << 6) | (unsigned int)(it - 1), tag_v = (a.epoch << 6) | (unsigned int)it;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));                                   // see filter_lattice: no hoisting across iterations
+        float io[PPT][CPW];
+        // wait for the marginals of my planes, run the Gaussian kernel on them and fold it into
+        // tmp1 = -U - (-w_g msg_g) (densecrf.cpp:122-127: Gaussian first, then bilateral); tmp1 is parked in LDS during the
+        // bilateral filter and io holds the marginals again on return
+        auto fetch_and_gauss = [&](auto gauss) {
+            float pu[PPT][CPW];                                        // -U of my planes at my pixels
+#pragma unroll
+            for (int p = 0; p < PPT; p++)
+#pragma unroll
+                for (int c = 0; c < CPW; c++)
+                    pu[p][c] = ld_f32(r_u, (uint32_t)tl * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
+            const unsigned long long *gp[PPT * CPW];
+            float qv[PPT * CPW];
+#pragma unroll
+            for (int p = 0; p < PPT; p++)
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                    const int i = tl + p * kWG;
+                    gp[p * CPW + c] = (i < N && c < nc) ? a.qg + img + (size_t)(c0 + c) * N + i : nullptr;
+                }
+            poll_granules<PPT * CPW>(gp, tag_q, qv, a.status);
+            DSRG_PSTAMP(2 + (it - 1) * 6 + 0);
+#pragma unroll
+            for (int p = 0; p < PPT; p++)
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                    io[p][c] = qv[p * CPW + c];
+                    stash[(p * CPW + c) * kWG + tl] = io[p][c];
+                }
+            gauss();
+#pragma unroll
+            for (int p = 0; p < PPT; p++)
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                    float v = pu[p][c];
+                    const float m1 = (-a.wg) * io[p][c];
+                    v = v - m1;
+                    io[p][c] = stash[(p * CPW + c) * kWG + tl];
+                    stash[(p * CPW + c) * kWG + tl] = v;
+                }
+            DSRG_PSTAMP(2 + (it - 1) * 6 + 1);
+        };
+        if (flags_g & 1) {
+            // diagonal Gaussian lattice (training scale): per-pixel arithmetic, done inside the bilateral filter's index-load
+            // shadow together with the wait for the marginals
+            filter_lattice<CPW, VPT_B, PPT, 5, true>(a.Lb, b, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mb, flags_b, [&]() {
+                fetch_and_gauss([&]() {
+                    filter_lattice<CPW, VPT_G, PPT, 2, true>(a.Lg, 0, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mg, flags_g);
+                });
+            });
+        } else {
+            fetch_and_gauss([&]() {
+                filter_lattice<CPW, VPT_G, PPT, 2, true>(a.Lg, 0, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mg, flags_g);
+            });
+            __syncthreads();                                           // LDS is reused
+            filter_lattice<CPW, VPT_B, PPT, 5, true>(a.Lb, b, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mb, flags_b);
+        }
+        DSRG_PSTAMP(2 + (it - 1) * 6 + 2);
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            const int i = tid + p * kWG;
+#pragma unroll
+            for (int c = 0; c < CPW; c++) {
+                if (i < N && c < nc) {
+                    float v = stash[(p * CPW + c) * kWG + tid];
+                    const float m2 = (-a.wb) * io[p][c];
+                    v = v - m2;
+                    store_granule(a.vg + img + (size_t)(c0 + c) * N + i, tag_v, v);
+                }
+            }
+        }
+        __syncthreads();
+        DSRG_PSTAMP(2 + (it - 1) * 6 + 3);
+        update_phase<true>(a, b, px0, px1, it, it == a.n_iters, scr);
+        DSRG_PSTAMP(2 + (it - 1) * 6 + 4);
+    }
+#undef DSRG_PSTAMP
+}
+
+// ---------------------------------------------------------------------------------
 void *g_filter_dbg = nullptr;   // set through dsrg_debug_set_filter_trace (tools only)
 
 template <int CPW_B, int CPW_G, int VPT_B, int PPT>
 static int launch_filter(const FilterArgs &a, int nblocks, size_t lds, hipStream_t stream, Profiler *prof) {
-    static size_t granted = 0;
+    static LdsGrant granted;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mf_filter_kernel<CPW_B, CPW_G, VPT_B, PPT>), lds, granted);
     if (rc) return rc;
     const bool timed = prof && prof->active && prof->used < prof->cap;
@@ -492,6 +773,44 @@ static int dispatch_vpt(const FilterArgs &a, int nblocks, size_t lds, int vpt, h
     if (vpt <= 25) return launch_filter<CPW_B, CPW_G, 25, 5>(a, nblocks, lds, stream, prof);
     if (vpt <= 32) return launch_filter<CPW_B, CPW_G, 32, 6>(a, nblocks, lds, stream, prof);
     return set_error(DSRG_ERR_UNSUPPORTED, "lattice too large for the LDS-resident filter (vpt=%d)", vpt);
+}
+
+template <int CPW, int VPT_B, int PPT>
+static int launch_persistent(const PersistArgs &a, int nblocks, size_t lds, hipStream_t stream, Profiler *prof) {
+    static LdsGrant granted;
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mf_persistent_kernel<CPW, VPT_B, PPT>), lds, granted);
+    if (rc) return rc;
+    const bool timed = prof && prof->active && prof->used < prof->cap;
+    if (timed) DSRG_HIP_CHECK(hipEventRecord(prof->start[prof->used], stream));
+    hipLaunchKernelGGL((mf_persistent_kernel<CPW, VPT_B, PPT>), dim3(nblocks), dim3(kWG), lds, stream, a);
+    DSRG_LAUNCH_CHECK();
+    if (timed) { DSRG_HIP_CHECK(hipEventRecord(prof->stop[prof->used], stream)); prof->used++; }
+    return DSRG_OK;
+}
+// instantiated for maps up to 10 vertices per thread only (41x41 and smaller: the training sizes); larger LDS-resident maps
+// (65x65) keep the launch-per-iteration loop
+constexpr int kPersistMaxVpt = 10;
+template <int CPW>
+static int dispatch_persistent(const PersistArgs &a, int nblocks, size_t lds, int vpt, hipStream_t stream, Profiler *prof) {
+    if (vpt <= 4) return launch_persistent<CPW, 4, 1>(a, nblocks, lds, stream, prof);
+    if (vpt <= 10) return launch_persistent<CPW, 10, 2>(a, nblocks, lds, stream, prof);
+    return set_error(DSRG_ERR_UNSUPPORTED, "lattice too large for the one-launch inference loop (vpt=%d)", vpt);
+}
+
+// Which inference loop runs: the launch-per-iteration loop (default; one filter + one update launch per iteration) or the
+// one-launch loop (mf_persistent_kernel), selected by DSRG_MEANFIELD=persistent.  Measured on MI355X (profiles/
+// r02_persistent_phase_trace.txt) the two take the same time at one image (0.446 ms per supervision step) and the one-launch
+// loop is SLOWER at 16 images (0.61 vs 0.53 ms): a hand-off between the workgroups of an image costs two memory round trips
+// (~3 us, what a kernel boundary plus the next kernel's first loads cost) and there are two per iteration, while the
+// per-iteration index traffic that dominates either way (~400 KB per workgroup) cannot stay resident — registers and LDS
+// are full.  Both produce bit-identical marginals (tests/test_gpu_parity.py).
+int g_meanfield_mode = -1;     // -1: from the environment at first use; 0: launches; 1: persistent (dsrg_debug_set_meanfield_mode)
+static bool persistent_enabled() {
+    if (g_meanfield_mode < 0) {
+        const char *e = getenv("DSRG_MEANFIELD");
+        g_meanfield_mode = (e && strcmp(e, "persistent") == 0) ? 1 : 0;
+    }
+    return g_meanfield_mode != 0;
 }
 
 static int launch_update(const float *neg_unary, const MeanfieldBufs &buf, float wg, float wb, int use_msgs,
@@ -530,6 +849,59 @@ int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const Meanfie
     if (N > ppt_tab * kWG) return set_error(DSRG_ERR_UNSUPPORTED, "pixel count %d exceeds the filter kernel", N);
     if (Lg.Mcap > ((vpt <= 4 ? 4 : vpt <= 10 ? 10 : vpt <= 16 ? 16 : vpt <= 25 ? 25 : 32) + 1) / 2 * kWG)
         return set_error(DSRG_ERR_UNSUPPORTED, "Gaussian lattice exceeds the filter kernel");
+
+    // ---- one launch for the whole loop (mf_persistent_kernel) whenever the hand-off buffers exist
+    if (persistent_enabled() && buf.qg && buf.vg && buf.status && buf.epoch && n_iters >= 1 && n_iters <= 62 &&
+        vpt <= kPersistMaxVpt) {
+        const int ppt_p = vpt <= 4 ? 1 : vpt <= 10 ? 2 : vpt <= 16 ? 3 : vpt <= 25 ? 5 : 6;
+        auto lds_p = [&](int cpw) {        // lattice values + normalised input planes + scratch + parked per-thread values
+            return (size_t)cpw * ((size_t)vs_b + N) * sizeof(float) + (size_t)(1 + ppt_p * cpw) * kWG * sizeof(float);
+        };
+        // one label plane per workgroup while that still fits one round of 256 CUs (a 1-plane block is no slower than a
+        // 2-plane one is faster: the same number of LDS gathers), two planes (8-byte gathers) beyond
+        int cpw = ((size_t)B * C <= 256 || lds_p(2) > kLds) ? 1 : 2;
+        if (lds_p(cpw) <= kLds) {
+            PersistArgs p;
+            p.Lg = Lg; p.Lb = Lb; p.neg_unary = neg_unary; p.qg = buf.qg; p.vg = buf.vg;
+            p.q_out = q_out; p.refined_out = refined_out; p.logq_out = logq_out; p.status = buf.status;
+            p.wg = wg; p.wb = wb; p.C = C; p.N = N; p.n_iters = n_iters;
+            p.groups = (C + cpw - 1) / cpw;
+            p.lds_val_stride = vs_b;
+            p.lp_shift = C <= 32 ? 5 : 6;
+            const int vpt_p = (Lb.Mcap + kWG - 1) / kWG;
+            p.dbg = reinterpret_cast<unsigned long long *>(g_filter_dbg);
+            // Every workgroup of an image must be resident at once, and one workgroup (16 waves, > 64 VGPRs) fills a CU:
+            // at most 256 per launch, and — the dispatcher deals blocks to the 8 XCDs round-robin — at most 32 per XCD.
+            const int bmax = 256 / p.groups > 0 ? 256 / p.groups : 1;
+            for (int b0 = 0; b0 < B; b0 += bmax) {
+                const int Bc = B - b0 < bmax ? B - b0 : bmax;
+                p.b0 = b0; p.B = b0 + Bc;
+                // preferred map: the workgroups of an image share blockIdx % 8 (one XCD: its L2 holds the image's index
+                // arrays) for the largest multiple of 8 images, the rest image-major; taken only if no XCD gets more than 32
+                p.lat_stride = Bc < 8 ? 8 : (Bc & ~7);
+                p.nblk_xcd = p.groups * p.lat_stride;
+                int tail = Bc > p.lat_stride ? p.groups * (Bc - p.lat_stride) : 0;
+                int worst = 0;
+                for (int x = 0; x < 8; x++) {
+                    int load = 0;
+                    for (int bb = x; bb < Bc && bb < p.lat_stride; bb += 8) load += p.groups;
+                    load += (tail + 7 - x) / 8;
+                    worst = load > worst ? load : worst;
+                }
+                if (worst > 32) {                  // spread every image over the XCDs instead (image-major everywhere)
+                    p.lat_stride = 0; p.nblk_xcd = 0; tail = p.groups * Bc;
+                }
+                const int nblk = p.nblk_xcd + tail;
+                unsigned int e = ++*buf.epoch;
+                if ((e & 0x03FFFFFFu) == 0) e = ++*buf.epoch;                  // tag 0 is the "never written" state
+                p.epoch = e & 0x03FFFFFFu;
+                int rc = cpw == 2 ? dispatch_persistent<2>(p, nblk, lds_p(2), vpt_p, stream, prof)
+                                  : dispatch_persistent<1>(p, nblk, lds_p(1), vpt_p, stream, prof);
+                if (rc) return rc;
+            }
+            return DSRG_OK;
+        }
+    }
 
     FilterArgs a;
     a.Lg = Lg; a.Lb = Lb; a.q = buf.q; a.msg_g = buf.msg_g; a.msg_b = buf.msg_b;

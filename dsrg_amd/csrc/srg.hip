@@ -275,7 +275,7 @@ int launch_srg(int B, int C, int H, int W, const float *labels, const float *cue
     size_t mask_bytes = (size_t)2 * (C + 1) * H * sizeof(Mask128);
     if (W > 128 || H > 128 || lds + mask_bytes > 150 * 1024) mask_bytes = 0;
     lds += mask_bytes;
-    static size_t granted = 0;
+    static LdsGrant granted;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&srg_grow_kernel), lds, granted);
     if (rc) return rc;
     hipLaunchKernelGGL(srg_grow_kernel, dim3(B), dim3(kSrgWG), lds, stream, C, H, W, labels, cues, refined, th1,

@@ -27,6 +27,18 @@ except ImportError:                     # stand-alone (tests, PyTorch trainer): 
 min_prob = 0.0001                        # pylayers.py:20
 
 
+MAX_LABELS = 64                          # kMaxLabels of libdsrg_hip.so (per-pixel label loops live in registers)
+
+
+def _check_labels(n, who):
+    """The HIP kernels hold a pixel's label column in registers: at most 64 labels.  The 81-class blobs of
+    AnnotationLayerCOCO (pylayers.py:387-507; no seed_mc prototxt wires them into these layers) are rejected here, at
+    reshape time, with a message that says so — not deep inside a launch."""
+    if n > MAX_LABELS:
+        raise Exception("%s: %d label planes, but this build of libdsrg_hip.so supports at most %d "
+                        "(the 81-class COCO variant is not supported on the MI355X path)" % (who, n, MAX_LABELS))
+
+
 def _dev(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device="cuda", dtype=dtype)
 
@@ -39,6 +51,7 @@ class SoftmaxLayer(_Base):
             raise Exception("Need two inputs to compute distance.")
 
     def reshape(self, bottom, top):
+        _check_labels(bottom[0].data.shape[1], "SoftmaxLayer")
         top[0].reshape(*bottom[0].data.shape)
 
     def forward(self, bottom, top):
@@ -58,6 +71,7 @@ class CRFLayer(_Base):
             raise Exception("The layer needs two inputs!")
 
     def reshape(self, bottom, top):
+        _check_labels(bottom[0].data.shape[1], "CRFLayer")
         top[0].reshape(*bottom[0].data.shape)
 
     def forward(self, bottom, top):
@@ -168,6 +182,7 @@ class DSRGLayer(_Base):
         # the reference forks a multiprocessing.Pool here; the batch runs as one kernel launch instead
 
     def reshape(self, bottom, top):
+        _check_labels(bottom[1].data.shape[1], "DSRGLayer")
         top[0].reshape(*bottom[1].data.shape)
 
     def forward(self, bottom, top):

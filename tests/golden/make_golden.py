@@ -10,6 +10,8 @@ What is genuine reference code here:
   * pylayers.CRFLayer.forward/backward, DSRGLayer.forward (the Python glue:
     in-place clip, scipy zoom, transposes, float64 clip/renorm, log, Pool.map)
                                     -> layer_glue.npz
+  * pylayers.AnnotationLayer.setup/reshape/forward on a synthetic cue dictionary
+                                    -> annotation_cases.npz
 What is NOT reference code: importing pylayers.py needs its module-level imports
 to resolve, so `caffe`, `theano`, `cPickle`, `cv2` are injected as EMPTY stub
 modules (none of them is called by the functions exercised), and
@@ -283,7 +285,40 @@ def main():
         print("glue %s: clipped %d probs, seeds %d -> %d" % (
             tag, int((probs < 1e-4).sum()), int(cues.sum()), int(dtop.data.sum())))
     np.savez_compressed(os.path.join(HERE, "layer_glue.npz"), **glue)
-    for f in ("cc_cases.npz", "srg_cases.npz", "layer_glue.npz"):
+
+    # ---- AnnotationLayer (pylayers.py:346-387): the reference class itself on a synthetic cue dictionary ----------
+    # (the real localization_cues-sal.pickle is a Google-Drive download; cPickle.load / open are served by stand-ins that
+    # hand the dictionary over, everything else — setup, reshape, forward, the np.random flip — is the reference's code)
+    ann = {}
+    rng = np.random.default_rng(21)
+    ids = np.array([7, 12, 3, 40], dtype=np.float32)
+    data = {}
+    for i in ids.astype(int):
+        data['%i_labels' % i] = np.array(sorted(rng.choice(np.arange(1, 21), size=int(rng.integers(1, 4)), replace=False)))
+        k = int(rng.integers(20, 60))
+        data['%i_cues' % i] = np.stack([rng.integers(0, 21, k), rng.integers(0, 41, k), rng.integers(0, 41, k)])
+        ann['%i_labels' % i], ann['%i_cues' % i] = data['%i_labels' % i], data['%i_cues' % i]
+    images = rng.standard_normal((len(ids), 3, 9, 13)).astype(np.float32)
+    sys.modules["cPickle"].load = lambda f: data
+    P.open = lambda *a, **k: None
+    for mirror in (False, True):
+        lay = P.AnnotationLayer()
+        lay.param_str = "{'cues': 'synthetic.pickle', 'mirror': %s}" % mirror
+        bottoms = [Blob(ids.copy()), Blob(images.copy())]
+        tops = [Blob(np.zeros(0, np.float32)), Blob(np.zeros(0, np.float32)), Blob(np.zeros(0, np.float32))]
+        lay.setup(bottoms, tops)
+        lay.reshape(bottoms, tops)
+        np.random.seed(1234)
+        lay.forward(bottoms, tops)
+        tag = "mirror" if mirror else "plain"
+        ann[tag + "_labels"], ann[tag + "_cues"], ann[tag + "_images"] = (tops[0].data.astype(np.uint8), tops[1].data.astype(np.uint8),
+                                                                         tops[2].data.copy())
+    del P.open
+    ann["ids"], ann["images"], ann["seed"] = ids, images, np.array(1234)
+    assert not np.array_equal(ann["mirror_cues"], ann["plain_cues"])
+    np.savez_compressed(os.path.join(HERE, "annotation_cases.npz"), **ann)
+    print("annotation layer: %d images, %d cue pixels" % (len(ids), int(ann["plain_cues"].sum())))
+    for f in ("cc_cases.npz", "srg_cases.npz", "layer_glue.npz", "annotation_cases.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -114,6 +114,63 @@ def test_annotation_layer_cue_pickle_format(tmp_path):
                 assert np.array_equal(tops[1].data[n], cues) and np.array_equal(tops[2].data[n], imgs.data[n])
 
 
+def test_annotation_layer_vs_reference_fixture(tmp_path):
+    """tests/golden/annotation_cases.npz: the reference's own AnnotationLayer (pylayers.py:346-387: setup, reshape,
+    forward, np.random flip) run by tests/golden/make_golden.py on a synthetic cue dictionary; the drop-in class must
+    produce the same three tops from the same pickle, ids, images and seed — without and with mirroring"""
+    import pickle
+    import pylayers
+    g = np.load(os.path.join(ROOT, "tests", "golden", "annotation_cases.npz"))
+    ids = g["ids"]
+    data = {}
+    for i in ids.astype(int):
+        data['%i_labels' % i], data['%i_cues' % i] = g['%i_labels' % i], g['%i_cues' % i]
+    path = os.path.join(str(tmp_path), "cues.pickle")
+    pickle.dump(data, open(path, "wb"), protocol=2)
+
+    class Blob(object):
+        def __init__(self, a=None):
+            self.data = a if a is not None else np.zeros((0,), np.float32)
+
+        def reshape(self, *s):
+            self.data = np.zeros(s, np.float32)
+    for shape in ((len(ids),), (len(ids), 1, 1, 1)):                       # the id blob as Caffe may shape it
+        for tag, mirror in (("plain", False), ("mirror", True)):
+            lay = pylayers.AnnotationLayer()
+            lay.param_str = "{'cues': %r, 'mirror': %s}" % (path, mirror)
+            bottoms = [Blob(ids.copy().reshape(shape)), Blob(g["images"].copy())]
+            tops = [Blob(), Blob(), Blob()]
+            lay.setup(bottoms, tops)
+            lay.reshape(bottoms, tops)
+            np.random.seed(int(g["seed"]))
+            lay.forward(bottoms, tops)
+            assert np.array_equal(tops[0].data, g[tag + "_labels"].astype(np.float32))
+            assert np.array_equal(tops[1].data, g[tag + "_cues"].astype(np.float32))
+            assert np.array_equal(tops[2].data, g[tag + "_images"])
+    with pytest.raises(Exception):
+        pylayers.AnnotationLayer().setup([Blob()], [Blob()])               # "The layer needs two inputs!"
+
+
+def test_more_than_64_labels_is_rejected_at_reshape():
+    """the 81-class blobs of the COCO variant: a clear Exception from reshape(), not an error code from a launch"""
+    import pylayers
+
+    class Blob(object):
+        def __init__(self, shape):
+            self.data = np.zeros(shape, np.float32)
+
+        def reshape(self, *s):
+            self.data = np.zeros(s, np.float32)
+    for cls, bottoms in [(pylayers.SoftmaxLayer, [Blob((1, 81, 41, 41))]),
+                         (pylayers.CRFLayer, [Blob((1, 81, 41, 41)), Blob((1, 3, 321, 321))]),
+                         (pylayers.DSRGLayer, [Blob((1, 1, 1, 81)), Blob((1, 81, 41, 41)), Blob((1, 81, 41, 41)), Blob((1, 3, 321, 321))])]:
+        lay = cls()
+        lay.param_str = "{'th1': 0.99, 'th2': 0.85}"
+        lay.setup(bottoms, [Blob((1,))])
+        with pytest.raises(Exception, match="at most 64"):
+            lay.reshape(bottoms, [Blob((1,))])
+
+
 def test_annotation_layer_coco(tmp_path):
     """AnnotationLayerCOCO (pylayers.py:387-507): list of image/label pairs -> image-level labels (B,1,1,81), one-hot
     cue planes (B,81,h,w), resized mean-subtracted RGB image; epoch wrap with reshuffle.  Checked against the reference's

@@ -206,6 +206,41 @@ def test_crf_refine_batch_vs_oracle(ops, O):
         assert np.abs(bd - O.crf_layer_backward(refined.cpu().numpy(), b["cues"])).max() < 1e-6
 
 
+@pytest.mark.parametrize("B,C,HW,scale", [(16, 21, (41, 41), 12.0), (1, 21, (41, 41), 12.0), (20, 21, (41, 41), 12.0),
+                                          (3, 30, (33, 29), 12.0), (2, 21, (65, 65), 12.0), (2, 5, (24, 31), 1.0),
+                                          (30, 7, (20, 20), 3.0), (2, 40, (9, 9), 12.0), (1, 2, (1, 9), 12.0)])
+def test_one_launch_meanfield_equals_the_launch_per_iteration_loop(ops, O, B, C, HW, scale):
+    """the persistent kernel (granule hand-offs between the workgroups of an image) against the 21-launch loop it replaces:
+    same arithmetic in the same order => the marginals must be bit-identical; also more images than fit one launch
+    (B = 30 x 7 planes is chunked), a non-diagonal Gaussian lattice (scale 1 / 3), > 32 labels (one image then needs more than
+    the 32 CUs of an XCD: spread map), degenerate maps, and a 65x65 map (falls back to the launch loop)"""
+    import ctypes
+    from dsrg_amd import _lib
+    L = _lib.lib()
+    H, W = HW
+    rng = np.random.default_rng(B * 131 + C)
+    img = S.make_images(rng, B, size=max(H, W, 8), kind="noise" if B == 2 else "smooth")[:, :, :H, :W] + S.MEAN_PIXEL[None, :, None, None]
+    im_u8 = np.ascontiguousarray(np.transpose(img, (0, 2, 3, 1))).astype(np.uint8)
+    unary = np.maximum(O.softmax_forward(S.make_logits(rng, B, C, H, W)), 1e-4)
+    outs = []
+    try:
+        for mode in (0, 1, 1):
+            L.dsrg_debug_set_meanfield_mode(mode)
+            ctx = ops.Context(B, C, H, W)
+            q = ops.crf_meanfield(dev(unary), dev(im_u8, torch.uint8), 10, scale, ctx=ctx)
+            q1 = ops.crf_meanfield(dev(unary), dev(im_u8, torch.uint8), 3, scale, ctx=ctx)       # same context, new epoch
+            torch.cuda.synchronize()
+            assert L.dsrg_debug_meanfield_status(ctx._h) == 0
+            outs.append((q.cpu().numpy(), q1.cpu().numpy()))
+    finally:
+        L.dsrg_debug_set_meanfield_mode(-1)
+    for k in (0, 1):
+        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[1][k], outs[2][k])
+    want = np.stack([np.transpose(O.CRF(im_u8[b], np.ascontiguousarray(np.transpose(unary[b], (1, 2, 0))), scale_factor=scale), (2, 0, 1))
+                     for b in range(min(B, 2))])
+    assert np.abs(outs[1][0][:min(B, 2)] - want).max() < CRF_TOL
+
+
 def test_crf_is_deterministic(ops, O):
     b = S.make_batch(9, 3)
     probs = O.softmax_forward(b["logits"])
