@@ -220,32 +220,25 @@ def _conv_relu(cin, cout, dilation=1, gemm=False):
 
 class _HeadsFn(torch.autograd.Function):
     """The four fc8-SEC_k classifiers + Eltwise SUM on bf16 activations with fp32 weights, fp32 accumulation and an fp32
-    NCHW result (one HIP pass, ops.heads_forward).  Backward: the gradient that continues into the bf16 trunk and the
-    weight gradients are hipBLASLt GEMMs with fp32 accumulation on the bf16-rounded score gradient — what autocast does
-    for every other layer; the weight and bias gradients come out in fp32."""
+    NCHW result (one HIP pass on the f32-input MFMA, ops.heads_forward).  Backward (ops.heads_backward): the gradient that
+    continues into the bf16 trunk is accumulated in fp32 and rounded once; weight and bias gradients are fp32."""
 
     @staticmethod
     def forward(ctx, weight, bias, *xs):
         from .ops import heads_forward
         xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+        weight = weight.contiguous()
         ctx.save_for_backward(weight, *xs)
-        return heads_forward(xs, weight.contiguous(), bias.contiguous())
+        return heads_forward(xs, weight, bias.contiguous())
 
     @staticmethod
     def backward(ctx, g):
+        from .ops import heads_backward
         weight, *xs = ctx.saved_tensors
         n, O, K = weight.shape
-        B, _, H, W = g.shape
+        gxs, gw = heads_backward(xs, weight, g, need_gx=any(ctx.needs_input_grad[2:]))
         gb1 = g.sum((0, 2, 3))                                            # fp32, the same for every branch
-        g2 = g.permute(0, 2, 3, 1).reshape(-1, O).to(torch.bfloat16)      # (M, O)
-        w16 = weight.to(torch.bfloat16)
-        gxs, gws = [], []
-        for k, x in enumerate(xs):
-            gx = torch.empty((B, K, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
-            torch.mm(g2, w16[k], out=gx.permute(0, 2, 3, 1).view(-1, K))
-            gxs.append(gx)
-            gws.append(torch.mm(g2.t(), x.permute(0, 2, 3, 1).reshape(-1, K), out_dtype=torch.float32))
-        return (torch.stack(gws), gb1.unsqueeze(0).expand(n, O).contiguous()) + tuple(gxs)
+        return (gw, gb1.unsqueeze(0).expand(n, O).contiguous()) + (tuple(gxs) if gxs is not None else (None,) * n)
 
 
 class VGG16ASPP(nn.Module):
@@ -285,8 +278,8 @@ class VGG16ASPP(nn.Module):
                 h = m(h)
             hs.append(h)
         heads = [br[-1] for br in self.branches]
-        if hs[0].is_cuda and hs[0].dtype == torch.bfloat16 and len(hs) <= 4 and heads[0].out_channels <= 24 \
-                and heads[0].in_channels % 64 == 0:
+        if hs[0].is_cuda and hs[0].dtype == torch.bfloat16 and len(hs) <= 4 and heads[0].out_channels <= 32 \
+                and heads[0].in_channels % 256 == 0:
             w = torch.stack([m.weight.reshape(m.out_channels, m.in_channels) for m in heads])
             b = torch.stack([m.bias for m in heads])
             return _HeadsFn.apply(w.float(), b.float(), *hs)

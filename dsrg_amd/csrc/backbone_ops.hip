@@ -303,13 +303,17 @@ int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, 
 
 
 // ---------------------------------------------------------------------------------
-// fc8-SEC heads: out[b][o][hw] = sum over the NBR branches k of ( x_k[(b,hw)][:] . W[k][o][:] + bias[k][o] )
-// (the four 1x1 classifiers fc8-SEC_k and their Eltwise SUM, train-s.prototxt:461-744) with bf16 activations, FLOAT32
-// weights, float32 accumulation and a float32 NCHW result — the scores that feed Softmax + 1e-4, the CRF and the 0.85 / 0.99
-// region-growing thresholds never pass through bf16.  bf16 -> f32 is exact, so this equals the fp32 convolution of the
-// (bf16-valued) fc7 outputs.  A skinny GEMM (N = 21): VALU FMAs, x and W tiles through LDS, each thread one row x 3 outputs.
+// fc8-SEC heads: the four 1x1 classifiers fc8-SEC_k and their Eltwise SUM (train-s.prototxt:461-744) with bf16
+// activations, FLOAT32 weights, float32 accumulation and a float32 NCHW result — the scores that feed Softmax + 1e-4, the
+// CRF and the 0.85 / 0.99 region-growing thresholds never pass through bf16.  bf16 -> f32 is exact, so the forward equals
+// the fp32 convolution of the (bf16-valued) fc7 outputs.  Skinny GEMMs (21 outputs): forward and weight gradient on the
+// f32-input MFMA (v_mfma_f32_32x32x2_f32: exact f32 fma chains at the f32 vector rate, operands straight from global
+// memory, no LDS staging), the data gradient on the VALU (output-bandwidth-bound).
+//   MFMA 32x32x2 operand maps (cdna_hip_programming.md §3): A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31],
+//   C/D: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
 namespace {
-constexpr int kHeadRows = 32, kHeadKC = 64, kHeadOutPad = 24, kHeadThreads = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kHeadOutPad = 32;          // MFMA tile width; outputs beyond O are computed on clamped rows and never stored
 struct HeadArgs {
     const uint16_t *x[4];      // NBR activations, (M, K) bf16 row-major (NHWC)
     const float *w;            // (NBR, O, K)
@@ -317,73 +321,241 @@ struct HeadArgs {
     float *out;                // (B, O, HW)
     int nbr, M, K, O, HW;
 };
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 &v, float (&f)[8]) {
+    f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+    f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+}
 }  // namespace
 
-__global__ __launch_bounds__(kHeadThreads) void heads_fwd_kernel(HeadArgs a) {
-    __shared__ __attribute__((aligned(16))) uint16_t xs[kHeadRows][kHeadKC + 4];      // row stride 136 B: 32 rows hit 32 distinct bank pairs
-    __shared__ __attribute__((aligned(16))) float ws[kHeadOutPad][kHeadKC + 4];
-    const int t = threadIdx.x, row = t & 31, og = t >> 5;                            // lanes 0..31 = rows, og = 0..7 -> outputs 3*og..3*og+2
-    const int m0 = blockIdx.x * kHeadRows;
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < a.nbr; k++) {
-        const uint16_t *x = a.x[k];
-        const float *w = a.w + (size_t)k * a.O * a.K;
-        for (int c0 = 0; c0 < a.K; c0 += kHeadKC) {
-            {   // x tile: 32 rows x 64 bf16 = 256 x 16 B; W tile: 24 x 64 f32 = 384 x 16 B
-                const int r = t >> 3, q = t & 7;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (m0 + r < a.M) v = *reinterpret_cast<const uint4 *>(x + (size_t)(m0 + r) * a.K + c0 + q * 8);
-                *reinterpret_cast<uint2 *>(&xs[r][q * 8]) = make_uint2(v.x, v.y);
-                *reinterpret_cast<uint2 *>(&xs[r][q * 8 + 4]) = make_uint2(v.z, v.w);
-                for (int e = t; e < kHeadOutPad * (kHeadKC / 4); e += kHeadThreads) {
-                    const int o = e / (kHeadKC / 4), q4 = e % (kHeadKC / 4);
-                    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (o < a.O) wv = *reinterpret_cast<const float4 *>(w + (size_t)o * a.K + c0 + q4 * 4);
-                    *reinterpret_cast<float4 *>(&ws[o][q4 * 4]) = wv;
-                }
-            }
-            __syncthreads();
+// one workgroup = one 32-row tile; wave k = branch k (its whole K range), partial tiles summed through LDS in branch order
+// (the reference's Eltwise SUM order, each with its own bias).  Per 8 MFMAs a lane loads 16 B of x and 32 B of W.
+__global__ __launch_bounds__(256) void heads_fwd_kernel(HeadArgs a) {
+    __shared__ float part[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 32;
+    const int row = lane & 31, half = lane >> 5;
+    f32x16 acc;
 #pragma unroll
-            for (int kk = 0; kk < kHeadKC; kk += 4) {
-                const uint2 xv = *reinterpret_cast<const uint2 *>(&xs[row][kk]);
-                const float x0 = bf16_lo(xv.x), x1 = bf16_hi(xv.x), x2 = bf16_lo(xv.y), x3 = bf16_hi(xv.y);
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    if (wave < a.nbr) {
+        const int mr = min(m0 + row, a.M - 1);                      // clamped rows are never stored
+        const uint16_t *xp = a.x[wave] + (size_t)mr * a.K + half * 8;
+        const float *wp = a.w + ((size_t)wave * a.O + min(row, a.O - 1)) * a.K + half * 8;
+        // two 16-channel steps in flight ahead of the MFMAs that consume them (K % 256 == 0)
+        uint4 xv[2];
+        float4 wv[2][2];
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const float4 wv = *reinterpret_cast<const float4 *>(&ws[og * 3 + j][kk]);
-                    acc[j] = __builtin_fmaf(x0, wv.x, acc[j]);
-                    acc[j] = __builtin_fmaf(x1, wv.y, acc[j]);
-                    acc[j] = __builtin_fmaf(x2, wv.z, acc[j]);
-                    acc[j] = __builtin_fmaf(x3, wv.w, acc[j]);
+        for (int u = 0; u < 2; u++) {
+            xv[u] = *reinterpret_cast<const uint4 *>(xp + u * 16);
+            wv[u][0] = *reinterpret_cast<const float4 *>(wp + u * 16);
+            wv[u][1] = *reinterpret_cast<const float4 *>(wp + u * 16 + 4);
+        }
+        for (int kb = 0; kb < a.K; kb += 32) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                float xf[8];
+                bf16x8_to_f32(xv[u], xf);
+                const float wf[8] = {wv[u][0].x, wv[u][0].y, wv[u][0].z, wv[u][0].w, wv[u][1].x, wv[u][1].y, wv[u][1].z, wv[u][1].w};
+                const int kn = kb + 32 + u * 16;
+                if (kn < a.K) {
+                    xv[u] = *reinterpret_cast<const uint4 *>(xp + kn);
+                    wv[u][0] = *reinterpret_cast<const float4 *>(wp + kn);
+                    wv[u][1] = *reinterpret_cast<const float4 *>(wp + kn + 4);
                 }
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[j], wf[j], acc, 0, 0, 0);
             }
-            __syncthreads();
         }
     }
-    const int m = m0 + row;
-    if (m < a.M) {
-        const int b = m / a.HW, hw = m - b * a.HW;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int o = og * 3 + j;
-            if (o < a.O) {
-                float s = acc[j];
-                if (a.bias)
-                    for (int k = 0; k < a.nbr; k++) s += a.bias[k * a.O + o];
-                a.out[((size_t)b * a.O + o) * a.HW + hw] = s;
+    for (int r = 0; r < 16; r++) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    // thread t: output column t / 8, rows 4 (t % 8) .. + 3 of the tile
+    const int col = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
+    if (col < a.O) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int rr = r4 + q, m = m0 + rr;
+            if (m >= a.M) break;
+            const int hf = (rr >> 2) & 1, reg = (rr & 3) + 4 * (rr >> 3), ln = col + 32 * hf;
+            float s = 0.0f;
+            for (int k = 0; k < a.nbr; k++) {
+                const float sk = part[k][reg][ln] + (a.bias ? a.bias[k * a.O + col] : 0.0f);
+                s = k == 0 ? sk : s + sk;
             }
+            const int b = m / a.HW, hw = m - b * a.HW;
+            a.out[((size_t)b * a.O + col) * a.HW + hw] = s;
         }
     }
 }
 
+// data gradient: gx_k[m][c] = sum_o g[m][o] W_k[o][c] -> bf16 (M, K) row-major.  One workgroup = 16 rows of one branch,
+// thread = 8 channels x 8 rows; g tile through LDS (broadcast reads), W rows straight from L2.
+__global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float *__restrict__ g, const float *__restrict__ w,
+                                                           uint4 *__restrict__ gx, int M, int K, int O, int HW, size_t branch_stride) {
+    __shared__ __attribute__((aligned(16))) float gs[32][16];        // [o][row]
+    const int k = blockIdx.y, m0 = blockIdx.x * 16, t = threadIdx.x;
+    for (int e = t; e < 32 * 16; e += 256) {
+        const int o = e >> 4, r = e & 15, m = m0 + r;
+        float v = 0.0f;
+        if (o < O && m < M) { const int b = m / HW, hw = m - b * HW; v = g[((size_t)b * O + o) * HW + hw]; }
+        gs[o][r] = v;
+    }
+    __syncthreads();
+    const int K8 = K / 8;
+    for (int cg = t & 127; cg < K8; cg += 128) {
+        const int rh = t >> 7;                                       // rows 8 rh .. 8 rh + 7
+        float acc[8][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc[r][c] = 0.0f;
+        const float *wk = w + (size_t)k * O * K + (size_t)cg * 8;
+#pragma unroll 7
+        for (int o = 0; o < O; o++) {
+            const float4 w0 = *reinterpret_cast<const float4 *>(wk + (size_t)o * K), w1 = *reinterpret_cast<const float4 *>(wk + (size_t)o * K + 4);
+            const float4 g0 = *reinterpret_cast<const float4 *>(&gs[o][rh * 8]), g1 = *reinterpret_cast<const float4 *>(&gs[o][rh * 8 + 4]);
+            const float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const float gf[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[r][c] = __builtin_fmaf(gf[r], wf[c], acc[r][c]);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(gx) + (size_t)k * branch_stride);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int m = m0 + rh * 8 + r;
+            if (m < M)
+                dst[(size_t)m * K8 + cg] = make_uint4(pack_bf16(acc[r][0], acc[r][1]), pack_bf16(acc[r][2], acc[r][3]),
+                                                      pack_bf16(acc[r][4], acc[r][5]), pack_bf16(acc[r][6], acc[r][7]));
+        }
+    }
+}
+
+// weight gradient, stage 1: partial[rc][k][o][c] = sum over the rows of chunk rc of g[m][o] x_k[m][c].  One workgroup = one
+// (branch, row chunk); wave q = channels [256 q, 256 q + 256): 8 MFMA tiles, tile t holding channels c0 + 8 j + t so that a lane's
+// 16-byte load of x feeds all eight.  g^T chunk through LDS.
+constexpr int kDwRows = 64;           // rows staged per LDS refill
+__global__ __launch_bounds__(256) void heads_bwd_dw_kernel(HeadArgs a, const float *__restrict__ g, float *__restrict__ partial,
+                                                           int rows_per_chunk) {
+    __shared__ float gs[kDwRows][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.y, rc = blockIdx.x;
+    const int mbeg = rc * rows_per_chunk, mend = min(a.M, mbeg + rows_per_chunk);
+    const int j = lane & 31, half = lane >> 5;
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    const int nq = a.K / 256;                                       // channel quarters handled by the waves in turn
+    for (int q0 = 0; q0 < nq; q0 += 4) {                            // workgroup-uniform trip count (barriers inside)
+        const int q = q0 + wave;
+        const bool live = q < nq;
+        const uint16_t *xq = a.x[k] + (size_t)(live ? q : 0) * 256 + j * 8;
+        for (int mb = mbeg; mb < mend; mb += kDwRows) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < kDwRows * 32; e += 256) {
+                const int o = e / kDwRows, r = e % kDwRows, m = mb + r;      // lanes along the rows: g is (B, O, HW), hw fastest
+                float v = 0.0f;
+                if (o < a.O && m < mend) { const int b = m / a.HW, hw = m - b * a.HW; v = g[((size_t)b * a.O + o) * a.HW + hw]; }
+                gs[r][o] = v;
+            }
+            __syncthreads();
+            // the 16-byte loads of 8 row pairs are in flight ahead of the 64 MFMAs that consume them; rows past the chunk
+            // read row mend - 1 (in range) and meet a zero in gs
+            if (live) {
+                constexpr int G = 8;
+                uint4 xv[G];
+                auto fetch = [&](int r2base) {
+#pragma unroll
+                    for (int u = 0; u < G; u++) {
+                        const int m = min(mb + r2base + 2 * u + half, mend - 1);
+                        xv[u] = *reinterpret_cast<const uint4 *>(xq + (size_t)m * a.K);
+                    }
+                };
+                fetch(0);
+                for (int r2 = 0; r2 < kDwRows; r2 += 2 * G) {
+                    float xf[G][8], gv[G];
+#pragma unroll
+                    for (int u = 0; u < G; u++) {
+                        bf16x8_to_f32(xv[u], xf[u]);
+                        gv[u] = gs[r2 + 2 * u + half][j];
+                    }
+                    if (r2 + 2 * G < kDwRows) fetch(r2 + 2 * G);
+#pragma unroll
+                    for (int u = 0; u < G; u++)
+#pragma unroll
+                        for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[u], xf[u][t], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // tile t, reg r, lane: o = (r & 3) + 8 (r >> 2) + 4 half, channel = 256 q + 8 j + t  -> 32 contiguous bytes per (lane, r)
+        float *pp = partial + (((size_t)rc * a.nbr + k) * a.O) * a.K + (size_t)(live ? q : 0) * 256 + j * 8;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (live && o < a.O) {
+                *reinterpret_cast<float4 *>(pp + (size_t)o * a.K) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                *reinterpret_cast<float4 *>(pp + (size_t)o * a.K + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    }
+}
+// stage 2: fixed-order sum over the row chunks
+__global__ void heads_bwd_dw_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, int nchunks, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int c = 0; c < nchunks; c++) s += partial[(size_t)c * n + i];
+    gw[i] = s;
+}
+
+static int heads_check(int nbr, int K, int O) {
+    if (nbr < 1 || nbr > 4 || O < 1 || O > kHeadOutPad || K < 256 || K % 256 != 0)
+        return set_error(DSRG_ERR_UNSUPPORTED, "heads: 1..4 branches, <= %d outputs, K a multiple of 256", kHeadOutPad);
+    return DSRG_OK;
+}
+
 int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float *bias, float *out, int B, int HW, int K, int O,
                      hipStream_t stream) {
-    if (nbr < 1 || nbr > 4 || O < 1 || O > kHeadOutPad || K < kHeadKC || K % kHeadKC != 0)
-        return set_error(DSRG_ERR_UNSUPPORTED, "heads: 1..4 branches, <= %d outputs, K a multiple of %d", kHeadOutPad, kHeadKC);
+    int rc = heads_check(nbr, K, O);
+    if (rc) return rc;
     HeadArgs a;
     for (int k = 0; k < 4; k++) a.x[k] = static_cast<const uint16_t *>(x[k < nbr ? k : 0]);
     a.w = w; a.bias = bias; a.out = out; a.nbr = nbr; a.M = B * HW; a.K = K; a.O = O; a.HW = HW;
-    hipLaunchKernelGGL(heads_fwd_kernel, dim3((a.M + kHeadRows - 1) / kHeadRows), dim3(kHeadThreads), 0, stream, a);
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
     DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+int heads_bwd_chunks(int M) { int c = (M + 511) / 512; return c < 1 ? 1 : (c > 64 ? 64 : c); }
+
+int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
+                     float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream) {
+    int rc = heads_check(nbr, K, O);
+    if (rc) return rc;
+    const int M = B * HW;
+    if (gx) {
+        hipLaunchKernelGGL(heads_bwd_dx_kernel, dim3((M + 15) / 16, nbr), dim3(256), 0, stream, g, w, static_cast<uint4 *>(gx), M, K, O,
+                           HW, gx_branch_stride);
+        DSRG_LAUNCH_CHECK();
+    }
+    if (gw) {
+        HeadArgs a;
+        for (int k = 0; k < 4; k++) a.x[k] = static_cast<const uint16_t *>(x[k < nbr ? k : 0]);
+        a.w = w; a.bias = nullptr; a.out = nullptr; a.nbr = nbr; a.M = M; a.K = K; a.O = O; a.HW = HW;
+        const int nch = heads_bwd_chunks(M), rows = ((M + nch - 1) / nch + 1) & ~1;
+        hipLaunchKernelGGL(heads_bwd_dw_kernel, dim3(nch, nbr), dim3(256), 0, stream, a, g, partial, rows);
+        DSRG_LAUNCH_CHECK();
+        const size_t n = (size_t)nbr * O * K;
+        hipLaunchKernelGGL(heads_bwd_dw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, gw, nch, n);
+        DSRG_LAUNCH_CHECK();
+    }
     return DSRG_OK;
 }
 

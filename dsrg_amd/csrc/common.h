@@ -139,6 +139,9 @@ int launch_avgpool3x3_s1(const void *in, void *out, int B, int H, int W, int C, 
 int launch_bias_grad(const void *g, float *bias_grad, float *part, int part_blocks, long rows, int C, hipStream_t stream);
 int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float *bias, float *out, int B, int HW, int K, int O,
                      hipStream_t stream);
+int heads_bwd_chunks(int M);
+int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
+                     float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream);
 int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,
                           hipStream_t stream);
 int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, int H, int W, int OH, int OW, int C,

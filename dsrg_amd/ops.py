@@ -371,6 +371,27 @@ def heads_forward(xs, weight, bias):
     return out
 
 
+def heads_backward(xs, weight, g, need_gx=True):
+    """backward of heads_forward from the float32 score gradient g (B,O,H,W): -> (list of gx_k (B,K,H,W) bf16 channels_last or
+    None, gw (n,O,K) float32)"""
+    B, K, H, W = xs[0].shape
+    n, O = weight.shape[0], weight.shape[1]
+    cl = torch.channels_last
+    xs = [x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl) for x in xs]
+    _f32c(weight, "weight")
+    g = g.contiguous()
+    _f32c(g, "g")
+    L = _lib.lib()
+    M = B * H * W
+    gx = torch.empty((n, B, H, W, K), dtype=torch.bfloat16, device=g.device) if need_gx else None
+    gw = torch.empty((n, O, K), dtype=torch.float32, device=g.device)
+    part = torch.empty(L.dsrg_heads_backward_chunks(M) * n * O * K, dtype=torch.float32, device=g.device)
+    ptrs = (ctypes.c_void_p * 4)(*([x.data_ptr() for x in xs] + [None] * (4 - n)))
+    check(L.dsrg_heads_backward_bf16(ptrs, n, _ptr(weight), _ptr(g), _ptr(gx), M * K * 2, _ptr(gw), _ptr(part), B, H * W, K, O,
+                                     _stream()))
+    return ([gx[k].permute(0, 3, 1, 2) for k in range(n)] if need_gx else None), gw
+
+
 def maxpool3x3_out_size(n, stride, ceil_mode):
     """output extent of a 3x3 / pad 1 pooling window walk over n pixels (Caffe's ceil rule, torch's with ceil_mode)"""
     num = n + 2 - 3

@@ -220,9 +220,18 @@ int dsrg_avgpool3x3_s1_bf16(const void *in_dev, void *out_dev, int B, int H, int
 /* The four fc8-SEC_k 1x1 classifiers and their Eltwise SUM (train-s.prototxt:461-744) in one pass with float32 weights,
  * float32 accumulation and a float32 NCHW result: out[b][o][hw] = sum_k ( x_k[(b,hw)][:] . w[k][o][:] + bias[k][o] ).
  * x_dev: host array of n_branches (<= 4) device pointers to (B*HW, K) bf16 row-major (NHWC) activations; w_dev
- * (n_branches, O, K) f32; bias_dev (n_branches, O) f32 or NULL; out_dev (B, O, HW) f32.  O <= 24, K % 64 == 0. */
+ * (n_branches, O, K) f32; bias_dev (n_branches, O) f32 or NULL; out_dev (B, O, HW) f32.  O <= 32, K % 256 == 0. */
 int dsrg_heads_forward_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *bias_dev,
                             float *out_dev, int B, int HW, int K, int O, void *stream);
+/* Its backward from the float32 score gradient g_dev (B, O, HW):
+ *   gx_dev (may be NULL): n_branches matrices (B*HW, K) bf16 row-major, branch k at byte offset k * gx_branch_stride_bytes:
+ *                         gx_k[m][c] = sum_o g[m][o] w[k][o][c]                       (float32 accumulation)
+ *   gw_dev (may be NULL): (n_branches, O, K) f32: gw[k][o][c] = sum_m g[m][o] x_k[m][c] (exact f32 fma chains, fixed order);
+ *                         partial_dev: scratch of dsrg_heads_backward_chunks(B*HW) * n_branches * O * K floats. */
+int dsrg_heads_backward_chunks(int M);
+int dsrg_heads_backward_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *g_dev,
+                             void *gx_dev, size_t gx_branch_stride_bytes, float *gw_dev, float *partial_dev, int B,
+                             int HW, int K, int O, void *stream);
 /* 3x3 max pooling, pad 1, stride 1 or 2, NHWC bf16 (the Pooling layers of train-s.prototxt:69-80 etc.; OH/OW chosen by
  * the caller, ceil mode included).  code_dev: B*OH*OW*C bytes, the window position (3*dy+dx) of the first maximum. */
 int dsrg_maxpool3x3_fwd_bf16(const void *in_dev, void *out_dev, void *code_dev, int B, int H, int W, int OH, int OW, int C,

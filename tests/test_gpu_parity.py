@@ -597,7 +597,8 @@ def test_fp32_heads_kernel_matches_fp32_convolutions(ops):
     import torch.nn.functional as F
     from dsrg_amd.backbone import _HeadsFn
     torch.manual_seed(7)
-    for B, K, H, W, O, n in [(2, 1024, 41, 41, 21, 4), (1, 128, 5, 7, 24, 2), (3, 64, 9, 9, 3, 1)]:
+    for B, K, H, W, O, n in [(2, 1024, 41, 41, 21, 4), (1, 256, 5, 7, 32, 2), (3, 512, 9, 9, 3, 1), (16, 1024, 41, 41, 21, 4),
+                             (1, 2048, 3, 3, 21, 3)]:
         xs = [torch.randn(B, K, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(n)]
         w = (torch.randn(n, O, K, device="cuda") * 0.05).requires_grad_(True)
         b = torch.randn(n, O, device="cuda").requires_grad_(True)
@@ -614,9 +615,10 @@ def test_fp32_heads_kernel_matches_fp32_convolutions(ops):
         xr = [x.float().requires_grad_(True) for x in xs]
         want2 = sum(F.conv2d(x, w[k].reshape(O, K, 1, 1), b[k]) for k, x in enumerate(xr))
         want2.backward(g)
-        assert (wa.grad - w.grad).norm() <= 0.01 * w.grad.norm() and (ba.grad - b.grad).norm() <= 1e-4 * b.grad.norm()
+        assert (wa.grad - w.grad).abs().max() <= 1e-4 * w.grad.abs().max()             # fp32 fma chains both sides
+        assert (ba.grad - b.grad).norm() <= 1e-4 * b.grad.norm()
         for u, v in zip(xa, xr):
-            assert u.grad.dtype == torch.bfloat16 and (u.grad.float() - v.grad).norm() <= 0.01 * v.grad.norm()
+            assert u.grad.dtype == torch.bfloat16 and (u.grad.float() - v.grad).norm() <= 0.005 * v.grad.norm()   # one bf16 rounding
 
 
 def test_fused_relu_dropout_backward_matches_unfused_sequence():
