@@ -80,7 +80,7 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     const size_t szRef = align256(sizeof(double) * (size_t)max_batch * C * N);
     const size_t szStats = align256(sizeof(double) * (size_t)max_batch * 5 * 8);   // [B][kStatSplit][5]
     const size_t szGran = align256(sizeof(unsigned long long) * (size_t)max_batch * C * N);
-    const size_t total = szLg + szLb + 3 * blob /*mf*/ + szIm + 3 * blob /*probs,logq,seeds*/ + szRef + szStats + 2 * szGran;
+    const size_t total = szLg + szLb + 3 * blob /*mf*/ + szIm + 3 * blob /*probs,logq,seeds*/ + szRef + szStats + 2 * szGran + 256;
     hipError_t e = hipMalloc(&c->arena, total);
     if (e != hipSuccess) {
         delete c;
@@ -108,11 +108,12 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     c->stats = reinterpret_cast<double *>(p); p += szStats;
     c->mf.qg = reinterpret_cast<unsigned long long *>(p); p += szGran;
     c->mf.vg = reinterpret_cast<unsigned long long *>(p); p += szGran;
+    c->mf.work_counter = reinterpret_cast<unsigned int *>(p); p += 256;
     c->mf.status_host = c->mf_status;
     c->mf.epoch = &c->mf_epoch;
     void *sdev = nullptr;
     e = hipHostGetDevicePointer(&sdev, c->mf_status, 0);
-    if (e == hipSuccess) e = hipMemset(c->mf.qg, 0, 2 * szGran);          // tag 0 = never written
+    if (e == hipSuccess) e = hipMemset(c->mf.qg, 0, 2 * szGran + 256);    // tag 0 = never written; unit counter 0
     if (e != hipSuccess) {
         (void)hipHostFree(c->mf_status);
         (void)hipFree(c->arena);
@@ -330,8 +331,8 @@ extern "C" int dsrg_ctx_lattice_dump(dsrg_ctx_t c, int kind, int b, int32_t *m_h
                 for (int v = 0; v < M; v++) {
                     const uint32_t w = t[(size_t)j * Mcap + v];
                     const int a = (int)(w & 0xFFFFu), z = (int)(w >> 16);
-                    if (n1_host) n1_host[(size_t)j * M + v] = a == Mcap ? -1 : a;
-                    if (n2_host) n2_host[(size_t)j * M + v] = z == Mcap ? -1 : z;
+                    if (n1_host) n1_host[(size_t)j * M + v] = a == M ? -1 : a;      // slot M = the zero sentinel = none
+                    if (n2_host) n2_host[(size_t)j * M + v] = z == M ? -1 : z;
                 }
         delete[] t;
         DSRG_HIP_CHECK(e);

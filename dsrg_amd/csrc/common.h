@@ -50,14 +50,16 @@ constexpr float kMinProb = 0.0001f;
 struct LatticeView {
     int d;                 // feature dimension (2 Gaussian, 5 bilateral)
     int N;                 // pixels
-    int Mcap;              // capacity = ((N+3)/4*4)*(d+1); index Mcap is the zero sentinel
+    int Mcap;              // capacity = ((N+3)/4*4)*(d+1); value slot M (<= Mcap) is the zero sentinel
     int nlat;              // number of lattices in this set (1 for the shared Gaussian, B for bilateral)
     // per lattice, strided by the quantities in brackets
     int *M;                // [1]        vertex count
-    int *flags;            // [1]        bit 0: lattice is diagonal (every vertex has one contributor, no blur neighbour)
+    int *flags;            // [1]        bit 0: lattice is diagonal (every vertex has one contributor, no blur neighbour);
+                           //            bit 2: every vertex has exactly one contributor (M == E)
     uint16_t *vid;         // [(d+1)*N]  vertex id of simplex corner r of pixel i   (r-major)
     float *bary;           // [(d+1)*N]  barycentric weight                         (r-major)
-    uint32_t *nb;          // [(d+1)*Mcap] blur neighbours along axis j: n1 | n2<<16 (Mcap = none)
+    uint32_t *nb;          // [(d+1)*Mcap] blur neighbours along axis j: n1 | n2<<16; M (the zero sentinel slot) = none, and
+                           //               so is every word of the unused tail v >= M
     uint32_t *row_start;   // [Mcap+1]   CSR of the splat: entries of vertex v
     uint16_t *csr_pix;     // [(d+1)*N]  source pixel of each entry, entry order = reference splat order
     float *csr_w;          // [(d+1)*N]  weight of each entry
@@ -97,6 +99,7 @@ struct MeanfieldBufs {
     unsigned int *status;          // host-mapped word (device address), set by the kernel if a hand-off timed out
     unsigned int *status_host;     // the same word, host address
     unsigned int *epoch;           // host counter, advanced once per launch (tag = epoch << 6 | iteration)
+    unsigned int *work_counter;    // device word: dynamic unit queue of mf_filter_kernel (reset by every mf_update_kernel launch)
 };
 // optional per-launch timing of the filter kernel with HIP events on the launch stream
 struct Profiler {

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
                     neighbour_key<D>(q, w, j, half != 0);
                     hq[j] = hash_key<KW>(q) & mask;
                     qc[j] = CompactKey<D>::make(q);
-                    found[j] = (uint32_t)Mcap;
+                    found[j] = (uint32_t)M;                      // "no neighbour" = the zero sentinel slot M
                 }
                 uint32_t pend = (1u << D1) - 1u;
                 if (fast_keys) {
@@ -268,17 +268,24 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
 #pragma unroll
                 for (int j = 0; j < D1; j++) {
                     word[j] |= found[j] << (half * 16);
-                    has_nb |= found[j] != (uint32_t)Mcap;
+                    has_nb |= found[j] != (uint32_t)M;
                 }
             }
 #pragma unroll
             for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = word[j];
         }
+        // the unused tail of every axis points at the sentinel too, so that consumers need no v < M test on the words
+        for (int v = M + tid; v < Mcap; v += kWG) {
+#pragma unroll
+            for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = (uint32_t)M | ((uint32_t)M << 16);
+        }
         {   // diagonal lattice: every entry owns its vertex and no vertex has a blur neighbour
             const int any_nb = __syncthreads_or(has_nb);
             const int any_bad = __syncthreads_or(key_range_bad);
             // bit 0: diagonal; bit 1: a key coordinate left the range the packed neighbour arithmetic covers
-            if (tid == 0) L.flags[b] = ((!any_nb && M == E) ? 1 : 0) | (any_bad ? 2 : 0);
+            // bit 0: diagonal; bit 1: a key coordinate left the range the packed neighbour arithmetic covers;
+            // bit 2: every vertex has exactly one contributor (M == E: entry e IS vertex e's only splat term)
+            if (tid == 0) L.flags[b] = ((!any_nb && M == E) ? 1 : 0) | (any_bad ? 2 : 0);      // bit 2 is added in phase 7
         }
     }
     DSRG_STAMP(4);
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     // ---- phase 7: norm = 1/sqrt(K 1 + 1e-20)  (pairwise.cpp:44,54-57), one channel through
         // Permutohedral::seqCompute (permutohedral.cpp:476-527): blur evaluated in double
         float *val = reinterpret_cast<float *>(smem);                             // [Mcap+1], aliases cnt
+        int multi_rows = 0;
         {
             float s0[VPT];
 #pragma unroll
@@ -355,6 +363,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
                 if (v < M) {
                     const uint32_t a0 = v == 0 ? 0u : cnt[v - 1], z0 = cnt[v];    // cnt[v] = END of row v
                     for (uint32_t pos = a0; pos < z0; pos++) s = s + wl[pos] * 1.0f;
+                    multi_rows |= (z0 - a0 != 1u);
                 }
                 s0[k] = s;
             }
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
                 const int v = tid + k * kWG;
                 if (v < M) val[v] = s0[k];
             }
-            if (tid == 0) val[Mcap] = 0.0f;
+            if (tid == 0) val[M] = 0.0f;                                          // zero sentinel = "no neighbour"
         }
         __syncthreads();
         DSRG_STAMP(8);
@@ -380,9 +389,9 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
                 for (int k = 0; k < VPT; k++) {
                     const int v = tid + k * kWG;
                     const bool ok = v < M;
-                    const int n1 = ok ? (int)(word[k] & 0xffffu) : Mcap, n2 = ok ? (int)(word[k] >> 16) : Mcap;
+                    const int n1 = ok ? (int)(word[k] & 0xffffu) : M, n2 = ok ? (int)(word[k] >> 16) : M;
                     const float s = val[n1] + val[n2];
-                    nv[k] = (float)((double)val[ok ? v : Mcap] + 0.5 * (double)s);
+                    nv[k] = (float)((double)val[ok ? v : M] + 0.5 * (double)s);
                 }
                 __syncthreads();
 #pragma unroll
@@ -405,6 +414,8 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
             }
             norm[i] = (float)(1.0 / sqrt((double)out + 1e-20));
         }
+        const int any_multi = __syncthreads_or(multi_rows);
+        if (tid == 0 && M == E && !any_multi) L.flags[b] |= 4;                    // every vertex has exactly one contributor
     }
     DSRG_STAMP(10);
 #undef DSRG_STAMP
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int c
                 neighbour_key<D>(q, w, j, half != 0);
                 hq[j] = hash_key<KW>(q) & mask;
                 qc[j] = CompactKey<D>::make(q);
-                found[j] = (uint32_t)Mcap;
+                found[j] = (uint32_t)M;                          // "no neighbour" = the zero sentinel slot M
             }
             uint32_t pend = (1u << D1) - 1u;
             if (fast_keys) {
@@ -506,6 +517,12 @@ __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int c
 #pragma unroll
         for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = word[j];
     }
+    // the unused tail of every axis points at the sentinel too (consumers need no v < M test on the words)
+    const int tail = Mcap - M, tchunk = (tail + kNeighSplit - 1) / kNeighSplit;
+    for (int v = M + part * tchunk + tid; v < min(Mcap, M + (part + 1) * tchunk); v += kWG) {
+#pragma unroll
+        for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = (uint32_t)M | ((uint32_t)M << 16);
+    }
 }
 
 // Split build, stage 3: norm = 1/sqrt(K 1 + 1e-20) (pairwise.cpp:44,54-57) through
@@ -528,6 +545,7 @@ __global__ __launch_bounds__(kWG) void lattice_norm_kernel(LatticeView L) {
         rs0[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
         rs1[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u) + 4u);
     }
+    int multi = 0;                                                               // some vertex has several contributors
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const int v = tid + k * kWG;
@@ -535,9 +553,10 @@ __global__ __launch_bounds__(kWG) void lattice_norm_kernel(LatticeView L) {
             float s = 0.0f;
             for (uint32_t pos = rs0[k]; pos < rs1[k]; pos++) s = s + ld_f32(r_cw, pos * 4u) * 1.0f;
             val[v] = s;
+            multi |= (rs1[k] - rs0[k] != 1u);
         }
     }
-    if (tid == 0) val[Mcap] = 0.0f;
+    if (tid == 0) val[M] = 0.0f;                                                 // zero sentinel = "no neighbour"
     __syncthreads();
     int has_nb = 0;
     for (int j = 0; j <= D; j++) {
@@ -550,10 +569,10 @@ __global__ __launch_bounds__(kWG) void lattice_norm_kernel(LatticeView L) {
         for (int k = 0; k < VPT; k++) {
             const int v = tid + k * kWG;
             const bool ok = v < M;
-            const int n1 = ok ? (int)(word[k] & 0xffffu) : Mcap, n2 = ok ? (int)(word[k] >> 16) : Mcap;
-            has_nb |= (n1 != Mcap) | (n2 != Mcap);
+            const int n1 = ok ? (int)(word[k] & 0xffffu) : M, n2 = ok ? (int)(word[k] >> 16) : M;
+            has_nb |= (n1 != M) | (n2 != M);
             const float s = val[n1] + val[n2];
-            nv[k] = (float)((double)val[ok ? v : Mcap] + 0.5 * (double)s);
+            nv[k] = (float)((double)val[ok ? v : M] + 0.5 * (double)s);
         }
         __syncthreads();
 #pragma unroll
@@ -576,7 +595,9 @@ __global__ __launch_bounds__(kWG) void lattice_norm_kernel(LatticeView L) {
         norm[i] = (float)(1.0 / sqrt((double)out + 1e-20));
     }
     const int any_nb = __syncthreads_or(has_nb);
-    if (tid == 0) L.flags[b] = (L.flags[b] & ~1) | ((!any_nb && M == E) ? 1 : 0);
+    const int any_multi = __syncthreads_or(multi);
+    // bit 2: every vertex has exactly one contributor and vice versa (row v of the splat list is entry v)
+    if (tid == 0) L.flags[b] = (L.flags[b] & ~5) | ((!any_nb && M == E) ? 1 : 0) | ((M == E && !any_multi) ? 4 : 0);
 }
 
 // ---------------------------------------------------------------------------------

@@ -31,10 +31,12 @@ struct FilterArgs {
     int nblk_xcd;            // the first groups_b * lat_stride blocks: index = group * lat_stride + image
     int lat_stride;          // a multiple of 8, so that the blocks of one image share blockIdx % 8 (one XCD and its L2)
     int groups_b;            // ceil(C / CPW_B)
-    int gau_stride;          // Gaussian blocks per plane group: ceil(B / ipb)
-    int ipb;                 // images per Gaussian block
+    int groups_g;            // ceil(C / CPW_G)
+    int nunits;              // nblk_b bilateral units (incl. the padding of the XCD map) + groups_g * B Gaussian units
+    unsigned int *counter;   // dynamic unit counter (zero at launch: the preceding update kernel resets it)
     int lds_val_stride;      // bilateral: vertices in the LDS value array (Mcap_b + 1, padded to 4)
     int lds_val_stride_g;    // Gaussian:  (Mcap_g + 1, padded to 4)
+    int lds_bytes;           // dynamic LDS of the launch: value buffer(s) from the start, input planes [N] at the end
     unsigned long long *dbg; // optional per-workgroup phase timestamps (100 MHz wall clock), 2 x 16 per block
 };
 
@@ -72,18 +74,42 @@ __device__ __forceinline__ void pv_set(float4 &v, int c, float x) {
 // kernel waits for the marginals there (and fills io), so the index round trip and the hand-off wait overlap.  M_pre /
 // flags_pre: the lattice size and flags when the caller already holds them (REG_IO; saves a dependent load per call).
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
+// the index words of one thread (splat entries, CSR rows, blur neighbours, slice corners, norm).  A caller that filters
+// several plane groups through the SAME lattice (the Gaussian lattice is shared by all images) passes one of these and
+// `reuse` = true from the second call on: nothing is fetched again (only possible when all D+1 axes fit the ring, D = 2).
+template <int VPT, int PPT, int D> struct FilterIdx {
+    static constexpr bool DEEP = VPT <= 10;
+    static constexpr int KC = DEEP ? VPT : 8, RING = 3, D1 = D + 1;
+    static constexpr bool kReusable = DEEP && D1 <= RING;
+    float nrm[PPT];
+    uint32_t epx[KC];
+    float ew[KC];
+    uint32_t rs0[KC], rs1[KC];
+    uint32_t nbw[DEEP ? RING : 1][KC];
+    uint32_t sv[PPT][D1];
+    float sw[PPT][D1];
+};
 template <int CPW, int VPT, int PPT, int D, bool REG_IO = false, typename Mid = NoMid>
 __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, const float *__restrict__ qb,
                                                float *__restrict__ out, int nc, int N,
                                                typename PlaneVec<CPW>::type *val,
                                                typename PlaneVec<CPW>::type *inq, unsigned long long *dbg,
-                                               float (*io)[CPW] = nullptr, int tid_in = 0, int M_pre = 0, int flags_pre = 0,
-                                               Mid mid = Mid()) {
+                                               float (*io)[CPW], int tid_in, int M_pre, int flags_pre,
+                                               Mid mid, int lds_elems, FilterIdx<VPT, PPT, D> &ix, bool reuse = false) {
     using vec_t = typename PlaneVec<CPW>::type;
     constexpr int D1 = D + 1;
     constexpr bool DEEP = VPT <= 10;             // all index words of a thread fit the register file
     constexpr int KC = DEEP ? VPT : 8;           // vertices per chunk of index loads otherwise
     constexpr int NCH = (VPT + KC - 1) / KC;
+    if (!FilterIdx<VPT, PPT, D>::kReusable) reuse = false;
+    float (&nrm)[PPT] = ix.nrm;
+    uint32_t (&epx)[KC] = ix.epx;
+    float (&ew)[KC] = ix.ew;
+    uint32_t (&rs0)[KC] = ix.rs0;
+    uint32_t (&rs1)[KC] = ix.rs1;
+    uint32_t (&nbw)[DEEP ? 3 : 1][KC] = ix.nbw;
+    uint32_t (&sv)[PPT][D1] = ix.sv;
+    float (&sw)[PPT][D1] = ix.sw;
     // inside the persistent kernel's iteration loop the thread index arrives laundered (tid_in): everything derived from
     // it is then recomputed per iteration instead of being hoisted out of the loop and held in registers across it
     const int tid = REG_IO ? tid_in : (int)threadIdx.x;
@@ -154,36 +180,46 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
     }
 
     // ---- stage A: everything that does not depend on anything, in one burst
-    float qv[PPT][CPW], nrm[PPT];
+    float qv[PPT][CPW];
 #pragma unroll
     for (int p = 0; p < PPT; p++) {
-        nrm[p] = ld_f32(r_norm, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u));
+        if (!reuse) nrm[p] = ld_f32(r_norm, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u));
         if constexpr (!REG_IO) {
 #pragma unroll
             for (int c = 0; c < CPW; c++)
                 qv[p][c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
         }
     }
-    uint32_t epx[KC];
-    float ew[KC];
-    uint32_t rs0[KC], rs1[KC];
+    if (!reuse) {
 #pragma unroll
-    for (int k = 0; k < KC; k++) {                 // splat entries e_k = tid + k*1024 and CSR rows of v_k
-        epx[k] = ld_u16(r_cp, (uint32_t)tid * 2u, (uint32_t)k * (kWG * 2u));
-        ew[k] = ld_f32(r_cw, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
-        rs0[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
-        rs1[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u) + 4u);
+        for (int k = 0; k < KC; k++) {             // splat entries e_k = tid + k*1024 and CSR rows of v_k
+            epx[k] = ld_u16(r_cp, (uint32_t)tid * 2u, (uint32_t)k * (kWG * 2u));
+            ew[k] = ld_f32(r_cw, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
+            rs0[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
+        }
+        // row end = the next vertex's row start: the neighbouring lane holds it; only the last lane of a wave loads it
+        if ((tid & 63) == 63) {
+#pragma unroll
+            for (int k = 0; k < KC; k++) rs1[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u) + 4u);
+        }
     }
     // neighbour words n1 | n2<<16 of my vertices: a ring of RING axes, fetched RING-1 passes ahead of
     // their use (a blur pass is shorter than one memory round trip)
     constexpr int RING = 3;
-    uint32_t nbw[DEEP ? RING : 1][KC];
     auto load_axis = [&](int j) {
+        if (reuse) return;
 #pragma unroll
         for (int k = 0; k < KC; k++)
             nbw[j % RING][k] = ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)j * (uint32_t)Mcap * 4u + (uint32_t)k * (kWG * 4u));
     };
     if constexpr (DEEP) load_axis(0);
+    if (!reuse) {
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const uint32_t up = __shfl_down(rs0[k], 1, 64);
+            if ((tid & 63) != 63) rs1[k] = up;
+        }
+    }
     mid();
     if constexpr (REG_IO) {
 #pragma unroll
@@ -212,6 +248,22 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
     // ordered sums over each vertex's contiguous row of products.  `prod` aliases `val`: the sums
     // wait in registers until every row has been read.
     vec_t *prod = val;
+    vec_t sacc[VPT];
+    const bool single = DEEP && (lat_flags & 4);
+    if (single) {
+        // every vertex has exactly one contributor (M == E; e.g. the Gaussian lattice at training scale): entry e is vertex
+        // e's only term, so the splat is values[v] = 0 + w_v * in[pixel_v] — no products pass, no row sums
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const vec_t x = inq[min((int)epx[k], N - 1)];
+#pragma unroll
+            for (int c = 0; c < CPW; c++) pv_set(sacc[k], c, 0.0f + ew[k] * pv_get(x, c));
+        }
+        if constexpr (DEEP) { if (1 < D1) load_axis(1); }
+        if constexpr (DEEP) { if (2 < D1) load_axis(2); }
+        DSRG_STAMP(2);
+        DSRG_STAMP(3);
+    } else {
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         if (ch > 0) {
@@ -236,7 +288,6 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
     if constexpr (DEEP) { if (1 < D1) load_axis(1); }   // the entry registers are free now
     __syncthreads();
     DSRG_STAMP(2);
-    vec_t sacc[VPT];
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         if (ch > 0) {
@@ -267,25 +318,30 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
     }
     DSRG_STAMP(3);
     if constexpr (DEEP) { if (2 < D1) load_axis(2); }
-    __syncthreads();                                     // every row of products has been consumed
+    }
+    __syncthreads();                                     // every row of products (or every input value) has been consumed
+    // two value buffers when the region holds them (the input planes are dead by now): an axis then gathers from one and
+    // writes the other — one barrier per axis instead of two
+    const int vstride = (M + 2) & ~1;
+    const bool pingpong = 2 * vstride <= lds_elems;
+    vec_t *cur = val, *nxt = pingpong ? val + vstride : val;
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const int v = tid + k * kWG;
-        if (v < M) val[v] = sacc[k];
+        if (v < M) cur[v] = sacc[k];
     }
-    if (tid == 0) {                                     // zero sentinel = "no neighbour" (permutohedral.cpp:561-562)
+    if (tid == 0) {                                     // zero sentinel = "no neighbour" (permutohedral.cpp:561-562): slot M
         vec_t z;
 #pragma unroll
         for (int c = 0; c < CPW; c++) pv_set(z, c, 0.0f);
-        val[Mcap] = z;
+        cur[M] = z;
+        nxt[M] = z;
     }
     __syncthreads();
     DSRG_STAMP(4);
 
     // ---- blur along the d+1 lattice axes (permutohedral.cpp:556-569): Jacobi per axis — new values
     // held in registers between the read barrier and the write barrier
-    uint32_t sv[PPT][D1];
-    float sw[PPT][D1];
 #pragma unroll
     for (int j = 0; j < D1; j++) {
         // sacc[k] holds the current value of my vertex v_k (no LDS read for it)
@@ -300,10 +356,10 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #pragma unroll
             for (int k = 0; k < KC; k++) {
                 if (ch * KC + k < VPT) {
+                    // (the words of the unused tail v >= M point at the zero sentinel: no test needed)
                     const uint32_t word = nbw[DEEP ? j % RING : 0][k];
-                    const bool ok = tid + (ch * KC + k) * kWG < M;
-                    const int n1 = ok ? (int)(word & 0xffffu) : Mcap, n2 = ok ? (int)(word >> 16) : Mcap;
-                    const vec_t x1 = val[n1], x2 = val[n2];
+                    const int n1 = (int)(word & 0xffffu), n2 = (int)(word >> 16);
+                    const vec_t x1 = cur[n1], x2 = cur[n2];
 #pragma unroll
                     for (int c = 0; c < CPW; c++) {
                         float s = pv_get(x1, c) + pv_get(x2, c);
@@ -315,7 +371,7 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
             }
         }
         if constexpr (DEEP) { if (j + RING < D1) load_axis(j + RING); }     // this axis' ring slot is free
-        if (j == (D1 >= 3 ? D1 - 3 : 0)) {           // slice corners, two passes ahead of their use
+        if (j == (D1 >= 3 ? D1 - 3 : 0) && !reuse) {   // slice corners, two passes ahead of their use
 #pragma unroll
             for (int p = 0; p < PPT; p++) {
 #pragma unroll
@@ -326,13 +382,23 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
                 }
             }
         }
-        __syncthreads();                             // all gathers of this axis are done
+        if (pingpong) {
 #pragma unroll
-        for (int k = 0; k < VPT; k++) {
-            const int v = tid + k * kWG;
-            if (v < M) val[v] = sacc[k];
+            for (int k = 0; k < VPT; k++) {
+                const int v = tid + k * kWG;
+                if (v < M) nxt[v] = sacc[k];
+            }
+            __syncthreads();                         // gathers of this axis done, values of the next one in place
+            vec_t *t = cur; cur = nxt; nxt = t;
+        } else {
+            __syncthreads();                         // all gathers of this axis are done
+#pragma unroll
+            for (int k = 0; k < VPT; k++) {
+                const int v = tid + k * kWG;
+                if (v < M) cur[v] = sacc[k];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         DSRG_STAMP(5 + j);
     }
 
@@ -348,7 +414,7 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #pragma unroll
             for (int r = 0; r < D1; r++) {
                 const float w = sw[p][r] * alpha;
-                const vec_t x = val[min(sv[p][r], (uint32_t)Mcap)];
+                const vec_t x = cur[min(sv[p][r], (uint32_t)M)];
 #pragma unroll
                 for (int c = 0; c < CPW; c++) acc[c] = acc[c] + w * pv_get(x, c);
             }
@@ -363,43 +429,73 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
     if (dbg && tid == 0) dbg[12] = (unsigned long long)M;
 }
 
-// One launch filters every label plane of every image through both lattices.  The bilateral work
-// (6 axes, M ~ 2-6 N vertices per image) goes to blocks of CPW_B planes of one image; the Gaussian
-// work (3 axes, one lattice shared by all images) to blocks of CPW_G planes of IPB images — the
-// block counts are chosen by the host so that both kinds finish together and all fit one round.
+// One launch filters every label plane of every image through both lattices.  Work units: first the bilateral ones
+// (CPW_B planes of one image: 6 axes, M ~ 2-6 N vertices, the long ones), then the Gaussian ones (CPW_G planes of one image
+// through the lattice all images share: 3 axes).  A workgroup starts with unit blockIdx.x and then pulls further units from
+// a counter (zeroed by the update kernel that precedes every filter launch), so that the CUs the bilateral units leave
+// idle (80 of 256 at 16 images) work through the Gaussian units and nothing queues behind a long unit; a workgroup that
+// runs several Gaussian units keeps the lattice's index words in registers between them.
+// Keeping the Gaussian lattice's index words in registers across a workgroup's Gaussian units was measured and lost: the
+// extra live registers slowed the first unit from 9.0 to 11.3 us (B = 16), more than the second unit gained.
+constexpr bool kKeepGaussIdx = false;
 template <int CPW_B, int CPW_G, int VPT_B, int PPT>
 __global__ __launch_bounds__(kWG) void mf_filter_kernel(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int VPT_G = (VPT_B + 1) / 2;                 // Mcap_gauss = Mcap_bilateral / 2
     unsigned long long *dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr;
-    if ((int)blockIdx.x < a.nblk_b) {
+    int *slot = reinterpret_cast<int *>(smem + a.lds_bytes);           // next-unit broadcast (16 bytes past the region)
+    // the next unit of this workgroup (workgroup-uniform); units are handed out in increasing order, so a workgroup sees its
+    // bilateral units first and its Gaussian units after them
+    auto next_unit = [&]() -> int {
+        if (a.nunits <= (int)gridDim.x) return a.nunits;                   // every unit was assigned statically
+        __syncthreads();                                                   // LDS is reused by the next unit
+        if (threadIdx.x == 0) {
+            // look before taking a ticket: the workgroups that finish the long units together would otherwise queue on the
+            // counter only to learn that nothing is left
+            int next = a.nunits;
+            if ((int)gridDim.x + (int)__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.nunits)
+                next = (int)gridDim.x + (int)atomicAdd(a.counter, 1u);
+            *slot = next;
+        }
+        __syncthreads();
+        return *slot;
+    };
+    int unit = blockIdx.x;
+    while (unit < a.nblk_b) {
         using vec_t = typename PlaneVec<CPW_B>::type;
-        // blocks of one image share blockIdx % 8, i.e. one XCD and its L2; the images beyond the last multiple of 8
-        // (B = 20: images 16..19) are laid out image-major so that they spread evenly over the XCDs — with the
-        // XCD-aware order alone 3 images x 11 blocks would land on a 32-CU XCD and force a second round there
+        // units of one image share unit % 8, i.e. (for the statically assigned ones) one XCD and its L2; the images beyond
+        // the last multiple of 8 (B = 20: images 16..19) are laid out image-major so that they spread evenly over the XCDs
         int g, b;
-        if ((int)blockIdx.x < a.nblk_xcd) { g = blockIdx.x / a.lat_stride; b = blockIdx.x % a.lat_stride; }
-        else { const int rel = blockIdx.x - a.nblk_xcd; b = a.lat_stride + rel / a.groups_b; g = rel % a.groups_b; }
-        if (b >= a.B) return;
-        const int c0 = g * CPW_B, nc = min(CPW_B, a.C - c0);
-        vec_t *val = reinterpret_cast<vec_t *>(smem);                      // [Mcap + 1] label-interleaved
-        vec_t *inq = val + a.lds_val_stride;                               // [N]
-        const size_t o = ((size_t)b * a.C + c0) * a.N;
-        filter_lattice<CPW_B, VPT_B, PPT, 5>(a.Lb, b, a.q + o, a.msg_b + o, nc, a.N, val, inq, dbg);
-    } else {
+        if (unit < a.nblk_xcd) { g = unit / a.lat_stride; b = unit % a.lat_stride; }
+        else { const int rel = unit - a.nblk_xcd; b = a.lat_stride + rel / a.groups_b; g = rel % a.groups_b; }
+        if (b < a.B) {
+            const int c0 = g * CPW_B, nc = min(CPW_B, a.C - c0);
+            vec_t *val = reinterpret_cast<vec_t *>(smem);                      // value buffer(s), label-interleaved
+            vec_t *inq = reinterpret_cast<vec_t *>(smem + a.lds_bytes) - a.N;  // [N] at the end of the region
+            const size_t o = ((size_t)b * a.C + c0) * a.N;
+            FilterIdx<VPT_B, PPT, 5> bix;
+            filter_lattice<CPW_B, VPT_B, PPT, 5>(a.Lb, b, a.q + o, a.msg_b + o, nc, a.N, val, inq,
+                                                 unit == (int)blockIdx.x ? dbg : nullptr, nullptr, 0, 0, 0, NoMid(),
+                                                 a.lds_bytes / (int)sizeof(vec_t), bix);
+        }
+        unit = next_unit();
+    }
+    {
         using vec_t = typename PlaneVec<CPW_G>::type;
-        const int rel = blockIdx.x - a.nblk_b;
-        const int g = rel / a.gau_stride, pb = rel % a.gau_stride;
-        const int c0 = g * CPW_G, nc = min(CPW_G, a.C - c0);
-        vec_t *val = reinterpret_cast<vec_t *>(smem);
-        vec_t *inq = val + a.lds_val_stride_g;
-        for (int ii = 0; ii < a.ipb; ii++) {
-            const int b = pb * a.ipb + ii;
-            if (b >= a.B) break;
-            if (ii) __syncthreads();                                       // LDS is reused
+        FilterIdx<VPT_G, PPT, 2> gix;                                          // kept across this workgroup's Gaussian units
+        bool g_loaded = false;
+        while (unit < a.nunits) {
+            const int rel = unit - a.nblk_b;
+            const int b = rel / a.groups_g, g = rel % a.groups_g;
+            const int c0 = g * CPW_G, nc = min(CPW_G, a.C - c0);
+            vec_t *val = reinterpret_cast<vec_t *>(smem);
+            vec_t *inq = reinterpret_cast<vec_t *>(smem + a.lds_bytes) - a.N;
             const size_t o = ((size_t)b * a.C + c0) * a.N;
             filter_lattice<CPW_G, VPT_G, PPT, 2>(a.Lg, 0, a.q + o, a.msg_g + o, nc, a.N, val, inq,
-                                                 (dbg && ii == 0) ? dbg + 16 : nullptr);
+                                                 (dbg && unit == (int)blockIdx.x) ? dbg + 16 : nullptr, nullptr, 0, 0, 0, NoMid(),
+                                                 a.lds_bytes / (int)sizeof(vec_t), gix, g_loaded);
+            g_loaded = kKeepGaussIdx;
+            unit = next_unit();
         }
     }
 }
@@ -442,8 +538,10 @@ __global__ __launch_bounds__(256) void mf_update_kernel(const float *__restrict_
                                                         const float *__restrict__ msg_b, float wg, float wb,
                                                         float *__restrict__ q_out,
                                                         double *__restrict__ refined_out,
-                                                        float *__restrict__ logq_out, int B, int C, int N) {
+                                                        float *__restrict__ logq_out, int B, int C, int N,
+                                                        unsigned int *__restrict__ work_counter) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && work_counter) *work_counter = 0u;          // the filter launch that follows starts its unit queue at 0
     if (idx >= B * N) return;
     const int b = idx / N, i = idx - b * N;
     const size_t base = (size_t)b * C * N + i;
@@ -715,17 +813,24 @@ __global__ __launch_bounds__(kWG) void mf_persistent_kernel(PersistArgs a) {
         if (flags_g & 1) {
             // diagonal Gaussian lattice (training scale): per-pixel arithmetic, done inside the bilateral filter's index-load
             // shadow together with the wait for the marginals
+            FilterIdx<VPT_B, PPT, 5> bix;
             filter_lattice<CPW, VPT_B, PPT, 5, true>(a.Lb, b, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mb, flags_b, [&]() {
                 fetch_and_gauss([&]() {
-                    filter_lattice<CPW, VPT_G, PPT, 2, true>(a.Lg, 0, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mg, flags_g);
+                    FilterIdx<VPT_G, PPT, 2> gix;
+                    filter_lattice<CPW, VPT_G, PPT, 2, true>(a.Lg, 0, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mg, flags_g,
+                                                             NoMid(), 0, gix);
                 });
-            });
+            }, 0, bix);
         } else {
             fetch_and_gauss([&]() {
-                filter_lattice<CPW, VPT_G, PPT, 2, true>(a.Lg, 0, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mg, flags_g);
+                FilterIdx<VPT_G, PPT, 2> gix;
+                filter_lattice<CPW, VPT_G, PPT, 2, true>(a.Lg, 0, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mg, flags_g,
+                                                         NoMid(), 0, gix);
             });
             __syncthreads();                                           // LDS is reused
-            filter_lattice<CPW, VPT_B, PPT, 5, true>(a.Lb, b, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mb, flags_b);
+            FilterIdx<VPT_B, PPT, 5> bix;
+            filter_lattice<CPW, VPT_B, PPT, 5, true>(a.Lb, b, nullptr, nullptr, nc, N, val, inq, nullptr, io, tl, Mb, flags_b,
+                                                     NoMid(), 0, bix);
         }
         DSRG_PSTAMP(2 + (it - 1) * 6 + 2);
 #pragma unroll
@@ -818,7 +923,7 @@ static int launch_update(const float *neg_unary, const MeanfieldBufs &buf, float
     const int threads = 256, blocks = (B * N + threads - 1) / threads;
 #define DSRG_UPD(CT_, UM_)                                                                                  \
     hipLaunchKernelGGL((mf_update_kernel<CT_, UM_>), dim3(blocks), dim3(threads), 0, stream, neg_unary,        \
-                       buf.msg_g, buf.msg_b, wg, wb, q_out, refined, logq, B, C, N)
+                       buf.msg_g, buf.msg_b, wg, wb, q_out, refined, logq, B, C, N, buf.work_counter)
     if (C <= 21) { if (use_msgs) DSRG_UPD(21, true); else DSRG_UPD(21, false); }
     else { if (use_msgs) DSRG_UPD(kMaxLabels, true); else DSRG_UPD(kMaxLabels, false); }
 #undef DSRG_UPD
@@ -914,14 +1019,38 @@ int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const Meanfie
     a.nblk_b = a.nblk_xcd + (B > a.lat_stride ? a.groups_b * (B - a.lat_stride) : 0);
     // Gaussian blocks come last in the grid and fill CUs as bilateral blocks (twice as long) drain; one image each
     // balances best up to B = 24, two images each beyond (measured: B = 16 20.0 vs 20.8 us, B = 32 39.2 vs 38.1 us)
-    const int groups_g = (C + cpw_g - 1) / cpw_g;
-    a.ipb = B > 24 ? 2 : 1;
-    a.gau_stride = (B + a.ipb - 1) / a.ipb;
+    // Gaussian units come last in the unit list: the CUs the bilateral units leave idle start on them at once and the rest
+    // are pulled from the counter as workgroups finish (see mf_filter_kernel)
+    a.groups_g = (C + cpw_g - 1) / cpw_g;
+    a.nunits = a.nblk_b + a.groups_g * B;
+    a.counter = buf.work_counter;
     a.lds_val_stride = vs_b;
     a.lds_val_stride_g = vs_g;
     a.dbg = reinterpret_cast<unsigned long long *>(g_filter_dbg);
-    const int nblocks = a.nblk_b + groups_g * a.gau_stride;
-    const size_t lds = lds_for(cpw_b, cpw_g);
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    // one workgroup per CU (its LDS); without a counter (or with DSRG_FILTER_QUEUE=0) every unit gets its own workgroup and
+    // the hardware dispatcher hands them out
+    // (measured, profiles/r02_filter_queue_ab.txt: the software queue — DSRG_FILTER_QUEUE=1 — loses to the hardware dispatcher
+    // at every batch size: 19.0-19.7 vs 18.6-19.3 us per launch at 16 images, 29.8-30.1 vs 27.1-27.6 at 20, 39.8-40.2 vs
+    // 36.0-36.5 at 32; it stays selectable for that comparison)
+    static const bool use_queue = [] { const char *e = getenv("DSRG_FILTER_QUEUE"); return e && e[0] == '1'; }();
+    const int nblocks = (use_queue && buf.work_counter && a.nunits > n_cus) ? n_cus : a.nunits;
+    // enough LDS for two value buffers of the largest lattice when the CU has it (filter_lattice then blurs ping-pong for
+    // every lattice whose actual vertex count fits), never less than one buffer + the input planes
+    size_t lds = lds_for(cpw_b, cpw_g);
+    {
+        const size_t pb = (size_t)cpw_b * 2 * ((size_t)Lb.Mcap + 2) * sizeof(float), pg = (size_t)cpw_g * 2 * ((size_t)Lg.Mcap + 2) * sizeof(float);
+        size_t want = pb > pg ? pb : pg;
+        if (want > kLds) want = kLds;
+        if (want > lds) lds = want;
+        lds = (lds + 15) & ~(size_t)15;
+    }
+    a.lds_bytes = (int)lds;
+    lds += 16;                                       // the next-unit broadcast slot behind the region
 
     // Q0 = expAndNormalize(-unary)   (densecrf.cpp:120)
     int rc = launch_update(neg_unary, buf, wg, wb, 0, n_iters > 0 ? buf.q : q_out,

@@ -61,8 +61,9 @@ def test_config2_backbone_forward_then_supervision_b1(ops, O):
     # ... and lean towards the cued classes around their cues, as a net a few hundred iterations into training does, so
     # that the region growing has something to grow
     from scipy.ndimage import gaussian_filter
-    bump = np.stack([gaussian_filter(c, 3.0) for c in b["cues"][0]])[None].astype(np.float32)
-    logits = np.ascontiguousarray(scores.cpu().numpy() + 40.0 * bump / max(bump.max(), 1e-12))
+    bump = np.stack([gaussian_filter(c, 3.0) for c in b["cues"][0]]).astype(np.float32)
+    bump = (bump / np.maximum(bump.max((1, 2), keepdims=True), 1e-12))[None]               # peak 1 for every cued class
+    logits = np.ascontiguousarray(scores.cpu().numpy() + 60.0 * bump)
     _check_fused_step(ops, O, logits, b["images"], b["labels"], b["cues"], "config 2 (B=1, backbone scores)")
     probs = O.softmax_forward(logits)
     refined, _ = O.crf_refine_batch(probs, b["images"], 12.0, 10)
