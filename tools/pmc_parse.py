@@ -2,7 +2,8 @@
 """Turn the counter_collection CSVs of two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into
 profiles/pmc_traffic.json: HBM bytes per launch for every hot-path kernel, corrected by the factor
 measured on the calibration launch (known byte count) as MI355X_MICROARCH.md §HBM prescribes.
-Usage: python tools/pmc_parse.py FETCH_CSV WRITE_CSV OUT_JSON"""
+Usage: python tools/pmc_parse.py FETCH_CSV WRITE_CSV OUT_JSON [commit]   (the commit the counters were collected at is
+stamped into the file: re-collect when a kernel changes)"""
 import csv
 import json
 import sys
@@ -21,8 +22,8 @@ def per_kernel(path, counter):
     return acc
 
 
-def main(fetch_csv, write_csv, out):
-    res = {"units": "bytes per launch; raw counters are KiB (FETCH_SIZE/WRITE_SIZE), corrected by the "
+def main(fetch_csv, write_csv, out, commit=""):
+    res = {"commit": commit, "units": "bytes per launch; raw counters are KiB (FETCH_SIZE/WRITE_SIZE), corrected by the "
                     "calibration factor of a %d-byte softmax_fwd_kernel launch" % CALIB_BYTES}
     factors = {}
     tables = {}
@@ -49,9 +50,12 @@ def main(fetch_csv, write_csv, out):
     filt = [e for k, e in kernels.items() if "mf_filter_kernel" in k]
     if filt:
         res["mf_filter_kernel_bytes_per_launch"] = filt[0]["hbm_bytes_per_launch"]
+    blur = [e for k, e in kernels.items() if "lg_blur2_kernel" in k]
+    if blur:
+        res["lg_blur2_kernel_bytes_per_launch"] = blur[0]["hbm_bytes_per_launch"]
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True)[:3000])
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
