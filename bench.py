@@ -139,7 +139,7 @@ def run_crf_fullres(args, device, rank):
         for _ in range(args.warmup):
             one()
         torch.cuda.synchronize()
-        crf.profile_start(args.steps * 60 + 8)
+        crf.profile_start(args.steps * 10 + 8)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one()
@@ -148,10 +148,9 @@ def run_crf_fullres(args, device, rank):
         blur_ms, blur_n = crf.profile_stop()
         mg, mb = crf.lattice_size(0), crf.lattice_size(1)
         N = H * W
-        # SURVEY 8d per blur axis: read own + two neighbour rows, write one row (4-byte values, C labels) + the (n1, n2) pair;
-        # launches of axes 0-2 carry both lattices, 3-5 the bilateral one only
-        axis_b, axis_g = 16 * C * mb + 8 * mb, 16 * C * mg + 8 * mg
-        alg_per_launch = (6 * axis_b + 3 * axis_g) / 6.0
+        # SURVEY 8d, the splat stage of filter(d, M) for both lattices in one launch: the marginals in (4 C N, read once), the
+        # (vertex, weight) pair of every (pixel, corner) entry (8 (d+1) N per lattice), the lattice rows out (4 C M per lattice)
+        alg_per_launch = 4 * C * N + 8 * (6 + 3) * N + 4 * C * (mb + mg)
         out_sizes.append(dict(H=H, W=W, images_per_s=args.steps / dt, ms_per_image=dt / args.steps * 1e3, M_gauss=mg, M_bil=mb,
                               blur_us_per_launch_event_bracket=blur_ms / max(blur_n, 1) * 1e3, blur_launches=blur_n,
                               alg_bytes_per_blur_launch=alg_per_launch,
@@ -172,19 +171,21 @@ def run_crf_fullres(args, device, rank):
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_fullres.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("lg_blur2_kernel_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("lg_splat2_kernel_bytes_per_launch")
         except Exception:
             traffic = None
     achieved = head["alg_bytes_per_blur_launch"] / per_launch_s / 1e9
-    roofline = {"kernel": "lg_blur2_kernel (one permutohedral blur axis over both lattices, values in HBM/L2)", "bound": "hbm",
+    roofline = {"kernel": "lg_splat2_kernel (permutohedral splat of both lattices: per-vertex ordered gather lists, values in HBM/L2)",
+                "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": head["alg_bytes_per_blur_launch"], "us_per_launch": per_launch_s * 1e6,
                 "us_per_launch_event_bracket": head["blur_us_per_launch_event_bracket"], "event_bracket_overhead_us": ev_us,
                 "launches": head["blur_launches"], "lattice_M_gauss": head["M_gauss"], "lattice_M_bilateral": head["M_bil"],
                 "hbm_gbs_from_pmc_traffic": (traffic / per_launch_s / 1e9) if traffic else None,
                 "whole_crf_alg_gbs": head["crf_alg_bytes"] / (head["ms_per_image"] * 1e-3) / 1e9,
-                "note": "the lattice values of a 321x321 image (%.1f MB per buffer) fit the L2s / Infinity Cache, so HBM counters "
-                        "may read below the algorithmic bytes" % ((head["M_gauss"] + head["M_bil"] + 2) * 24 * 4 / 1e6)}
+                "note": "a row of the splat is a chain of dependent gathers (entry -> pixel -> 96-byte label row, ~25 entries per "
+                        "vertex): latency-, not bandwidth-bound; the counter traffic exceeds the algorithmic bytes because every "
+                        "entry re-reads its pixel's row (L2 hits are not HBM traffic, FETCH_SIZE counts the fabric side)"}
     out = {"metric": "images/sec full-resolution dense CRF (test-ms.py:84-111; %dx%d, 21 labels, 10 iterations, lattices built "
                      "per image)" % (head["H"], head["W"]),
            "value": head["images_per_s"], "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

@@ -660,7 +660,7 @@ extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
     return DSRG_OK;
 }
 // measurement hook of the object API: brackets the dominant kernel of this handle's path with HIP events on its stream —
-// lg_blur2_kernel (one launch per blur axis) on the global-memory path, the mean-field kernel on the LDS-resident path
+// lg_splat2_kernel (one launch per iteration) on the global-memory path, the mean-field filter kernel on the LDS-resident path
 extern "C" int dsrg_crf_profile_start(dsrg_crf_t h, int max_launches) {
     if (!h || max_launches < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
     return prof_start(h->large ? *large_crf_profiler(h->large) : h->ctx->prof, max_launches);

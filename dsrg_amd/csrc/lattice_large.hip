@@ -204,6 +204,18 @@ __device__ __forceinline__ void lg_splat_row(const LargeLattice &L, int v, int l
     const uint32_t p0 = L.row_start[v], p1 = L.row_start[v + 1];
     float s = 0.0f;
     uint32_t pos = p0;
+    // a row is a chain of dependent gathers (entry -> pixel -> value): eight entries in flight per round trip (rows hold
+    // ~25 entries on average at image resolution, hundreds in flat regions)
+    for (; pos + 8 <= p1; pos += 8) {
+        uint32_t px[8];
+        float w[8], x[8], nv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { px[u] = L.csr_pix[pos + u]; w[u] = L.csr_w[pos + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { x[u] = in[(size_t)px[u] * CP + lane]; nv[u] = L.norm[px[u]]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) s = s + w[u] * (x[u] * nv[u]);
+    }
     for (; pos + 4 <= p1; pos += 4) {
         uint32_t px[4];
         float w[4], x[4];
@@ -350,7 +362,7 @@ struct LargeCrf {
     float *stage;                          // [N][C] host-layout staging
     bool lattices_valid;                   // Lg/Lb were built for the current image and kernel widths
     dsrg_crf_params built_for;
-    Profiler prof;                         // optional HIP-event brackets around the blur launches (dsrg_crf_profile_*)
+    Profiler prof;                         // optional HIP-event brackets around the splat launches (dsrg_crf_profile_*)
 };
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -529,16 +541,16 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
     while ((1 << lpv_shift) < CP && lpv_shift < 6) lpv_shift++;
     const size_t g_off = ((size_t)Mb + 1) * CP;                          // Gaussian rows follow the bilateral ones
     for (int it = 0; it < n_iters; it++) {
+        const bool timed = c->prof.active && c->prof.used < c->prof.cap;      // the dominant kernel of this path (dsrg_crf_profile_*)
+        if (timed) DSRG_HIP_CHECK(hipEventRecord(c->prof.start[c->prof.used], s));
         hipLaunchKernelGGL(lg_splat2_kernel, dim3(blocks_for(need, 256 >> lpv_shift)), dim3(256), 0, s, c->Lb, c->Lg, CP,
                            lpv_shift, c->q, c->val_a, c->val_a + g_off);
+        if (timed) { DSRG_HIP_CHECK(hipEventRecord(c->prof.stop[c->prof.used], s)); c->prof.used++; }
         float *a = c->val_a, *b = c->val_b;
         for (int j = 0; j < 6; j++) {
             const size_t rows = j < 3 ? need : (size_t)Mb + 1;
-            const bool timed = c->prof.active && c->prof.used < c->prof.cap;
-            if (timed) DSRG_HIP_CHECK(hipEventRecord(c->prof.start[c->prof.used], s));
             hipLaunchKernelGGL(lg_blur2_kernel, dim3(blocks_for(rows * CP4, 256)), dim3(256), 0, s, c->Lb, c->Lg, CP4, j,
                                (const float4 *)a, (float4 *)b, (const float4 *)(a + g_off), (float4 *)(b + g_off));
-            if (timed) { DSRG_HIP_CHECK(hipEventRecord(c->prof.stop[c->prof.used], s)); c->prof.used++; }
             float *t = a; a = b; b = t;
         }
         // after 6 swaps the bilateral result is back in val_a; the Gaussian one stopped after 3 swaps, in val_b

@@ -74,7 +74,7 @@ int dsrg_crf_nlabels(dsrg_crf_t h);
 int dsrg_crf_lattice_size(dsrg_crf_t h, int k);
 
 /* measurement hook (no reference counterpart): while on, every launch of the dominant kernel of this object's path — the
- * per-axis blur of the global-memory path (full-resolution maps), the mean-field kernel of the LDS-resident path — is
+ * splat of the global-memory path (full-resolution maps), the mean-field filter kernel of the LDS-resident path — is
  * bracketed by HIP events on its stream; _stop synchronises and returns the summed time and the launch count. */
 int dsrg_crf_profile_start(dsrg_crf_t h, int max_launches);
 int dsrg_crf_profile_stop(dsrg_crf_t h, double *total_ms_host, int32_t *launches_host);

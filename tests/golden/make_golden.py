@@ -318,6 +318,10 @@ def main():
     assert not np.array_equal(ann["mirror_cues"], ann["plain_cues"])
     np.savez_compressed(os.path.join(HERE, "annotation_cases.npz"), **ann)
     print("annotation layer: %d images, %d cue pixels" % (len(ids), int(ann["plain_cues"].sum())))
+    # (pylayers/pylayers/layer.py — ImageSegDataLayer / BatchLoader / SimpleTransformer of train-f — is Python 2 only: the
+    # print statements at layer.py:96,248-251 are syntax errors under this image's Python 3.10, so the module cannot be
+    # imported and no fixture can be captured from it; dsrg_amd/data.py restates it and is tested against the statement-by-
+    # statement expectations in tests/test_retrain_data.py.)
     for f in ("cc_cases.npz", "srg_cases.npz", "layer_glue.npz", "annotation_cases.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 

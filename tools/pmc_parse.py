@@ -50,9 +50,10 @@ def main(fetch_csv, write_csv, out, commit=""):
     filt = [e for k, e in kernels.items() if "mf_filter_kernel" in k]
     if filt:
         res["mf_filter_kernel_bytes_per_launch"] = filt[0]["hbm_bytes_per_launch"]
-    blur = [e for k, e in kernels.items() if "lg_blur2_kernel" in k]
-    if blur:
-        res["lg_blur2_kernel_bytes_per_launch"] = blur[0]["hbm_bytes_per_launch"]
+    for name in ("lg_blur2_kernel", "lg_splat2_kernel", "lg_slice_update_kernel"):
+        sel = [e for k, e in kernels.items() if name in k]
+        if sel:
+            res[name + "_bytes_per_launch"] = sel[0]["hbm_bytes_per_launch"]
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True)[:3000])
 
