@@ -25,7 +25,7 @@ import time
 # hipBLASLt solution selection by PyTorch's own online tuner (TunableOp): each GEMM shape of the backbone is timed once
 # during the warm-up steps and the fastest solution kept (+1.3 % measured); set PYTORCH_TUNABLEOP_ENABLED=0 to opt out
 os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
-os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/dsrg_tunableop.csv")
+os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/dsrg_tunableop_%s.csv" % os.environ.get("LOCAL_RANK", "0"))   # one file per rank
 os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
 
 import numpy as np
@@ -297,7 +297,7 @@ def main():
     retrainer = None
     if args.mode == "train-f":
         from dsrg_amd.retrain import RetrainTrainer
-        retrainer = RetrainTrainer(device, world_size=2 if use_dist else 1, backbone=args.backbone)
+        retrainer = RetrainTrainer(device, world_size=world, ddp=use_dist, backbone=args.backbone)
         g = torch.Generator(device="cpu").manual_seed(2000 + rank)
         f_images = torch.randn(B, 3, args.size, args.size, generator=g).to(device)
         f_label = torch.randint(0, 21, (B, 1, args.size, args.size), generator=g).float().to(device)

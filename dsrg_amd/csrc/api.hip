@@ -456,9 +456,12 @@ extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, c
         return set_error(DSRG_ERR_INVALID, "NULL argument");
     if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
     const bool prepared = images == nullptr;      // lattices were built by dsrg_crf_prepare_batch
-    if (prepared) {
+    {
         int prc = check_params(prm);
         if (prc) return prc;
+    }
+    if (!prepared && (img_h < 1 || img_w < 1)) return set_error(DSRG_ERR_INVALID, "bad image size");
+    if (prepared) {
         if (c->prepared_B != B || memcmp(&c->prepared_prm, prm, offsetof(dsrg_crf_params, n_iters)) != 0)
             return set_error(DSRG_ERR_INVALID, "images_dev is NULL but dsrg_crf_prepare_batch was not called "
                                                "for this batch size / these kernel parameters");
@@ -466,13 +469,15 @@ extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int C = c->C, N = c->N;
     const size_t nb = sizeof(float) * (size_t)B * C * N;
-    int rc = launch_softmax_fwd(B, C, N, logits, c->probs, s);                     // Softmax
+    // Softmax, with the in-place clip CRFLayer.forward applies to this blob next (pylayers.py:67) folded into the same pass:
+    // the unclipped blob has no other reader (A.3: both losses read it after the CRF layer ran)
+    int rc = launch_softmax_fwd(B, C, N, logits, c->probs, s, kMinProb);
     if (rc) return rc;
     if (!prepared) {
-        rc = dsrg_crf_refine_batch(c, B, c->probs, images, img_h, img_w, prm, c->refined, c->logq, stream);   // CRF (once)
+        rc = launch_prepare_images(images, B, img_h, img_w, c->H, c->W, c->im_u8, s);   // pylayers.py:70-75
+        if (!rc) rc = crf_run(c, B, c->probs, c->im_u8, prm, nullptr, c->refined, c->logq, s);    // CRF (once)
     } else {
-        rc = launch_clip_min(c->probs, (size_t)B * C * N, s);                      // pylayers.py:67
-        if (!rc) rc = crf_run(c, B, c->probs, c->im_u8, prm, nullptr, c->refined, c->logq, s, true);
+        rc = crf_run(c, B, c->probs, c->im_u8, prm, nullptr, c->refined, c->logq, s, true);
         c->prepared_B = 0;                                                         // consumed
     }
     if (rc) return rc;

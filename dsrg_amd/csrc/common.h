@@ -116,7 +116,7 @@ int launch_clip_min(float *p, size_t n, hipStream_t stream);
 int launch_prepare_images(const float *images, int B, int Hi, int Wi, int H, int W, unsigned char *im_u8,
                           hipStream_t stream);
 
-int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream);
+int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream, float floor_at = 0.0f);
 int launch_softmax_bwd(int B, int C, int HW, const float *x, const float *g, float *dx, hipStream_t stream);
 int launch_crf_bwd(size_t n, const double *refined, const float *td, float *bd, hipStream_t stream);
 int launch_seed_loss(int B, int C, int HW, const float *p, const float *S, float *loss, float *grad,

@@ -66,7 +66,7 @@ int launch_prepare_images(const float *images, int B, int Hi, int Wi, int H, int
 // forward: s = softmax_c(x); p = (s + 1e-4) / sum_c(s + 1e-4), fp32
 template <int CT>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int C, int HW, const float *__restrict__ x,
-                                                          float *__restrict__ p) {
+                                                          float *__restrict__ p, float floor_at) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
     const int b = idx / HW, i = idx - b * HW;
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int C, int HW, 
     for (int c = 0; c < CT; c++) { t[c] = t[c] / z + kMinProb; z2 = (c < C) ? z2 + t[c] : z2; }
 #pragma unroll
     for (int c = 0; c < CT; c++)
-        if (c < C) p[base + (size_t)c * HW] = t[c] / z2;
-}
+        if (c < C) p[base + (size_t)c * HW] = fmaxf(t[c] / z2, floor_at);     // floor_at = 0: the plain layer; 1e-4: the in-place
+}                                                                             // clip CRFLayer.forward applies next (pylayers.py:67)
 // backward = T.grad(sum(probs*g), preds):  dx_j = s_j (g_j - sum_k s_k g_k) / Z,  Z = sum_c (s_c + 1e-4)
 template <int CT>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, const float *__restrict__ x,
@@ -118,11 +118,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, 
     for (int c = 0; c < CT; c++)
         if (c < C) dx[base + (size_t)c * HW] = s[c] * (gg[c] - sg) / Z;
 }
-int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream) {
+int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream, float floor_at) {
     if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
     const int threads = 256, blocks = (B * HW + threads - 1) / threads;
-    if (C <= 21) hipLaunchKernelGGL(softmax_fwd_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p);
-    else hipLaunchKernelGGL(softmax_fwd_kernel<kMaxLabels>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p);
+    if (C <= 21) hipLaunchKernelGGL(softmax_fwd_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p, floor_at);
+    else hipLaunchKernelGGL(softmax_fwd_kernel<kMaxLabels>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p, floor_at);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

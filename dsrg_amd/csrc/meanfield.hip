@@ -601,6 +601,104 @@ __global__ __launch_bounds__(256) void mf_update_kernel(const float *__restrict_
     }
 }
 
+// The same update with kUpdParts threads per pixel: lanes = 64 consecutive pixels (coalesced plane loads), wave p of the
+// workgroup takes the labels c = p, p + kUpdParts, ...  The ~1.4 us chain of 21 dependent fp64 exps per thread of the kernel
+// above (it runs at less than one wave per SIMD: nothing hides it) becomes ceil(C / kUpdParts) exps; the column max, the
+// label-order sum and numpy's pairwise sum go through LDS in exactly the reference's order, so the results are bit-identical.
+constexpr int kUpdParts = 4, kUpdPix = 64;
+template <int CT, bool USE_MSGS>   // CT = compile-time bound on C
+__global__ __launch_bounds__(kUpdParts * kUpdPix) void mf_update_split_kernel(
+    const float *__restrict__ neg_unary, const float *__restrict__ msg_g, const float *__restrict__ msg_b, float wg, float wb,
+    float *__restrict__ q_out, double *__restrict__ refined_out, float *__restrict__ logq_out, int B, int C, int N,
+    unsigned int *__restrict__ work_counter) {
+    __shared__ float ev[CT][kUpdPix];                      // e, then q per (label, pixel)
+    __shared__ float pm[kUpdParts][kUpdPix];               // partial column maxima
+    const int px = threadIdx.x & (kUpdPix - 1), part = threadIdx.x >> 6;
+    const int idx = blockIdx.x * kUpdPix + px;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && work_counter) *work_counter = 0u;
+    const bool live = idx < B * N;
+    const int b = live ? idx / N : 0, i = live ? idx - b * N : 0;
+    const size_t base = (size_t)b * C * N + i;
+    constexpr int LPT = (CT + kUpdParts - 1) / kUpdParts;
+    float t[LPT], mg[LPT], mb[LPT];
+#pragma unroll
+    for (int k = 0; k < LPT; k++) {                        // all loads first, unconditionally (label index clamped)
+        const size_t o = base + (size_t)min(part + k * kUpdParts, C - 1) * N;
+        t[k] = neg_unary[o];
+        if (USE_MSGS) { mg[k] = msg_g[o]; mb[k] = msg_b[o]; }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < LPT; k++) {
+        const int c = part + k * kUpdParts;
+        float v = t[k];
+        if (USE_MSGS) {
+            // tmp2 = -w * filter(Q); tmp1 -= tmp2  — Gaussian first, then bilateral
+            const float m1 = (-wg) * mg[k];
+            v = v - m1;
+            const float m2 = (-wb) * mb[k];
+            v = v - m2;
+        }
+        t[k] = (c < C) ? v : -INFINITY;
+        mx = fmaxf(mx, t[k]);
+    }
+    pm[part][px] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(pm[0][px], pm[1][px]), fmaxf(pm[2][px], pm[3][px]));      // fmax is order-independent
+#pragma unroll
+    for (int k = 0; k < LPT; k++) {
+        const int c = part + k * kUpdParts;
+        if (c < C) ev[c][px] = exp_cr(t[k] - mx);
+    }
+    __syncthreads();
+    float sum = 0.0f;                                      // label-order sum, as the reference's column sum
+    for (int c = 0; c < C; c++) sum = sum + ev[c][px];
+    float q[LPT];
+#pragma unroll
+    for (int k = 0; k < LPT; k++) {
+        const int c = part + k * kUpdParts;
+        q[k] = (c < C) ? ev[c][px] / sum : 0.0f;
+        if (c < C && live && q_out) q_out[base + (size_t)c * N] = q[k];
+    }
+    if (refined_out) {
+        // pylayers.py:84-88: float64, clip at min_prob, divide by numpy's pairwise label sum, log
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            const int c = part + k * kUpdParts;
+            if (c < C) ev[c][px] = q[k];
+        }
+        __syncthreads();
+        auto col = [&](int k) { const double v = (double)ev[k][px]; return v < 0.0001 ? 0.0001 : v; };
+        double s;
+        if (C < 8) {
+            s = 0.0;
+            for (int k = 0; k < C; k++) s += col(k);
+        } else {
+            const int full = C - (C % 8);
+            double rs[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) rs[k] = col(k);
+            for (int k0 = 8; k0 < full; k0 += 8) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) rs[k] += col(k0 + k);
+            }
+            s = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+            for (int k = full; k < C; k++) s += col(k);
+        }
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            const int c = part + k * kUpdParts;
+            if (c < C && live) {
+                const double qd = (double)q[k];
+                const double r = (qd < 0.0001 ? 0.0001 : qd) / s;
+                refined_out[base + (size_t)c * N] = r;
+                if (logq_out) logq_out[base + (size_t)c * N] = (float)log(r);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // The whole inference loop (densecrf.cpp:115-131) as ONE launch: workgroup (b, g) keeps plane group g of image b for all
 // iterations.  An iteration has a plane-parallel half (the two filters on my planes, for every pixel) and a pixel-parallel
@@ -920,6 +1018,19 @@ static bool persistent_enabled() {
 
 static int launch_update(const float *neg_unary, const MeanfieldBufs &buf, float wg, float wb, int use_msgs,
                          float *q_out, double *refined, float *logq, int B, int C, int N, hipStream_t stream) {
+    // DSRG_UPDATE=pixel selects the one-thread-per-pixel kernel (round 1); default: kUpdParts threads per pixel
+    static const bool split = [] { const char *e = getenv("DSRG_UPDATE"); return !(e && strcmp(e, "pixel") == 0); }();
+    if (split) {
+        const int blocks = (B * N + kUpdPix - 1) / kUpdPix;
+#define DSRG_UPDS(CT_, UM_)                                                                                               \
+    hipLaunchKernelGGL((mf_update_split_kernel<CT_, UM_>), dim3(blocks), dim3(kUpdParts * kUpdPix), 0, stream, neg_unary,     \
+                       buf.msg_g, buf.msg_b, wg, wb, q_out, refined, logq, B, C, N, buf.work_counter)
+        if (C <= 21) { if (use_msgs) DSRG_UPDS(21, true); else DSRG_UPDS(21, false); }
+        else { if (use_msgs) DSRG_UPDS(kMaxLabels, true); else DSRG_UPDS(kMaxLabels, false); }
+#undef DSRG_UPDS
+        DSRG_LAUNCH_CHECK();
+        return DSRG_OK;
+    }
     const int threads = 256, blocks = (B * N + threads - 1) / threads;
 #define DSRG_UPD(CT_, UM_)                                                                                  \
     hipLaunchKernelGGL((mf_update_kernel<CT_, UM_>), dim3(blocks), dim3(threads), 0, stream, neg_unary,        \

@@ -129,7 +129,7 @@ class RetrainTrainer(object):
     """one train-f step: backbone -> (logits, labels shrunk by 8) -> softmax loss -> SGD with poly LR"""
 
     def __init__(self, device, world_size=1, backbone="vgg16", base_lr=1e-3, max_iter=20000, seed=0,
-                 amp_dtype=torch.bfloat16, net=None, weights=None, snapshot=None):
+                 amp_dtype=torch.bfloat16, net=None, weights=None, snapshot=None, ddp=None):
         """weights: run.sh:9 `--weights models/model-s_iter_8000.caffemodel` — stage 2 starts from the stage-1 model
         (copied by layer name: .caffemodel / .npz / torch file); snapshot: a solverstate written by save()."""
         torch.manual_seed(seed)
@@ -142,7 +142,7 @@ class RetrainTrainer(object):
         if device.type == "cuda":
             net = net.to(memory_format=torch.channels_last)
         self.net = self.model = net
-        if world_size > 1:
+        if (world_size > 1) if ddp is None else ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=32,
                              gradient_as_bucket_view=True)

@@ -68,10 +68,19 @@ def test_predict_mask_ms_vs_reference_restatement():
     e = np.exp(scores_all - scores_all.max(2, keepdims=True))
     probs = e / e.sum(2, keepdims=True)
     probs[probs < 0.00001] = 0.00001
-    want = np.argmax(O.CRF(im, np.log(probs), scale_factor=1.0), axis=2)
+    q = O.CRF(im, np.log(probs), scale_factor=1.0)
+    want = np.argmax(q, axis=2)
     agree = (got == want).mean()
-    print("multi-scale + CRF mask agreement with the reference restatement: %.5f" % agree)
+    # the two pipelines differ upstream of the CRF (fp32 GPU convolution and torch's bilinear resampling against an fp64
+    # convolution and scipy's zoom): a pixel may come out differently only where the reference's own decision is a near tie
+    top2 = np.sort(q, axis=2)[:, :, -2:]
+    margin = top2[:, :, 1] - top2[:, :, 0]
+    bad = got != want
+    print("multi-scale + CRF mask agreement with the reference restatement: %.5f; %d differing pixels, largest reference "
+          "top-2 margin among them %.4f" % (agree, int(bad.sum()), float(margin[bad].max()) if bad.any() else 0.0))
     assert got.shape == (H, W) and agree > 0.995
+    assert not bad.any() or margin[bad].max() < 0.05
+    assert (got[~bad] == want[~bad]).all() and (margin[~bad] >= 0).all()
     # pseudo-label generation restricted to the image labels (generate_train_gt.py:78-106)
     mask = I.predict_train_gt(net, im, labels=[3, 7], smooth=True)
     assert set(np.unique(mask)) <= {0, 3, 7}
