@@ -533,7 +533,9 @@ int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float 
     return DSRG_OK;
 }
 
-int heads_bwd_chunks(int M) { int c = (M + 511) / 512; return c < 1 ? 1 : (c > 64 ? 64 : c); }
+// row chunks of the weight gradient: ~256 rows each so that two workgroups share a CU (one wave per SIMD each) and one's
+// loads hide behind the other's MFMAs; capped so that the partial sums stay small (chunks x n x O x K floats)
+int heads_bwd_chunks(int M) { int c = (M + 255) / 256; return c < 1 ? 1 : (c > 128 ? 128 : c); }
 
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
                      float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream) {
