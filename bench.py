@@ -205,6 +205,59 @@ def run_crf_fullres(args, device, rank):
     print(json.dumps(out))
 
 
+def run_infer(args, device, rank):
+    """--mode infer (BASELINE.json configs[1]): VGG16-ASPP forward (bf16 autocast, fp32 heads, eval mode) + Softmax + dense
+    CRF + seeded region growing on the network's own scores, no losses, no backward — the inference-only supervision path.
+    Default batch 1."""
+    from dsrg_amd import ops, synthetic as S
+    from dsrg_amd.backbone import VGG16ASPP, count_flops_per_image
+    B = args.batch
+    batch_np = S.make_batch(1000 + rank, B)
+    images = torch.from_numpy(batch_np["images"]).to(device)
+    labels = torch.from_numpy(batch_np["labels"]).to(device)
+    cues = torch.from_numpy(batch_np["cues"]).to(device)
+    torch.manual_seed(0)
+    net = VGG16ASPP().to(device).to(memory_format=torch.channels_last).eval()
+    ctx = ops.get_context(B, 21, 41, 41)
+    x = images.contiguous(memory_format=torch.channels_last)
+
+    @torch.no_grad()
+    def one():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            scores = net(x)
+        probs = ops.softmax_forward(scores.contiguous())
+        refined, _ = ops.crf_refine(probs, images, ctx=ctx, want_log=False)
+        return ops.srg_grow(labels, cues, refined)
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seeds = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    e0.record()
+    for _ in range(10):
+        probs = ops.softmax_forward(torch.from_numpy(batch_np["logits"]).to(device))
+        refined, _ = ops.crf_refine(probs, images, ctx=ctx, want_log=False)
+        ops.srg_grow(labels, cues, refined)
+    e1.record()
+    torch.cuda.synchronize()
+    if rank != 0:
+        return
+    out = {"metric": "images/sec VGG16-ASPP forward + Softmax + dense CRF + SRG (inference-only supervision path, 321x321, 21-class)",
+           "value": B * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16 backbone forward (fp32 heads) + f32/f64 CRF and SRG", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[1]: backbone forward + CRF (10 it, scale 12) + SRG, batch %d" % B,
+                      "per_gpu_batch": B},
+           "supervision_only_ms": e0.elapsed_time(e1) / 10,
+           "backbone_forward_tflops": count_flops_per_image() * B * args.steps / dt / 1e12,
+           "grown_seed_pixels": int(seeds.sum().item() - cues.sum().item())}
+    print(json.dumps(out))
+
+
 def fp32_leg(device, images, labels, cues, steps, warmup=3):
     """the same train-s step with the backbone in float32 (the reference's Caffe arithmetic, train-s.prototxt:41-744):
     ms per step at this batch size, timed like the headline (synchronised brackets)"""
@@ -243,8 +296,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU (weak scaling)")
-    ap.add_argument("--mode", choices=["train", "supervision", "train-f", "crf-fullres"], default="train",
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 16, 1 for --mode infer")
+    ap.add_argument("--mode", choices=["train", "supervision", "train-f", "crf-fullres", "infer"], default="train",
                     help="train = seed_mc train-s step (the headline metric); supervision = hot path on fixed logits; "
                          "train-f = stage-2 retrain step (no SRG/CRF inside; BASELINE.json configs[4] with "
                          "--backbone resnet101 --size 513)")
@@ -273,8 +326,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
 
-    if args.mode == "crf-fullres":
-        run_crf_fullres(args, device, rank)
+    if args.batch is None:
+        args.batch = 1 if args.mode == "infer" else 16
+    if args.mode in ("crf-fullres", "infer"):
+        (run_crf_fullres if args.mode == "crf-fullres" else run_infer)(args, device, rank)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
