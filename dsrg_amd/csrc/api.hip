@@ -243,17 +243,28 @@ extern "C" int dsrg_crf_prepare_batch(dsrg_ctx_t c, int B, const float *images, 
 
 extern "C" int dsrg_crf_refine_batch(dsrg_ctx_t c, int B, float *probs, const float *images, int img_h, int img_w,
                                      const dsrg_crf_params *prm, double *refined, float *logq, void *stream) {
-    if (!c || !probs || !images || !refined) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (!c || !probs || !refined) return set_error(DSRG_ERR_INVALID, "NULL argument");
     if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
-    if (img_h < 1 || img_w < 1) return set_error(DSRG_ERR_INVALID, "bad image size");
     int rc = check_params(prm);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool prepared = images == nullptr;      // lattices were built by dsrg_crf_prepare_batch
+    if (prepared) {
+        if (c->prepared_B != B || memcmp(&c->prepared_prm, prm, offsetof(dsrg_crf_params, n_iters)) != 0)
+            return set_error(DSRG_ERR_INVALID, "images_dev is NULL but dsrg_crf_prepare_batch was not called "
+                                               "for this batch size / these kernel parameters");
+    } else if (img_h < 1 || img_w < 1) {
+        return set_error(DSRG_ERR_INVALID, "bad image size");
+    }
     rc = launch_clip_min(probs, (size_t)B * c->C * c->N, s);                    // pylayers.py:67
     if (rc) return rc;
-    rc = launch_prepare_images(images, B, img_h, img_w, c->H, c->W, c->im_u8, s);   // pylayers.py:70-75
-    if (rc) return rc;
-    return crf_run(c, B, probs, c->im_u8, prm, nullptr, refined, logq, s);    // CRF.py:28: -(-unary) = probs
+    if (!prepared) {
+        rc = launch_prepare_images(images, B, img_h, img_w, c->H, c->W, c->im_u8, s);   // pylayers.py:70-75
+        if (rc) return rc;
+    } else {
+        c->prepared_B = 0;                                                        // consumed
+    }
+    return crf_run(c, B, probs, c->im_u8, prm, nullptr, refined, logq, s, prepared);    // CRF.py:28: -(-unary) = probs
 }
 
 extern "C" int dsrg_crf_meanfield_batch(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,

@@ -118,11 +118,12 @@ def softmax_backward(x, top_diff):
     return dx
 
 
-def crf_refine(probs, images, scale_factor=12.0, maxiter=10, ctx=None, want_log=True):
+def crf_refine(probs, images, scale_factor=12.0, maxiter=10, ctx=None, want_log=True, prepared=False):
     """CRFLayer.forward / DSRGLayer.refinement (pylayers.py:63-88,310-331).
 
     probs (B,C,H,W) f32 is clipped IN PLACE (as the reference does to its bottom blob);
-    returns (refined float64 (B,C,H,W), log-marginals float32 or None)."""
+    returns (refined float64 (B,C,H,W), log-marginals float32 or None).  prepared: the lattices of `images` were built
+    by crf_prepare on this context (e.g. on a side stream under the backbone forward)."""
     _f32c(probs, "probs"), _f32c(images, "images")
     B, C, H, W = probs.shape
     if images.shape[0] != B or images.shape[1] != 3:
@@ -131,8 +132,8 @@ def crf_refine(probs, images, scale_factor=12.0, maxiter=10, ctx=None, want_log=
     refined = torch.empty((B, C, H, W), dtype=torch.float64, device=probs.device)
     logq = torch.empty_like(probs) if want_log else None
     prm = CrfParams.from_crf_args(maxiter, scale_factor)
-    check(_lib.lib().dsrg_crf_refine_batch(ctx._h, B, _ptr(probs), _ptr(images), images.shape[2], images.shape[3],
-                                           ctypes.byref(prm), _ptr(refined), _ptr(logq), _stream()))
+    check(_lib.lib().dsrg_crf_refine_batch(ctx._h, B, _ptr(probs), None if prepared else _ptr(images), images.shape[2],
+                                           images.shape[3], ctypes.byref(prm), _ptr(refined), _ptr(logq), _stream()))
     return refined, logq
 
 

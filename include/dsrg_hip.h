@@ -111,7 +111,8 @@ int dsrg_ctx_destroy(dsrg_ctx_t ctx);
  *               (H,W) with the align-corners order-1 zoom, + mean pixel
  *               (104,117,123), round-half-even, cast to uint8 (pylayers.py:70-75)
  *   refined_dev (B,C,H,W) f64   clip(Q,1e-4)/sum  (pylayers.py:84-86) = self.result
- *   logq_dev    (B,C,H,W) f32   log(refined)      (pylayers.py:88); may be NULL */
+ *   logq_dev    (B,C,H,W) f32   log(refined)      (pylayers.py:88); may be NULL
+ * images_dev may be NULL when dsrg_crf_prepare_batch has been called for this batch (see below). */
 int dsrg_crf_refine_batch(dsrg_ctx_t ctx, int B, float *probs_dev, const float *images_dev,
                           int img_h, int img_w, const dsrg_crf_params *params,
                           double *refined_dev, float *logq_dev, void *stream);

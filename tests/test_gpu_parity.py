@@ -363,6 +363,15 @@ def test_prepared_lattices_on_side_stream(ops):
     from dsrg_amd import _lib
     with pytest.raises(_lib.DsrgError):                      # prepared lattices are single-use
         ops.supervision_step(*args, ctx=ctx, prepared=True)
+    # the same for the CRF layer alone (bench.py --mode infer)
+    from oracle import oracle as O
+    probs = O.softmax_forward(b["logits"])
+    r0, q0 = ops.crf_refine(dev(probs), args[1], ctx=ctx)
+    with torch.cuda.stream(side):
+        ops.crf_prepare(args[1], 21, 41, 41, ctx=ctx)
+    torch.cuda.current_stream().wait_stream(side)
+    r1, q1 = ops.crf_refine(dev(probs), args[1], ctx=ctx, prepared=True)
+    assert torch.equal(r0, r1) and torch.equal(q0, q1)
 
 
 def test_autograd_function(ops):
