@@ -12,6 +12,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+import os as _os
+# output channels from which the weight gradient of a 3x3 convolution at the 41x41 stages is the GEMM im2col(x)^T @ g
+# (tools/wgrad_ab.sh measures the alternatives)
+_WGRAD_MIN_COUT = int(_os.environ.get("DSRG_WGRAD_MIN_COUT", "512"))
+_WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
+
+
 def _im2col_gemm(x, weight, bias, dilation, relu, want_cols=False):
     """(B,C,H,W) bf16 -> conv(+ReLU) output as a channels_last tensor: NHWC im2col (HIP) + one hipBLASLt GEMM whose
     epilogue adds the bias (and applies the ReLU)."""
@@ -58,7 +65,7 @@ class _ConvFn(torch.autograd.Function):
         cols = None
         if gemm:
             # the im2col matrix is kept for the layers whose weight gradient is a GEMM too (see backward)
-            keep = k == 3 and weight.shape[0] >= 1024 and x.shape[1] % 8 == 0 and x.shape[2] * x.shape[3] <= 2048
+            keep = k == 3 and weight.shape[0] >= _WGRAD_MIN_COUT and x.shape[1] % 8 == 0 and x.shape[2] * x.shape[3] <= 2048
             out = _im2col_gemm(x, weight, bias, dilation, relu, want_cols=keep)
             if keep:
                 out, cols = out
@@ -104,10 +111,12 @@ class _ConvFn(torch.autograd.Function):
             gx = col2im3x3_nhwc(torch.mm(g.permute(0, 2, 3, 1).reshape(-1, cout), wmat.t()), B_, H_, W_, cin, ctx.dilation)
         elif gemm_dgrad:
             gx = _im2col_gemm(g, weight.flip(2, 3).transpose(0, 1), None, ctx.dilation, False)
-        # weight gradient = im2col(x)^T @ g, again one hipBLASLt GEMM (K = B*H*W).  Only where MIOpen's wrw is slow: the
-        # 512 -> 1024 dilated fc6 layers (650 TFLOP/s; measured 883 -> 902 images/s); at 512 -> 512 MIOpen already runs
-        # at ~1 PFLOP/s and the GEMM route loses (864 images/s with it everywhere)
-        gemm_wgrad = gemm_dgrad and x.shape[1] % 8 == 0 and cout >= 1024
+        # weight gradient = im2col(x)^T @ g, again one hipBLASLt GEMM (K = B*H*W), for the 41x41 layers with >= 512 output
+        # channels: the 512 -> 1024 dilated fc6 layers (MIOpen's wrw 650 TFLOP/s there; 883 -> 902 images/s in round 1) and,
+        # since the hipBLASLt solutions are picked by TunableOp, the 512 -> 512 / 256 -> 512 layers too (round 2, A/B on one
+        # box: 932.8 / 931.4 images/s with the 1024 threshold, 939.9 / 938.9 with 512, 934.1 / 932.4 with 256; the transposed
+        # product g^T @ im2col(x) another +0.6 %)
+        gemm_wgrad = gemm_dgrad and x.shape[1] % 8 == 0 and cout >= _WGRAD_MIN_COUT
         gw = None
         if gemm_wgrad:
             cin = x.shape[1]
@@ -115,7 +124,10 @@ class _ConvFn(torch.autograd.Function):
                 from .ops import im2col3x3_nhwc
                 cols = im2col3x3_nhwc(x.permute(0, 2, 3, 1).contiguous(), ctx.dilation)  # (M, 9*Cin)
             g2d = g.permute(0, 2, 3, 1).reshape(-1, cout)                                # (M, Cout), NHWC memory
-            gw = torch.mm(cols.t(), g2d).view(3, 3, cin, cout).permute(3, 2, 0, 1)
+            if _WGRAD_T:
+                gw = torch.mm(g2d.t(), cols).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+            else:
+                gw = torch.mm(cols.t(), g2d).view(3, 3, cin, cout).permute(3, 2, 0, 1)
         gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
             g, x, weight, None if fused else [weight.shape[0]], [1, 1], [pad, pad],
             [ctx.dilation, ctx.dilation], False, [0, 0], 1,
