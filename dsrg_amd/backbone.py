@@ -16,6 +16,7 @@ import os as _os
 # output channels from which the weight gradient of a 3x3 convolution at the 41x41 stages is the GEMM im2col(x)^T @ g
 # (tools/wgrad_ab.sh measures the alternatives)
 _WGRAD_MIN_COUT = int(_os.environ.get("DSRG_WGRAD_MIN_COUT", "512"))
+_DIRECT_C64 = _os.environ.get("DSRG_DIRECT_C64", "1") == "1"  # conv1_2 by the direct MFMA kernel (0: MIOpen)
 _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
 
 
@@ -63,7 +64,14 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, dilation, relu, gemm, drop_p):
         k = weight.shape[2]
         cols = None
-        if gemm:
+        # 64 -> 64 channels at full resolution (conv1_2): the direct MFMA kernel (weights in registers, bias + ReLU in the
+        # epilogue; csrc/conv64.hip) — MIOpen's implicit GEMM runs this shape at ~255 TFLOP/s, the im2col route would move 1.9 GB
+        direct = _DIRECT_C64 and k == 3 and dilation == 1 and tuple(weight.shape[:2]) == (64, 64) and x.is_cuda \
+            and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+        if direct:
+            from .ops import conv3x3_c64
+            out = conv3x3_c64(x, weight, bias, relu)
+        elif gemm:
             # the im2col matrix is kept for the layers whose weight gradient is a GEMM too (see backward)
             keep = k == 3 and weight.shape[0] >= _WGRAD_MIN_COUT and x.shape[1] % 8 == 0 and x.shape[2] * x.shape[3] <= 2048
             out = _im2col_gemm(x, weight, bias, dilation, relu, want_cols=keep)
@@ -77,6 +85,7 @@ class _ConvFn(torch.autograd.Function):
             out = torch.ops.aten.native_dropout(out, drop_p, True)[0]    # out = relu * mask / (1 - p)
         ctx.save_for_backward(x, weight, out if relu else None, cols)
         ctx.dilation, ctx.k, ctx.relu, ctx.scale, ctx.gemm = dilation, k, relu, 1.0 / (1.0 - drop_p), gemm
+        ctx.direct = direct
         return out
 
     @staticmethod
@@ -102,7 +111,12 @@ class _ConvFn(torch.autograd.Function):
         gemm_dgrad = ctx.gemm and ctx.k == 3 and ctx.needs_input_grad[0] and g.dtype in (torch.bfloat16, torch.float32) \
             and cout % 8 == 0 and x.shape[2] * x.shape[3] <= 2048    # larger maps: the im2col of g costs more than it saves (measured at 81x81)
         gx = None
-        if gemm_dgrad and cout > x.shape[1] and x.shape[1] % 8 == 0 and g.dtype == torch.bfloat16:
+        if ctx.direct and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16:
+            # the data gradient is the same convolution with the kernel flipped and its channel axes swapped
+            from .ops import conv3x3_c64
+            gx = conv3x3_c64(g, weight.flip(2, 3).transpose(0, 1), None, False)
+            gemm_dgrad = True
+        elif gemm_dgrad and cout > x.shape[1] and x.shape[1] % 8 == 0 and g.dtype == torch.bfloat16:
             # more output than input channels (fc6: 1024 vs 512): g @ W^T first, then gather the nine taps (col2im) —
             # half the traffic of an im2col of the wide g
             from .ops import col2im3x3_nhwc

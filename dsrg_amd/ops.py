@@ -354,6 +354,23 @@ def avgpool3x3_s1(x):
     return out
 
 
+def conv3x3_c64(x, weight, bias=None, relu=False):
+    """3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels: x (B,64,H,W) bf16 channels_last, weight (64,64,3,3) bf16
+    (made channels_last here), bias (64) f32 or None -> (B,64,H,W) bf16 channels_last; fp32 accumulation, bias and ReLU fused"""
+    B, C, H, W = x.shape
+    cl = torch.channels_last
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and C == 64 and tuple(weight.shape) == (64, 64, 3, 3)
+            and weight.dtype == torch.bfloat16):
+        raise ValueError("conv3x3_c64 needs a bf16 CUDA input with 64 channels and a (64,64,3,3) bf16 kernel")
+    x = x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl)
+    w = weight if weight.is_contiguous(memory_format=cl) else weight.contiguous(memory_format=cl)
+    if bias is not None:
+        bias = bias.float().contiguous()
+    y = torch.empty((B, 64, H, W), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    check(_lib.lib().dsrg_conv3x3_c64_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, int(relu), _stream()))
+    return y
+
+
 def heads_forward(xs, weight, bias):
     """fc8-SEC_k + Eltwise SUM in float32: xs = list of <= 4 (B,K,H,W) bf16 channels_last activations, weight (n,O,K) f32,
     bias (n,O) f32 or None -> (B,O,H,W) float32, NCHW-contiguous (what the supervision path reads)."""
