@@ -16,7 +16,8 @@ import os as _os
 # output channels from which the weight gradient of a 3x3 convolution at the 41x41 stages is the GEMM im2col(x)^T @ g
 # (tools/wgrad_ab.sh measures the alternatives)
 _WGRAD_MIN_COUT = int(_os.environ.get("DSRG_WGRAD_MIN_COUT", "512"))
-_DIRECT_C64 = _os.environ.get("DSRG_DIRECT_C64", "1") == "1"  # conv1_2 by the direct MFMA kernel (0: MIOpen)
+# conv1_2 / conv2_1 / conv2_2 by the direct MFMA kernel: "1" all of them, "64" only conv1_2, "0" none (MIOpen / im2col + GEMM)
+_DIRECT_CONV = _os.environ.get("DSRG_DIRECT_CONV", "1")
 _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
 
 
@@ -64,13 +65,15 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, dilation, relu, gemm, drop_p):
         k = weight.shape[2]
         cols = None
-        # 64 -> 64 channels at full resolution (conv1_2): the direct MFMA kernel (weights in registers, bias + ReLU in the
-        # epilogue; csrc/conv64.hip) — MIOpen's implicit GEMM runs this shape at ~255 TFLOP/s, the im2col route would move 1.9 GB
-        direct = _DIRECT_C64 and k == 3 and dilation == 1 and tuple(weight.shape[:2]) == (64, 64) and x.is_cuda \
-            and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+        # 64 / 128 channels on both sides (conv1_2 at full resolution, conv2_1 / conv2_2 at half): the direct MFMA kernel
+        # (weights in registers, bias + ReLU in the epilogue; csrc/conv_direct.hip) — MIOpen's implicit GEMM runs conv1_2 at
+        # ~255 TFLOP/s, the im2col route would move 1.9 GB there and 0.96 GB for conv2_2
+        shape = tuple(weight.shape[:2])
+        direct = k == 3 and dilation == 1 and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and (
+            (_DIRECT_CONV == "1" and shape[0] in (64, 128) and shape[1] in (64, 128)) or (_DIRECT_CONV == "64" and shape == (64, 64)))
         if direct:
-            from .ops import conv3x3_c64
-            out = conv3x3_c64(x, weight, bias, relu)
+            from .ops import conv3x3_direct
+            out = conv3x3_direct(x, weight, bias, relu)
         elif gemm:
             # the im2col matrix is kept for the layers whose weight gradient is a GEMM too (see backward)
             keep = k == 3 and weight.shape[0] >= _WGRAD_MIN_COUT and x.shape[1] % 8 == 0 and x.shape[2] * x.shape[3] <= 2048
@@ -113,8 +116,8 @@ class _ConvFn(torch.autograd.Function):
         gx = None
         if ctx.direct and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16:
             # the data gradient is the same convolution with the kernel flipped and its channel axes swapped
-            from .ops import conv3x3_c64
-            gx = conv3x3_c64(g, weight.flip(2, 3).transpose(0, 1), None, False)
+            from .ops import conv3x3_direct
+            gx = conv3x3_direct(g, weight.flip(2, 3).transpose(0, 1), None, False)
             gemm_dgrad = True
         elif gemm_dgrad and cout > x.shape[1] and x.shape[1] % 8 == 0 and g.dtype == torch.bfloat16:
             # more output than input channels (fc6: 1024 vs 512): g @ W^T first, then gather the nine taps (col2im) —

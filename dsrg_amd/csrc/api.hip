@@ -437,10 +437,10 @@ extern "C" int dsrg_heads_forward_bf16(const void *const *x_dev, int n_branches,
         if (!x_dev[k]) return set_error(DSRG_ERR_INVALID, "NULL branch input");
     return launch_heads_fwd(x_dev, n_branches, w_dev, bias_dev, out_dev, B, HW, K, O, static_cast<hipStream_t>(stream));
 }
-extern "C" int dsrg_conv3x3_c64_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int B, int H, int W,
-                                     int relu, void *stream) {
+extern "C" int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int B, int H,
+                                        int W, int cin, int cout, int relu, void *stream) {
     if (!x_dev || !w_dev || !y_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
-    return launch_conv3x3_c64(x_dev, w_dev, bias_dev, y_dev, B, H, W, relu, static_cast<hipStream_t>(stream));
+    return launch_conv3x3_direct(x_dev, w_dev, bias_dev, y_dev, B, H, W, cin, cout, relu, static_cast<hipStream_t>(stream));
 }
 extern "C" int dsrg_heads_backward_chunks(int M) { return heads_bwd_chunks(M); }
 extern "C" int dsrg_heads_backward_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *g_dev,

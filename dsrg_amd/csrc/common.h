@@ -142,8 +142,9 @@ int launch_avgpool3x3_s1(const void *in, void *out, int B, int H, int W, int C, 
 int launch_bias_grad(const void *g, float *bias_grad, float *part, int part_blocks, long rows, int C, hipStream_t stream);
 int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float *bias, float *out, int B, int HW, int K, int O,
                      hipStream_t stream);
-int launch_conv3x3_c64(const void *x, const void *w, const float *bias, void *y, int B, int H, int W, int relu,
-                       hipStream_t stream);
+bool conv3x3_direct_supported(int cin, int cout);
+int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void *y, int B, int H, int W, int cin, int cout,
+                          int relu, hipStream_t stream);
 int heads_bwd_chunks(int M);
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
                      float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream);

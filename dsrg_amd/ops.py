@@ -354,20 +354,25 @@ def avgpool3x3_s1(x):
     return out
 
 
-def conv3x3_c64(x, weight, bias=None, relu=False):
-    """3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels: x (B,64,H,W) bf16 channels_last, weight (64,64,3,3) bf16
-    (made channels_last here), bias (64) f32 or None -> (B,64,H,W) bf16 channels_last; fp32 accumulation, bias and ReLU fused"""
+DIRECT_CONV_CHANNELS = (64, 128)
+
+
+def conv3x3_direct(x, weight, bias=None, relu=False):
+    """3x3 / stride 1 / pad 1 convolution with 64 or 128 channels on either side: x (B,cin,H,W) bf16 channels_last, weight
+    (cout,cin,3,3) bf16 (made channels_last here), bias (cout) f32 or None -> (B,cout,H,W) bf16 channels_last; fp32
+    accumulation, bias and ReLU fused"""
     B, C, H, W = x.shape
     cl = torch.channels_last
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and C == 64 and tuple(weight.shape) == (64, 64, 3, 3)
-            and weight.dtype == torch.bfloat16):
-        raise ValueError("conv3x3_c64 needs a bf16 CUDA input with 64 channels and a (64,64,3,3) bf16 kernel")
+    cout = weight.shape[0]
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and tuple(weight.shape) == (cout, C, 3, 3)
+            and C in DIRECT_CONV_CHANNELS and cout in DIRECT_CONV_CHANNELS):
+        raise ValueError("conv3x3_direct needs a bf16 CUDA input and a (cout,cin,3,3) bf16 kernel with cin, cout in (64, 128)")
     x = x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl)
     w = weight if weight.is_contiguous(memory_format=cl) else weight.contiguous(memory_format=cl)
     if bias is not None:
         bias = bias.float().contiguous()
-    y = torch.empty((B, 64, H, W), dtype=torch.bfloat16, device=x.device, memory_format=cl)
-    check(_lib.lib().dsrg_conv3x3_c64_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, int(relu), _stream()))
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    check(_lib.lib().dsrg_conv3x3_direct_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, C, cout, int(bool(relu)), _stream()))
     return y
 
 

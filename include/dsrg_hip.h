@@ -218,13 +218,14 @@ int dsrg_bias_grad_bf16(const void *g_dev, float *bias_grad_dev, float *partials
 /* 3x3 / stride 1 / pad 1 average pooling over padded windows (Caffe AVE pooling, pool5a of train-s.prototxt), NHWC bf16,
  * C % 8 == 0.  The stencil is symmetric: the backward pass is the same call on the output gradient. */
 int dsrg_avgpool3x3_s1_bf16(const void *in_dev, void *out_dev, int B, int H, int W, int C, void *stream);
-/* Direct 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (conv1_2 of train-s.prototxt:65-98 at
- * full resolution), NHWC bf16 in and out, fp32 accumulation, optional bias (64 f32) and ReLU in the epilogue:
+/* Direct 3x3 / stride 1 / pad 1 convolution for the narrow layers at the large resolutions: cin, cout in {64, 128}
+ * (conv1_2 at 321x321, conv2_1 / conv2_2 at 161x161 of train-s.prototxt:65-160), NHWC bf16 in and out, fp32
+ * accumulation, optional bias (cout f32) and ReLU in the epilogue:
  *   y[b,y,x,o] = relu?( bias[o] + sum_{dy,dx,c} w[o][dy+1][dx+1][c] * x[b,y+dy,x+dx,c] )
- * w_dev: (64, 3, 3, 64) bf16 = the memory of a channels_last (out, in, 3, 3) tensor.  With the kernel flipped and its
- * channel axes swapped the same call is the data gradient of that convolution. */
-int dsrg_conv3x3_c64_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int B, int H, int W,
-                          int relu, void *stream);
+ * w_dev: (cout, 3, 3, cin) bf16 = the memory of a channels_last (out, in, 3, 3) tensor.  With the kernel flipped and its
+ * channel axes swapped the same call is the data gradient of that convolution.  Other channel counts: DSRG_ERR_INVALID. */
+int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int B, int H, int W,
+                             int cin, int cout, int relu, void *stream);
 /* The four fc8-SEC_k 1x1 classifiers and their Eltwise SUM (train-s.prototxt:461-744) in one pass with float32 weights,
  * float32 accumulation and a float32 NCHW result: out[b][o][hw] = sum_k ( x_k[(b,hw)][:] . w[k][o][:] + bias[k][o] ).
  * x_dev: host array of n_branches (<= 4) device pointers to (B*HW, K) bf16 row-major (NHWC) activations; w_dev

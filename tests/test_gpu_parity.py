@@ -644,30 +644,32 @@ def test_fp32_heads_kernel_matches_fp32_convolutions(ops):
             assert u.grad.dtype == torch.bfloat16 and (u.grad.float() - v.grad).norm() <= 0.005 * v.grad.norm()   # one bf16 rounding
 
 
-def test_direct_conv_c64_matches_torch(ops):
-    """the direct 64 -> 64 3x3 convolution (one MFMA kernel, weights in registers) against F.conv2d in fp32 on the same
-    bf16-valued operands: odd sizes, partial tiles, bias / ReLU, and the data-gradient form (flipped, transposed kernel)"""
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 128), (128, 64)])
+def test_direct_conv_matches_torch(ops, cin, cout):
+    """the direct 3x3 convolutions (one MFMA kernel, weights in registers) against F.conv2d in fp32 on the same bf16-valued
+    operands: odd sizes, partial tiles, bias / ReLU, and the data-gradient form (flipped, transposed kernel)"""
     import torch.nn.functional as F
     torch.manual_seed(11)
     cl = torch.channels_last
-    for B, H, W, relu, bias in [(2, 33, 29, True, True), (1, 8, 16, False, False), (3, 1, 1, True, True), (1, 321, 321, True, True),
-                                (2, 17, 40, False, True)]:
-        x = torch.randn(B, 64, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
-        w = (torch.randn(64, 64, 3, 3, device="cuda") * 0.05).bfloat16()
-        b = torch.randn(64, device="cuda") if bias else None
+    big = (1, 321, 321, True, True) if cin == 64 and cout == 64 else (2, 161, 161, True, True)
+    for B, H, W, relu, bias in [(2, 33, 29, True, True), (1, 8, 16, False, False), (3, 1, 1, True, True), big, (2, 17, 40, False, True)]:
+        x = torch.randn(B, cin, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        w = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).bfloat16()
+        b = torch.randn(cout, device="cuda") if bias else None
         want = F.conv2d(x.float(), w.float(), b, padding=1)
         if relu:
             want = torch.relu(want)
-        got = ops.conv3x3_c64(x, w, b, relu)
+        got = ops.conv3x3_direct(x, w, b, relu)
         assert got.shape == want.shape and got.dtype == torch.bfloat16 and got.is_contiguous(memory_format=cl)
         err = (got.float() - want).abs().max()
         assert err <= 0.01 * want.abs().max() + 1e-3, (B, H, W, float(err), float(want.abs().max()))
-        assert torch.equal(got, ops.conv3x3_c64(x, w, b, relu))                       # deterministic
+        assert torch.equal(got, ops.conv3x3_direct(x, w, b, relu))                    # deterministic
         # data gradient of y = conv(x, w): conv(g, flip(w)^T)
-        g = torch.randn(B, 64, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        g = torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
         xr = x.float().requires_grad_(True)
         F.conv2d(xr, w.float(), None, padding=1).backward(g.float())
-        gx = ops.conv3x3_c64(g, w.flip(2, 3).transpose(0, 1).contiguous(), None, False)
+        gx = ops.conv3x3_direct(g, w.flip(2, 3).transpose(0, 1).contiguous(), None, False)
+        assert gx.shape == x.shape
         assert (gx.float() - xr.grad).abs().max() <= 0.01 * xr.grad.abs().max() + 1e-3
 
 
