@@ -18,6 +18,7 @@ import os as _os
 _WGRAD_MIN_COUT = int(_os.environ.get("DSRG_WGRAD_MIN_COUT", "512"))
 # conv1_2 / conv2_1 / conv2_2 by the direct MFMA kernel: "1" all of them, "64" only conv1_2, "0" none (MIOpen / im2col + GEMM)
 _DIRECT_CONV = _os.environ.get("DSRG_DIRECT_CONV", "1")
+_DIRECT_WGRAD = _os.environ.get("DSRG_DIRECT_WGRAD", "1") == "1"   # their weight gradients by the direct kernel too (0: MIOpen)
 _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
 
 
@@ -135,7 +136,12 @@ class _ConvFn(torch.autograd.Function):
         # product g^T @ im2col(x) another +0.6 %)
         gemm_wgrad = gemm_dgrad and x.shape[1] % 8 == 0 and cout >= _WGRAD_MIN_COUT
         gw = None
-        if gemm_wgrad:
+        if ctx.direct and _DIRECT_WGRAD and g.dtype == torch.bfloat16 and (x.shape[1], cout) in ((64, 64), (64, 128), (128, 128)):
+            # the narrow full-resolution layers again: MIOpen's wrw kernels run them at ~250 TFLOP/s (conv1_2: 0.48 ms)
+            from .ops import conv3x3_wgrad
+            gw = conv3x3_wgrad(x, g)
+            gemm_wgrad = True
+        elif gemm_wgrad:
             cin = x.shape[1]
             if cols is None or cols.dtype != g.dtype:
                 from .ops import im2col3x3_nhwc
@@ -145,10 +151,12 @@ class _ConvFn(torch.autograd.Function):
                 gw = torch.mm(g2d.t(), cols).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
             else:
                 gw = torch.mm(cols.t(), g2d).view(3, 3, cin, cout).permute(3, 2, 0, 1)
-        gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
-            g, x, weight, None if fused else [weight.shape[0]], [1, 1], [pad, pad],
-            [ctx.dilation, ctx.dilation], False, [0, 0], 1,
-            [ctx.needs_input_grad[0] and not gemm_dgrad, not gemm_wgrad, not fused])
+        mask = [ctx.needs_input_grad[0] and not gemm_dgrad, not gemm_wgrad, not fused]
+        gx2 = gw2 = gb2 = None
+        if any(mask):
+            gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
+                g, x, weight, None if fused else [weight.shape[0]], [1, 1], [pad, pad],
+                [ctx.dilation, ctx.dilation], False, [0, 0], 1, mask)
         return (gx if gemm_dgrad else gx2), (gw if gemm_wgrad else gw2), (gb if fused else gb2), None, None, None, None
 
 

@@ -442,6 +442,15 @@ extern "C" int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, co
     if (!x_dev || !w_dev || !y_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
     return launch_conv3x3_direct(x_dev, w_dev, bias_dev, y_dev, B, H, W, cin, cout, relu, static_cast<hipStream_t>(stream));
 }
+extern "C" size_t dsrg_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
+    return conv3x3_wgrad_workspace(B, H, W, cin, cout);
+}
+extern "C" int dsrg_conv3x3_wgrad_bf16(const void *x_dev, const void *g_dev, void *gw_dev, void *workspace_dev, size_t workspace_bytes,
+                                       int B, int H, int W, int cin, int cout, void *stream) {
+    if (!x_dev || !g_dev || !gw_dev || !workspace_dev) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return launch_conv3x3_wgrad(x_dev, g_dev, gw_dev, static_cast<float *>(workspace_dev), workspace_bytes, B, H, W, cin, cout,
+                                static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_heads_backward_chunks(int M) { return heads_bwd_chunks(M); }
 extern "C" int dsrg_heads_backward_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *g_dev,
                                         void *gx_dev, size_t gx_branch_stride_bytes, float *gw_dev, float *partial_dev, int B,

@@ -143,6 +143,9 @@ int launch_bias_grad(const void *g, float *bias_grad, float *part, int part_bloc
 int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float *bias, float *out, int B, int HW, int K, int O,
                      hipStream_t stream);
 bool conv3x3_direct_supported(int cin, int cout);
+size_t conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout);
+int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspace, size_t workspace_bytes, int B, int H, int W,
+                         int cin, int cout, hipStream_t stream);
 int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void *y, int B, int H, int W, int cin, int cout,
                           int relu, hipStream_t stream);
 int heads_bwd_chunks(int M);

@@ -225,7 +225,251 @@ int launch_variant(const ConvArgs &a, int n_cus, hipStream_t stream) {
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers: gw[o][tap][c] = sum over pixels of g[px][o] * x[px + tap][c], a GEMM whose reduction
+// runs over the pixels — the slow axis of both NHWC operands.  gfx950's transposing LDS read (ds_read_b64_tr_b16: a
+// 16-lane group reads a [4 pixels][16 channels] block, lane i supplying the 8-byte address of row i / 4, chunk i % 4, and
+// lane c receiving column c) turns the plain NHWC tiles in LDS into MFMA fragments with 8 consecutive pixels per lane, so
+// the tiles are staged exactly as in the forward kernel (a 10 x 18 halo of x, the 8 x 16 tile of g) and the nine taps are
+// nine pixel offsets into the same x tile.  Pixel strides of 64 bytes (mod 256) keep the four rows of a read on distinct
+// bank quarters.
+//
+// Work split: the reduction is split over persistent workgroups, each accumulating its partial gw for a 64-channel slice of
+// x in registers across all its tiles: a wave owns 32 channels of g x 32 channels of x x 9 taps = 144 accumulator VGPRs, a
+// workgroup has one wave per pair (4 waves for 64-channel g, 8 for 128: two waves per SIMD); 128-channel x is two slices
+// handled by alternating workgroups.
+// The partials (one per workgroup) are summed in a fixed order by a second kernel that also rounds to bf16: deterministic.
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
+#define DSRG_LDS __attribute__((address_space(3)))
+
+template <int CO_TILES> struct WCfg {                      // CO_TILES = channels of g / 32 (2 or 4)
+    static constexpr int COUT = 32 * CO_TILES;
+    static constexpr int THREADS = CO_TILES * 128;         // one wave per (32 channels of g, 32 of the 64 channels of x)
+    static constexpr int NT = 9;                           // accumulator tiles per wave: the taps
+    static constexpr int SX = 192;                         // bytes per halo pixel of the x slice (128 + 64)
+    static constexpr int SG = COUT * 2 + 64;               // bytes per pixel of g (192 / 320)
+    static constexpr int X_BYTES = kHH * kHW * SX, G_BYTES = kTH * kTW * SG, BUF = X_BYTES + G_BYTES;
+    static constexpr int XV = kHH * kHW * 8, XVT = (XV + THREADS - 1) / THREADS;   // 16-byte vectors of the x tile, per thread (6 / 3)
+    static constexpr int GVP = COUT / 8, GVT = kTH * kTW * GVP / THREADS;          // of the g tile (4)
+    static constexpr int PART = COUT * 9 * 64;             // floats of one workgroup's partial
+};
+
+struct WgradArgs {
+    const uint16_t *x;      // (B, H, W, cin) bf16
+    const uint16_t *g;      // (B, H, W, cout) bf16
+    float *part;            // (workgroups, cout, 9, 64) f32
+    int B, H, W, cin, tiles_x, tiles_y, nitems, roles;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(DSRG_LDS unsigned char *p, int stride4) {
+    bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<DSRG_LDS bf16x4v *>(p));
+    bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<DSRG_LDS bf16x4v *>(p + stride4));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int CO_TILES>
+__global__ __launch_bounds__(CO_TILES * 128) void conv3x3_wgrad_kernel(WgradArgs a) {
+    using C = WCfg<CO_TILES>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char conv_lds[];
+    DSRG_LDS unsigned char *lds = (DSRG_LDS unsigned char *)conv_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, gq = lane >> 4;
+    const int otile = wave % CO_TILES;                             // this wave's 32 channels of g
+    const int ct0 = wave / CO_TILES;                               // its 32-channel tile of the x slice
+    const int role = blockIdx.x % a.roles;                         // the 64-channel slice of x this workgroup reduces
+    // the address this lane supplies to a transposing read: pixel (gq / 2) * 8 + i16 / 4 of the k-step (the second read of a
+    // fragment 4 pixels further), channels (gq % 2) * 16 + 4 (i16 % 4) .. + 3 of the 32-channel tile
+    const int rowsel = (gq >> 1) * 8 + (i16 >> 2), colsel = (gq & 1) * 16 + 4 * (i16 & 3);
+    const int x_lane = rowsel * C::SX + (ct0 * 32 + colsel) * 2;
+    const int g_lane = C::X_BYTES + rowsel * C::SG + (otile * 32 + colsel) * 2;
+
+    auto tile_origin = [&](int item, int &b, int &y0, int &x0) {
+        const int t = item / a.roles, per = a.tiles_x * a.tiles_y;
+        b = t / per;
+        const int r = t - b * per;
+        y0 = (r / a.tiles_x) * kTH;
+        x0 = (r % a.tiles_x) * kTW;
+    };
+    uint4 prx[C::XVT], prg[C::GVT];
+    auto fetch = [&](int item) {
+        int b, y0, x0;
+        tile_origin(item, b, y0, x0);
+#pragma unroll
+        for (int u = 0; u < C::XVT; u++) {
+            const int v = tid + u * C::THREADS;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (v < C::XV) {
+                const int px = v >> 3, cg = v & 7, hy = px / kHW, hx = px - hy * kHW;
+                const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+                    val = *reinterpret_cast<const uint4 *>(a.x + (((size_t)b * a.H + yy) * a.W + xx) * a.cin + role * 64 + cg * 8);
+            }
+            prx[u] = val;
+        }
+#pragma unroll
+        for (int u = 0; u < C::GVT; u++) {
+            const int v = tid + u * C::THREADS, px = v / C::GVP, cg = v % C::GVP;
+            const int yy = y0 + (px >> 4), xx = x0 + (px & 15);
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);                 // pixels past the image edge add nothing
+            if (yy < a.H && xx < a.W)
+                val = *reinterpret_cast<const uint4 *>(a.g + (((size_t)b * a.H + yy) * a.W + xx) * C::COUT + cg * 8);
+            prg[u] = val;
+        }
+    };
+    auto park = [&](unsigned char *buf) {
+#pragma unroll
+        for (int u = 0; u < C::XVT; u++) {
+            const int v = tid + u * C::THREADS;
+            if (v < C::XV) *reinterpret_cast<uint4 *>(buf + (v >> 3) * C::SX + (v & 7) * 16) = prx[u];
+        }
+#pragma unroll
+        for (int u = 0; u < C::GVT; u++) {
+            const int v = tid + u * C::THREADS;
+            *reinterpret_cast<uint4 *>(buf + C::X_BYTES + (v / C::GVP) * C::SG + (v % C::GVP) * 16) = prg[u];
+        }
+    };
+
+    f32x16 acc[C::NT];
+#pragma unroll
+    for (int n = 0; n < C::NT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.0f;
+
+    int item = blockIdx.x, cur = 0;
+    if (item < a.nitems) {
+        fetch(item);
+        park(conv_lds);
+    }
+    __syncthreads();
+    for (; item < a.nitems; item += gridDim.x) {
+        const int nxt = item + gridDim.x;
+        const bool more = nxt < a.nitems;
+        if (more) fetch(nxt);                                    // the next tiles on their way while this one is reduced
+        DSRG_LDS unsigned char *in = lds + cur * C::BUF;
+        DSRG_LDS unsigned char *xb = in + x_lane, *gb = in + g_lane;
+        // k-step ks = tile row ks of g (16 pixels); accumulator tile = tap (dy, dx): its x fragment starts at halo pixel
+        // (ks + dy, dx).  So the loop runs over the ten halo rows R: the three fragments of row R (dx = 0, 1, 2) are read
+        // once and meet the g fragments of rows R, R - 1, R - 2 (dy = 0, 1, 2) — 76 transposing reads per tile instead of 160.
+        // The reads of row R + 1 are issued before the MFMAs of row R (see the forward kernel).
+        bf16x8 ga[4], bx[2][3];
+        ga[0] = tr_frag(gb, 4 * C::SG);
+#pragma unroll
+        for (int u = 0; u < 3; u++) bx[0][u] = tr_frag(xb + u * C::SX, 4 * C::SX);
+#pragma unroll
+        for (int R = 0; R < kHH; R++) {
+            if (R + 1 < kHH) {
+#pragma unroll
+                for (int u = 0; u < 3; u++) bx[(R + 1) & 1][u] = tr_frag(xb + ((R + 1) * kHW + u) * C::SX, 4 * C::SX);
+                if (R + 1 < kTH) ga[(R + 1) & 3] = tr_frag(gb + (R + 1) * kTW * C::SG, 4 * C::SG);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const int ks = R - dy;
+                if (ks >= 0 && ks < kTH) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; dx++)
+                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks & 3], bx[R & 1][dx], acc[dy * 3 + dx], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) park(conv_lds + (cur ^ 1) * C::BUF);
+        __syncthreads();                                         // the other buffer is complete, this one is free
+        cur ^= 1;
+    }
+    // C[row = channel of g][col = channel of x]: lane holds column lane % 32, rows (reg & 3) + 8 (reg >> 2) + 4 (lane / 32)
+    float *pp = a.part + (size_t)blockIdx.x * C::PART;
+#pragma unroll
+    for (int n = 0; n < C::NT; n++) {
+        const int tap = n, c = ct0 * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = otile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            pp[(o * 9 + tap) * 64 + c] = acc[n][r];
+        }
+    }
+}
+
+// gw[o][tap][c] (bf16, the memory of a channels_last (cout, cin, 3, 3) tensor) = sum of the partials of slice c / 64 in
+// workgroup order.  256 threads = 64 consecutive channels x 4 interleaved quarters of the workgroups.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *part, uint16_t *gw, int nwg, int roles, int cout,
+                                                                   int cin) {
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int e0 = blockIdx.x * 64;                              // first element (o, tap, c) of this block; c % 64 == 0
+    const int o = e0 / (9 * cin), rem = e0 - o * 9 * cin, tap = rem / cin, c0 = rem - tap * cin, role = c0 >> 6;
+    const size_t stride = (size_t)cout * 9 * 64;
+    const float *p = part + ((size_t)o * 9 + tap) * 64 + el;
+    float s = 0.0f;
+    for (int w = role + ch * roles; w < nwg; w += 4 * roles) s += p[(size_t)w * stride];
+    red[ch][el] = s;
+    __syncthreads();
+    if (ch == 0) {
+        const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        f32x2 v = {t, 0.0f};
+        bf16x2 bv = __builtin_convertvector(v, bf16x2);
+        gw[(size_t)e0 + el] = *reinterpret_cast<uint16_t *>(&bv);
+    }
+}
+
+template <int CO_TILES>
+int launch_wgrad_variant(const WgradArgs &a, int grid, hipStream_t stream) {
+    using C = WCfg<CO_TILES>;
+    static LdsGrant grant;
+    const size_t lds = 2 * (size_t)C::BUF;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<CO_TILES>), lds, grant)) return rc;
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<CO_TILES>), dim3(grid), dim3(C::THREADS), lds, stream, a);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+int device_cus() {
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 2) n = 256;
+        return n;
+    }();
+    return n_cus;
+}
+
+bool wgrad_supported(int cin, int cout) { return (cin == 64 && (cout == 64 || cout == 128)) || (cin == 128 && cout == 128); }
+
+// workgroups of the reduction for (B, H, W): a multiple of the slices of x
+int wgrad_grid(int B, int H, int W, int cin) {
+    const int roles = cin / 64;
+    const long items = (long)B * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH) * roles;
+    const long cap = device_cus() / roles * roles;
+    return (int)(items < cap ? items : cap);
+}
 }  // namespace
+
+size_t conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
+    if (!wgrad_supported(cin, cout) || B < 1 || H < 1 || W < 1) return 0;
+    return (size_t)wgrad_grid(B, H, W, cin) * cout * 9 * 64 * sizeof(float);
+}
+
+int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspace, size_t workspace_bytes, int B, int H, int W,
+                         int cin, int cout, hipStream_t stream) {
+    if (!wgrad_supported(cin, cout))
+        return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: %d -> %d channels is not one of 64 -> 64, 64 -> 128, 128 -> 128", cin, cout);
+    WgradArgs a;
+    a.x = static_cast<const uint16_t *>(x); a.g = static_cast<const uint16_t *>(g); a.part = workspace;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.roles = cin / 64;
+    a.tiles_x = (W + kTW - 1) / kTW; a.tiles_y = (H + kTH - 1) / kTH;
+    const long items = (long)B * a.tiles_x * a.tiles_y * a.roles;
+    if (B < 1 || H < 1 || W < 1 || items > 0x7fffffffL) return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: bad shape");
+    a.nitems = (int)items;
+    const int grid = wgrad_grid(B, H, W, cin);
+    if (workspace_bytes < conv3x3_wgrad_workspace(B, H, W, cin, cout))
+        return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: workspace of %zu bytes, %zu needed", workspace_bytes,
+                         conv3x3_wgrad_workspace(B, H, W, cin, cout));
+    if (int rc = cout == 64 ? launch_wgrad_variant<2>(a, grid, stream) : launch_wgrad_variant<4>(a, grid, stream)) return rc;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cout * 9 * cin / 64), dim3(256), 0, stream, workspace,
+                       static_cast<uint16_t *>(gw), grid, a.roles, cout, cin);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
 
 bool conv3x3_direct_supported(int cin, int cout) {
     return (cin == 64 || cin == 128) && (cout == 64 || cout == 128);
@@ -242,11 +486,7 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
     const long nt = (long)B * a.tiles_x * a.tiles_y;
     if (B < 1 || H < 1 || W < 1 || nt > 0x7fffffffL) return set_error(DSRG_ERR_INVALID, "conv3x3_direct: bad shape");
     a.ntiles = (int)nt;
-    static const int n_cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        return n;
-    }();
+    const int n_cus = device_cus();
     if (cin == 64) return cout == 64 ? launch_variant<64, 64>(a, n_cus, stream) : launch_variant<64, 128>(a, n_cus, stream);
     return cout == 64 ? launch_variant<128, 64>(a, n_cus, stream) : launch_variant<128, 128>(a, n_cus, stream);
 }

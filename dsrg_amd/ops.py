@@ -376,6 +376,31 @@ def conv3x3_direct(x, weight, bias=None, relu=False):
     return y
 
 
+WGRAD_CONV_SHAPES = ((64, 64), (64, 128), (128, 128))      # (cin, cout)
+_wgrad_ws = {}
+
+
+def conv3x3_wgrad(x, g):
+    """weight gradient of the 3x3 / stride 1 / pad 1 convolution y = conv(x, w): x (B,cin,H,W) and g = dL/dy (B,cout,H,W) bf16
+    channels_last, (cin, cout) in WGRAD_CONV_SHAPES -> (cout,cin,3,3) bf16 channels_last; fp32 accumulation, deterministic"""
+    B, cin, H, W = x.shape
+    cout = g.shape[1]
+    cl = torch.channels_last
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and tuple(g.shape) == (B, cout, H, W)
+            and (cin, cout) in WGRAD_CONV_SHAPES):
+        raise ValueError("conv3x3_wgrad needs bf16 CUDA tensors with (cin, cout) in %s" % (WGRAD_CONV_SHAPES,))
+    x = x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl)
+    g = g if g.is_contiguous(memory_format=cl) else g.contiguous(memory_format=cl)
+    need = _lib.lib().dsrg_conv3x3_wgrad_workspace(B, H, W, cin, cout)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_ws.get(key)                                          # per-stream scratch, reused across layers and steps
+    if ws is None or ws.numel() < need:
+        ws = _wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    gw = torch.empty((cout, cin, 3, 3), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    check(_lib.lib().dsrg_conv3x3_wgrad_bf16(_ptr(x), _ptr(g), _ptr(gw), _ptr(ws), ws.numel(), B, H, W, cin, cout, _stream()))
+    return gw
+
+
 def heads_forward(xs, weight, bias):
     """fc8-SEC_k + Eltwise SUM in float32: xs = list of <= 4 (B,K,H,W) bf16 channels_last activations, weight (n,O,K) f32,
     bias (n,O) f32 or None -> (B,O,H,W) float32, NCHW-contiguous (what the supervision path reads)."""

@@ -226,6 +226,14 @@ int dsrg_avgpool3x3_s1_bf16(const void *in_dev, void *out_dev, int B, int H, int
  * channel axes swapped the same call is the data gradient of that convolution.  Other channel counts: DSRG_ERR_INVALID. */
 int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int B, int H, int W,
                              int cin, int cout, int relu, void *stream);
+/* Weight gradient of the same convolution for (cin, cout) in {(64, 64), (64, 128), (128, 128)}:
+ *   gw[o][dy+1][dx+1][c] = sum_{b,y,x} g[b,y,x,o] * x[b,y+dy,x+dx,c]      (zero padding)
+ * x_dev (B,H,W,cin) and g_dev (B,H,W,cout) NHWC bf16; gw_dev (cout, 3, 3, cin) bf16 = the memory of a channels_last
+ * (out, in, 3, 3) tensor; fp32 accumulation, summed in a fixed order (deterministic).  workspace_dev: device scratch of
+ * dsrg_conv3x3_wgrad_workspace(B, H, W, cin, cout) bytes (0 = unsupported channel counts). */
+size_t dsrg_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout);
+int dsrg_conv3x3_wgrad_bf16(const void *x_dev, const void *g_dev, void *gw_dev, void *workspace_dev, size_t workspace_bytes,
+                            int B, int H, int W, int cin, int cout, void *stream);
 /* The four fc8-SEC_k 1x1 classifiers and their Eltwise SUM (train-s.prototxt:461-744) in one pass with float32 weights,
  * float32 accumulation and a float32 NCHW result: out[b][o][hw] = sum_k ( x_k[(b,hw)][:] . w[k][o][:] + bias[k][o] ).
  * x_dev: host array of n_branches (<= 4) device pointers to (B*HW, K) bf16 row-major (NHWC) activations; w_dev

@@ -673,6 +673,42 @@ def test_direct_conv_matches_torch(ops, cin, cout):
         assert (gx.float() - xr.grad).abs().max() <= 0.01 * xr.grad.abs().max() + 1e-3
 
 
+def test_lds_transposing_read_lane_map(ops):
+    """the lane map the weight-gradient kernel assumes of ds_read_b64_tr_b16, checked through the smallest case that
+    exercises it: one pixel row, delta inputs — gw[o][tap][c] must pick exactly x[px + tap][c] * g[px][o]"""
+    cl = torch.channels_last
+    for px, o, c in [(0, 0, 0), (5, 17, 33), (15, 63, 62), (9, 31, 16), (3, 48, 5)]:
+        x = torch.zeros(1, 64, 1, 16, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=cl)
+        g = torch.zeros_like(x)
+        x[0, c, 0, px] = 2.0
+        g[0, o, 0, px] = 3.0
+        gw = ops.conv3x3_wgrad(x, g).float()
+        want = torch.zeros(64, 64, 3, 3, device="cuda")
+        want[o, c, 1, 1] = 6.0                                       # only the centre tap sees the same pixel
+        assert torch.equal(gw, want), (px, o, c, gw.nonzero().tolist()[:8])
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 128)])
+def test_direct_conv_weight_gradient_matches_torch(ops, cin, cout):
+    """the direct weight-gradient kernel (transposing LDS reads + MFMA, per-workgroup partials summed in a fixed order)
+    against autograd through F.conv2d in fp32 on the same bf16-valued operands: partial tiles, one pixel, many tiles per
+    workgroup, both slices of a 128-channel input"""
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    cl = torch.channels_last
+    big = (2, 321, 321) if cin == 64 and cout == 64 else (4, 161, 161)
+    for B, H, W in [(2, 33, 29), (1, 8, 16), (3, 1, 1), (2, 17, 40), big]:
+        x = torch.randn(B, cin, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        g = (torch.randn(B, cout, H, W, device="cuda") * (torch.rand(B, cout, H, W, device="cuda") < 0.5)).bfloat16().contiguous(memory_format=cl)
+        w = torch.zeros(cout, cin, 3, 3, device="cuda", requires_grad=True)
+        F.conv2d(x.float(), w, None, padding=1).backward(g.float())
+        got = ops.conv3x3_wgrad(x, g)
+        assert got.shape == w.shape and got.dtype == torch.bfloat16
+        err = (got.float() - w.grad).abs().max()
+        assert err <= 0.006 * w.grad.abs().max() + 1e-3, (B, H, W, float(err), float(w.grad.abs().max()))   # one bf16 rounding of the sum
+        assert torch.equal(got, ops.conv3x3_wgrad(x, g))                                                    # deterministic
+
+
 def test_fused_relu_dropout_backward_matches_unfused_sequence():
     """conv + ReLU + Dropout in one autograd function: same dropout mask as F.dropout under the same seed, and the fused
     backward (one pass reading the sign of the dropped output) equals conv -> relu -> dropout differentiated by torch"""

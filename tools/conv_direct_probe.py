@@ -25,3 +25,13 @@ for cin, cout, hw in [(64, 64, 321), (64, 128, 161), (128, 128, 161), (128, 64, 
     print("%3d -> %3d @ %d: direct kernel  %.1f us  %.0f TFLOP/s  %.2f TB/s of in+out" % (cin, cout, hw, us, flops / us / 1e6, byts / us / 1e6))
     us = t(lambda: torch.relu_(F.conv2d(x, w, b.bfloat16(), padding=1)))
     print("%3d -> %3d @ %d: F.conv2d+relu  %.1f us  %.0f TFLOP/s" % (cin, cout, hw, us, flops / us / 1e6))
+print("weight gradients")
+for cin, cout, hw in [(64, 64, 321), (64, 128, 161), (128, 128, 161)]:
+    x = torch.randn(16, cin, hw, hw, device="cuda").bfloat16().contiguous(memory_format=cl)
+    g = torch.randn(16, cout, hw, hw, device="cuda").bfloat16().contiguous(memory_format=cl)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).bfloat16().contiguous(memory_format=cl)
+    flops = 2 * 16 * hw * hw * cout * 9 * cin
+    us = t(lambda: ops.conv3x3_wgrad(x, g))
+    print("%3d -> %3d @ %d: direct wgrad  %.1f us  %.0f TFLOP/s  %.2f TB/s of x+g" % (cin, cout, hw, us, flops / us / 1e6, 16 * hw * hw * (cin + cout) * 2 / us / 1e6))
+    us = t(lambda: torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+    print("%3d -> %3d @ %d: MIOpen wrw    %.1f us  %.0f TFLOP/s" % (cin, cout, hw, us, flops / us / 1e6))
