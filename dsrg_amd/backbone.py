@@ -18,6 +18,7 @@ import os as _os
 _WGRAD_MIN_COUT = int(_os.environ.get("DSRG_WGRAD_MIN_COUT", "512"))
 # conv1_2 / conv2_1 / conv2_2 by the direct MFMA kernel: "1" all of them, "64" only conv1_2, "0" none (MIOpen / im2col + GEMM)
 _DIRECT_CONV = _os.environ.get("DSRG_DIRECT_CONV", "1")
+_GEMM_1X1_BWD = _os.environ.get("DSRG_GEMM_1X1_BWD", "1") == "1"   # 1x1 layers (fc7): both gradients as hipBLASLt GEMMs (0: MIOpen/CK)
 _DIRECT_WGRAD = _os.environ.get("DSRG_DIRECT_WGRAD", "1") == "1"   # their weight gradients by the direct kernel too (0: MIOpen)
 _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
 
@@ -115,7 +116,17 @@ class _ConvFn(torch.autograd.Function):
         gemm_dgrad = ctx.gemm and ctx.k == 3 and ctx.needs_input_grad[0] and g.dtype in (torch.bfloat16, torch.float32) \
             and cout % 8 == 0 and x.shape[2] * x.shape[3] <= 2048    # larger maps: the im2col of g costs more than it saves (measured at 81x81)
         gx = None
-        if ctx.direct and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16:
+        gemm_1x1 = _GEMM_1X1_BWD and ctx.gemm and ctx.k == 1 and g.dtype in (torch.bfloat16, torch.float32) and cout % 8 == 0 \
+            and x.shape[1] % 8 == 0 and g.dtype == x.dtype
+        if gemm_1x1:
+            # fc7 (1024 -> 1024, 1x1): both gradients are plain GEMMs over the NHWC matrices (MIOpen's wrw 120 us and CK's dgrad
+            # 98 us per branch at 56 GFLOP each)
+            cin = x.shape[1]
+            g2d = g.permute(0, 2, 3, 1).reshape(-1, cout)
+            if ctx.needs_input_grad[0]:
+                gx = torch.mm(g2d, weight.reshape(cout, cin)).view(x.shape[0], x.shape[2], x.shape[3], cin).permute(0, 3, 1, 2)
+            gemm_dgrad = True
+        elif ctx.direct and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16:
             # the data gradient is the same convolution with the kernel flipped and its channel axes swapped
             from .ops import conv3x3_direct
             gx = conv3x3_direct(g, weight.flip(2, 3).transpose(0, 1), None, False)
@@ -136,7 +147,11 @@ class _ConvFn(torch.autograd.Function):
         # product g^T @ im2col(x) another +0.6 %)
         gemm_wgrad = gemm_dgrad and x.shape[1] % 8 == 0 and cout >= _WGRAD_MIN_COUT
         gw = None
-        if ctx.direct and _DIRECT_WGRAD and g.dtype == torch.bfloat16 and (x.shape[1], cout) in ((64, 64), (64, 128), (128, 128)):
+        if gemm_1x1:
+            x2d = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])       # NHWC memory of a channels_last activation
+            gw = torch.mm(g2d.t(), x2d).view(cout, x.shape[1], 1, 1)
+            gemm_wgrad = True
+        elif ctx.direct and _DIRECT_WGRAD and g.dtype == torch.bfloat16 and (x.shape[1], cout) in ((64, 64), (64, 128), (128, 128)):
             # the narrow full-resolution layers again: MIOpen's wrw kernels run them at ~250 TFLOP/s (conv1_2: 0.48 ms)
             from .ops import conv3x3_wgrad
             gw = conv3x3_wgrad(x, g)

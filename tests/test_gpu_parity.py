@@ -709,6 +709,29 @@ def test_direct_conv_weight_gradient_matches_torch(ops, cin, cout):
         assert torch.equal(got, ops.conv3x3_wgrad(x, g))                                                    # deterministic
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 128)])
+def test_narrow_conv_layers_differentiate_like_torch(ops, cin, cout):
+    """conv1_2 / conv2_1 / conv2_2 as the backbone runs them (GemmConv2d + fused ReLU under autocast: direct forward, data and
+    weight gradient kernels, fused ReLU-mask + bias gradient) against nn.Conv2d + relu differentiated by torch"""
+    import torch.nn.functional as F
+    from dsrg_amd.backbone import GemmConv2d
+    torch.manual_seed(9)
+    cl = torch.channels_last
+    a = GemmConv2d(cin, cout, 3, padding=1, fuse_relu=True).cuda().to(memory_format=cl)
+    b = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda().to(memory_format=cl)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, cin, 37, 45, device="cuda").contiguous(memory_format=cl)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = a(xa)
+        yb = torch.relu(b(xb))
+    assert ya.dtype == torch.bfloat16 and (ya.float() - yb.float()).norm() <= 0.01 * yb.float().norm()
+    g = torch.randn_like(yb)
+    ya.backward(g.to(ya.dtype)); yb.backward(g)
+    for u, v in [(xa.grad, xb.grad), (a.weight.grad, b.weight.grad), (a.bias.grad, b.bias.grad)]:
+        assert u.shape == v.shape and (u.float() - v.float()).norm() <= 0.02 * v.float().norm()
+
+
 def test_fused_relu_dropout_backward_matches_unfused_sequence():
     """conv + ReLU + Dropout in one autograd function: same dropout mask as F.dropout under the same seed, and the fused
     backward (one pass reading the sign of the dropped output) equals conv -> relu -> dropout differentiated by torch"""
