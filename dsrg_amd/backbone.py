@@ -18,6 +18,7 @@ import os as _os
 _WGRAD_MIN_COUT = int(_os.environ.get("DSRG_WGRAD_MIN_COUT", "512"))
 # conv1_2 / conv2_1 / conv2_2 by the direct MFMA kernel: "1" all of them, "64" only conv1_2, "0" none (MIOpen / im2col + GEMM)
 _DIRECT_CONV = _os.environ.get("DSRG_DIRECT_CONV", "1")
+_DIRECT_C3 = _os.environ.get("DSRG_DIRECT_C3", "1") == "1"          # conv1_1 (3 -> 64) forward with bias + ReLU in one pass (0: MIOpen + 2 passes)
 _GEMM_1X1_BWD = _os.environ.get("DSRG_GEMM_1X1_BWD", "1") == "1"   # 1x1 layers (fc7): both gradients as hipBLASLt GEMMs (0: MIOpen/CK)
 _DIRECT_WGRAD = _os.environ.get("DSRG_DIRECT_WGRAD", "1") == "1"   # their weight gradients by the direct kernel too (0: MIOpen)
 _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
@@ -72,7 +73,8 @@ class _ConvFn(torch.autograd.Function):
         # ~255 TFLOP/s, the im2col route would move 1.9 GB there and 0.96 GB for conv2_2
         shape = tuple(weight.shape[:2])
         direct = k == 3 and dilation == 1 and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and (
-            (_DIRECT_CONV == "1" and shape[0] in (64, 128) and shape[1] in (64, 128)) or (_DIRECT_CONV == "64" and shape == (64, 64)))
+            (_DIRECT_CONV == "1" and shape[0] in (64, 128) and shape[1] in (64, 128)) or (_DIRECT_CONV == "64" and shape == (64, 64))
+            or (_DIRECT_CONV == "1" and _DIRECT_C3 and shape == (64, 3)))
         if direct:
             from .ops import conv3x3_direct
             out = conv3x3_direct(x, weight, bias, relu)
@@ -126,7 +128,7 @@ class _ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = torch.mm(g2d, weight.reshape(cout, cin)).view(x.shape[0], x.shape[2], x.shape[3], cin).permute(0, 3, 1, 2)
             gemm_dgrad = True
-        elif ctx.direct and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16:
+        elif ctx.direct and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and x.shape[1] in (64, 128):
             # the data gradient is the same convolution with the kernel flipped and its channel axes swapped
             from .ops import conv3x3_direct
             gx = conv3x3_direct(g, weight.flip(2, 3).transpose(0, 1), None, False)
@@ -151,7 +153,8 @@ class _ConvFn(torch.autograd.Function):
             x2d = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])       # NHWC memory of a channels_last activation
             gw = torch.mm(g2d.t(), x2d).view(cout, x.shape[1], 1, 1)
             gemm_wgrad = True
-        elif ctx.direct and _DIRECT_WGRAD and g.dtype == torch.bfloat16 and (x.shape[1], cout) in ((64, 64), (64, 128), (128, 128)):
+        elif ctx.direct and _DIRECT_WGRAD and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and \
+                (x.shape[1], cout) in ((3, 64), (64, 64), (64, 128), (128, 128)):
             # the narrow full-resolution layers again: MIOpen's wrw kernels run them at ~250 TFLOP/s (conv1_2: 0.48 ms)
             from .ops import conv3x3_wgrad
             gw = conv3x3_wgrad(x, g)

@@ -226,6 +226,134 @@ int launch_variant(const ConvArgs &a, int n_cus, hipStream_t stream) {
     return DSRG_OK;
 }
 // ------------------------------------------------------------------------------------------------------------------
+// The first layer, 3 -> 64 channels at full resolution (conv1_1, train-s.prototxt:44-64): output-bandwidth-bound (211 MB at
+// batch 16), which MIOpen's forward (96 us) + a separate bias add (80 us) + ReLU (63 us) passes over three times.  Same tile
+// and epilogue as above; the halo keeps 4 channels per pixel (3 + a zero: 8 bytes), k = tap * 4 + channel padded from 36 to
+// 48 = three 16-wide k-steps, so a lane's fragment is two 8-byte LDS reads (two taps) and the taps past the ninth meet zero
+// weights.
+constexpr int kC3Pix = 8;                                  // bytes per halo pixel
+
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvArgs a) {   // x (B,H,W,3), w (64,3,3,3) = [o][ky][kx][c], y (B,H,W,64)
+    __shared__ __attribute__((aligned(16))) unsigned char halo[2][kHH * kHW * kC3Pix];
+    __shared__ __attribute__((aligned(16))) unsigned char ot[kTH * kTW * 144];
+    constexpr int kOutStride = 144;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, kgrp = lane >> 5;
+
+    bf16x8 wf[2][3];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; s3++) {
+            uint16_t v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int tap = 4 * s3 + 2 * kgrp + (e >> 2), c = e & 3;
+                v[e] = (tap < 9 && c < 3) ? a.w[((nt * 32 + m) * 9 + tap) * 3 + c] : (uint16_t)0;
+            }
+            uint4 pk = make_uint4(v[0] | (uint32_t)v[1] << 16, v[2] | (uint32_t)v[3] << 16, v[4] | (uint32_t)v[5] << 16,
+                                  v[6] | (uint32_t)v[7] << 16);
+            wf[nt][s3] = *reinterpret_cast<bf16x8 *>(&pk);
+        }
+    float bias_r[2][4][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) bias_r[nt][q][e] = a.bias ? a.bias[nt * 32 + q * 8 + kgrp * 4 + e] : 0.0f;
+    // byte offsets of this lane's two taps per k-step inside the halo (taps past the ninth: any pixel, their weights are zero)
+    int toff[3][2];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; s3++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int tap = min(4 * s3 + 2 * kgrp + h, 8);
+            toff[s3][h] = ((tap / 3) * kHW + tap % 3) * kC3Pix;
+        }
+
+    auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
+        const int per = a.tiles_x * a.tiles_y;
+        b = t / per;
+        const int r = t - b * per;
+        y0 = (r / a.tiles_x) * kTH;
+        x0 = (r % a.tiles_x) * kTW;
+    };
+    uint2 pre = make_uint2(0u, 0u);
+    auto fetch = [&](int t) {                                    // threads 0 .. 179: one halo pixel each
+        int b, y0, x0;
+        tile_origin(t, b, y0, x0);
+        pre = make_uint2(0u, 0u);
+        if (tid < kHH * kHW) {
+            const int hy = tid / kHW, hx = tid - hy * kHW, yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const uint16_t *p = a.x + (((size_t)b * a.H + yy) * a.W + xx) * 3;
+                pre = make_uint2(p[0] | (uint32_t)p[1] << 16, p[2]);
+            }
+        }
+    };
+    auto park = [&](unsigned char *buf) {
+        if (tid < kHH * kHW) *reinterpret_cast<uint2 *>(buf + tid * kC3Pix) = pre;
+    };
+
+    int t = blockIdx.x, cur = 0;
+    if (t >= a.ntiles) return;
+    fetch(t);
+    park(halo[0]);
+    __syncthreads();
+    const int ty = 2 * wave + (m >> 4), tx = m & 15;
+    const int pix_off = (ty * kHW + tx) * kC3Pix;
+    for (; t < a.ntiles; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        const bool more = tn < a.ntiles;
+        if (more) fetch(tn);
+        const unsigned char *in = halo[cur] + pix_off;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+#pragma unroll
+        for (int s3 = 0; s3 < 3; s3++) {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(in + toff[s3][0]), hi = *reinterpret_cast<const uint2 *>(in + toff[s3][1]);
+            uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            const bf16x8 ar = *reinterpret_cast<bf16x8 *>(&pk);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][s3], ar, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][s3], ar, acc1, 0, 0, 0);
+        }
+        // transposed product as above: a lane holds runs of four consecutive output channels of one pixel
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c0 = nt * 32 + q * 8 + kgrp * 4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    v[e] = (nt ? acc1[q * 4 + e] : acc0[q * 4 + e]) + bias_r[nt][q][e];
+                    if (a.relu) v[e] = fmaxf(v[e], 0.0f);
+                }
+                *reinterpret_cast<uint2 *>(ot + (wave * 32 + m) * kOutStride + c0 * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+            }
+        }
+        if (more) park(halo[cur ^ 1]);
+        __syncthreads();                                         // output tile and next halo complete
+        {
+            int b, y0, x0;
+            tile_origin(t, b, y0, x0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                        // 128 pixels x 8 vectors of 16 bytes
+                const int v = tid + u * 256, px = v >> 3, cg = v & 7;
+                const int yy = y0 + (px >> 4), xx = x0 + (px & 15);
+                if (yy < a.H && xx < a.W)
+                    *reinterpret_cast<uint4 *>(a.y + (((size_t)b * a.H + yy) * a.W + xx) * 64 + cg * 8) =
+                        *reinterpret_cast<const uint4 *>(ot + px * kOutStride + cg * 16);
+            }
+        }
+        __syncthreads();                                         // the output tile is free again
+        cur ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same layers: gw[o][tap][c] = sum over pixels of g[px][o] * x[px + tap][c], a GEMM whose reduction
 // runs over the pixels — the slow axis of both NHWC operands.  gfx950's transposing LDS read (ds_read_b64_tr_b16: a
 // 16-lane group reads a [4 pixels][16 channels] block, lane i supplying the 8-byte address of row i / 4, chunk i % 4, and
@@ -413,6 +541,121 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *
     }
 }
 
+// Weight gradient of the first layer (x 3 channels, g 64): gw[o][tap][c] = sum over pixels of g[px][o] * x[px + tap][c].  The
+// nine taps of a pixel are gathered from the 4-channel halo into an im2col tile [pixel][n = tap * 4 + c] (36 of 64 columns
+// used, the rest stay zero), after which it is the same transposing-read GEMM as above with one accumulator tile per wave
+// (32 channels of g x 32 columns).  Partials [workgroup][64][64] f32, summed by conv3x3_c3_wgrad_reduce_kernel.
+constexpr int kC3Row = 192;                                // bytes per pixel row of the g tile and of the im2col tile (128 + 64)
+
+__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(WgradArgs a) {      // x (B,H,W,3), g (B,H,W,64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char conv_lds[];
+    constexpr int kHaloB = kHH * kHW * kC3Pix, kTileB = kTH * kTW * kC3Row;      // 1 440, 24 576
+    auto halo = [&](int b) { return conv_lds + b * kHaloB; };
+    auto gt = [&](int b) { return conv_lds + 2 * kHaloB + b * kTileB; };
+    unsigned char *xc = conv_lds + 2 * kHaloB + 2 * kTileB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, gq = lane >> 4;
+    const int otile = wave & 1, ntile = wave >> 1;
+    const int rowsel = (gq >> 1) * 8 + (i16 >> 2), colsel = (gq & 1) * 16 + 4 * (i16 & 3);
+    const int g_lane = rowsel * kC3Row + (otile * 32 + colsel) * 2, x_lane = rowsel * kC3Row + (ntile * 32 + colsel) * 2;
+    for (int v = tid; v < kTH * kTW * kC3Row / 16; v += 256) reinterpret_cast<uint4 *>(xc)[v] = make_uint4(0u, 0u, 0u, 0u);
+
+    auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
+        const int per = a.tiles_x * a.tiles_y;
+        b = t / per;
+        const int r = t - b * per;
+        y0 = (r / a.tiles_x) * kTH;
+        x0 = (r % a.tiles_x) * kTW;
+    };
+    uint2 prx = make_uint2(0u, 0u);
+    uint4 prg[4];
+    auto fetch = [&](int t) {
+        int b, y0, x0;
+        tile_origin(t, b, y0, x0);
+        prx = make_uint2(0u, 0u);
+        if (tid < kHH * kHW) {
+            const int hy = tid / kHW, hx = tid - hy * kHW, yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const uint16_t *p = a.x + (((size_t)b * a.H + yy) * a.W + xx) * 3;
+                prx = make_uint2(p[0] | (uint32_t)p[1] << 16, p[2]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = tid + u * 256, px = v >> 3, cg = v & 7;
+            const int yy = y0 + (px >> 4), xx = x0 + (px & 15);
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);                 // pixels past the image edge add nothing
+            if (yy < a.H && xx < a.W) val = *reinterpret_cast<const uint4 *>(a.g + (((size_t)b * a.H + yy) * a.W + xx) * 64 + cg * 8);
+            prg[u] = val;
+        }
+    };
+    auto park = [&](int buf) {
+        if (tid < kHH * kHW) *reinterpret_cast<uint2 *>(halo(buf) + tid * kC3Pix) = prx;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = tid + u * 256;
+            *reinterpret_cast<uint4 *>(gt(buf) + (v >> 3) * kC3Row + (v & 7) * 16) = prg[u];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    int t = blockIdx.x, cur = 0;
+    if (t < a.nitems) {
+        fetch(t);
+        park(0);
+    }
+    __syncthreads();
+    const int cpx = tid >> 1, chalf = tid & 1;                   // im2col: two threads per pixel, taps 0-4 and 5-8
+    const int cty = cpx >> 4, ctx_ = cpx & 15;
+    for (; t < a.nitems; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        const bool more = tn < a.nitems;
+        if (more) fetch(tn);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int tap = chalf * 5 + k;
+            if (tap < 9)
+                *reinterpret_cast<uint2 *>(xc + cpx * kC3Row + tap * 8) =
+                    *reinterpret_cast<const uint2 *>(halo(cur) + ((cty + tap / 3) * kHW + ctx_ + tap % 3) * kC3Pix);
+        }
+        __syncthreads();                                         // im2col tile complete
+        DSRG_LDS unsigned char *gb = (DSRG_LDS unsigned char *)gt(cur) + g_lane, *xb = (DSRG_LDS unsigned char *)xc + x_lane;
+#pragma unroll
+        for (int ks = 0; ks < kTH; ks++) {
+            const bf16x8 ga = tr_frag(gb + ks * kTW * kC3Row, 4 * kC3Row), bx = tr_frag(xb + ks * kTW * kC3Row, 4 * kC3Row);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bx, acc, 0, 0, 0);
+        }
+        if (more) park(cur ^ 1);
+        __syncthreads();                                         // next tiles parked, im2col tile free
+        cur ^= 1;
+    }
+    float *pp = a.part + (size_t)blockIdx.x * 64 * 64;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int o = otile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        pp[o * 64 + ntile * 32 + (lane & 31)] = acc[r];
+    }
+}
+
+// gw[o][tap][c] (bf16, (64, 3, 3, 3) channels_last) = sum over the workgroups of part[wg][o][tap * 4 + c], in workgroup order
+__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_reduce_kernel(const float *part, uint16_t *gw, int nwg) {
+    const int e = blockIdx.x * 256 + threadIdx.x;                // (o, tap, c)
+    if (e >= 64 * 27) return;
+    const int o = e / 27, rem = e - o * 27, tap = rem / 3, c = rem - tap * 3;
+    const float *p = part + o * 64 + tap * 4 + c;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int w = 0;
+    for (; w + 3 < nwg; w += 4) {
+        s0 += p[(size_t)w * 4096]; s1 += p[(size_t)(w + 1) * 4096]; s2 += p[(size_t)(w + 2) * 4096]; s3 += p[(size_t)(w + 3) * 4096];
+    }
+    for (; w < nwg; w++) s0 += p[(size_t)w * 4096];
+    f32x2 v = {(s0 + s1) + (s2 + s3), 0.0f};
+    bf16x2 bv = __builtin_convertvector(v, bf16x2);
+    gw[e] = *reinterpret_cast<uint16_t *>(&bv);
+}
+
 template <int CO_TILES>
 int launch_wgrad_variant(const WgradArgs &a, int grid, hipStream_t stream) {
     using C = WCfg<CO_TILES>;
@@ -433,11 +676,13 @@ int device_cus() {
     return n_cus;
 }
 
-bool wgrad_supported(int cin, int cout) { return (cin == 64 && (cout == 64 || cout == 128)) || (cin == 128 && cout == 128); }
+bool wgrad_supported(int cin, int cout) {
+    return (cin == 64 && (cout == 64 || cout == 128)) || (cin == 128 && cout == 128) || (cin == 3 && cout == 64);
+}
 
 // workgroups of the reduction for (B, H, W): a multiple of the slices of x
 int wgrad_grid(int B, int H, int W, int cin) {
-    const int roles = cin / 64;
+    const int roles = cin < 64 ? 1 : cin / 64;
     const long items = (long)B * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH) * roles;
     const long cap = device_cus() / roles * roles;
     return (int)(items < cap ? items : cap);
@@ -446,16 +691,17 @@ int wgrad_grid(int B, int H, int W, int cin) {
 
 size_t conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
     if (!wgrad_supported(cin, cout) || B < 1 || H < 1 || W < 1) return 0;
+    if (cin == 3) return (size_t)wgrad_grid(B, H, W, cin) * 64 * 64 * sizeof(float);
     return (size_t)wgrad_grid(B, H, W, cin) * cout * 9 * 64 * sizeof(float);
 }
 
 int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspace, size_t workspace_bytes, int B, int H, int W,
                          int cin, int cout, hipStream_t stream) {
     if (!wgrad_supported(cin, cout))
-        return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: %d -> %d channels is not one of 64 -> 64, 64 -> 128, 128 -> 128", cin, cout);
+        return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: %d -> %d channels is not one of 3 -> 64, 64 -> 64, 64 -> 128, 128 -> 128", cin, cout);
     WgradArgs a;
     a.x = static_cast<const uint16_t *>(x); a.g = static_cast<const uint16_t *>(g); a.part = workspace;
-    a.B = B; a.H = H; a.W = W; a.cin = cin; a.roles = cin / 64;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.roles = cin < 64 ? 1 : cin / 64;
     a.tiles_x = (W + kTW - 1) / kTW; a.tiles_y = (H + kTH - 1) / kTH;
     const long items = (long)B * a.tiles_x * a.tiles_y * a.roles;
     if (B < 1 || H < 1 || W < 1 || items > 0x7fffffffL) return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: bad shape");
@@ -464,6 +710,17 @@ int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspac
     if (workspace_bytes < conv3x3_wgrad_workspace(B, H, W, cin, cout))
         return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: workspace of %zu bytes, %zu needed", workspace_bytes,
                          conv3x3_wgrad_workspace(B, H, W, cin, cout));
+    if (cin == 3) {
+        static LdsGrant grant;
+        const size_t lds = 2 * kHH * kHW * kC3Pix + 3 * kTH * kTW * kC3Row;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_c3_wgrad_kernel), lds, grant)) return rc;
+        hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel, dim3(grid), dim3(256), lds, stream, a);
+        DSRG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv3x3_c3_wgrad_reduce_kernel, dim3((64 * 27 + 255) / 256), dim3(256), 0, stream, workspace,
+                           static_cast<uint16_t *>(gw), grid);
+        DSRG_LAUNCH_CHECK();
+        return DSRG_OK;
+    }
     if (int rc = cout == 64 ? launch_wgrad_variant<2>(a, grid, stream) : launch_wgrad_variant<4>(a, grid, stream)) return rc;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cout * 9 * cin / 64), dim3(256), 0, stream, workspace,
                        static_cast<uint16_t *>(gw), grid, a.roles, cout, cin);
@@ -472,13 +729,13 @@ int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspac
 }
 
 bool conv3x3_direct_supported(int cin, int cout) {
-    return (cin == 64 || cin == 128) && (cout == 64 || cout == 128);
+    return ((cin == 64 || cin == 128) && (cout == 64 || cout == 128)) || (cin == 3 && cout == 64);
 }
 
 int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void *y, int B, int H, int W, int cin, int cout,
                           int relu, hipStream_t stream) {
     if (!conv3x3_direct_supported(cin, cout))
-        return set_error(DSRG_ERR_INVALID, "conv3x3_direct: %d -> %d channels is not one of 64/128 -> 64/128", cin, cout);
+        return set_error(DSRG_ERR_INVALID, "conv3x3_direct: %d -> %d channels is not one of 64/128 -> 64/128 or 3 -> 64", cin, cout);
     ConvArgs a;
     a.x = static_cast<const uint16_t *>(x); a.w = static_cast<const uint16_t *>(w); a.bias = bias;
     a.y = static_cast<uint16_t *>(y); a.B = B; a.H = H; a.W = W; a.relu = relu ? 1 : 0;
@@ -487,6 +744,11 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
     if (B < 1 || H < 1 || W < 1 || nt > 0x7fffffffL) return set_error(DSRG_ERR_INVALID, "conv3x3_direct: bad shape");
     a.ntiles = (int)nt;
     const int n_cus = device_cus();
+    if (cin == 3) {
+        hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(a.ntiles < n_cus ? a.ntiles : n_cus), dim3(256), 0, stream, a);
+        DSRG_LAUNCH_CHECK();
+        return DSRG_OK;
+    }
     if (cin == 64) return cout == 64 ? launch_variant<64, 64>(a, n_cus, stream) : launch_variant<64, 128>(a, n_cus, stream);
     return cout == 64 ? launch_variant<128, 64>(a, n_cus, stream) : launch_variant<128, 128>(a, n_cus, stream);
 }

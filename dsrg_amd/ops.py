@@ -358,15 +358,15 @@ DIRECT_CONV_CHANNELS = (64, 128)
 
 
 def conv3x3_direct(x, weight, bias=None, relu=False):
-    """3x3 / stride 1 / pad 1 convolution with 64 or 128 channels on either side: x (B,cin,H,W) bf16 channels_last, weight
+    """3x3 / stride 1 / pad 1 convolution with 64 or 128 channels on either side, or 3 -> 64: x (B,cin,H,W) bf16 channels_last, weight
     (cout,cin,3,3) bf16 (made channels_last here), bias (cout) f32 or None -> (B,cout,H,W) bf16 channels_last; fp32
     accumulation, bias and ReLU fused"""
     B, C, H, W = x.shape
     cl = torch.channels_last
     cout = weight.shape[0]
     if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and tuple(weight.shape) == (cout, C, 3, 3)
-            and C in DIRECT_CONV_CHANNELS and cout in DIRECT_CONV_CHANNELS):
-        raise ValueError("conv3x3_direct needs a bf16 CUDA input and a (cout,cin,3,3) bf16 kernel with cin, cout in (64, 128)")
+            and ((C in DIRECT_CONV_CHANNELS and cout in DIRECT_CONV_CHANNELS) or (C, cout) == (3, 64))):
+        raise ValueError("conv3x3_direct needs a bf16 CUDA input and a (cout,cin,3,3) bf16 kernel with cin, cout in (64, 128) or 3 -> 64")
     x = x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl)
     w = weight if weight.is_contiguous(memory_format=cl) else weight.contiguous(memory_format=cl)
     if bias is not None:
@@ -376,7 +376,7 @@ def conv3x3_direct(x, weight, bias=None, relu=False):
     return y
 
 
-WGRAD_CONV_SHAPES = ((64, 64), (64, 128), (128, 128))      # (cin, cout)
+WGRAD_CONV_SHAPES = ((3, 64), (64, 64), (64, 128), (128, 128))      # (cin, cout)
 _wgrad_ws = {}
 
 

@@ -219,14 +219,14 @@ int dsrg_bias_grad_bf16(const void *g_dev, float *bias_grad_dev, float *partials
  * C % 8 == 0.  The stencil is symmetric: the backward pass is the same call on the output gradient. */
 int dsrg_avgpool3x3_s1_bf16(const void *in_dev, void *out_dev, int B, int H, int W, int C, void *stream);
 /* Direct 3x3 / stride 1 / pad 1 convolution for the narrow layers at the large resolutions: cin, cout in {64, 128}
- * (conv1_2 at 321x321, conv2_1 / conv2_2 at 161x161 of train-s.prototxt:65-160), NHWC bf16 in and out, fp32
+ * (conv1_2 at 321x321, conv2_1 / conv2_2 at 161x161 of train-s.prototxt:65-160) and 3 -> 64 (conv1_1, :44-64), NHWC bf16 in and out, fp32
  * accumulation, optional bias (cout f32) and ReLU in the epilogue:
  *   y[b,y,x,o] = relu?( bias[o] + sum_{dy,dx,c} w[o][dy+1][dx+1][c] * x[b,y+dy,x+dx,c] )
  * w_dev: (cout, 3, 3, cin) bf16 = the memory of a channels_last (out, in, 3, 3) tensor.  With the kernel flipped and its
  * channel axes swapped the same call is the data gradient of that convolution.  Other channel counts: DSRG_ERR_INVALID. */
 int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int B, int H, int W,
                              int cin, int cout, int relu, void *stream);
-/* Weight gradient of the same convolution for (cin, cout) in {(64, 64), (64, 128), (128, 128)}:
+/* Weight gradient of the same convolution for (cin, cout) in {(3, 64), (64, 64), (64, 128), (128, 128)}:
  *   gw[o][dy+1][dx+1][c] = sum_{b,y,x} g[b,y,x,o] * x[b,y+dy,x+dx,c]      (zero padding)
  * x_dev (B,H,W,cin) and g_dev (B,H,W,cout) NHWC bf16; gw_dev (cout, 3, 3, cin) bf16 = the memory of a channels_last
  * (out, in, 3, 3) tensor; fp32 accumulation, summed in a fixed order (deterministic).  workspace_dev: device scratch of
