@@ -5,6 +5,8 @@
 //   maxpool3x3    : 3x3 max pooling (stride 1 or 2, pad 1, optional ceil mode) forward with a 1-byte window code,
 //                   and the gather-form backward that reads the codes (no atomics, deterministic)
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace dsrg {
 
@@ -595,6 +597,182 @@ __global__ void heads_bwd_dw_reduce_kernel(const float *__restrict__ partial, fl
     gw[i] = s;
 }
 
+// ---- the same two GEMMs on the bf16 MFMA with the float32 operand split into three bf16 terms -------------------------------
+// f = t0 + t1 + t2 with t0 = bf16(f), t1 = bf16(f - t0), t2 = bf16(f - t0 - t1): exact for normal f (3 x 8 significant bits),
+// each product with a bf16 activation is exact in f32 and the MFMA accumulates in f32 — float32 weights / gradients without
+// the 16-pass f32 MFMA: three 8-pass v_mfma_f32_32x32x16_bf16 cover 16 channels where 32x32x2_f32 needs eight 16-pass ones.
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2;
+typedef __attribute__((ext_vector_type(2))) float hf32x2;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 hbf16x4v;
+#define DSRG_LDS_AS __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {          // v_cvt_pk_bf16_f32, round to nearest even
+    hf32x2 v = {lo, hi};
+    hbf16x2 b = __builtin_convertvector(v, hbf16x2);
+    return *reinterpret_cast<uint32_t *>(&b);
+}
+__device__ __forceinline__ void split3(const float (&f)[8], hbf16x8 &t0, hbf16x8 &t1, hbf16x8 &t2) {
+    uint32_t p0[4], p1[4], p2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float a = f[2 * i], b = f[2 * i + 1];
+        p0[i] = cvt_pk_bf16(a, b);
+        a -= bf16_lo(p0[i]); b -= bf16_hi(p0[i]);                              // exact
+        p1[i] = cvt_pk_bf16(a, b);
+        a -= bf16_lo(p1[i]); b -= bf16_hi(p1[i]);
+        p2[i] = cvt_pk_bf16(a, b);
+    }
+    uint4 q0 = make_uint4(p0[0], p0[1], p0[2], p0[3]), q1 = make_uint4(p1[0], p1[1], p1[2], p1[3]), q2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    t0 = *reinterpret_cast<hbf16x8 *>(&q0); t1 = *reinterpret_cast<hbf16x8 *>(&q1); t2 = *reinterpret_cast<hbf16x8 *>(&q2);
+}
+__device__ __forceinline__ hbf16x8 tr_frag16(DSRG_LDS_AS unsigned char *p, int stride4) {   // see conv_direct.hip
+    hbf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<DSRG_LDS_AS hbf16x4v *>(p));
+    hbf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<DSRG_LDS_AS hbf16x4v *>(p + stride4));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+}  // namespace
+
+// forward: as heads_fwd_kernel (one workgroup = one 32-row tile, wave = branch), the x fragment is the lane's 16-byte load as it
+// is, the weight fragment its 32-byte load split in three
+__global__ __launch_bounds__(256) void heads_fwd_split_kernel(HeadArgs a) {
+    __shared__ float part[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 32;
+    const int row = lane & 31, half = lane >> 5;
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; acc2[r] = 0.0f; }
+    if (wave < a.nbr) {
+        const int mr = min(m0 + row, a.M - 1);                      // clamped rows are never stored
+        const uint16_t *xp = a.x[wave] + (size_t)mr * a.K + half * 8;
+        const float *wp = a.w + ((size_t)wave * a.O + min(row, a.O - 1)) * a.K + half * 8;
+        constexpr int G = 4;                                        // 16-channel steps in flight (K % 256 == 0)
+        uint4 xv[G];
+        float4 wv[G][2];
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            xv[u] = *reinterpret_cast<const uint4 *>(xp + u * 16);
+            wv[u][0] = *reinterpret_cast<const float4 *>(wp + u * 16);
+            wv[u][1] = *reinterpret_cast<const float4 *>(wp + u * 16 + 4);
+        }
+        for (int kb = 0; kb < a.K; kb += 16 * G) {
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const hbf16x8 xa = *reinterpret_cast<hbf16x8 *>(&xv[u]);
+                const float wf[8] = {wv[u][0].x, wv[u][0].y, wv[u][0].z, wv[u][0].w, wv[u][1].x, wv[u][1].y, wv[u][1].z, wv[u][1].w};
+                const int kn = kb + 16 * G + u * 16;
+                if (kn < a.K) {
+                    xv[u] = *reinterpret_cast<const uint4 *>(xp + kn);
+                    wv[u][0] = *reinterpret_cast<const float4 *>(wp + kn);
+                    wv[u][1] = *reinterpret_cast<const float4 *>(wp + kn + 4);
+                }
+                hbf16x8 w0, w1, w2;
+                split3(wf, w0, w1, w2);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, w0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, w1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, w2, acc2, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) part[wave][r][lane] = acc0[r] + (acc1[r] + acc2[r]);
+    __syncthreads();
+    const int col = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
+    if (col < a.O) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int rr = r4 + q, m = m0 + rr;
+            if (m >= a.M) break;
+            const int hf = (rr >> 2) & 1, reg = (rr & 3) + 4 * (rr >> 3), ln = col + 32 * hf;
+            float s = 0.0f;
+            for (int k = 0; k < a.nbr; k++) {
+                const float sk = part[k][reg][ln] + (a.bias ? a.bias[k * a.O + col] : 0.0f);
+                s = k == 0 ? sk : s + sk;
+            }
+            const int b = m / a.HW, hw = m - b * a.HW;
+            a.out[((size_t)b * a.O + col) * a.HW + hw] = s;
+        }
+    }
+}
+
+// weight gradient, stage 1 (same partial layout [rc][k][o][c]): 32 rows of x_k (all K channels, NHWC as it lies in memory, row
+// stride K * 2 + 64 bytes) and of g^T per refill in LDS; per 16-row k-step a lane takes its 8 values of g (split in three) and
+// eight x fragments by transposing reads (ds_read_b64_tr_b16), wave q = channels [256 q, 256 q + 256) = 8 accumulator tiles.
+constexpr int kDwRows2 = 32, kDwGPitch = 36;
+__global__ __launch_bounds__(256, 2) void heads_bwd_dw_split_kernel(HeadArgs a, const float *__restrict__ g, float *__restrict__ partial,
+                                                                 int rows_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_lds[];
+    const int xstride = a.K * 2 + 64, K8 = a.K / 8;
+    unsigned char *xt = dw_lds;
+    float *gs = reinterpret_cast<float *>(dw_lds + kDwRows2 * xstride);          // [o][row], pitch 36 floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.y, rc = blockIdx.x;
+    const int mbeg = rc * rows_per_chunk, mend = min(a.M, mbeg + rows_per_chunk);
+    const int i16 = lane & 15, gq = lane >> 4;
+    const int rowsel = (gq >> 1) * 8 + (i16 >> 2), colsel = (gq & 1) * 16 + 4 * (i16 & 3);
+    const int nq = a.K / 256;
+    const uint16_t *xk = a.x[k];
+    for (int q0 = 0; q0 < nq; q0 += 4) {                            // workgroup-uniform trip count (barriers inside)
+        const int q = q0 + wave;
+        const bool live = q < nq;
+        f32x16 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+        DSRG_LDS_AS unsigned char *xb = (DSRG_LDS_AS unsigned char *)xt + rowsel * xstride + ((live ? q : 0) * 256 + colsel) * 2;
+        for (int mb = mbeg; mb < mend; mb += kDwRows2) {
+            __syncthreads();                                        // the previous refill has been consumed
+            for (int e = threadIdx.x; e < kDwRows2 * 32; e += 256) {
+                const int o = e / kDwRows2, r = e % kDwRows2, m = mb + r;        // lanes along the rows: g is (B, O, HW), hw fastest
+                float v = 0.0f;                                     // rows past the chunk and outputs past O add nothing
+                if (o < a.O && m < mend) { const int b = m / a.HW, hw = m - b * a.HW; v = g[((size_t)b * a.O + o) * a.HW + hw]; }
+                gs[o * kDwGPitch + r] = v;
+            }
+#pragma unroll 8
+            for (int v = threadIdx.x; v < kDwRows2 * K8; v += 256) {
+                const int r = v / K8, cg = v - r * K8, m = min(mb + r, mend - 1);   // rows past the chunk: any row in range, g is 0 there
+                *reinterpret_cast<uint4 *>(xt + r * xstride + cg * 16) = *reinterpret_cast<const uint4 *>(xk + (size_t)m * a.K + cg * 8);
+            }
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int s2 = 0; s2 < kDwRows2 / 16; s2++) {
+                    const float *gp = gs + (lane & 31) * kDwGPitch + s2 * 16 + (lane >> 5) * 8;
+                    const float4 g0 = *reinterpret_cast<const float4 *>(gp), g1 = *reinterpret_cast<const float4 *>(gp + 4);
+                    const float gf[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                    hbf16x8 a0, a1, a2, bx[8];
+                    split3(gf, a0, a1, a2);
+#pragma unroll
+                    for (int t = 0; t < 8; t++) bx[t] = tr_frag16(xb + s2 * 16 * xstride + t * 64, 4 * xstride);
+#pragma unroll
+                    for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bx[t], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx[t], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bx[t], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // tile t, reg r, lane: o = (r & 3) + 8 (r >> 2) + 4 (lane / 32), channel = 256 q + 32 t + lane % 32
+        if (live) {
+            float *pp = partial + (((size_t)rc * a.nbr + k) * a.O) * a.K + (size_t)q * 256 + (lane & 31);
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (o < a.O) pp[(size_t)o * a.K + t * 32] = acc[t][r];
+                }
+        }
+    }
+}
+
+// DSRG_HEADS_MFMA=f32 selects the round-2a kernels on the f32-input MFMA (exact fma chains); default: the bf16 MFMA on split operands
+static bool heads_f32_mfma() {
+    static const bool f32 = [] { const char *e = getenv("DSRG_HEADS_MFMA"); return e && !strcmp(e, "f32"); }();
+    return f32;
+}
 static int heads_check(int nbr, int K, int O) {
     if (nbr < 1 || nbr > 4 || O < 1 || O > kHeadOutPad || K < 256 || K % 256 != 0)
         return set_error(DSRG_ERR_UNSUPPORTED, "heads: 1..4 branches, <= %d outputs, K a multiple of 256", kHeadOutPad);
@@ -608,7 +786,10 @@ int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float 
     HeadArgs a;
     for (int k = 0; k < 4; k++) a.x[k] = static_cast<const uint16_t *>(x[k < nbr ? k : 0]);
     a.w = w; a.bias = bias; a.out = out; a.nbr = nbr; a.M = B * HW; a.K = K; a.O = O; a.HW = HW;
-    hipLaunchKernelGGL(heads_fwd_kernel, dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
+    if (heads_f32_mfma())
+        hipLaunchKernelGGL(heads_fwd_kernel, dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(heads_fwd_split_kernel, dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
@@ -632,7 +813,14 @@ int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float 
         for (int k = 0; k < 4; k++) a.x[k] = static_cast<const uint16_t *>(x[k < nbr ? k : 0]);
         a.w = w; a.bias = nullptr; a.out = nullptr; a.nbr = nbr; a.M = M; a.K = K; a.O = O; a.HW = HW;
         const int nch = heads_bwd_chunks(M), rows = ((M + nch - 1) / nch + 1) & ~1;
-        hipLaunchKernelGGL(heads_bwd_dw_kernel, dim3(nch, nbr), dim3(256), 0, stream, a, g, partial, rows);
+        const size_t lds = (size_t)kDwRows2 * (K * 2 + 64) + 32 * kDwGPitch * sizeof(float);
+        if (heads_f32_mfma() || lds > 160 * 1024) {
+            hipLaunchKernelGGL(heads_bwd_dw_kernel, dim3(nch, nbr), dim3(256), 0, stream, a, g, partial, rows);
+        } else {
+            static LdsGrant grant;
+            if (int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&heads_bwd_dw_split_kernel), lds, grant)) return rc2;
+            hipLaunchKernelGGL(heads_bwd_dw_split_kernel, dim3(nch, nbr), dim3(256), lds, stream, a, g, partial, rows);
+        }
         DSRG_LAUNCH_CHECK();
         const size_t n = (size_t)nbr * O * K;
         hipLaunchKernelGGL(heads_bwd_dw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, gw, nch, n);
