@@ -20,6 +20,8 @@
 // (v_mfma_f32_32x32x16_bf16) of an M-tile and parked in the other buffer after them.  The output tile goes back through LDS
 // for 16-byte coalesced NHWC stores.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace dsrg {
 namespace {
@@ -30,14 +32,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int kTH = 8, kTW = 16;             // output tile (pixels): 4 M-tiles of (2 rows x 16 columns)
 constexpr int kHH = kTH + 2, kHW = kTW + 2;  // halo tile
 
-template <int CIN, int COUT> struct Cfg {
+template <int CIN, int COUT, int TPW_ = (CIN == 64 ? 2 : 1)> struct Cfg {
     static constexpr int CG = CIN / 16;                    // 16-channel k-steps per tap
     static constexpr int KS = 9 * CG;                      // k-steps
-    static constexpr int TPW = CIN == 64 ? 2 : 1;          // 32-channel output tiles per wave: TPW * KS * 4 = 288 VGPRs
+    static constexpr int TPW = TPW_;                       // 32-channel output tiles per wave: TPW * KS * 4 = 288 (or 144) VGPRs
+    static constexpr int WGS = TPW * KS * 4 <= 144 ? 2 : 1;   // workgroups per CU the register budget is cut for
     static constexpr int NG = COUT / (32 * TPW);           // waves across the output channels
     static constexpr int PG = 4 / NG;                      // waves across the pixels
     static constexpr int MT = 4 / PG;                      // 32-pixel M-tiles per wave
-    static constexpr int SPT = CG / 4;                     // steps (4 k-steps) per tap
+    static constexpr int KPS = WGS == 2 ? 2 : 4;           // k-steps per step of the MFMA loop (the operand prefetch unit)
+    static constexpr int SPT = CG / KPS;                   // steps per tap
     static constexpr int STEPS = 9 * SPT;
     static constexpr int IN_STRIDE = CIN * 2 + 16;         // bytes per halo pixel in LDS
     static constexpr int OUT_STRIDE = COUT * 2 + 16;       // bytes per pixel of the output tile in LDS (2-way on the 8-byte stores)
@@ -67,9 +71,9 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // v_cvt_pk_bf
     return *reinterpret_cast<uint32_t *>(&b);
 }
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvArgs a) {
-    using C = Cfg<CIN, COUT>;
+template <int CIN, int COUT, int TPW_>
+__global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direct_kernel(ConvArgs a) {
+    using C = Cfg<CIN, COUT, TPW_>;
     extern __shared__ __attribute__((aligned(16))) unsigned char conv_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, kgrp = lane >> 5;
@@ -83,14 +87,18 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvArgs a) {
         for (int ks = 0; ks < C::KS; ks++)
             wf[j][ks] = *reinterpret_cast<const bf16x8 *>(a.w + (size_t)((ng * C::TPW + j) * 32 + m) * (9 * CIN) + ks * 16 + kgrp * 8);
 
-    float bias_r[C::TPW][4][4];               // the bias of the output channels this lane writes
+    // the bias of the output channels this lane writes: in registers where there is room, re-read in the epilogue otherwise
+    constexpr bool kBiasRegs = C::WGS == 1;
+    float bias_r[kBiasRegs ? C::TPW : 1][4][4];
+    if (kBiasRegs) {
 #pragma unroll
-    for (int j = 0; j < C::TPW; j++)
+        for (int j = 0; j < C::TPW; j++)
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                bias_r[j][q][e] = a.bias ? a.bias[(ng * C::TPW + j) * 32 + q * 8 + kgrp * 4 + e] : 0.0f;
+                for (int e = 0; e < 4; e++)
+                    bias_r[j][q][e] = a.bias ? a.bias[(ng * C::TPW + j) * 32 + q * 8 + kgrp * 4 + e] : 0.0f;
+    }
 
     auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
         const int per = a.tiles_x * a.tiles_y;
@@ -152,23 +160,23 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvArgs a) {
             // every read next to its use and the wave waits out the LDS latency at every step)
             auto a_ptr = [&](int s) {
                 const int tap = s / C::SPT, h = s % C::SPT;
-                return in + ((ty + tap / 3) * kHW + (tx + tap % 3)) * C::IN_STRIDE + h * 128 + kgrp * 16;
+                return in + ((ty + tap / 3) * kHW + (tx + tap % 3)) * C::IN_STRIDE + h * (32 * C::KPS) + kgrp * 16;
             };
-            bf16x8 ar[2][4];
+            bf16x8 ar[2][C::KPS];
 #pragma unroll
-            for (int i = 0; i < 4; i++) ar[0][i] = *reinterpret_cast<const bf16x8 *>(a_ptr(0) + i * 32);
+            for (int i = 0; i < C::KPS; i++) ar[0][i] = *reinterpret_cast<const bf16x8 *>(a_ptr(0) + i * 32);
 #pragma unroll
             for (int s = 0; s < C::STEPS; s++) {
                 if (s + 1 < C::STEPS) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) ar[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(a_ptr(s + 1) + i * 32);
+                    for (int i = 0; i < C::KPS; i++) ar[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(a_ptr(s + 1) + i * 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < C::KPS; i++)
 #pragma unroll
                     for (int j = 0; j < C::TPW; j++)
-                        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s * 4 + i], ar[s & 1][i], acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s * C::KPS + i], ar[s & 1][i], acc[mt][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (more) park(other, mt);
@@ -185,10 +193,14 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int c0 = (ng * C::TPW + j) * 32 + q * 8 + kgrp * 4;
-                    float v[4];
+                    float v[4], bq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (!kBiasRegs && a.bias) {
+                        const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + c0);
+                        bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        v[e] = acc[mt][j][q * 4 + e] + bias_r[j][q][e];
+                        v[e] = acc[mt][j][q * 4 + e] + (kBiasRegs ? bias_r[j][q][e] : bq[e]);
                         if (a.relu) v[e] = fmaxf(v[e], 0.0f);
                     }
                     *reinterpret_cast<uint2 *>(ot + ((pg * C::MT + mt) * 32 + m) * C::OUT_STRIDE + c0 * 2) =
@@ -214,14 +226,15 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvArgs a) {
     }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int TPW_>
 int launch_variant(const ConvArgs &a, int n_cus, hipStream_t stream) {
-    using C = Cfg<CIN, COUT>;
+    using C = Cfg<CIN, COUT, TPW_>;
     static LdsGrant grant;
     const size_t lds = 2 * (size_t)C::BUF;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_direct_kernel<CIN, COUT>), lds, grant)) return rc;
-    const int grid = a.ntiles < n_cus ? a.ntiles : n_cus;        // persistent: one workgroup per CU
-    hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, stream, a);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_direct_kernel<CIN, COUT, TPW_>), lds, grant)) return rc;
+    const int slots = n_cus * C::WGS;                            // persistent: one or two workgroups per CU
+    const int grid = a.ntiles < slots ? a.ntiles : slots;
+    hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT, TPW_>), dim3(grid), dim3(256), lds, stream, a);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
@@ -749,8 +762,12 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
         DSRG_LAUNCH_CHECK();
         return DSRG_OK;
     }
-    if (cin == 64) return cout == 64 ? launch_variant<64, 64>(a, n_cus, stream) : launch_variant<64, 128>(a, n_cus, stream);
-    return cout == 64 ? launch_variant<128, 64>(a, n_cus, stream) : launch_variant<128, 128>(a, n_cus, stream);
+    // 64 -> 64: one output tile per wave (144 weight VGPRs) and two workgroups per CU by default — the halo loads of a
+    // workgroup are its only memory parallelism (24 KB in flight), a second one doubles it; DSRG_CONV_OCC=1: two tiles per wave
+    static const bool occ2 = [] { const char *e = getenv("DSRG_CONV_OCC"); return !(e && !strcmp(e, "1")); }();
+    if (cin == 64 && cout == 64 && occ2) return launch_variant<64, 64, 1>(a, n_cus, stream);
+    if (cin == 64) return cout == 64 ? launch_variant<64, 64, 2>(a, n_cus, stream) : launch_variant<64, 128, 2>(a, n_cus, stream);
+    return cout == 64 ? launch_variant<128, 64, 1>(a, n_cus, stream) : launch_variant<128, 128, 1>(a, n_cus, stream);
 }
 
 }  // namespace dsrg
