@@ -393,6 +393,9 @@ template <int CO_TILES> struct WCfg {                      // CO_TILES = channel
     static constexpr int XV = kHH * kHW * 8, XVT = (XV + THREADS - 1) / THREADS;   // 16-byte vectors of the x tile, per thread (6 / 3)
     static constexpr int GVP = COUT / 8, GVT = kTH * kTW * GVP / THREADS;          // of the g tile (4)
     static constexpr int PART = COUT * 9 * 64;             // floats of one workgroup's partial
+    // 64-channel g: 4 waves of < 256 VGPRs, so two workgroups share a CU (each with ONE tile buffer: 59 KB) and one's loads and
+    // barriers hide behind the other's MFMAs; 128-channel g: 8 waves, one workgroup per CU, two buffers
+    static constexpr int WGS = CO_TILES == 2 ? 2 : 1, NBUF = WGS == 2 ? 1 : 2;
 };
 
 struct WgradArgs {
@@ -409,7 +412,7 @@ __device__ __forceinline__ bf16x8 tr_frag(DSRG_LDS unsigned char *p, int stride4
 }
 
 template <int CO_TILES>
-__global__ __launch_bounds__(CO_TILES * 128) void conv3x3_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(CO_TILES * 128, (CO_TILES == 2 ? 2 : 1)) void conv3x3_wgrad_kernel(WgradArgs a) {
     using C = WCfg<CO_TILES>;
     extern __shared__ __attribute__((aligned(16))) unsigned char conv_lds[];
     DSRG_LDS unsigned char *lds = (DSRG_LDS unsigned char *)conv_lds;
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(CO_TILES * 128) void conv3x3_wgrad_kernel(WgradArgs
         const int nxt = item + gridDim.x;
         const bool more = nxt < a.nitems;
         if (more) fetch(nxt);                                    // the next tiles on their way while this one is reduced
-        DSRG_LDS unsigned char *in = lds + cur * C::BUF;
+        DSRG_LDS unsigned char *in = lds + (C::NBUF == 2 ? cur : 0) * C::BUF;
         DSRG_LDS unsigned char *xb = in + x_lane, *gb = in + g_lane;
         // k-step ks = tile row ks of g (16 pixels); accumulator tile = tap (dy, dx): its x fragment starts at halo pixel
         // (ks + dy, dx).  So the loop runs over the ten halo rows R: the three fragments of row R (dx = 0, 1, 2) are read
@@ -515,9 +518,15 @@ __global__ __launch_bounds__(CO_TILES * 128) void conv3x3_wgrad_kernel(WgradArgs
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) park(conv_lds + (cur ^ 1) * C::BUF);
-        __syncthreads();                                         // the other buffer is complete, this one is free
-        cur ^= 1;
+        if (C::NBUF == 2) {
+            if (more) park(conv_lds + (cur ^ 1) * C::BUF);
+            __syncthreads();                                     // the other buffer is complete, this one is free
+            cur ^= 1;
+        } else {
+            __syncthreads();                                     // every wave is done with the tile
+            if (more) park(conv_lds);
+            __syncthreads();
+        }
     }
     // C[row = channel of g][col = channel of x]: lane holds column lane % 32, rows (reg & 3) + 8 (reg >> 2) + 4 (lane / 32)
     float *pp = a.part + (size_t)blockIdx.x * C::PART;
@@ -673,7 +682,7 @@ template <int CO_TILES>
 int launch_wgrad_variant(const WgradArgs &a, int grid, hipStream_t stream) {
     using C = WCfg<CO_TILES>;
     static LdsGrant grant;
-    const size_t lds = 2 * (size_t)C::BUF;
+    const size_t lds = C::NBUF * (size_t)C::BUF;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<CO_TILES>), lds, grant)) return rc;
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<CO_TILES>), dim3(grid), dim3(C::THREADS), lds, stream, a);
     DSRG_LAUNCH_CHECK();
@@ -694,18 +703,19 @@ bool wgrad_supported(int cin, int cout) {
 }
 
 // workgroups of the reduction for (B, H, W): a multiple of the slices of x
-int wgrad_grid(int B, int H, int W, int cin) {
+int wgrad_grid(int B, int H, int W, int cin, int cout) {
     const int roles = cin < 64 ? 1 : cin / 64;
     const long items = (long)B * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH) * roles;
-    const long cap = device_cus() / roles * roles;
+    const int per_cu = cout == 64 ? 2 : 1;                       // workgroups that share a CU (WCfg::WGS; the 3-channel kernel too)
+    const long cap = (long)device_cus() * per_cu / roles * roles;
     return (int)(items < cap ? items : cap);
 }
 }  // namespace
 
 size_t conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
     if (!wgrad_supported(cin, cout) || B < 1 || H < 1 || W < 1) return 0;
-    if (cin == 3) return (size_t)wgrad_grid(B, H, W, cin) * 64 * 64 * sizeof(float);
-    return (size_t)wgrad_grid(B, H, W, cin) * cout * 9 * 64 * sizeof(float);
+    if (cin == 3) return (size_t)wgrad_grid(B, H, W, cin, cout) * 64 * 64 * sizeof(float);
+    return (size_t)wgrad_grid(B, H, W, cin, cout) * cout * 9 * 64 * sizeof(float);
 }
 
 int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspace, size_t workspace_bytes, int B, int H, int W,
@@ -719,7 +729,7 @@ int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspac
     const long items = (long)B * a.tiles_x * a.tiles_y * a.roles;
     if (B < 1 || H < 1 || W < 1 || items > 0x7fffffffL) return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: bad shape");
     a.nitems = (int)items;
-    const int grid = wgrad_grid(B, H, W, cin);
+    const int grid = wgrad_grid(B, H, W, cin, cout);
     if (workspace_bytes < conv3x3_wgrad_workspace(B, H, W, cin, cout))
         return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: workspace of %zu bytes, %zu needed", workspace_bytes,
                          conv3x3_wgrad_workspace(B, H, W, cin, cout));
@@ -758,7 +768,7 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
     a.ntiles = (int)nt;
     const int n_cus = device_cus();
     if (cin == 3) {
-        hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(a.ntiles < n_cus ? a.ntiles : n_cus), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(a.ntiles < 4 * n_cus ? a.ntiles : 4 * n_cus), dim3(256), 0, stream, a);   // 21 KB of LDS, ~100 VGPRs
         DSRG_LAUNCH_CHECK();
         return DSRG_OK;
     }

@@ -35,3 +35,11 @@ for cin, cout, hw in [(64, 64, 321), (64, 128, 161), (128, 128, 161)]:
     print("%3d -> %3d @ %d: direct wgrad  %.1f us  %.0f TFLOP/s  %.2f TB/s of x+g" % (cin, cout, hw, us, flops / us / 1e6, 16 * hw * hw * (cin + cout) * 2 / us / 1e6))
     us = t(lambda: torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
     print("%3d -> %3d @ %d: MIOpen wrw    %.1f us  %.0f TFLOP/s" % (cin, cout, hw, us, flops / us / 1e6))
+x = torch.randn(16, 3, 321, 321, device="cuda").bfloat16().contiguous(memory_format=cl)
+w = (torch.randn(64, 3, 3, 3, device="cuda") * 0.05).bfloat16().contiguous(memory_format=cl)
+b = torch.randn(64, device="cuda")
+g = torch.randn(16, 64, 321, 321, device="cuda").bfloat16().contiguous(memory_format=cl)
+print("  3 ->  64 @ 321: direct kernel %.1f us, F.conv2d + bias + relu %.1f us; direct wgrad %.1f us, MIOpen wrw %.1f us" % (
+    t(lambda: ops.conv3x3_direct(x, w, b, True)), t(lambda: torch.relu_(F.conv2d(x, w, b.bfloat16(), padding=1))),
+    t(lambda: ops.conv3x3_wgrad(x, g)),
+    t(lambda: torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))))
