@@ -542,21 +542,25 @@ __global__ __launch_bounds__(CO_TILES * 128, (CO_TILES == 2 ? 2 : 1)) void conv3
 }
 
 // gw[o][tap][c] (bf16, the memory of a channels_last (cout, cin, 3, 3) tensor) = sum of the partials of slice c / 64 in
-// workgroup order.  256 threads = 64 consecutive channels x 4 interleaved quarters of the workgroups.
-__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *part, uint16_t *gw, int nwg, int roles, int cout,
-                                                                   int cin) {
-    __shared__ float red[4][64];
+// workgroup order.  1024 threads = 64 consecutive channels x 16 interleaved sixteenths of the workgroups (loads of many
+// partials in flight per thread: the sum is a latency chain otherwise), combined in a fixed order.
+constexpr int kRedChunks = 16;
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float *part, uint16_t *gw, int nwg, int roles, int cout,
+                                                                    int cin) {
+    __shared__ float red[kRedChunks][64];
     const int el = threadIdx.x & 63, ch = threadIdx.x >> 6;
     const int e0 = blockIdx.x * 64;                              // first element (o, tap, c) of this block; c % 64 == 0
     const int o = e0 / (9 * cin), rem = e0 - o * 9 * cin, tap = rem / cin, c0 = rem - tap * cin, role = c0 >> 6;
     const size_t stride = (size_t)cout * 9 * 64;
     const float *p = part + ((size_t)o * 9 + tap) * 64 + el;
     float s = 0.0f;
-    for (int w = role + ch * roles; w < nwg; w += 4 * roles) s += p[(size_t)w * stride];
+    for (int w = role + ch * roles; w < nwg; w += kRedChunks * roles) s += p[(size_t)w * stride];
     red[ch][el] = s;
     __syncthreads();
     if (ch == 0) {
-        const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kRedChunks; k++) t += red[k][el];
         f32x2 v = {t, 0.0f};
         bf16x2 bv = __builtin_convertvector(v, bf16x2);
         gw[(size_t)e0 + el] = *reinterpret_cast<uint16_t *>(&bv);
@@ -661,21 +665,26 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(WgradArgs a) {   
     }
 }
 
-// gw[o][tap][c] (bf16, (64, 3, 3, 3) channels_last) = sum over the workgroups of part[wg][o][tap * 4 + c], in workgroup order
-__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_reduce_kernel(const float *part, uint16_t *gw, int nwg) {
-    const int e = blockIdx.x * 256 + threadIdx.x;                // (o, tap, c)
-    if (e >= 64 * 27) return;
-    const int o = e / 27, rem = e - o * 27, tap = rem / 3, c = rem - tap * 3;
-    const float *p = part + o * 64 + tap * 4 + c;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int w = 0;
-    for (; w + 3 < nwg; w += 4) {
-        s0 += p[(size_t)w * 4096]; s1 += p[(size_t)(w + 1) * 4096]; s2 += p[(size_t)(w + 2) * 4096]; s3 += p[(size_t)(w + 3) * 4096];
+// gw[o][tap][c] (bf16, (64, 3, 3, 3) channels_last) = sum over the workgroups of part[wg][o][tap * 4 + c], in a fixed order;
+// as above: 64 consecutive entries of the 64 x 64 partial x 16 interleaved sixteenths of the workgroups per block
+__global__ __launch_bounds__(1024) void conv3x3_c3_wgrad_reduce_kernel(const float *part, uint16_t *gw, int nwg) {
+    __shared__ float red[kRedChunks][64];
+    const int el = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int o = blockIdx.x;                                    // one row of the partial: n = tap * 4 + c
+    const float *p = part + o * 64 + el;
+    float s = 0.0f;
+    for (int w = ch; w < nwg; w += kRedChunks) s += p[(size_t)w * 4096];
+    red[ch][el] = s;
+    __syncthreads();
+    const int tap = el >> 2, c = el & 3;
+    if (ch == 0 && tap < 9 && c < 3) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kRedChunks; k++) t += red[k][el];
+        f32x2 v = {t, 0.0f};
+        bf16x2 bv = __builtin_convertvector(v, bf16x2);
+        gw[(o * 9 + tap) * 3 + c] = *reinterpret_cast<uint16_t *>(&bv);
     }
-    for (; w < nwg; w++) s0 += p[(size_t)w * 4096];
-    f32x2 v = {(s0 + s1) + (s2 + s3), 0.0f};
-    bf16x2 bv = __builtin_convertvector(v, bf16x2);
-    gw[e] = *reinterpret_cast<uint16_t *>(&bv);
 }
 
 template <int CO_TILES>
@@ -739,13 +748,12 @@ int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspac
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_c3_wgrad_kernel), lds, grant)) return rc;
         hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel, dim3(grid), dim3(256), lds, stream, a);
         DSRG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv3x3_c3_wgrad_reduce_kernel, dim3((64 * 27 + 255) / 256), dim3(256), 0, stream, workspace,
-                           static_cast<uint16_t *>(gw), grid);
+        hipLaunchKernelGGL(conv3x3_c3_wgrad_reduce_kernel, dim3(64), dim3(1024), 0, stream, workspace, static_cast<uint16_t *>(gw), grid);
         DSRG_LAUNCH_CHECK();
         return DSRG_OK;
     }
     if (int rc = cout == 64 ? launch_wgrad_variant<2>(a, grid, stream) : launch_wgrad_variant<4>(a, grid, stream)) return rc;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cout * 9 * cin / 64), dim3(256), 0, stream, workspace,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cout * 9 * cin / 64), dim3(1024), 0, stream, workspace,
                        static_cast<uint16_t *>(gw), grid, a.roles, cout, cin);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
