@@ -19,6 +19,7 @@ _WGRAD_MIN_COUT = int(_os.environ.get("DSRG_WGRAD_MIN_COUT", "512"))
 # conv1_2 / conv2_1 / conv2_2 by the direct MFMA kernel: "1" all of them, "64" only conv1_2, "0" none (MIOpen / im2col + GEMM)
 _DIRECT_CONV = _os.environ.get("DSRG_DIRECT_CONV", "1")
 _DIRECT_C3 = _os.environ.get("DSRG_DIRECT_C3", "1") == "1"          # conv1_1 (3 -> 64) forward with bias + ReLU in one pass (0: MIOpen + 2 passes)
+_FUSE_POOL = _os.environ.get("DSRG_FUSE_POOL", "1") == "1"           # pool1-3 inside the conv node: pool backward + ReLU mask + bias gradient in one pass
 _GEMM_1X1_BWD = _os.environ.get("DSRG_GEMM_1X1_BWD", "1") == "1"   # 1x1 layers (fc7): both gradients as hipBLASLt GEMMs (0: MIOpen/CK)
 _DIRECT_WGRAD = _os.environ.get("DSRG_DIRECT_WGRAD", "1") == "1"   # their weight gradients by the direct kernel too (0: MIOpen)
 _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
@@ -65,7 +66,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
-    def forward(ctx, x, weight, bias, dilation, relu, gemm, drop_p):
+    def forward(ctx, x, weight, bias, dilation, relu, gemm, drop_p, pool=None):
         k = weight.shape[2]
         cols = None
         # 64 / 128 channels on both sides (conv1_2 at full resolution, conv2_1 / conv2_2 at half): the direct MFMA kernel
@@ -90,19 +91,30 @@ class _ConvFn(torch.autograd.Function):
                 out.relu_()
         if drop_p > 0.0:
             out = torch.ops.aten.native_dropout(out, drop_p, True)[0]    # out = relu * mask / (1 - p)
-        ctx.save_for_backward(x, weight, out if relu else None, cols)
+        code, pooled = None, None
+        if pool is not None:
+            # conv + ReLU + 3x3 max pool as one autograd node (conv1_2, conv2_2, conv3_3): the pool's backward then masks with
+            # this ReLU and sums the bias gradient in the same pass (ops.maxpool3x3_bwd_relu) instead of handing an unmasked
+            # gradient to a separate relu_bwd_bias pass — three fewer passes over the largest activations of the net
+            from .ops import maxpool3x3_fwd
+            pooled, code = maxpool3x3_fwd(out, pool[0], pool[1])
+        ctx.save_for_backward(x, weight, out if relu else None, cols, code)
         ctx.dilation, ctx.k, ctx.relu, ctx.scale, ctx.gemm = dilation, k, relu, 1.0 / (1.0 - drop_p), gemm
-        ctx.direct = direct
-        return out
+        ctx.direct, ctx.pool = direct, pool
+        return out if pool is None else pooled
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        x, weight, y, cols = ctx.saved_tensors
+        x, weight, y, cols, code = ctx.saved_tensors
         pad = ctx.dilation * (ctx.k // 2)
         cout = weight.shape[0]
         fused = g.dtype == torch.bfloat16 and ((cout % 8 == 0 and cout <= 2048) or (not ctx.relu and cout <= 256))
-        if fused and ctx.relu:
+        if ctx.pool is not None:                                        # forward guaranteed bf16, ReLU, no dropout, cout | 2048
+            from .ops import maxpool3x3_bwd_relu
+            g, gb = maxpool3x3_bwd_relu(g, code, y, ctx.pool[0])
+            fused = True
+        elif fused and ctx.relu:
             from .ops import relu_bwd_bias
             g, gb = relu_bwd_bias(g, y, ctx.scale)
         elif fused:
@@ -175,7 +187,7 @@ class _ConvFn(torch.autograd.Function):
             gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
                 g, x, weight, None if fused else [weight.shape[0]], [1, 1], [pad, pad],
                 [ctx.dilation, ctx.dilation], False, [0, 0], 1, mask)
-        return (gx if gemm_dgrad else gx2), (gw if gemm_wgrad else gw2), (gb if fused else gb2), None, None, None, None
+        return (gx if gemm_dgrad else gx2), (gw if gemm_wgrad else gw2), (gb if fused else gb2), None, None, None, None, None
 
 
 class GemmConv2d(nn.Conv2d):
@@ -183,25 +195,39 @@ class GemmConv2d(nn.Conv2d):
     with the following ReLU (`fuse_relu`) and Dropout (`fuse_dropout` = p, needs fuse_relu) fused; on the CPU it is the
     plain convolution (+ ReLU (+ Dropout))."""
 
-    def __init__(self, *args, fuse_relu=False, gemm=True, fuse_dropout=0.0, **kw):
+    def __init__(self, *args, fuse_relu=False, gemm=True, fuse_dropout=0.0, fuse_pool=None, **kw):
         super().__init__(*args, **kw)
         if fuse_dropout and not fuse_relu:
             raise ValueError("fuse_dropout needs fuse_relu (the fused backward reads both masks from the output sign)")
+        if fuse_pool is not None and (not fuse_relu or fuse_dropout or fuse_pool[0] != 2):
+            raise ValueError("fuse_pool = (2, ceil_mode) follows a fused ReLU without dropout")
         self.fuse_relu, self.gemm, self.fuse_dropout = fuse_relu, gemm, float(fuse_dropout)
+        self.fuse_pool = fuse_pool                                      # the 3x3 / stride 2 / pad 1 max pool behind the ReLU, (2, ceil_mode)
 
     def forward(self, x):
         p = self.fuse_dropout if self.training else 0.0
+        pool = self.fuse_pool
         if x.is_cuda and self.stride == (1, 1) and self.kernel_size[0] in (1, 3) and \
                 self.padding[0] == self.dilation[0] * (self.kernel_size[0] // 2):
-            return _ConvFn.apply(x, self.weight, self.bias, self.dilation[0], self.fuse_relu, self.gemm, p)
+            # the pool rides inside the node when its kernels apply: bf16 activations (autocast), 8 | channels, (channels / 8) | 256
+            cout = self.out_channels
+            in_node = pool is not None and _FUSE_POOL and cout % 8 == 0 and 256 % (cout // 8) == 0 and self.bias is not None and (
+                x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16))
+            out = _ConvFn.apply(x, self.weight, self.bias, self.dilation[0], self.fuse_relu, self.gemm, p, pool if in_node else None)
+            return out if pool is None or in_node else _pool3x3(out, pool[0], pool[1])
         out = super().forward(x)
         out = F.relu(out) if self.fuse_relu else out
-        return F.dropout(out, p, True) if p > 0.0 else out
+        out = F.dropout(out, p, True) if p > 0.0 else out
+        return out if pool is None else _pool3x3(out, pool[0], pool[1])
 
 
 class FusedReLU(nn.Identity):
     """placeholder that keeps the Sequential indices (and state_dict keys) of the conv/ReLU pairs: the ReLU itself
     runs inside the GemmConv2d in front of it"""
+
+
+class FusedPool(nn.Identity):
+    """placeholder for the max-pool layer that runs inside the GemmConv2d two slots in front of it (`fuse_pool`)"""
 
 
 class FusedDropout(nn.Identity):
@@ -268,9 +294,17 @@ class MaxPool3x3(nn.MaxPool2d):
         return super().forward(x)
 
 
-def _conv_relu(cin, cout, dilation=1, gemm=False):
-    conv = GemmConv2d(cin, cout, 3, padding=dilation, dilation=dilation, fuse_relu=True, gemm=gemm)
-    return [conv, FusedReLU()]
+def _pool3x3(x, stride, ceil_mode):
+    """3x3 / pad 1 max pool outside a conv node: the HIP pass for bf16 channels_last activations, torch's otherwise"""
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last):
+        return _MaxPool3x3Fn.apply(x, stride, ceil_mode)
+    return F.max_pool2d(x, 3, stride, 1, ceil_mode=ceil_mode)
+
+
+def _conv_relu(cin, cout, dilation=1, gemm=False, pool=None):
+    """conv + ReLU (+ the stride-2 max pool behind them, `pool` = (2, ceil_mode)): Sequential slots as in the prototxt"""
+    conv = GemmConv2d(cin, cout, 3, padding=dilation, dilation=dilation, fuse_relu=True, gemm=gemm, fuse_pool=pool)
+    return [conv, FusedReLU()] + ([FusedPool()] if pool is not None else [])
 
 
 class _HeadsFn(torch.autograd.Function):
@@ -300,9 +334,10 @@ class VGG16ASPP(nn.Module):
     def __init__(self, num_classes=21, dropout=0.5, gemm_convs=True):
         super().__init__()
         L = []
-        L += _conv_relu(3, 64) + _conv_relu(64, 64) + [MaxPool3x3(2, ceil_mode=True)]
-        L += _conv_relu(64, 128, 1, gemm_convs) + _conv_relu(128, 128, 1, gemm_convs) + [MaxPool3x3(2, ceil_mode=True)]
-        L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + [MaxPool3x3(2, ceil_mode=True)]
+        p2 = (2, True)                                                  # pool1-3: 3x3 / stride 2 / pad 1, ceil mode (Caffe), inside the conv node
+        L += _conv_relu(3, 64) + _conv_relu(64, 64, pool=p2)
+        L += _conv_relu(64, 128, 1, gemm_convs) + _conv_relu(128, 128, 1, gemm_convs, pool=p2)
+        L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs, pool=p2)
         g = gemm_convs                                                  # the 41x41 stages
         L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g) + _conv_relu(512, 512, 1, g) + [MaxPool3x3(1)]
         L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + [MaxPool3x3(1)]

@@ -269,6 +269,107 @@ __global__ void maxpool3x3_s2_bwd_kernel(const uint4 *__restrict__ gout, const u
     }
 }
 
+// The same with the ReLU backward of the layer in front of the pool and its bias gradient fused in (conv + ReLU + pool is
+// how conv1_2, conv2_2 and conv3_3 sit in train-s.prototxt:65-226): gin = (y > 0) ? pooled-back gradient : 0, written once, and
+// part[block][c] = this block's column sums of gin — instead of writing the unmasked gradient and passing over it again with
+// relu_bwd_bias_kernel (three more passes over the largest activations of the net).  A block owns a contiguous range of
+// (2 x 2 pixel block, channel group) items, 256 per round, so a thread keeps its channel group (256 % C8 == 0).
+__global__ __launch_bounds__(kRbThreads) void maxpool3x3_s2_bwd_relu_kernel(const uint4 *__restrict__ gout, const uint2 *__restrict__ code,
+                                                                             const uint4 *__restrict__ y, uint4 *__restrict__ gin,
+                                                                             float *__restrict__ part, int B, int H, int W, int OH,
+                                                                             int OW, int C8, size_t items_per_block) {
+    __shared__ float red[kRbThreads][9];
+    const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+    const size_t total = (size_t)B * H2 * W2 * C8;
+    const size_t beg = (size_t)blockIdx.x * items_per_block, end = beg + items_per_block < total ? beg + items_per_block : total;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t idx = beg + threadIdx.x; idx < end; idx += kRbThreads) {
+        const int c = (int)(idx % C8);
+        size_t r = idx / C8;
+        const int x2 = (int)(r % W2);
+        r /= W2;
+        const int y2 = (int)(r % H2);
+        const int b = (int)(r / H2);
+        uint32_t gw[2][2][4], cw[2][2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 gv = make_uint4(0u, 0u, 0u, 0u);
+                uint2 cd = make_uint2(0xffffffffu, 0xffffffffu);             // no window: matches no tap
+                if (y2 + i < OH && x2 + j < OW) {
+                    const size_t o = (((size_t)b * OH + y2 + i) * OW + x2 + j) * C8 + c;
+                    cd = code[o];
+                    gv = gout[o];
+                }
+                gw[i][j][0] = gv.x; gw[i][j][1] = gv.y; gw[i][j][2] = gv.z; gw[i][j][3] = gv.w;
+                cw[i][j][0] = cd.x; cw[i][j][1] = cd.y;
+            }
+        auto take = [&](float (&acc)[8], int i, int j, uint32_t want) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t w = cw[i][j][k >> 1];
+                const uint32_t c0 = (w >> (16 * (k & 1))) & 0xffu, c1 = (w >> (16 * (k & 1) + 8)) & 0xffu;
+                if (c0 == want) acc[2 * k] += bf16_lo(gw[i][j][k]);
+                if (c1 == want) acc[2 * k + 1] += bf16_hi(gw[i][j][k]);
+            }
+        };
+        auto store = [&](const float (&acc)[8], int yy, int xx) {
+            if (yy >= H || xx >= W) return;
+            const size_t i = (((size_t)b * H + yy) * W + xx) * C8 + c;
+            const uint4 yv = y[i];
+            const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool plo = (yw[k] & 0x8000u) == 0 && (yw[k] & 0x7fffu) != 0;          // as relu_bwd_bias_kernel
+                const bool phi = (yw[k] & 0x80000000u) == 0 && (yw[k] & 0x7fff0000u) != 0;
+                const uint32_t m = (plo ? 0xffffu : 0u) | (phi ? 0xffff0000u : 0u);
+                ow[k] = pack_bf16(acc[2 * k], acc[2 * k + 1]) & m;
+                bsum[2 * k] += bf16_lo(ow[k]);
+                bsum[2 * k + 1] += bf16_hi(ow[k]);
+            }
+            gin[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        };
+        const int y0 = 2 * y2, x0 = 2 * x2;
+        {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            take(acc, 0, 0, 4u);
+            store(acc, y0, x0);
+        }
+        {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            take(acc, 0, 1, 3u);
+            take(acc, 0, 0, 5u);
+            store(acc, y0, x0 + 1);
+        }
+        {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            take(acc, 1, 0, 1u);
+            take(acc, 0, 0, 7u);
+            store(acc, y0 + 1, x0);
+        }
+        {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            take(acc, 1, 1, 0u);
+            take(acc, 1, 0, 2u);
+            take(acc, 0, 1, 6u);
+            take(acc, 0, 0, 8u);
+            store(acc, y0 + 1, x0 + 1);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = bsum[k];
+    __syncthreads();
+    const int lanes = kRbThreads / C8;                                       // threads that share a channel group: t % C8 equal
+    for (int ch = threadIdx.x; ch < C8 * 8; ch += kRbThreads) {
+        const int g8 = ch >> 3, k = ch & 7;
+        float s2 = 0.f;
+        for (int l = 0; l < lanes; ++l) s2 += red[l * C8 + g8][k];
+        part[(size_t)blockIdx.x * (C8 * 8) + ch] = s2;
+    }
+}
+
 // ---- 3x3 / stride 1 / pad 1 average pooling over padded windows (Caffe AVE pooling = count_include_pad), NHWC bf16 --------
 // out = (sum of the in-image taps) / 9.  The stencil is symmetric, so the backward pass is the same kernel on the gradient.
 __global__ void avgpool3x3_s1_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, int B, int H, int W, int C8) {
@@ -360,6 +461,25 @@ int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, i
     const size_t total = (size_t)B * OH * OW * (C / 8);
     hipLaunchKernelGGL(maxpool3x3_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint4 *)in,
                        (uint4 *)out, (uint2 *)code, B, H, W, OH, OW, C / 8, stride);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y, void *gin, float *bias_grad, float *part,
+                                int part_blocks, int B, int H, int W, int OH, int OW, int C, hipStream_t stream) {
+    int rc = pool_check(B, H, W, OH, OW, C, 2);
+    if (rc) return rc;
+    const int C8 = C / 8;
+    if (kRbThreads % C8 != 0) return set_error(DSRG_ERR_UNSUPPORTED, "maxpool3x3_bwd_relu: channels / 8 must divide %d", kRbThreads);
+    if (part_blocks < 1) return set_error(DSRG_ERR_INVALID, "maxpool3x3_bwd_relu: no partial-sum blocks");
+    const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * C8;
+    size_t ipb = (total + part_blocks - 1) / part_blocks;
+    ipb = (ipb + kRbThreads - 1) / kRbThreads * kRbThreads;                  // whole rounds: a thread keeps its channel group
+    const int nblk = (int)((total + ipb - 1) / ipb);
+    hipLaunchKernelGGL(maxpool3x3_s2_bwd_relu_kernel, dim3(nblk), dim3(kRbThreads), 0, stream, (const uint4 *)gout, (const uint2 *)code,
+                       (const uint4 *)y, (uint4 *)gin, part, B, H, W, OH, OW, C8, ipb);
+    DSRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

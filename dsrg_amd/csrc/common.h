@@ -151,6 +151,8 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
 int heads_bwd_chunks(int M);
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
                      float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream);
+int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y, void *gin, float *bias_grad, float *part,
+                                int part_blocks, int B, int H, int W, int OH, int OW, int C, hipStream_t stream);
 int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,
                           hipStream_t stream);
 int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, int H, int W, int OH, int OW, int C,

@@ -255,6 +255,14 @@ int dsrg_maxpool3x3_fwd_bf16(const void *in_dev, void *out_dev, void *code_dev, 
                              int stride, void *stream);
 int dsrg_maxpool3x3_bwd_bf16(const void *gout_dev, const void *code_dev, void *gin_dev, int B, int H, int W, int OH, int OW,
                              int C, int stride, void *stream);
+/* Stride-2 pooling backward fused with the ReLU backward and the bias gradient of the convolution in front of the pool
+ * (conv + ReLU + pool, train-s.prototxt:65-226): relu_out_dev = the pool's input = that ReLU's output (B,H,W,C) bf16;
+ * gin = (relu_out > 0) ? pooled-back gradient : 0 (bit-identical to dsrg_maxpool3x3_bwd_bf16 followed by
+ * dsrg_relu_bwd_bias_bf16), bias_grad_dev[c] = sum of gin over (b, y, x).  partials_dev: partial_blocks * C floats;
+ * (C / 8) must divide 256. */
+int dsrg_maxpool3x3_bwd_relu_bf16(const void *gout_dev, const void *code_dev, const void *relu_out_dev, void *gin_dev,
+                                  float *bias_grad_dev, float *partials_dev, int partial_blocks, int B, int H, int W, int OH,
+                                  int OW, int C, void *stream);
 
 /* The five Python layers of train-s.prototxt:746-810 as ONE stream-ordered
  * sequence (Softmax -> CRF -> DSRG -> BalancedSeedLoss + ConstrainLoss, then

@@ -734,6 +734,47 @@ def test_narrow_conv_layers_differentiate_like_torch(ops, cin, cout):
         assert u.shape == v.shape and (u.float() - v.float()).norm() <= 0.02 * v.float().norm()
 
 
+def test_pool_backward_with_fused_relu_mask_and_bias_gradient(ops):
+    """conv + ReLU + stride-2 max pool as one node: the fused backward pass (pool backward, ReLU mask, bias gradient) writes the
+    same masked gradient, bit for bit, as maxpool3x3_bwd followed by relu_bwd_bias; then the module against torch's sequence"""
+    import torch.nn.functional as F
+    from dsrg_amd.backbone import GemmConv2d
+    torch.manual_seed(13)
+    cl = torch.channels_last
+    for B, C, H, W, ceil in [(2, 64, 33, 29, True), (1, 128, 6, 6, False), (2, 256, 41, 40, True), (16, 64, 321, 321, True), (1, 8, 2, 3, True)]:
+        y = torch.relu(torch.randn(B, C, H, W, device="cuda")).bfloat16().contiguous(memory_format=cl)
+        pooled, code = ops.maxpool3x3_fwd(y, 2, ceil)
+        go = torch.randn_like(pooled)
+        g_ref, gb_ref = ops.relu_bwd_bias(ops.maxpool3x3_bwd(go, code, y.shape, 2), y, 1.0)
+        g, gb = ops.maxpool3x3_bwd_relu(go, code, y, 2)
+        assert torch.equal(g, g_ref), (B, C, H, W)
+        assert (gb - gb_ref).abs().max() <= 1e-4 * gb_ref.abs().max() + 1e-4                    # fp32 sums, other grouping
+    from dsrg_amd.backbone import _pool3x3
+    for cin, cout in [(64, 64), (128, 128), (256, 256)]:
+        a = GemmConv2d(cin, cout, 3, padding=1, fuse_relu=True, fuse_pool=(2, True)).cuda().to(memory_format=cl)
+        b = GemmConv2d(cin, cout, 3, padding=1, fuse_relu=True).cuda().to(memory_format=cl)      # the same convolution, pool as a node of its own
+        c = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda().to(memory_format=cl)
+        b.load_state_dict(a.state_dict()); c.load_state_dict(a.state_dict())
+        x = torch.randn(2, cin, 37, 45, device="cuda").contiguous(memory_format=cl)
+        xa, xb, xc = (x.clone().requires_grad_(True) for _ in range(3))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ya = a(xa)
+            yb = _pool3x3(b(xb), 2, True)
+            yc = F.max_pool2d(torch.relu(c(xc)), 3, 2, 1, ceil_mode=True)
+        assert torch.equal(ya, yb)
+        assert ya.shape == yc.shape and (ya.float() - yc.float()).norm() <= 0.01 * yc.float().norm()
+        g = torch.randn_like(yc)
+        ya.backward(g.to(ya.dtype)); yb.backward(g.to(yb.dtype)); yc.backward(g)
+        assert torch.equal(xa.grad, xb.grad) and torch.equal(a.weight.grad, b.weight.grad)       # the same masked gradient into the same kernels
+        assert (a.bias.grad - b.bias.grad).abs().max() <= 1e-4 * b.bias.grad.abs().max() + 1e-4
+        # against torch's conv -> relu -> max_pool2d only loosely: two convolution kernels round a few outputs differently, and a
+        # window whose two largest values swap order routes its gradient to another pixel
+        for u, v in [(xa.grad, xc.grad), (a.weight.grad, c.weight.grad), (a.bias.grad, c.bias.grad)]:
+            assert u.shape == v.shape and (u.float() - v.float()).norm() <= 0.15 * v.float().norm()
+        with torch.no_grad():                                                                    # float32 / no autocast: the pool runs behind the node
+            assert a(x).shape == ya.shape
+
+
 def test_fused_relu_dropout_backward_matches_unfused_sequence():
     """conv + ReLU + Dropout in one autograd function: same dropout mask as F.dropout under the same seed, and the fused
     backward (one pass reading the sign of the dropped output) equals conv -> relu -> dropout differentiated by torch"""
