@@ -3,6 +3,7 @@ the solver's `snapshot_prefix` do in the reference (tools/train.py:53-63, run.sh
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from dsrg_amd import checkpoint as CK
@@ -101,3 +102,27 @@ def test_snapshot_resume_continues_the_same_trajectory(tmp_path):
     for vb, vd in zip(b.net.state_dict().values(), d.net.state_dict().values()):
         assert torch.equal(vb, vd)
     assert d.opt.iter == 0                       # --weights does not restore the solver
+
+
+def test_fused_pool_keeps_the_sequential_slots_and_the_cpu_arithmetic():
+    """pool1-3 run inside the convolution node in front of them on the GPU (GemmConv2d(fuse_pool=...)); the Sequential keeps a
+    placeholder in the pool's slot, so state_dict keys and the Caffe layer map are those of the plain conv / ReLU / pool stack,
+    and on the CPU the module is conv -> ReLU -> 3x3 / stride 2 / pad 1 ceil-mode max pool"""
+    import torch.nn.functional as F
+    from dsrg_amd.backbone import VGG16ASPP, GemmConv2d, FusedPool, MaxPool3x3
+    from dsrg_amd.checkpoint import caffe_layer_map
+    torch.manual_seed(0)
+    net = VGG16ASPP()
+    kinds = [type(m).__name__ for m in net.features]
+    assert len(kinds) == 32 and kinds[4] == kinds[9] == kinds[16] == "FusedPool" and kinds.count("MaxPool3x3") == 2
+    conv_slots = [i for i, m in enumerate(net.features) if isinstance(m, torch.nn.Conv2d)]
+    assert conv_slots == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]            # train-s.prototxt's conv1_1 ... conv5_3
+    assert [net.features[i].fuse_pool for i in (2, 7, 14)] == [(2, True)] * 3
+    lm = caffe_layer_map(net)
+    assert lm["conv1_2"] is net.features[2] and lm["conv3_3"] is net.features[14] and lm["conv5_3"] is net.features[28]
+    a = GemmConv2d(8, 16, 3, padding=1, fuse_relu=True, fuse_pool=(2, True))
+    x = torch.randn(2, 8, 13, 10)
+    want = F.max_pool2d(F.relu(F.conv2d(x, a.weight, a.bias, padding=1)), 3, 2, 1, ceil_mode=True)
+    assert torch.equal(a(x), want)
+    with pytest.raises(ValueError):
+        GemmConv2d(8, 16, 3, padding=1, fuse_pool=(2, True))                          # no ReLU in front of the pool
