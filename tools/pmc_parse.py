@@ -39,7 +39,7 @@ def main(fetch_csv, write_csv, out, commit=""):
         for (k, g), vals in t.items():
             if CALIB_KERNEL in k and g > 1000000:
                 continue
-            short = k.split("(")[0]
+            short = k.replace("(anonymous namespace)::", "").split("(")[0]
             e = kernels.setdefault(short, {})
             e[name + "_raw_bytes"] = sum(vals) / len(vals) * 1024.0
             e[name + "_bytes"] = e[name + "_raw_bytes"] * factors[name]
