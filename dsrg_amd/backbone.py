@@ -401,3 +401,38 @@ def count_flops_per_image(size=321):
         macs += n * cin * cout * 9 * h * h
     macs += 4 * (512 * 1024 * 9 + 1024 * 1024 + 1024 * 21) * h4 * h4
     return 2 * macs
+
+
+class GraphedForward(object):
+    """An eval-mode forward of `net` captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed per call.  At batch 1
+    the VGG16-ASPP forward is ~150 launches of 3-30 us and launch-bound (1.6 ms eager, 0.7 ms replayed); its shapes, weights
+    and buffers are static at test time, and every HIP kernel of this package launches on torch's current stream, which is
+    the capture stream.  The eager warm-up runs first so that TunableOp has picked its GEMM solutions and the kernels have
+    reserved their LDS outside the capture.  __call__(x) copies x into the captured input buffer and returns the captured
+    output buffer (overwritten by the next call)."""
+
+    def __init__(self, net, example, amp_dtype=torch.bfloat16, warmup=3):
+        if net.training:
+            raise ValueError("GraphedForward captures an eval-mode forward (dropout would replay one mask)")
+        self.net, self.amp = net, amp_dtype
+        self.x = example.detach().clone(memory_format=torch.preserve_format)
+        warm = torch.cuda.Stream(device=example.device)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            for _ in range(warmup):
+                self._fwd()
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._fwd()
+
+    def _fwd(self):
+        with torch.no_grad(), torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
+            return self.net(self.x).contiguous()
+
+    def __call__(self, x=None):
+        if x is not None and x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x)
+        self.graph.replay()
+        return self.out

@@ -97,3 +97,29 @@ def test_generate_m_rule():
     pred = rng.integers(0, 21, size=3000).astype(np.uint8)
     cm = ConfusionMatrix(21)
     assert np.array_equal(cm.generateM((gt, pred)), O.confusion_matrix(gt, pred, 21, rule_lt=True))
+
+
+@pytest.mark.gpu
+def test_backbone_forward_replays_from_a_hip_graph():
+    """bench.py --mode infer replays the VGG16-ASPP forward from a hipGraph (torch.cuda.CUDAGraph): every HIP kernel of the
+    forward (direct convolutions, pooling, heads) takes torch's current stream, so it is capturable, and in eval mode the
+    replayed scores equal the eager ones bit for bit — also after the input buffer has been overwritten in place"""
+    from dsrg_amd.backbone import VGG16ASPP
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    net = VGG16ASPP().to(dev).to(memory_format=torch.channels_last).eval()
+    x = torch.randn(1, 3, 97, 113, device=dev).contiguous(memory_format=torch.channels_last)
+
+    from dsrg_amd.backbone import GraphedForward
+
+    def fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return net(x).contiguous()
+    g = GraphedForward(net, x)
+    for seed in (5, 6):
+        torch.manual_seed(seed)
+        x.copy_(torch.randn_like(x))
+        static = g(x)
+        assert static.dtype == torch.float32 and torch.equal(static, fwd())
+    with pytest.raises(ValueError):
+        GraphedForward(net.train(), x)
