@@ -59,6 +59,29 @@ def test_fails_loudly_without_gpu():
         lay.forward([b], [t])
 
 
+def test_direct_convolution_entry_points_check_their_arguments():
+    """host-side checks of the direct convolution entry points (no kernel is launched): channel counts outside the built
+    variants are DSRG_ERR_INVALID with a message, the weight-gradient workspace is workgroups x cout x 9 x 64 floats (two
+    workgroups per CU for 64-channel gradients) and 0 for shapes it does not serve"""
+    import ctypes
+    from dsrg_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(16)                                             # never dereferenced: the checks come first
+    assert L.dsrg_conv3x3_direct_bf16(one, one, None, one, 1, 8, 16, 32, 64, 1, None) != 0
+    assert b"channels" in L.dsrg_last_error()
+    assert L.dsrg_conv3x3_direct_bf16(None, one, None, one, 1, 8, 16, 64, 64, 1, None) != 0
+    assert L.dsrg_conv3x3_wgrad_bf16(one, one, one, one, 1 << 30, 1, 8, 16, 128, 64, None) != 0      # 128 -> 64 has no weight-gradient kernel
+    assert L.dsrg_conv3x3_wgrad_workspace(1, 8, 16, 128, 64) == 0 and L.dsrg_conv3x3_wgrad_workspace(1, 8, 16, 64, 32) == 0
+    assert L.dsrg_conv3x3_wgrad_workspace(1, 8, 16, 64, 64) == 1 * 64 * 9 * 64 * 4               # one tile -> one workgroup
+    assert L.dsrg_conv3x3_wgrad_workspace(1, 8, 16, 128, 128) == 2 * 128 * 9 * 64 * 4            # two 64-channel slices of x
+    assert L.dsrg_conv3x3_wgrad_workspace(1, 8, 16, 3, 64) == 64 * 64 * 4
+    big = L.dsrg_conv3x3_wgrad_workspace(16, 321, 321, 64, 64)
+    assert big % (64 * 9 * 64 * 4) == 0 and big // (64 * 9 * 64 * 4) >= 2                        # capped by the device, not by the 13 776 tiles
+    assert L.dsrg_conv3x3_wgrad_bf16(one, one, one, one, 16, 1, 8, 16, 64, 64, None) != 0       # workspace too small
+    assert b"workspace" in L.dsrg_last_error()
+    assert L.dsrg_maxpool3x3_bwd_relu_bf16(one, one, one, one, one, one, 512, 1, 8, 8, 4, 4, 24, None) != 0   # 24 / 8 does not divide 256
+
+
 def test_layer_protocol_errors_match_reference():
     """wrong bottom counts raise plain Exception (pylayers.py:27-28,57-58,280-281)."""
     import pylayers
