@@ -614,6 +614,41 @@ def test_backbone_runs_with_and_without_autocast():
         assert torch.isfinite(ga).all() and (ga - gb).norm() < tol * gb.norm(), (name, float((ga - gb).norm() / gb.norm()))
 
 
+def test_supervision_entry_points_capture_into_a_hip_graph(ops):
+    """the batched entry points are stream-ordered and never synchronise, so a fixed-shape sequence can be
+    captured into a hipGraph — here the lattice build on a side stream, Softmax, the ten mean-field iterations and region
+    growing; the replay reproduces the launched path's seeds and marginals bit for bit, also on new inputs written in place"""
+    from dsrg_amd import synthetic as S
+    B = 2
+    b = S.make_batch(77, B)
+    d = lambda a: torch.from_numpy(a).cuda()
+    logits, images, labels, cues = d(b["logits"]), d(b["images"]), d(b["labels"]), d(b["cues"])
+    ctx = ops.get_context(B, 21, 41, 41)
+    side = torch.cuda.Stream()
+
+    def run():
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.crf_prepare(images, 21, 41, 41, ctx=ctx)
+        probs = ops.softmax_forward(logits)
+        main.wait_stream(side)
+        refined, _ = ops.crf_refine(probs, images, ctx=ctx, want_log=False, prepared=True)
+        return ops.srg_grow(labels, cues, refined), refined
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        seeds_s, refined_s = run()
+    for seed in (78, 79):
+        nb = S.make_batch(seed, B)
+        logits.copy_(d(nb["logits"])); images.copy_(d(nb["images"])); labels.copy_(d(nb["labels"])); cues.copy_(d(nb["cues"]))
+        g.replay()
+        seeds, refined = run()
+        assert torch.equal(seeds_s, seeds) and torch.equal(refined_s, refined)
+
+
 def test_fp32_heads_kernel_matches_fp32_convolutions(ops):
     """fc8-SEC_k + Eltwise SUM in one HIP pass (bf16 activations, fp32 weights/accumulation/result, NCHW) against the fp32
     1x1 convolutions of the same bf16-valued activations; the backward of the autograd wrapper against torch's"""
