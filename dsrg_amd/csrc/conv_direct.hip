@@ -9,9 +9,11 @@
 // forward (bias + ReLU in the epilogue) and the data gradient (the same convolution with the kernel flipped and its channel
 // axes swapped, prepared by the caller).
 //
-// Shape of the kernel: persistent workgroups of 4 waves at one wave per SIMD, each wave with its share of the weight tensor
-// in registers as MFMA fragments — 288 VGPRs in every variant (the file has 512 at this occupancy):
-//     64 -> 64    every wave holds all 64 outputs (2 tiles x 36 k-steps), the 4 waves split the 128 pixels of a tile
+// Shape of the kernel: persistent workgroups of 4 waves, each wave with its share of the weight tensor in registers as MFMA
+// fragments — 288 VGPRs at one wave per SIMD (the file has 512 at that occupancy), or 144 at two:
+//     64 -> 64    a wave holds 32 of the outputs (1 tile x 36 k-steps = 144 VGPRs), 2 x 2 waves split outputs x pixels, and TWO
+//                 workgroups share a CU: the 24 KB halo fetch of a workgroup is its only memory parallelism and the kernel is
+//                 bound by exactly that (DSRG_CONV_OCC=1: all 64 outputs per wave, one workgroup per CU, 202 instead of 169 us)
 //     64 -> 128   a wave holds 64 of the outputs, 2 x 2 waves split outputs x pixels (2 M-tiles of 32 pixels per wave)
 //    128 -> 128   a wave holds 32 of the outputs (1 tile x 72 k-steps) and visits all 4 M-tiles
 //    128 -> 64    a wave holds 32 of the outputs, 2 x 2 waves split outputs x pixels
