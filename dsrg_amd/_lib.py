@@ -60,10 +60,12 @@ SIGNATURES = {
     "dsrg_ctx_lattice_sizes": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dsrg_ctx_lattice_dump": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsrg_ctx_read_refined": (_i, [_vp, _i, _vp, _vp]),
+    "dsrg_ctx_lattice_norm": (_i, [_vp, _i, _i, _vp, _vp]),
+    "dsrg_ctx_filter_once": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "dsrg_ctx_profile_start": (_i, [_vp, _i]),
     "dsrg_ctx_profile_stop": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
     "dsrg_crf_layer_backward": (_i, [_sz, _vp, _vp, _vp, _vp]),
-    "dsrg_srg_grow_batch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _d, _d, _vp, _vp]),
+    "dsrg_srg_grow_batch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp]),
     "dsrg_softmax_forward": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "dsrg_softmax_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dsrg_seed_loss": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -37,19 +37,19 @@ struct dsrg_ctx_s {
     float *probs, *logq, *seeds;
     double *refined;
     double *stats;               // (maxB, 5)
+    uint16_t *srg_code;          // (maxB, N) per-pixel codes handed from the SRG classification pass to the growth pass
     Profiler prof;
     int prepared_B;              // batch whose lattices dsrg_crf_prepare_batch built (0 = none)
     dsrg_crf_params prepared_prm;
-    unsigned int mf_epoch;       // launch counter of the one-launch inference loop (granule tags)
-    unsigned int *mf_status;     // host-mapped: non-zero after a hand-off inside that kernel timed out
+    int gauss_local;             // the cached Gaussian lattice's kLatticeLocal flag as read back by the host: 1 yes, 0 no,
+                                 // -1 not read (built inside a stream capture): the kernels then test the flag themselves
 };
 
-namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; extern int g_meanfield_mode; }
-// tests / tools only (not in the public header): 1 = the one-launch inference loop, 0 = one filter + one update launch per
-// iteration, -1 = back to the DSRG_MEANFIELD environment variable
-extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_meanfield_mode(int mode) { dsrg::g_meanfield_mode = mode; }
-// tests only: the hand-off status word of a context (non-zero after a timed-out hand-off)
-extern "C" __attribute__((visibility("default"))) int dsrg_debug_meanfield_status(dsrg_ctx_t c);
+namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; extern int g_filter_opts; }
+// tests / tools only (not in the public header): option bits of the mean-field filter launch (meanfield.hip, kOpt*: 1 = a
+// pixel-local Gaussian lattice is evaluated by the update kernel, 2 = slot guard); -1 = back to the DSRG_FILTER_OPTS environment variable / the default (all on).  Every combination yields
+// bit-identical marginals (tests/test_gpu_parity.py).
+extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_opts(int opts) { dsrg::g_filter_opts = opts; }
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_build_trace(void *dev_buf) { dsrg::g_build_dbg = dev_buf; }
 // tools only (not in the public header): device buffer of 16 u64 per filter block receiving phase timestamps
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_trace(void *dev_buf) { dsrg::g_filter_dbg = dev_buf; }
@@ -79,21 +79,14 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     const size_t szIm = align256((size_t)max_batch * N * 3);
     const size_t szRef = align256(sizeof(double) * (size_t)max_batch * C * N);
     const size_t szStats = align256(sizeof(double) * (size_t)max_batch * 5 * 8);   // [B][kStatSplit][5]
-    const size_t szGran = align256(sizeof(unsigned long long) * (size_t)max_batch * C * N);
-    const size_t total = szLg + szLb + 3 * blob /*mf*/ + szIm + 3 * blob /*probs,logq,seeds*/ + szRef + szStats + 2 * szGran + 256;
+    const size_t szCode = align256(sizeof(uint16_t) * (size_t)max_batch * N);
+    const size_t total = szLg + szLb + 3 * blob /*mf*/ + szIm + 3 * blob /*probs,logq,seeds*/ + szRef + szStats + szCode + 256;
     hipError_t e = hipMalloc(&c->arena, total);
     if (e != hipSuccess) {
         delete c;
         return set_error(DSRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
     }
-    c->mf_epoch = 0; c->mf_status = nullptr;
-    e = hipHostMalloc(reinterpret_cast<void **>(&c->mf_status), sizeof(unsigned int), hipHostMallocMapped);
-    if (e != hipSuccess) {
-        (void)hipFree(c->arena);
-        delete c;
-        return set_error(DSRG_ERR_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
-    }
-    *c->mf_status = 0;
+    c->gauss_local = -1;
     unsigned char *p = static_cast<unsigned char *>(c->arena);
     lattice_carve(c->Lg, p, 2, N, 1); p += szLg;
     lattice_carve(c->Lb, p, 5, N, max_batch); p += szLb;
@@ -106,21 +99,7 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     c->seeds = reinterpret_cast<float *>(p); p += blob;
     c->refined = reinterpret_cast<double *>(p); p += szRef;
     c->stats = reinterpret_cast<double *>(p); p += szStats;
-    c->mf.qg = reinterpret_cast<unsigned long long *>(p); p += szGran;
-    c->mf.vg = reinterpret_cast<unsigned long long *>(p); p += szGran;
-    c->mf.work_counter = reinterpret_cast<unsigned int *>(p); p += 256;
-    c->mf.status_host = c->mf_status;
-    c->mf.epoch = &c->mf_epoch;
-    void *sdev = nullptr;
-    e = hipHostGetDevicePointer(&sdev, c->mf_status, 0);
-    if (e == hipSuccess) e = hipMemset(c->mf.qg, 0, 2 * szGran + 256);    // tag 0 = never written; unit counter 0
-    if (e != hipSuccess) {
-        (void)hipHostFree(c->mf_status);
-        (void)hipFree(c->arena);
-        delete c;
-        return set_error(DSRG_ERR_HIP, "context set-up failed: %s", hipGetErrorString(e));
-    }
-    c->mf.status = static_cast<unsigned int *>(sdev);
+    c->srg_code = reinterpret_cast<uint16_t *>(p); p += szCode;
     *out = c;
     return DSRG_OK;
 }
@@ -171,13 +150,10 @@ extern "C" int dsrg_ctx_profile_stop(dsrg_ctx_t c, double *total_ms, int32_t *la
     return prof_stop(c->prof, total_ms, launches);
 }
 
-extern "C" int dsrg_debug_meanfield_status(dsrg_ctx_t c) { return (c && c->mf_status) ? (int)*c->mf_status : -1; }
-
 extern "C" int dsrg_ctx_destroy(dsrg_ctx_t c) {
     if (!c) return DSRG_OK;
     prof_free(c->prof);
     if (c->arena) (void)hipFree(c->arena);
-    if (c->mf_status) (void)hipHostFree(c->mf_status);
     delete c;
     return DSRG_OK;
 }
@@ -204,6 +180,18 @@ static int crf_build(dsrg_ctx_t c, int B, const unsigned char *im_u8, const dsrg
         if (rc) return rc;
         c->Fg_built = Fg;
         c->gauss_valid = true;
+        // Once per (shape, theta_gamma): read the lattice's flags back so that later filter launches can leave the Gaussian
+        // workgroups out of the grid when the lattice is pixel-local.  Not inside a stream capture (no host sync there):
+        // the kernels then decide from the device-side flag and the launch merely carries workgroups that exit at once.
+        c->gauss_local = -1;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+        if (cap == hipStreamCaptureStatusNone) {
+            int fl = 0;
+            DSRG_HIP_CHECK(hipMemcpyAsync(&fl, c->Lg.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+            DSRG_HIP_CHECK(hipStreamSynchronize(s));
+            c->gauss_local = (fl & kLatticeLocal) ? 1 : 0;
+        }
     }
     return launch_lattice_build(c->Lb, Fb, im_u8, B, s);
 }
@@ -212,16 +200,12 @@ static int crf_build(dsrg_ctx_t c, int B, const unsigned char *im_u8, const dsrg
 static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,
                    const dsrg_crf_params *prm, float *q_out, double *refined, float *logq, hipStream_t s,
                    bool prepared = false) {
-    if (c->mf_status && *c->mf_status)
-        return set_error(DSRG_ERR_HIP, "a hand-off inside the one-launch mean-field kernel timed out in an earlier call on this "
-                                       "context (workgroups of one image not co-resident?); results since then are invalid — "
-                                       "DSRG_MEANFIELD=launches selects the multi-launch loop");
     if (!prepared) {
         int rc = crf_build(c, B, im_u8, prm, s);
         if (rc) return rc;
     }
     return launch_meanfield(c->Lg, c->Lb, c->mf, B, c->C, neg_unary, prm->w_gaussian, prm->w_bilateral,
-                            prm->n_iters, q_out, refined, logq, s, &c->prof);
+                            prm->n_iters, q_out, refined, logq, c->gauss_local == 1, s, &c->prof);
 }
 
 extern "C" int dsrg_crf_prepare_batch(dsrg_ctx_t c, int B, const float *images, int img_h, int img_w,
@@ -359,16 +343,39 @@ extern "C" int dsrg_ctx_read_refined(dsrg_ctx_t c, int B, double *refined_dev, v
     return DSRG_OK;
 }
 
+// introspection (tests): norm = 1/sqrt(K 1 + 1e-20) of one lattice (DenseKernel::initLattice, pairwise.cpp:44,54-57)
+extern "C" int dsrg_ctx_lattice_norm(dsrg_ctx_t c, int kind, int b, float *norm_host, void *stream) {
+    if (!c || (kind != 0 && kind != 1) || !norm_host) return set_error(DSRG_ERR_INVALID, "bad argument");
+    const LatticeView &L = kind == 0 ? c->Lg : c->Lb;
+    if (b < 0 || b >= L.nlat) return set_error(DSRG_ERR_INVALID, "lattice index %d outside 0..%d", b, L.nlat - 1);
+    DSRG_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    DSRG_HIP_CHECK(hipMemcpy(norm_host, L.norm + (size_t)b * L.N, sizeof(float) * (size_t)L.N, hipMemcpyDeviceToHost));
+    return DSRG_OK;
+}
+
+// introspection (tests): ONE application of one normalised kernel, out = norm . K (norm . q) (DenseKernel::filter,
+// pairwise.cpp:63-80, through Permutohedral::compute, permutohedral.cpp:529-604) with the lattices of the last refine /
+// prepare / meanfield / supervision call — exactly the code path the inference loop takes, incl. the per-pixel evaluation
+// of a pixel-local Gaussian lattice.  q_dev / out_dev: (B,C,H,W) f32 planes.
+extern "C" int dsrg_ctx_filter_once(dsrg_ctx_t c, int kind, int B, const float *q_dev, float *out_dev, void *stream) {
+    if (!c || (kind != 0 && kind != 1) || !q_dev || !out_dev) return set_error(DSRG_ERR_INVALID, "bad argument");
+    if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
+    if (!c->gauss_valid) return set_error(DSRG_ERR_INVALID, "no lattice has been built on this context yet");
+    return launch_filter_once(c->Lg, c->Lb, c->mf, B, c->C, kind, q_dev, out_dev, c->gauss_local == 1,
+                              static_cast<hipStream_t>(stream));
+}
+
 extern "C" int dsrg_crf_layer_backward(size_t n, const double *refined, const float *td, float *bd, void *stream) {
     if (!refined || !td || !bd) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_crf_bwd(n, refined, td, bd, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dsrg_srg_grow_batch(int B, int C, int H, int W, const float *labels, const float *cues,
-                                   const double *refined, double th1, double th2, float *seeds, void *stream) {
-    if (!labels || !cues || !refined || !seeds) return set_error(DSRG_ERR_INVALID, "NULL argument");
+                                   const double *refined, double th1, double th2, float *seeds, void *scratch, void *stream) {
+    if (!labels || !cues || !refined || !seeds || !scratch) return set_error(DSRG_ERR_INVALID, "NULL argument");
     if (B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "bad shape");
-    return launch_srg(B, C, H, W, labels, cues, refined, th1, th2, seeds, static_cast<hipStream_t>(stream));
+    return launch_srg(B, C, H, W, labels, cues, refined, th1, th2, seeds, static_cast<uint16_t *>(scratch),
+                      static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dsrg_softmax_forward(int B, int C, int HW, const float *x, float *p, void *stream) {
@@ -514,7 +521,7 @@ extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, c
         c->prepared_B = 0;                                                         // consumed
     }
     if (rc) return rc;
-    rc = launch_srg(B, C, c->H, c->W, labels, cues, c->refined, th1, th2, c->seeds, s);    // DSRG
+    rc = launch_srg(B, C, c->H, c->W, labels, cues, c->refined, th1, th2, c->seeds, c->srg_code, s);    // DSRG
     if (rc) return rc;
     rc = launch_sup_loss_backward(B, C, N, logits, c->probs, c->seeds, c->logq, c->refined, c->stats, grad_logits,
                                   losses, s);                                        // losses + backward

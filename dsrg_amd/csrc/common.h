@@ -40,7 +40,8 @@ inline int ensure_dynamic_lds(const void *fn, size_t bytes, size_t &granted) {
 }
 
 constexpr int kWG = 1024;          // threads per workgroup of the lattice kernels (16 waves)
-constexpr int kMaxLabels = 64;     // per-pixel label loops keep at most this many values in registers
+constexpr int kMaxLabels = 96;     // per-pixel label loops keep at most this many values in registers / LDS columns (the
+                                   // 81-class blobs of AnnotationLayerCOCO, pylayers.py:389-512, fit)
 constexpr float kMinProb = 0.0001f;
 
 // ---- permutohedral lattice, device-resident ----------------------------------
@@ -55,15 +56,21 @@ struct LatticeView {
     // per lattice, strided by the quantities in brackets
     int *M;                // [1]        vertex count
     int *flags;            // [1]        bit 0: lattice is diagonal (every vertex has one contributor, no blur neighbour);
-                           //            bit 2: every vertex has exactly one contributor (M == E)
+                           //            bit 2: every vertex has exactly one contributor (M == E);
+                           //            bit 4 (kLatticeLocal, d = 2 only): pixel-local — see loc_a
     uint16_t *vid;         // [(d+1)*N]  vertex id of simplex corner r of pixel i   (r-major)
     float *bary;           // [(d+1)*N]  barycentric weight                         (r-major)
     uint32_t *nb;          // [(d+1)*Mcap] blur neighbours along axis j: n1 | n2<<16; M (the zero sentinel slot) = none, and
                            //               so is every word of the unused tail v >= M
-    uint32_t *row_start;   // [Mcap+1]   CSR of the splat: entries of vertex v
+    uint16_t *row_start;   // [Mcap+2]   CSR of the splat: entries of vertex v (E < 65536 on this path)
     uint16_t *csr_pix;     // [(d+1)*N]  source pixel of each entry, entry order = reference splat order
     float *csr_w;          // [(d+1)*N]  weight of each entry
     float *norm;           // [N]        1/sqrt(K 1 + 1e-20)
+    // d = 2 only, valid when flag kLatticeLocal is set: every vertex has one contributor and the only blur neighbours of a
+    // pixel's three corners are each other (the spatial kernel at training scale, sigma = 0.25 px).  Corners relabelled per
+    // pixel so that blur axis j exchanges between relabelled corners (j, j+1 mod 3); see meanfield.hip, GaussLocal
+    float *loc_a;          // [4*N]      (norm, weight of relabelled corner 0, 1, 2)
+    uint32_t *loc_z;       // [N]        relabelled index of original corner 2 (the last term of the slice sum)
     // build scratch
     uint32_t *key_e;       // [Epad*KW]  packed keys of every (pixel, corner) entry, Epad = Npad*(d+1)
     uint16_t *slot_e;      // [Epad]     hash slot of every entry
@@ -92,24 +99,23 @@ bool lattice_supported(int d, int N);
 // ---- mean field -------------------------------------------------------------------
 struct MeanfieldBufs {
     float *q;        // (B,C,N) current marginals
-    float *msg_g;    // (B,C,N) normalised Gaussian message  K~_g Q
+    float *msg_g;    // (B,C,N) normalised Gaussian message  K~_g Q (unused while the Gaussian lattice is pixel-local)
     float *msg_b;    // (B,C,N) normalised bilateral message K~_b Q
-    // the one-launch (persistent) inference loop: {tag, value} granules handed between the workgroups of an image
-    unsigned long long *qg, *vg;   // (B,C,N) each, zeroed at creation (tag 0 is never used); null = multi-launch path only
-    unsigned int *status;          // host-mapped word (device address), set by the kernel if a hand-off timed out
-    unsigned int *status_host;     // the same word, host address
-    unsigned int *epoch;           // host counter, advanced once per launch (tag = epoch << 6 | iteration)
-    unsigned int *work_counter;    // device word: dynamic unit queue of mf_filter_kernel (reset by every mf_update_kernel launch)
 };
+constexpr int kLatticeLocal = 16;      // LatticeView::flags bit 4
 // optional per-launch timing of the filter kernel with HIP events on the launch stream
 struct Profiler {
     hipEvent_t *start, *stop;   // [cap]
     int cap, used;
     bool active;
 };
+// gauss_local: the host has read the Gaussian lattice's flags and found kLatticeLocal (its workgroups are then left out of
+// the filter launches; without that knowledge they are launched and exit on the device-side flag)
 int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C,
                      const float *neg_unary, float wg, float wb, int n_iters, float *q_out,
-                     double *refined_out, float *logq_out, hipStream_t stream, Profiler *prof = nullptr);
+                     double *refined_out, float *logq_out, bool gauss_local, hipStream_t stream, Profiler *prof = nullptr);
+int launch_filter_once(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C, int kind,
+                       const float *q_in, float *out, bool gauss_local, hipStream_t stream);
 
 // ---- pointwise / prep ----------------------------------------------------------------
 int launch_clip_min(float *p, size_t n, hipStream_t stream);
@@ -191,7 +197,8 @@ __device__ __forceinline__ uint32_t ld_u16(rsrc_t r, uint32_t voff, uint32_t sof
 #endif
 
 // ---- seeded region growing ---------------------------------------------------------------
+// code: device scratch of B*H*W uint16 (per-pixel classification handed from the first kernel to the second)
 int launch_srg(int B, int C, int H, int W, const float *labels, const float *cues, const double *refined,
-               double th1, double th2, float *seeds, hipStream_t stream);
+               double th1, double th2, float *seeds, uint16_t *code, hipStream_t stream);
 
 }  // namespace dsrg

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     uint16_t *vid = L.vid + (size_t)b * D1 * N;
     float *bary = L.bary + (size_t)b * D1 * N;
     uint32_t *nb = L.nb + (size_t)b * D1 * Mcap;
-    uint32_t *row_start = L.row_start + (size_t)b * (Mcap + 1);
+    uint16_t *row_start = L.row_start + (size_t)b * (Mcap + 2);
     uint16_t *csr_pix = L.csr_pix + (size_t)b * E;
     float *csr_w = L.csr_w + (size_t)b * E;
     float *norm = L.norm + (size_t)b * N;
@@ -311,10 +311,10 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         for (int v = v0; v < v1; v++) {
             int c = (int)cnt[v];
             cnt[v] = (uint32_t)run;
-            row_start[v] = (uint32_t)run;
+            row_start[v] = (uint16_t)run;
             run += c;
         }
-        if (tid == 0) row_start[M] = (uint32_t)E;
+        if (tid == 0) row_start[M] = (uint16_t)E;
     }
     __syncthreads();
     DSRG_STAMP(5);
@@ -537,13 +537,13 @@ __global__ __launch_bounds__(kWG) void lattice_norm_kernel(LatticeView L) {
     const uint16_t *vid = L.vid + (size_t)b * D1 * N;
     const float *bary = L.bary + (size_t)b * D1 * N;
     const rsrc_t r_nb = make_rsrc(L.nb + (size_t)b * D1 * Mcap, sizeof(uint32_t) * (size_t)D1 * Mcap);
-    const rsrc_t r_rs = make_rsrc(L.row_start + (size_t)b * (Mcap + 1), sizeof(uint32_t) * (size_t)(Mcap + 1));
+    const rsrc_t r_rs = make_rsrc(L.row_start + (size_t)b * (Mcap + 2), sizeof(uint16_t) * (size_t)(Mcap + 2));
     const rsrc_t r_cw = make_rsrc(L.csr_w + (size_t)b * E, sizeof(float) * (size_t)E);
     uint32_t rs0[VPT], rs1[VPT];
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
-        rs0[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
-        rs1[k] = ld_u32(r_rs, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u) + 4u);
+        rs0[k] = ld_u16(r_rs, (uint32_t)tid * 2u, (uint32_t)k * (kWG * 2u));
+        rs1[k] = ld_u16(r_rs, (uint32_t)tid * 2u, (uint32_t)k * (kWG * 2u) + 2u);
     }
     int multi = 0;                                                               // some vertex has several contributors
 #pragma unroll
@@ -601,17 +601,87 @@ __global__ __launch_bounds__(kWG) void lattice_norm_kernel(LatticeView L) {
 }
 
 // ---------------------------------------------------------------------------------
+// Pixel-local test of a d = 2 lattice (flag kLatticeLocal) and the per-pixel form the mean-field update kernel evaluates
+// (meanfield.hip, GaussLocal).  At training scale the spatial kernel of CRF.py:31-32 has sigma = 3/12 = 0.25 px: a pixel's
+// simplex shares no vertex with any other pixel's, so every vertex has one contributor (flag bit 2) and the only blur
+// neighbours (permutohedral.cpp:303-318) of its three corners are each other — corner r+1 = corner r + the step of axis
+// j(r), i.e. along each axis exactly one pair (a, b) with n2(a) = b and n1(b) = a.  The kernel VERIFIES that structure for
+// every pixel from the built tables (it does not assume it), relabels the corners so that axis j pairs relabelled corners
+// (j, j+1 mod 3), and stores norm + relabelled weights + the relabelled index of original corner 2.  One workgroup.
+__global__ __launch_bounds__(kWG) void lattice_local_kernel(LatticeView L) {
+    const int N = L.N, Mcap = L.Mcap, M = L.M[0], tid = threadIdx.x;
+    const bool single = (L.flags[0] & 4) != 0;            // every vertex has exactly one contributor
+    int bad = single ? 0 : 1;
+    for (int i = tid; i < N && single; i += kWG) {
+        uint32_t V[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) V[r] = L.vid[(size_t)r * N + i];
+        auto local_of = [&](uint32_t v) { return v == V[0] ? 0 : v == V[1] ? 1 : v == V[2] ? 2 : -1; };
+        int pa[3], pb[3];                                  // the exchanging pair of each axis (original corner indices)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            pa[j] = pb[j] = -1;
+            int links = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint32_t w = L.nb[(size_t)j * Mcap + V[r]];
+                const uint32_t n1 = w & 0xffffu, n2 = w >> 16;
+                if (n2 != (uint32_t)M) {                   // r -> n2 must stay inside the pixel and be mirrored by n1
+                    const int t = local_of(n2);
+                    if (t < 0 || t == r || (L.nb[(size_t)j * Mcap + n2] & 0xffffu) != V[r]) bad = 1;
+                    else { pa[j] = r; pb[j] = t; links++; }
+                }
+                if (n1 != (uint32_t)M) {
+                    const int t = local_of(n1);
+                    if (t < 0 || t == r || (L.nb[(size_t)j * Mcap + n1] >> 16) != V[r]) bad = 1;
+                }
+            }
+            if (links != 1) bad = 1;
+        }
+        if (V[0] == V[1] || V[1] == V[2] || V[0] == V[2]) bad = 1;
+        // relabelling sigma: the corner shared by the pairs of axes 2 and 0 -> 0, of axes 0 and 1 -> 1, of axes 1 and 2 -> 2
+        int sigma[3] = {-1, -1, -1};
+        if (!bad) {
+            auto shared = [&](int j0, int j1) {
+                if (pa[j0] == pa[j1] || pa[j0] == pb[j1]) return pa[j0];
+                if (pb[j0] == pa[j1] || pb[j0] == pb[j1]) return pb[j0];
+                return -1;
+            };
+            const int c0 = shared(2, 0), c1 = shared(0, 1), c2 = shared(1, 2);
+            if (c0 < 0 || c1 < 0 || c2 < 0 || c0 == c1 || c1 == c2 || c0 == c2) bad = 1;
+            else { sigma[c0] = 0; sigma[c1] = 1; sigma[c2] = 2; }
+        }
+        float w[3] = {0.f, 0.f, 0.f};
+        if (!bad) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const float br = L.bary[(size_t)r * N + i];
+#pragma unroll
+                for (int q = 0; q < 3; q++) if (sigma[r] == q) w[q] = br;
+            }
+        }
+        L.loc_a[(size_t)4 * i + 0] = L.norm[i];
+        L.loc_a[(size_t)4 * i + 1] = w[0];
+        L.loc_a[(size_t)4 * i + 2] = w[1];
+        L.loc_a[(size_t)4 * i + 3] = w[2];
+        L.loc_z[i] = bad ? 0u : (uint32_t)sigma[2];
+    }
+    const int any_bad = __syncthreads_or(bad);
+    if (tid == 0) L.flags[0] = (L.flags[0] & ~kLatticeLocal) | (any_bad ? 0 : kLatticeLocal);
+}
+
+// ---------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static void lattice_layout(int d, int N, int nlat, size_t off[15], size_t &total) {
+static void lattice_layout(int d, int N, int nlat, size_t off[17], size_t &total) {
     const int d1 = d + 1, Npad = (N + 3) / 4 * 4, Mcap = Npad * d1, E = N * d1, Epad = Npad * d1;
     const int KW = (d * 16 + 31) / 32;
-    size_t sz[14] = {
+    size_t sz[16] = {
         sizeof(int) * (size_t)nlat,                          // M
         sizeof(uint16_t) * (size_t)E * nlat,                 // vid
         sizeof(float) * (size_t)E * nlat,                    // bary
         sizeof(uint32_t) * (size_t)d1 * Mcap * nlat,         // nb
-        sizeof(uint32_t) * (size_t)(Mcap + 1) * nlat,        // row_start
+        sizeof(uint16_t) * (size_t)(Mcap + 2) * nlat,        // row_start
         sizeof(uint16_t) * (size_t)E * nlat,                 // csr_pix
         sizeof(float) * (size_t)E * nlat,                    // csr_w
         sizeof(float) * (size_t)N * nlat,                    // norm
@@ -621,20 +691,22 @@ static void lattice_layout(int d, int N, int nlat, size_t off[15], size_t &total
         sizeof(int) * (size_t)nlat,                          // flags
         sizeof(uint16_t) * (size_t)lattice_table_cap(Mcap) * nlat,     // tab_g
         sizeof(unsigned long long) * (size_t)Mcap * nlat,     // ckeys_g
+        d == 2 ? sizeof(float) * 4 * (size_t)N * nlat : 0,   // loc_a
+        d == 2 ? sizeof(uint32_t) * (size_t)N * nlat : 0,    // loc_z
     };
     size_t cur = 0;
-    for (int i = 0; i < 14; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
+    for (int i = 0; i < 16; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
     total = cur;
 }
 
 size_t lattice_bytes(int d, int N, int nlat) {
-    size_t off[15], total;
+    size_t off[17], total;
     lattice_layout(d, N, nlat, off, total);
     return total;
 }
 
 void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
-    size_t off[15], total;
+    size_t off[17], total;
     lattice_layout(d, N, nlat, off, total);
     unsigned char *p = static_cast<unsigned char *>(base);
     L.d = d; L.N = N; L.Mcap = ((N + 3) / 4 * 4) * (d + 1); L.nlat = nlat;
@@ -642,7 +714,7 @@ void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
     L.vid = reinterpret_cast<uint16_t *>(p + off[1]);
     L.bary = reinterpret_cast<float *>(p + off[2]);
     L.nb = reinterpret_cast<uint32_t *>(p + off[3]);
-    L.row_start = reinterpret_cast<uint32_t *>(p + off[4]);
+    L.row_start = reinterpret_cast<uint16_t *>(p + off[4]);
     L.csr_pix = reinterpret_cast<uint16_t *>(p + off[5]);
     L.csr_w = reinterpret_cast<float *>(p + off[6]);
     L.norm = reinterpret_cast<float *>(p + off[7]);
@@ -652,6 +724,8 @@ void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
     L.flags = reinterpret_cast<int *>(p + off[11]);
     L.tab_g = reinterpret_cast<uint32_t *>(p + off[12]);
     L.ckeys_g = reinterpret_cast<unsigned long long *>(p + off[13]);
+    L.loc_a = d == 2 ? reinterpret_cast<float *>(p + off[14]) : nullptr;
+    L.loc_z = d == 2 ? reinterpret_cast<uint32_t *>(p + off[15]) : nullptr;
 }
 
 void lattice_feat_init(LatticeFeat &F, int d, int W, int H, float sx, float sy, float sr, float sg, float sb) {
@@ -726,6 +800,10 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
 #undef DSRG_BUILD_V
 #undef DSRG_BUILD
     DSRG_LAUNCH_CHECK();
+    if (L.d == 2 && nlat == 1) {
+        hipLaunchKernelGGL(lattice_local_kernel, dim3(1), dim3(kWG), 0, stream, L);
+        DSRG_LAUNCH_CHECK();
+    }
     return DSRG_OK;
 }
 

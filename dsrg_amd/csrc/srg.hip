@@ -1,5 +1,6 @@
-// Seeded region growing on gfx950: one workgroup per image, label map and growth
-// front resident in LDS with a one-pixel halo.
+// Seeded region growing on gfx950: a pixel-parallel classification pass over the
+// whole batch, then one workgroup per image that grows the components with the
+// label map and growth front resident in LDS (one-pixel halo).
 //
 // Replaces generate_seed_step (pylayers/pylayers/pylayers.py:237-275) including
 // the per-class connected-component labelling it calls
@@ -44,84 +45,92 @@ __device__ __forceinline__ Mask128 m_shfl(Mask128 a, int src_lane) {
     return r;
 }
 
-__global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W,
-                                                          const float *__restrict__ labels,
-                                                          const float *__restrict__ cues,
-                                                          const double *__restrict__ refined, double th1,
-                                                          double th2, float *__restrict__ seeds, int mask_bytes) {
+// ---- stage 1: classification, pixel-parallel over the whole batch (grid = pixel tiles x images) -------------------------
+// Per pixel one sweep over the labels: highest cued class (numpy's fancy assignment, pylayers.py:248-250), cue sum, argmax /
+// max of the float64 marginals over the PRESENT classes with the first maximum winning (pylayers.py:241-243), the threshold
+// rule (pylayers.py:251-257) -> one 16-bit code per pixel for the growth stage, and the pass-through copy seeds = cues
+// (absent classes and non-grown pixels keep their cues, pylayers.py:259-273).
+//   code bits 0..7: label-map value (class + 1; 0 = not part of any present class's mask), bit 8: the pixel is a cue of its
+//   own class (a seed of its component, :266), bit 9: exclusion rule (own cue absent and exactly one other cue, :268-269)
+constexpr int kSrgCodeSeed = 1 << 8, kSrgCodeExcl = 1 << 9;
+constexpr int kSrgTile = 256;
+template <int CT>   // CT > 0: C <= CT, every load of a pixel issued before the first use; CT = 0: any C, 8 labels per batch
+__global__ __launch_bounds__(kSrgTile) void srg_classify_kernel(int C, int N, const float *__restrict__ labels,
+                                                                 const float *__restrict__ cues,
+                                                                 const double *__restrict__ refined, double th1, double th2,
+                                                                 float *__restrict__ seeds, uint16_t *__restrict__ code) {
+    const int b = blockIdx.y, p = blockIdx.x * kSrgTile + threadIdx.x;
+    const float *lab = labels + (size_t)b * C;           // workgroup-uniform: scalar loads
+    const float *cu = cues + (size_t)b * C * N;
+    const double *rf = refined + (size_t)b * C * N;
+    float *out = seeds + (size_t)b * C * N;
+    const int pc = min(p, N - 1);
+    int lmv = 0, best = -1;
+    float cuesum = 0.0f, own_best = 0.0f;                // own_best: the cue of the arg-max class at this pixel
+    double v = 0.0;
+    constexpr int CH = CT > 0 ? CT : 8;
+    float own_lm = 0.0f;                                 // the cue of the highest cued class (1 by construction when lmv > 0)
+    for (int c0 = 0; c0 < C; c0 += CH) {
+        float sc[CH];
+        double rc[CH];
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const size_t o = (size_t)min(c0 + q, C - 1) * N + pc;
+            sc[q] = cu[o];
+            rc[q] = rf[o];
+        }
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const int c = c0 + q;
+            if (c < C) {
+                if (p < N) out[(size_t)c * N + p] = sc[q];                          // seeds start as the cues
+                if (sc[q] > 0.0f) { lmv = c + 1; own_lm = sc[q]; }
+                cuesum += sc[q];
+                if (lab[c] == 1.0f && (best < 0 || rc[q] > v)) { v = rc[q]; best = c; own_best = sc[q]; }
+            }
+        }
+    }
+    if (p >= N) return;
+    float own = own_lm;
+    if (best >= 0 && v > th2) {                          // pylayers.py:253-257, strict float64 compares
+        if (best != 0) { lmv = best + 1; own = own_best; }
+        else if (v > th1) { lmv = 1; own = own_best; }
+    }
+    const bool active = lmv > 0 && lab[lmv - 1] == 1.0f;                          // only present classes are grown (:259)
+    int cd = 0;
+    if (active) {
+        cd = lmv;
+        if (own == 1.0f) cd |= kSrgCodeSeed;                                        // seeds of the component (:266)
+        else if (cuesum == 1.0f) cd |= kSrgCodeExcl;                                // cued by exactly one OTHER class (:268-269)
+    }
+    code[(size_t)b * N + p] = (uint16_t)cd;
+}
+
+// ---- stage 2: growth, one workgroup per image ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W, const uint16_t *__restrict__ code,
+                                                          float *__restrict__ seeds, int mask_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int N = H * W, Wp = W + 2, Np = (H + 2) * Wp;
     unsigned char *lm = smem;                 // [(H+2)*(W+2)] label-map value (class+1), 0 = none / halo
     unsigned char *grown = smem + ((Np + 15) & ~15);      // same shape: 1 = member of a seeded component
-    unsigned char *excl = grown + ((Np + 15) & ~15);      // [N] exclusion rule flag
-
-    const float *lab = labels + (size_t)b * C;
-    const float *cu = cues + (size_t)b * C * N;
-    const double *rf = refined + (size_t)b * C * N;
+    unsigned char *excl = grown + ((Np + 15) & ~15);      // [N] 1 = the pixel's own plane is not to be written (seed already / rule)
+    uint32_t *present = reinterpret_cast<uint32_t *>(excl + ((N + 15) & ~15));    // [4] labels that occur in the label map
+    const uint16_t *cd = code + (size_t)b * N;
     float *out = seeds + (size_t)b * C * N;
 
-    // present classes (labels == 1, pylayers.py:240) as a bit mask; C <= 64
-    const unsigned long long present = __ballot(lane < C && lab[min(lane, C - 1)] == 1.0f);   // one load per wave
-
     for (int p = tid; p < Np; p += kSrgWG) { lm[p] = 0; grown[p] = 0; }
+    if (tid < 4) present[tid] = 0u;
     __syncthreads();
-
-    constexpr int CH = 8;                        // labels per batch of loads (all issued before use)
-    constexpr int PB = 2;                        // pixels per batch
-    for (int p0 = tid; p0 < N; p0 += PB * kSrgWG) {
-        // one sweep over the labels, CH at a time, for PB pixels at once: highest cued class
-        // (pylayers.py:248-250), cue sum, argmax / max over the present classes with the first
-        // maximum winning (pylayers.py:241-243)
-        int lmv[PB], best[PB];
-        float cuesum[PB];
-        double v[PB];
-#pragma unroll
-        for (int u = 0; u < PB; u++) { lmv[u] = 0; best[u] = -1; cuesum[u] = 0.0f; v[u] = 0.0; }
-        for (int c0 = 0; c0 < C; c0 += CH) {
-            float sc[PB][CH];
-            double rc[PB][CH];
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-                const int p = min(p0 + u * kSrgWG, N - 1);
-#pragma unroll
-                for (int q = 0; q < CH; q++) {
-                    const size_t o = (size_t)min(c0 + q, C - 1) * N + p;
-                    sc[u][q] = cu[o];
-                    rc[u][q] = rf[o];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-#pragma unroll
-                for (int q = 0; q < CH; q++) {
-                    const int c = c0 + q;
-                    if (c < C) {
-                        if (sc[u][q] > 0.0f) lmv[u] = c + 1;
-                        cuesum[u] += sc[u][q];
-                        if (((present >> c) & 1ull) && (best[u] < 0 || rc[u][q] > v[u])) { v[u] = rc[u][q]; best[u] = c; }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PB; u++) {
-            const int p = p0 + u * kSrgWG;
-            if (p < N) {
-                if (best[u] >= 0 && v[u] > th2) {      // pylayers.py:253-257, strict float64 compares
-                    if (best[u] != 0) lmv[u] = best[u] + 1;
-                    else if (v[u] > th1) lmv[u] = 1;
-                }
-                const int cls = lmv[u] - 1;
-                const bool active = lmv[u] > 0 && ((present >> cls) & 1ull);   // only present classes are grown (:259)
-                const float own = active ? cu[(size_t)cls * N + p] : 0.0f;
-                const int y = p / W, x = p - y * W;
-                const int pp = (y + 1) * Wp + (x + 1);
-                lm[pp] = active ? (unsigned char)lmv[u] : 0;
-                grown[pp] = (active && own == 1.0f) ? 1 : 0;               // seeds of the component (:266)
-                excl[p] = (active && own != 1.0f && cuesum[u] == 1.0f) ? 1 : 0;   // cued by exactly one OTHER class (:268-269)
-            }
-        }
+    for (int p = tid; p < N; p += kSrgWG) {
+        const int k = cd[p];
+        const int y = p / W, x = p - y * W;
+        const int pp = (y + 1) * Wp + (x + 1);
+        const int l = k & 0xff;
+        lm[pp] = (unsigned char)l;
+        grown[pp] = (k & kSrgCodeSeed) ? 1 : 0;
+        excl[p] = (k & (kSrgCodeSeed | kSrgCodeExcl)) ? 1 : 0;     // a seed's plane already holds 1 (its cue)
+        if (l) atomicOr(&present[(l - 1) >> 5], 1u << ((l - 1) & 31));
     }
     __syncthreads();
 
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W,
         // Masks are assembled with wave ballots; then ONE lane per label sweeps the rows down and up —
         // a row step is "dilate the neighbouring row's members by one pixel, intersect with M, close
         // along the row's runs with a carry chain" — until nothing changes (a handful of sweeps).
-        Mask128 *Mm = reinterpret_cast<Mask128 *>(excl + ((N + 15) & ~15));       // [(C+1)][H]
+        Mask128 *Mm = reinterpret_cast<Mask128 *>(reinterpret_cast<unsigned char *>(present) + 16);       // [(C+1)][H]
         Mask128 *Gm = Mm + (size_t)(C + 1) * H;
         const int wave = tid >> 6, nwaves = kSrgWG >> 6;
         for (int y = wave; y < H; y += nwaves) {
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W,
                 const unsigned char l = (x < W) ? lm[pp] : 0;
                 const unsigned char gr = (x < W) ? grown[pp] : 0;
                 for (int c = 1; c <= C; c++) {
-                    if (!((present >> (c - 1)) & 1ull)) continue;                 // wave-uniform
+                    if (!((present[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u)) continue;   // workgroup-uniform
                     const unsigned long long mb = __ballot(l == c), gb = __ballot(l == c && gr);
                     if (lane == 0) {
                         if (xh == 0) { Mm[c * H + y].lo = mb; Gm[c * H + y].lo = gb; if (W <= 64) { Mm[c * H + y].hi = 0; Gm[c * H + y].hi = 0; } }
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W,
         constexpr int RPL = 2;                                                    // rows per lane (H <= 128)
         if (H <= 64 * RPL) {
             for (int c = 1 + wave; c <= C; c += nwaves) {
-                if (!((present >> (c - 1)) & 1ull)) continue;                     // wave-uniform
+                if (!((present[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u)) continue;       // workgroup-uniform
                 Mask128 M[RPL], G[RPL];
 #pragma unroll
                 for (int k = 0; k < RPL; k++) {
@@ -233,43 +242,22 @@ __global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W,
         }
     }
 
-    // seeds = cues, plus every member pixel of its own class unless excluded (pylayers.py:271-273)
-    for (int p0 = tid; p0 < N; p0 += PB * kSrgWG) {
-        int cls[PB];
-        bool add[PB];
-#pragma unroll
-        for (int u = 0; u < PB; u++) {
-            const int p = min(p0 + u * kSrgWG, N - 1);
-            const int y = p / W, x = p - y * W;
-            const int pp = (y + 1) * Wp + (x + 1);
-            cls[u] = (int)lm[pp] - 1;
-            add[u] = cls[u] >= 0 && grown[pp] && !excl[p];
-        }
-        for (int c0 = 0; c0 < C; c0 += CH) {
-            float sc[PB][CH];
-#pragma unroll
-            for (int u = 0; u < PB; u++)
-#pragma unroll
-                for (int q = 0; q < CH; q++)
-                    sc[u][q] = cu[(size_t)min(c0 + q, C - 1) * N + min(p0 + u * kSrgWG, N - 1)];
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-                const int p = p0 + u * kSrgWG;
-#pragma unroll
-                for (int q = 0; q < CH; q++) {
-                    const int c = c0 + q;
-                    if (c < C && p < N) out[(size_t)c * N + p] = (add[u] && c == cls[u]) ? 1.0f : sc[u][q];
-                }
-            }
-        }
+    // every member pixel of a seeded component joins its class's seeds unless excluded (pylayers.py:271-273); all other
+    // entries keep the cues the classification stage copied
+    for (int p = tid; p < N; p += kSrgWG) {
+        const int y = p / W, x = p - y * W;
+        const int pp = (y + 1) * Wp + (x + 1);
+        const int cls = (int)lm[pp] - 1;
+        if (cls >= 0 && grown[pp] && !excl[p]) out[(size_t)cls * N + p] = 1.0f;
     }
 }
 
 int launch_srg(int B, int C, int H, int W, const float *labels, const float *cues, const double *refined,
-               double th1, double th2, float *seeds, hipStream_t stream) {
-    if (C < 1 || C > 64) return set_error(DSRG_ERR_UNSUPPORTED, "SRG supports 1..64 classes, got %d", C);
+               double th1, double th2, float *seeds, uint16_t *code, hipStream_t stream) {
+    if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "SRG supports 1..%d classes, got %d", kMaxLabels, C);
+    const int N = H * W;
     const size_t Np = (size_t)(H + 2) * (W + 2);
-    size_t lds = 2 * ((Np + 15) & ~(size_t)15) + (((size_t)H * W + 15) & ~(size_t)15);
+    size_t lds = 2 * ((Np + 15) & ~(size_t)15) + (((size_t)N + 15) & ~(size_t)15) + 16;
     if (lds > 150 * 1024) return set_error(DSRG_ERR_UNSUPPORTED, "SRG map %dx%d exceeds LDS", H, W);
     // row masks for the fast growth path: 2 x (C+1) x H 128-bit masks
     size_t mask_bytes = (size_t)2 * (C + 1) * H * sizeof(Mask128);
@@ -278,8 +266,15 @@ int launch_srg(int B, int C, int H, int W, const float *labels, const float *cue
     static LdsGrant granted;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&srg_grow_kernel), lds, granted);
     if (rc) return rc;
-    hipLaunchKernelGGL(srg_grow_kernel, dim3(B), dim3(kSrgWG), lds, stream, C, H, W, labels, cues, refined, th1,
-                       th2, seeds, (int)mask_bytes);
+    const dim3 grid((N + kSrgTile - 1) / kSrgTile, B);
+    if (C <= 21)
+        hipLaunchKernelGGL(srg_classify_kernel<21>, grid, dim3(kSrgTile), 0, stream, C, N, labels, cues, refined, th1, th2,
+                           seeds, code);
+    else
+        hipLaunchKernelGGL(srg_classify_kernel<0>, grid, dim3(kSrgTile), 0, stream, C, N, labels, cues, refined, th1, th2,
+                           seeds, code);
+    DSRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(srg_grow_kernel, dim3(B), dim3(kSrgWG), lds, stream, C, H, W, code, seeds, (int)mask_bytes);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

@@ -27,16 +27,15 @@ except ImportError:                     # stand-alone (tests, PyTorch trainer): 
 min_prob = 0.0001                        # pylayers.py:20
 
 
-MAX_LABELS = 64                          # kMaxLabels of libdsrg_hip.so (per-pixel label loops live in registers)
+MAX_LABELS = 96                          # kMaxLabels of libdsrg_hip.so (per-pixel label columns live in registers / LDS)
 
 
 def _check_labels(n, who):
-    """The HIP kernels hold a pixel's label column in registers: at most 64 labels.  The 81-class blobs of
-    AnnotationLayerCOCO (pylayers.py:387-507; no seed_mc prototxt wires them into these layers) are rejected here, at
-    reshape time, with a message that says so — not deep inside a launch."""
+    """The HIP kernels hold a pixel's label column in registers / LDS: at most 96 labels, which covers the 81-class blobs of
+    AnnotationLayerCOCO (pylayers.py:387-507).  More is rejected here, at reshape time, with a message that says so — not
+    deep inside a launch."""
     if n > MAX_LABELS:
-        raise Exception("%s: %d label planes, but this build of libdsrg_hip.so supports at most %d "
-                        "(the 81-class COCO variant is not supported on the MI355X path)" % (who, n, MAX_LABELS))
+        raise Exception("%s: %d label planes, but this build of libdsrg_hip.so supports at most %d" % (who, n, MAX_LABELS))
 
 
 def _dev(a, dtype=torch.float32):

@@ -81,6 +81,21 @@ class Context(object):
                                       n1.ctypes.data, n2.ctypes.data, _stream()))
         return dict(M=M, keys=keys, vid=vid, bary=bary, n1=n1, n2=n2)
 
+    def lattice_norm(self, kind, b=0):
+        """norm = 1/sqrt(K 1 + 1e-20) of one lattice (pairwise.cpp:44,54-57), (N,) float32 numpy (tests)"""
+        import numpy as np
+        out = np.empty(self.H * self.W, np.float32)
+        check(_lib.lib().dsrg_ctx_lattice_norm(self._h, kind, b, out.ctypes.data, _stream()))
+        return out
+
+    def filter_once(self, kind, q):
+        """one application of the normalised kernel `kind` (0 Gaussian, 1 bilateral) to q (B,C,H,W) with the lattices of
+        the last CRF call on this context: DenseKernel::filter (pairwise.cpp:63-80) (tests)"""
+        _f32c(q, "q")
+        out = torch.empty_like(q)
+        check(_lib.lib().dsrg_ctx_filter_once(self._h, kind, q.shape[0], _ptr(q), _ptr(out), _stream()))
+        return out
+
     def read_refined(self, B):
         """float64 marginals (B,C,H,W) the last supervision_step on this context thresholded (tests)"""
         out = torch.empty((B, self.C, self.H, self.W), dtype=torch.float64, device="cuda")
@@ -184,8 +199,9 @@ def srg_grow(labels, cues, refined, th1=0.99, th2=0.85):
     if labels.numel() != B * C:
         raise ValueError("labels must hold B*C values")
     seeds = torch.empty_like(cues)
+    scratch = torch.empty(B * H * W, dtype=torch.int16, device=cues.device)
     check(_lib.lib().dsrg_srg_grow_batch(B, C, H, W, _ptr(labels), _ptr(cues), _ptr(refined), float(th1), float(th2),
-                                         _ptr(seeds), _stream()))
+                                         _ptr(seeds), _ptr(scratch), _stream()))
     return seeds
 
 

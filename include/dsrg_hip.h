@@ -144,6 +144,13 @@ int dsrg_ctx_lattice_sizes(dsrg_ctx_t ctx, int B, int32_t *m_gauss_host, int32_t
  * Any array may be NULL; *m_host receives M (size the arrays with dsrg_ctx_lattice_sizes first).  Synchronises. */
 int dsrg_ctx_lattice_dump(dsrg_ctx_t ctx, int kind, int b, int32_t *m_host, int16_t *keys_host, int32_t *vid_host,
                           float *bary_host, int32_t *n1_host, int32_t *n2_host, void *stream);
+/* introspection for the parity tests: norm_host [N] = 1/sqrt(K 1 + 1e-20) of lattice (kind, b) as dsrg_ctx_lattice_dump
+ * addresses it (DenseKernel::initLattice, CRF/src/pairwise.cpp:44,54-57).  Synchronises. */
+int dsrg_ctx_lattice_norm(dsrg_ctx_t ctx, int kind, int b, float *norm_host, void *stream);
+/* introspection for the parity tests: ONE application of the normalised kernel `kind` (0 Gaussian, 1 bilateral),
+ * out = norm . K (norm . q)  (DenseKernel::filter, CRF/src/pairwise.cpp:63-80; splat / blur / slice of
+ * CRF/src/permutohedral.cpp:529-589), through the kernels and lattices of the inference loop.  q_dev, out_dev (B,C,H,W) f32. */
+int dsrg_ctx_filter_once(dsrg_ctx_t ctx, int kind, int B, const float *q_dev, float *out_dev, void *stream);
 /* introspection for the parity tests: the float64 marginals (`self.result`, pylayers.py:84-86) the last
  * dsrg_supervision_step thresholded, copied to refined_dev (B,C,H,W) f64 in stream order. */
 int dsrg_ctx_read_refined(dsrg_ctx_t ctx, int B, double *refined_dev, void *stream);
@@ -162,10 +169,12 @@ int dsrg_crf_layer_backward(size_t n, const double *refined_dev, const float *to
  * 297-304,333-344) incl. CC_lab (CC_labeling_8.py:112-197), given the refined
  * marginals:
  *   labels_dev (B,1,1,C) f32 0/1, cues_dev (B,C,H,W) f32 0/1,
- *   refined_dev (B,C,H,W) f64, seeds_dev (B,C,H,W) f32 0/1 (output) */
+ *   refined_dev (B,C,H,W) f64, seeds_dev (B,C,H,W) f32 0/1 (output),
+ *   scratch_dev: B*H*W uint16 of device scratch (the per-pixel classification handed from the
+ *   pixel-parallel pass to the per-image growth pass).  C <= 96. */
 int dsrg_srg_grow_batch(int B, int C, int H, int W, const float *labels_dev, const float *cues_dev,
                         const double *refined_dev, double th1, double th2, float *seeds_dev,
-                        void *stream);
+                        void *scratch_dev, void *stream);
 
 /* SoftmaxLayer.forward / backward (pylayers.py:30-51) */
 int dsrg_softmax_forward(int B, int C, int HW, const float *x_dev, float *p_dev, void *stream);

@@ -463,6 +463,18 @@ ORC_API void orc_crf_lattice_filter(const orc_crf *c, int k, const float *in, fl
     orc_lattice_compute(&c->kern[k].lat, out, in, vs);
 }
 
+/* one application of DenseKernel::filter (pairwise.cpp:63-80, NORMALIZE_SYMMETRIC): out = norm . K (norm . in), without
+ * the label compatibility; in/out [N*vs] label-fastest.  orc_kernel_apply above is this followed by Potts. */
+ORC_API void orc_crf_kernel_filter(const orc_crf *c, int k, const float *in, float *out, int vs) {
+    const orc_kernel *K = &c->kern[k];
+    const int N = K->lat.N;
+    for (int i = 0; i < N; i++)
+        for (int l = 0; l < vs; l++) out[(size_t)i * vs + l] = in[(size_t)i * vs + l] * K->norm[i];
+    orc_lattice_compute(&K->lat, out, out, vs);
+    for (int i = 0; i < N; i++)
+        for (int l = 0; l < vs; l++) out[(size_t)i * vs + l] = out[(size_t)i * vs + l] * K->norm[i];
+}
+
 /* ------------------------------------------------------------------------- */
 /* Layer glue — pylayers/pylayers/pylayers.py                                  */
 /* ------------------------------------------------------------------------- */

@@ -48,6 +48,7 @@ def lib():
         L.orc_crf_lattice_dump.argtypes = [ctypes.c_void_p, ctypes.c_int, c_short_p, c_int_p, c_float_p]
         L.orc_crf_lattice_neighbours.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p]
         L.orc_crf_lattice_filter.argtypes = [ctypes.c_void_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int]
+        L.orc_crf_kernel_filter.argtypes = [ctypes.c_void_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int]
         L.orc_crf_refine_batch.argtypes = [ctypes.c_int] * 4 + [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                                               ctypes.c_double, ctypes.c_int, c_double_p, c_float_p]
         L.orc_crf_layer_backward.argtypes = [ctypes.c_size_t, c_double_p, c_float_p, c_float_p]
@@ -144,6 +145,13 @@ class DenseCRF(object):
         x = _f32(x)
         out = np.empty_like(x)
         lib().orc_crf_lattice_filter(self._h, k, _p(x, c_float_p), _p(out, c_float_p), x.shape[1])
+        return out
+
+    def kernel_filter(self, k, x):
+        """DenseKernel::filter (pairwise.cpp:63-80): norm . K (norm . x); x (N, vs) float32 label-fastest."""
+        x = _f32(x)
+        out = np.empty_like(x)
+        lib().orc_crf_kernel_filter(self._h, k, _p(x, c_float_p), _p(out, c_float_p), x.shape[1])
         return out
 
 

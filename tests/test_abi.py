@@ -174,8 +174,9 @@ def test_annotation_layer_vs_reference_fixture(tmp_path):
         pylayers.AnnotationLayer().setup([Blob()], [Blob()])               # "The layer needs two inputs!"
 
 
-def test_more_than_64_labels_is_rejected_at_reshape():
-    """the 81-class blobs of the COCO variant: a clear Exception from reshape(), not an error code from a launch"""
+def test_more_than_96_labels_is_rejected_at_reshape():
+    """beyond kMaxLabels = 96 (the 81-class blobs of the COCO variant fit): a clear Exception from reshape(), not an error
+    code from a launch"""
     import pylayers
 
     class Blob(object):
@@ -184,13 +185,13 @@ def test_more_than_64_labels_is_rejected_at_reshape():
 
         def reshape(self, *s):
             self.data = np.zeros(s, np.float32)
-    for cls, bottoms in [(pylayers.SoftmaxLayer, [Blob((1, 81, 41, 41))]),
-                         (pylayers.CRFLayer, [Blob((1, 81, 41, 41)), Blob((1, 3, 321, 321))]),
-                         (pylayers.DSRGLayer, [Blob((1, 1, 1, 81)), Blob((1, 81, 41, 41)), Blob((1, 81, 41, 41)), Blob((1, 3, 321, 321))])]:
+    for cls, bottoms in [(pylayers.SoftmaxLayer, [Blob((1, 97, 41, 41))]),
+                         (pylayers.CRFLayer, [Blob((1, 97, 41, 41)), Blob((1, 3, 321, 321))]),
+                         (pylayers.DSRGLayer, [Blob((1, 1, 1, 97)), Blob((1, 97, 41, 41)), Blob((1, 97, 41, 41)), Blob((1, 3, 321, 321))])]:
         lay = cls()
         lay.param_str = "{'th1': 0.99, 'th2': 0.85}"
         lay.setup(bottoms, [Blob((1,))])
-        with pytest.raises(Exception, match="at most 64"):
+        with pytest.raises(Exception, match="at most 96"):
             lay.reshape(bottoms, [Blob((1,))])
 
 

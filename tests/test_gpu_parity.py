@@ -40,9 +40,9 @@ def test_srg_golden_vectors_bit_exact(ops, golden_srg):
 
 def test_srg_random_batches_vs_oracle(ops, O):
     rng = np.random.default_rng(5)
-    for trial in range(6):
-        B, C = 5, 21
-        H, W = (41, 41) if trial < 3 else (int(rng.integers(3, 70)), int(rng.integers(3, 70)))
+    for trial in range(8):
+        B, C = 5, (21 if trial < 6 else 81 + 15 * (trial - 6))              # 81 = COCO (pylayers.py:389-512), 96 = the cap
+        H, W = (41, 41) if trial < 3 or trial >= 6 else (int(rng.integers(3, 70)), int(rng.integers(3, 70)))
         labels, cues = S.make_labels_cues(rng, B, C, max(H, 7), max(W, 7))
         cues = np.ascontiguousarray(cues[:, :, :H, :W])
         refined = np.empty((B, C, H, W))
@@ -222,13 +222,13 @@ def test_crf_refine_batch_vs_oracle(ops, O):
 
 @pytest.mark.parametrize("B,C,HW,scale", [(16, 21, (41, 41), 12.0), (1, 21, (41, 41), 12.0), (20, 21, (41, 41), 12.0),
                                           (3, 30, (33, 29), 12.0), (2, 21, (65, 65), 12.0), (2, 5, (24, 31), 1.0),
-                                          (30, 7, (20, 20), 3.0), (2, 40, (9, 9), 12.0), (1, 2, (1, 9), 12.0)])
-def test_one_launch_meanfield_equals_the_launch_per_iteration_loop(ops, O, B, C, HW, scale):
-    """the persistent kernel (granule hand-offs between the workgroups of an image) against the 21-launch loop it replaces:
-    same arithmetic in the same order => the marginals must be bit-identical; also more images than fit one launch
-    (B = 30 x 7 planes is chunked), a non-diagonal Gaussian lattice (scale 1 / 3), > 32 labels (one image then needs more than
-    the 32 CUs of an XCD: spread map), degenerate maps, and a 65x65 map (falls back to the launch loop)"""
-    import ctypes
+                                          (30, 7, (20, 20), 3.0), (2, 40, (9, 9), 12.0), (1, 2, (1, 9), 12.0), (2, 81, (41, 41), 12.0)])
+def test_filter_variants_are_bit_identical(ops, O, B, C, HW, scale):
+    """Every option of the mean-field launch (meanfield.hip kOpt*) keeps the arithmetic and its order: the marginals must be
+    BIT-IDENTICAL to the plain launch loop (options 0 = the round-2 kernels: Gaussian workgroups in the filter launch, all
+    vertex slots).  Option 1 moves the pixel-local Gaussian lattice of the training scale into the
+    update kernel (per-pixel evaluation in registers); shapes with scale 1 / 3 have a non-local Gaussian lattice and take the
+    general path under every option; 65x65 takes the chunked-index variant; 81 labels = the COCO blobs."""
     from dsrg_amd import _lib
     L = _lib.lib()
     H, W = HW
@@ -236,23 +236,60 @@ def test_one_launch_meanfield_equals_the_launch_per_iteration_loop(ops, O, B, C,
     img = S.make_images(rng, B, size=max(H, W, 8), kind="noise" if B == 2 else "smooth")[:, :, :H, :W] + S.MEAN_PIXEL[None, :, None, None]
     im_u8 = np.ascontiguousarray(np.transpose(img, (0, 2, 3, 1))).astype(np.uint8)
     unary = np.maximum(O.softmax_forward(S.make_logits(rng, B, C, H, W)), 1e-4)
-    outs = []
+    outs = {}
     try:
-        for mode in (0, 1, 1):
-            L.dsrg_debug_set_meanfield_mode(mode)
+        for opts in (0, 3, 1, 2):
+            L.dsrg_debug_set_filter_opts(opts)
             ctx = ops.Context(B, C, H, W)
             q = ops.crf_meanfield(dev(unary), dev(im_u8, torch.uint8), 10, scale, ctx=ctx)
-            q1 = ops.crf_meanfield(dev(unary), dev(im_u8, torch.uint8), 3, scale, ctx=ctx)       # same context, new epoch
-            torch.cuda.synchronize()
-            assert L.dsrg_debug_meanfield_status(ctx._h) == 0
-            outs.append((q.cpu().numpy(), q1.cpu().numpy()))
+            q1 = ops.crf_meanfield(dev(unary), dev(im_u8, torch.uint8), 3, scale, ctx=ctx)       # same context, cached Gaussian lattice
+            outs[opts] = (q.cpu().numpy(), q1.cpu().numpy())
     finally:
-        L.dsrg_debug_set_meanfield_mode(-1)
-    for k in (0, 1):
-        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[1][k], outs[2][k])
+        L.dsrg_debug_set_filter_opts(-1)
+    for opts, o in outs.items():
+        for k in (0, 1):
+            assert np.array_equal(outs[0][k], o[k]), "options %d differ from the plain launch loop" % opts
     want = np.stack([np.transpose(O.CRF(im_u8[b], np.ascontiguousarray(np.transpose(unary[b], (1, 2, 0))), scale_factor=scale), (2, 0, 1))
                      for b in range(min(B, 2))])
-    assert np.abs(outs[1][0][:min(B, 2)] - want).max() < CRF_TOL
+    assert np.abs(outs[3][0][:min(B, 2)] - want).max() < CRF_TOL
+
+
+@pytest.mark.parametrize("kind,scale,HW,C", [("smooth", 12.0, (41, 41), 21), ("noise", 12.0, (41, 41), 21), ("smooth", 12.0, (65, 65), 21),
+                                             ("dark_corner", 12.0, (41, 41), 5), ("noise", 1.0, (24, 31), 7), ("smooth", 3.0, (17, 40), 4)])
+def test_single_filter_application_and_norm_vs_oracle(ops, O, kind, scale, HW, C):
+    """a7 / a9 without the softmax contraction of ten iterations: the normalisation vector of DenseKernel::initLattice
+    (pairwise.cpp:40-62) and ONE application of DenseKernel::filter (pairwise.cpp:63-80: x norm, Permutohedral::compute
+    permutohedral.cpp:529-604, x norm) on both lattices, HIP against the oracle.  The arithmetic and its order are the
+    oracle's, so the results are compared to 2 ulp (observed: bit-equal)."""
+    H, W = HW
+    B, N = 2, H * W
+    rng = np.random.default_rng(hash((kind, H, W, C)) % 2 ** 31)
+    img = S.make_images(rng, B, size=max(H, W), kind=kind)[:, :, :H, :W] + S.MEAN_PIXEL[None, :, None, None]
+    im_u8 = np.ascontiguousarray(np.transpose(img, (0, 2, 3, 1))).astype(np.uint8)
+    q = O.softmax_forward(S.make_logits(rng, B, C, H, W, gain=8.0))          # a valid marginal field
+    ctx = ops.Context(B, C, H, W)
+    ops.crf_meanfield(dev(q), dev(im_u8, torch.uint8), 1, scale, ctx=ctx)     # builds the lattices of these images
+    got = {k: ctx.filter_once(k, dev(q)).cpu().numpy() for k in (0, 1)}
+
+    def ulps(a, b):
+        a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+        return int(np.abs(ia - ib).max())
+    for b in range(B):
+        oc = O.DenseCRF(W, H, C)
+        oc.add_pairwise_energy(10, 80 / scale, 80 / scale, 13, 13, 13, 3, 3 / scale, 3 / scale, im_u8[b].ravel())
+        qlf = np.ascontiguousarray(np.transpose(q[b].reshape(C, N), (1, 0)))                   # (N, C) label-fastest
+        for k in (0, 1):
+            tag = "%s %dx%d scale %g image %d kernel %d" % (kind, H, W, scale, b, k)
+            norm_o = oc.lattice_norm(k)
+            norm_g = ctx.lattice_norm(k, b if k == 1 else 0)
+            assert ulps(norm_g, norm_o) <= 2, tag
+            want = oc.kernel_filter(k, qlf)                                                     # (N, C)
+            have = np.transpose(got[k][b].reshape(C, N), (1, 0))
+            assert (want > 0).all() and ulps(have, want) <= 2, "%s: %d ulp" % (tag, ulps(have, want))
+            # and the raw lattice filter of a 1-channel field of ones is what the norm was made from (pairwise.cpp:44)
+            k1 = oc.lattice_filter(k, np.ones((N, 1), np.float32))[:, 0]
+            assert np.allclose(1.0 / np.sqrt(k1.astype(np.float64) + 1e-20), norm_o, rtol=1e-6, atol=0)
 
 
 def test_crf_is_deterministic(ops, O):
@@ -480,11 +517,11 @@ def test_relu_bwd_bias_and_maxpool_match_torch(ops):
 
 
 @pytest.mark.parametrize("B,C,HW", [(16, 21, (41, 41)), (20, 21, (41, 41)), (2, 30, (33, 29)), (2, 21, (65, 65)),
-                                    (1, 21, (41, 41))])
+                                    (1, 21, (41, 41)), (3, 81, (41, 41))])
 def test_fused_step_other_shapes_vs_oracle(ops, O, B, C, HW):
     """BASELINE configs[2]'s batch of 16, the reference's batch size 20, more than 21 labels (generic-width kernels),
-    the 65x65 map of a 513x513 input, and a lone image (BASELINE configs[1]; one label plane per workgroup) through the
-    fused step, against the oracle layer by layer"""
+    the 65x65 map of a 513x513 input, a lone image (BASELINE configs[1]; one label plane per workgroup), and the 81-label
+    blobs of AnnotationLayerCOCO (pylayers.py:389-512) through the fused step, against the oracle layer by layer"""
     H, W = HW
     rng = np.random.default_rng(B * 1000 + C)
     size = 8 * (H - 1) + 1
@@ -561,7 +598,7 @@ def test_error_paths_return_codes(ops):
     assert b"" != L.dsrg_last_error()
     h = ctypes.c_void_p()
     assert L.dsrg_crf_create(0, 5, 3, ctypes.byref(h)) != 0
-    assert L.dsrg_crf_create(5, 5, 100, ctypes.byref(h)) != 0                 # more than 64 labels
+    assert L.dsrg_crf_create(5, 5, 100, ctypes.byref(h)) != 0                 # more than 96 labels
     with pytest.raises(ValueError):
         ops.supervision_step(x, torch.zeros(1, 3, 321, 321, device="cuda"), torch.zeros(2, 1, 1, 21, device="cuda"),
                              torch.zeros(2, 21, 41, 41, device="cuda"))            # batch mismatch images vs logits

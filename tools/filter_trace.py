@@ -23,9 +23,11 @@ L.dsrg_debug_set_filter_trace(None)
 t = buf.cpu().numpy().reshape(nblk, 32)
 bil = t[t[:, 0] > 0][:, 0:16]
 gau = t[t[:, 16] > 0][:, 16:32]
-t0 = min(bil[:, 0].min(), gau[:, 0].min())
+t0 = min([x[:, 0].min() for x in (bil, gau) if len(x)])
 print("bilateral blocks", len(bil), "gaussian blocks", len(gau))
-for kind, sel, nb in (("bilateral", bil, 6), ("gaussian(first image of the block)", gau, 3)):
+for kind, sel, nb in (("bilateral", bil, 6), ("gaussian", gau, 3)):
+    if not len(sel):
+        continue
     print("%s: M mean %.0f  start (us) min %.2f max %.2f  end max %.2f" % (
         kind, sel[:, 12].mean(), (sel[:, 0].min() - t0) / 100.0, (sel[:, 0].max() - t0) / 100.0, (sel[:, 11].max() - t0) / 100.0))
     stamps = [1, 2, 3, 4] + [5 + j for j in range(nb)] + [11]
