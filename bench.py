@@ -1,20 +1,22 @@
 #!/usr/bin/env python
 """bench.py — images/s of a full DSRG train-s step on N MI355X (BASELINE.json metric).
 
-A step = VGG16-ASPP forward (bf16 autocast, MIOpen) -> supervision hot path in
-libdsrg_hip.so (Softmax, dense-CRF mean field, seeded region growing, seed +
-constrain losses, backward) -> backbone backward -> Caffe-style SGD, on one
-synthetic batch of 16 images per GPU (BASELINE.json configs[2]; configs[3] at N=8).
-Synthetic inputs are resident in HBM before the timed region.
+A step = VGG16-ASPP forward (bf16 autocast) -> supervision hot path in libdsrg_hip.so (Softmax, dense-CRF mean field,
+seeded region growing, seed + constrain losses, backward) -> backbone backward -> Caffe-style SGD, on one synthetic batch of
+16 images per GPU (BASELINE.json configs[2]; configs[3] at N=8).  Synthetic inputs are resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode train|supervision]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode train|supervision|infer|crf-fullres|train-f]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      — the dominant hot-path kernel (mean-field filter = permutohedral
-                  splat/blur/slice): algorithmic bytes per launch / HIP-event time per launch
-  cpu_baseline  — the CPU oracle (a port of the reference's CPU path) timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only)
+  roofline      — the dominant hot-path kernel (mean-field filter = permutohedral splat/blur/slice): modelled LDS bytes per
+                  launch / HIP-event time per launch, measured in a separate untimed pass (the event brackets cost ~5 us each)
+  cpu_baseline  — the CPU oracle (a port of the reference's CPU path) timed on this box's host cores on a bounded sample of
+                  the same workload (rank 0, N=1 only)
+  legs          — the bf16-autocast leg (= value) and the float32-backbone leg (the reference's Caffe precision), same steps
+  modes         — (N=1, --mode train) bounded sub-records of the other quoted configurations, each with its own roofline and
+                  cpu_baseline: supervision (hot path alone, 16 images), supervision_b1, infer_b1 (BASELINE.json configs[1]),
+                  crf_fullres
 """
 import argparse
 import json
@@ -43,19 +45,36 @@ def filter_bytes(d, M, C, N):
 
 
 # MI355X_MICROARCH.md, LDS table: bytes per clock per CU by instruction, x 256 CUs x 2.4 GHz
-LDS_RATE_GBS = {"read_b64": 256 * 256 * 2.4, "read_b32": 128 * 256 * 2.4, "write_b64": 85 * 256 * 2.4, "write_b32": 64 * 256 * 2.4}
+LDS_RATE_GBS = {"read_b128": 256 * 256 * 2.4, "read_b64": 256 * 256 * 2.4, "read_b32": 128 * 256 * 2.4,
+                "write_b128": 79 * 256 * 2.4, "write_b64": 85 * 256 * 2.4, "write_b32": 64 * 256 * 2.4}
 
 
-def lds_filter_traffic(d, M, N, cpw):
-    """LDS bytes one workgroup of mf_filter_kernel moves for one lattice (dsrg_amd/csrc/meanfield.hip, filter_lattice):
-    reads  = splat products (E gathers of the input plane) + ordered row sums (E) + blur (2 gathers per vertex and axis)
-             + slice (d+1 gathers per pixel);
-    writes = input planes (N) + products (E) + lattice values (M) + blur (M per axis);   E = (d+1) N, cpw planes of 4 bytes
-    interleaved per element (8-byte accesses at cpw = 2).  A diagonal lattice (Gaussian kernel at training scale) moves none."""
-    E = (d + 1) * N
-    reads = (2 * E + 2 * (d + 1) * M + (d + 1) * N) * 4 * cpw
-    writes = (N + E + M + (d + 1) * M) * 4 * cpw
+def lds_filter_traffic(d, M, X, N, cpw):
+    """LDS bytes one workgroup of mf_filter_kernel moves for one lattice (dsrg_amd/csrc/meanfield.hip, filter_lattice), cpw
+    label planes of 4 bytes interleaved per element (8-byte accesses at cpw = 2, 16-byte at cpw = 4):
+    reads  = first splat term of every vertex (M gathers of the input planes) + products of the X further entries (X gathers)
+             + ordered row sums over those products (X) + blur (2 gathers per vertex and axis) + slice (d+1 per pixel);
+    writes = input planes (N) + products (X) + lattice values (M) + blur (M per axis).
+    A pixel-local Gaussian lattice (training scale) is evaluated in registers by the update kernel: no LDS bytes."""
+    reads = (M + 2 * X + 2 * (d + 1) * M + (d + 1) * N) * 4 * cpw
+    writes = (N + X + M + (d + 1) * M) * 4 * cpw
     return reads, writes
+
+
+def lds_filter_instructions(d, M, X, N, vpt=10, wg=1024):
+    """wave-level LDS instructions of the same workgroup as ISSUED (what SQ_INSTS_LDS counts): vertex slots come in batches
+    of (5, 4, 1) x 1024 and a batch is issued when its first vertex exists, pixels in ceil(N / 1024) rounds, entries in
+    rounds of 1024 — the check of the byte model against the counter (profiles/r03_lds_counters.json)"""
+    waves = wg // 64
+    bounds = [0, min(5, vpt), min(9, vpt), vpt]
+    slots = sum(bounds[i + 1] - bounds[i] for i in range(3) if bounds[i] * wg < M)
+    xs = -(-X // wg) if X else 0
+    xs = min(vpt, -(-xs // 5) * 5) if xs else 0
+    ppt = -(-N // wg)
+    reads = slots + xs + 2 * (d + 1) * slots + (d + 1) * ppt            # first terms, extra products, blur, slice
+    writes = ppt + xs + -(-M // wg) + (d + 1) * -(-M // wg) + 1          # input planes, products, values, blur (+ sentinel)
+    # the ordered row sums are data-dependent loops (one read per further entry of the longest row of a wave's 64): not modelled
+    return (reads + writes) * waves
 
 
 def cpu_baseline(batch_np, target_s=12.0):
@@ -111,16 +130,35 @@ def cpu_baseline_all_cores(seconds=6.0, max_workers=32, timeout_s=90.0):
                       "logical CPUs" % (n, workers - failed, span, time.perf_counter() - t0, os.cpu_count() or 0)}
 
 
-def run_crf_fullres(args, device, rank):
-    """--mode crf-fullres (training/tools/test-ms.py:84-111): the test-time dense CRF at image resolution —
-    log-probability unaries, scale_factor 1, 21 labels, 10 iterations — through krahenbuhl2013's object API with device
-    pointers (dsrg_amd.crf.DenseCRF; what CRF_device does per call).  One step = one image: unary + pairwise set-up
-    (both lattices are built) + inference.  This is the path where HBM/L2 bandwidth is the bound: lattice values live in
-    HBM and one launch streams them per blur axis."""
+def event_overhead_ms(stream=None):
+    """a HIP-event bracket also times the event signalling itself: the cost of an empty bracket on the same stream, to be
+    taken off so that a per-launch figure is the kernel's duration as rocprofv3 --kernel-trace sees it"""
+    st = stream or torch.cuda.current_stream()
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for _ in range(2):
+        for a, b in pairs:
+            a.record(st)
+            b.record(st)
+        torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in pairs]))
+
+
+def _load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def crf_fullres_record(device, steps, warmup, cpu=True, size=321):
+    """SURVEY 8f-1, training/tools/test-ms.py:84-111: the test-time dense CRF at image resolution — log-probability unaries,
+    scale_factor 1, 21 labels, 10 iterations — through krahenbuhl2013's object API with device pointers (dsrg_amd.crf.DenseCRF;
+    what CRF_device does per call).  One step = one image: unary + pairwise set-up (both lattices are built) + inference.
+    This is the path where HBM/L2 bandwidth is the bound: lattice values live in HBM and one launch streams them per blur axis."""
     from dsrg_amd import synthetic as S
     from dsrg_amd.crf import DenseCRF
     C, out_sizes = 21, []
-    sizes = [(321, 321), (375, 500)] if args.size == 321 else [(args.size, args.size)]
+    sizes = [(321, 321), (375, 500)] if size == 321 else [(size, size)]
     for (H, W) in sizes:
         rng = np.random.default_rng(3000 + H)
         img = S.make_images(rng, 1, size=max(H, W))[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]
@@ -136,82 +174,68 @@ def run_crf_fullres(args, device, rank):
             crf.set_unary_energy(neg)
             crf.add_pairwise_energy(10, 80.0, 80.0, 13, 13, 13, 3, 3.0, 3.0, im)
             crf.inference(10, out=out)
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             one()
         torch.cuda.synchronize()
-        crf.profile_start(args.steps * 10 + 8)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             one()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        nprof = max(2, min(steps, 5))
+        crf.profile_start(nprof * 10 + 8)                   # the dominant kernel, bracketed in a separate untimed pass
+        for _ in range(nprof):
+            one()
+        torch.cuda.synchronize()
         blur_ms, blur_n = crf.profile_stop()
         mg, mb = crf.lattice_size(0), crf.lattice_size(1)
         N = H * W
         # SURVEY 8d, the splat stage of filter(d, M) for both lattices in one launch: the marginals in (4 C N, read once), the
         # (vertex, weight) pair of every (pixel, corner) entry (8 (d+1) N per lattice), the lattice rows out (4 C M per lattice)
         alg_per_launch = 4 * C * N + 8 * (6 + 3) * N + 4 * C * (mb + mg)
-        out_sizes.append(dict(H=H, W=W, images_per_s=args.steps / dt, ms_per_image=dt / args.steps * 1e3, M_gauss=mg, M_bil=mb,
-                              blur_us_per_launch_event_bracket=blur_ms / max(blur_n, 1) * 1e3, blur_launches=blur_n,
-                              alg_bytes_per_blur_launch=alg_per_launch,
+        out_sizes.append(dict(H=H, W=W, images_per_s=steps / dt, ms_per_image=dt / steps * 1e3, M_gauss=mg, M_bil=mb,
+                              splat_us_per_launch_event_bracket=blur_ms / max(blur_n, 1) * 1e3, splat_launches=blur_n,
+                              alg_bytes_per_splat_launch=alg_per_launch,
                               crf_alg_bytes=10 * (filter_bytes(2, mg, C, N) + filter_bytes(5, mb, C, N) + 8 * C * N),
                               q=out.cpu().numpy(), im=im_np, un=un_np, dt=dt))
-    if rank != 0:
-        return
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-    for _ in range(2):
-        for a, b in pairs:
-            a.record(torch.cuda.default_stream())
-            b.record(torch.cuda.default_stream())
-        torch.cuda.synchronize()
-    ev_us = float(np.median([a.elapsed_time(b) for a, b in pairs])) * 1e3
+    ev_us = event_overhead_ms(torch.cuda.default_stream()) * 1e3
     head = out_sizes[0]
-    per_launch_s = max(head["blur_us_per_launch_event_bracket"] - ev_us, 1e-3) * 1e-6
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_fullres.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("lg_splat2_kernel_bytes_per_launch")
-        except Exception:
-            traffic = None
-    achieved = head["alg_bytes_per_blur_launch"] / per_launch_s / 1e9
+    per_launch_s = max(head["splat_us_per_launch_event_bracket"] - ev_us, 1e-3) * 1e-6
+    tj = _load_json("r03_pmc_traffic_fullres.json") or _load_json("pmc_traffic_fullres.json") or {}
+    traffic = tj.get("lg_splat2_kernel_bytes_per_launch")
+    achieved = head["alg_bytes_per_splat_launch"] / per_launch_s / 1e9
     roofline = {"kernel": "lg_splat2_kernel (permutohedral splat of both lattices: per-vertex ordered gather lists, values in HBM/L2)",
                 "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "alg_bytes_per_launch": head["alg_bytes_per_blur_launch"], "us_per_launch": per_launch_s * 1e6,
-                "us_per_launch_event_bracket": head["blur_us_per_launch_event_bracket"], "event_bracket_overhead_us": ev_us,
-                "launches": head["blur_launches"], "lattice_M_gauss": head["M_gauss"], "lattice_M_bilateral": head["M_bil"],
+                "alg_bytes_per_launch": head["alg_bytes_per_splat_launch"], "us_per_launch": per_launch_s * 1e6,
+                "us_per_launch_event_bracket": head["splat_us_per_launch_event_bracket"], "event_bracket_overhead_us": ev_us,
+                "launches": head["splat_launches"], "lattice_M_gauss": head["M_gauss"], "lattice_M_bilateral": head["M_bil"],
                 "hbm_gbs_from_pmc_traffic": (traffic / per_launch_s / 1e9) if traffic else None,
-                "whole_crf_alg_gbs": head["crf_alg_bytes"] / (head["ms_per_image"] * 1e-3) / 1e9,
-                "note": "a row of the splat is a chain of dependent gathers (entry -> pixel -> 96-byte label row, ~25 entries per "
-                        "vertex): latency-, not bandwidth-bound; the counter traffic exceeds the algorithmic bytes because every "
-                        "entry re-reads its pixel's row (L2 hits are not HBM traffic, FETCH_SIZE counts the fabric side)"}
-    out = {"metric": "images/sec full-resolution dense CRF (test-ms.py:84-111; %dx%d, 21 labels, 10 iterations, lattices built "
+                "whole_crf_alg_gbs": head["crf_alg_bytes"] / (head["ms_per_image"] * 1e-3) / 1e9}
+    rec = {"metric": "images/sec full-resolution dense CRF (test-ms.py:84-111; %dx%d, 21 labels, 10 iterations, lattices built "
                      "per image)" % (head["H"], head["W"]),
-           "value": head["images_per_s"], "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "value": head["images_per_s"], "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
            "ms_per_step": head["ms_per_image"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "krahenbuhl2013.CRF on device tensors, log-prob unaries, scale_factor 1, maxiter 10"},
            "sizes": [{k: v for k, v in o.items() if k not in ("q", "im", "un", "dt")} for o in out_sizes],
            "roofline": roofline}
-    if not args.no_cpu_baseline:
+    if cpu:
         from oracle import oracle as O
         t0 = time.perf_counter()
         want = O.CRF(head["im"], head["un"], scale_factor=1.0)
         t_cpu = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "images/s", "cores": 1, "kind": "port",
+        rec["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "images/s", "cores": 1, "kind": "port",
                                "sample": "1 image %dx%d, oracle/dsrg_oracle.c single-threaded, %.2f s" % (head["H"], head["W"], t_cpu)}
-        out["max_abs_dq_vs_oracle"] = float(np.abs(head["q"] - want).max())
-    print(json.dumps(out))
+        rec["max_abs_dq_vs_oracle"] = float(np.abs(head["q"] - want).max())
+    return rec
 
 
-def run_infer(args, device, rank):
-    """--mode infer (BASELINE.json configs[1]): VGG16-ASPP forward (bf16 autocast, fp32 heads, eval mode) + Softmax + dense
-    CRF + seeded region growing on the network's own scores, no losses, no backward — the inference-only supervision path.
-    Default batch 1."""
+def infer_record(device, rank, B, steps, warmup, use_graph=True):
+    """BASELINE.json configs[1]: VGG16-ASPP forward (bf16 autocast, fp32 heads, eval mode) + Softmax + dense CRF + seeded
+    region growing on the network's own scores, no losses, no backward — the inference-only supervision path."""
     from dsrg_amd import ops, synthetic as S
     from dsrg_amd.backbone import VGG16ASPP, count_flops_per_image
-    B = args.batch
     batch_np = S.make_batch(1000 + rank, B)
     images = torch.from_numpy(batch_np["images"]).to(device)
     labels = torch.from_numpy(batch_np["labels"]).to(device)
@@ -220,7 +244,6 @@ def run_infer(args, device, rank):
     net = VGG16ASPP().to(device).to(memory_format=torch.channels_last).eval()
     ctx = ops.get_context(B, 21, 41, 41)
     x = images.contiguous(memory_format=torch.channels_last)
-
     side = torch.cuda.Stream(device=device)
 
     # The forward at batch 1 is ~150 launches of 3-30 us: launch-bound.  Its shapes, weights and input buffer are static, so it
@@ -228,7 +251,7 @@ def run_infer(args, device, rank):
     # capture stream) and replayed per image; --no-graph keeps the eager launches.  Eager warm-up first: TunableOp picks its
     # GEMM solutions and the kernels reserve their LDS outside the capture.
     graph, graph_note = None, "eager"
-    if not args.no_graph:
+    if use_graph:
         try:
             from dsrg_amd.backbone import GraphedForward
             graph = GraphedForward(net, x)
@@ -256,35 +279,160 @@ def run_infer(args, device, rank):
         main.wait_stream(side)
         refined, _ = ops.crf_refine(probs, images, ctx=ctx, want_log=False, prepared=True)
         return ops.srg_grow(labels, cues, refined)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         seeds = one()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lg = torch.from_numpy(batch_np["logits"]).to(device)
     e0.record()
     for _ in range(10):
-        probs = ops.softmax_forward(torch.from_numpy(batch_np["logits"]).to(device))
+        probs = ops.softmax_forward(lg)
         refined, _ = ops.crf_refine(probs, images, ctx=ctx, want_log=False)
         ops.srg_grow(labels, cues, refined)
     e1.record()
     torch.cuda.synchronize()
-    if rank != 0:
-        return
-    out = {"metric": "images/sec VGG16-ASPP forward + Softmax + dense CRF + SRG (inference-only supervision path, 321x321, 21-class)",
-           "value": B * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16 backbone forward (fp32 heads) + f32/f64 CRF and SRG", "data": "synthetic",
-           "config": {"workload": "BASELINE.json configs[1]: backbone forward + CRF (10 it, scale 12) + SRG, batch %d" % B,
-                      "per_gpu_batch": B},
-           "backbone_launch": graph_note,
-           "supervision_only_ms": e0.elapsed_time(e1) / 10,
-           "backbone_forward_tflops": count_flops_per_image() * B * args.steps / dt / 1e12,
-           "grown_seed_pixels": int(seeds.sum().item() - cues.sum().item())}
-    print(json.dumps(out))
+    del net, graph
+    return {"metric": "images/sec VGG16-ASPP forward + Softmax + dense CRF + SRG (inference-only supervision path, 321x321, 21-class)",
+            "value": B * steps / dt, "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 backbone forward (fp32 heads) + f32/f64 CRF and SRG", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: backbone forward + CRF (10 it, scale 12) + SRG, batch %d" % B,
+                       "per_gpu_batch": B},
+            "backbone_launch": graph_note,
+            "supervision_only_ms": e0.elapsed_time(e1) / 10,
+            "backbone_forward_tflops": count_flops_per_image() * B * steps / dt / 1e12,
+            "grown_seed_pixels": int(seeds.sum().item() - cues.sum().item())}
+
+
+def filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead_ms):
+    """roofline object of mf_filter_kernel from a HIP-event-bracketed pass (dsrg_ctx_profile_start/stop).  The lattice values
+    never leave LDS between splat and slice, so the roof that binds this kernel is LDS bandwidth, not HBM: bytes through LDS
+    per launch from the instruction mix (lds_filter_traffic, measured M and X per image) against the per-instruction rates of
+    MI355X_MICROARCH.md (reads and writes have different rates: the peak is the byte-weighted blend)."""
+    mg, mb = ctx.lattice_sizes(B)
+    xg, xb = ctx.lattice_extras(B)
+    gflags_local = mg == 3 * N and xg == 0                      # pixel-local at training scale (M = 3 N private vertices)
+    raw_launch_us = filt_ms / filt_n * 1e3
+    per_launch_s = (filt_ms / filt_n - ev_overhead_ms) * 1e-3
+    alg_bytes = sum(filter_bytes(2, mg, C, N) + filter_bytes(5, m, C, N) for m in mb)   # SURVEY 8d, one filter launch
+    cpw_b, cpw_g = (2, 4) if B * ((C + 1) // 2) >= 64 else (1, 2)
+    groups_b, groups_g = (C + cpw_b - 1) // cpw_b, (C + cpw_g - 1) // cpw_g
+    rd = sum(lds_filter_traffic(5, m, x, N, cpw_b)[0] for m, x in zip(mb, xb)) * groups_b
+    wr = sum(lds_filter_traffic(5, m, x, N, cpw_b)[1] for m, x in zip(mb, xb)) * groups_b
+    insts = sum(lds_filter_instructions(5, m, x, N) for m, x in zip(mb, xb)) * groups_b
+    rate_r = LDS_RATE_GBS["read_b64" if cpw_b == 2 else "read_b32"]
+    rate_w = LDS_RATE_GBS["write_b64" if cpw_b == 2 else "write_b32"]
+    t_peak = rd / rate_r + wr / rate_w
+    gauss_rd = gauss_wr = 0
+    if not gflags_local:                                        # the Gaussian workgroups ride in the same launch
+        g_r, g_w = lds_filter_traffic(2, mg, xg, N, cpw_g)
+        gauss_rd, gauss_wr = g_r * groups_g * B, g_w * groups_g * B
+        t_peak += gauss_rd / LDS_RATE_GBS["read_b128" if cpw_g == 4 else "read_b64"] + \
+            gauss_wr / LDS_RATE_GBS["write_b128" if cpw_g == 4 else "write_b64"]
+        insts += lds_filter_instructions(2, mg, xg, N, vpt=5) * groups_g * B
+    total = rd + wr + gauss_rd + gauss_wr
+    lds_peak = total / t_peak
+    lds_achieved = total / per_launch_s / 1e9
+    tj = _load_json("r03_pmc_traffic.json") or _load_json("pmc_traffic.json") or {}
+    traffic = tj.get("mf_filter_kernel_bytes_per_launch")
+    counters = None
+    cj = _load_json("r03_lds_counters.json")
+    if cj:
+        ck = [v for k, v in cj.get("kernels", {}).items() if "mf_filter_kernel" in k]
+        if ck:
+            counters = {k: ck[0].get(k) for k in ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS",
+                                                  "SQ_WAVE_CYCLES", "lds_conflict_share", "avg_duration_us_under_pmc")}
+            counters["collected_at_commit"] = cj.get("commit")
+            if counters.get("SQ_LDS_IDX_ACTIVE") and counters.get("avg_duration_us_under_pmc"):
+                counters["lds_array_busy_frac_at_2.4GHz"] = counters["SQ_LDS_IDX_ACTIVE"] / (
+                    256 * counters["avg_duration_us_under_pmc"] * 1e-6 * 2.4e9)
+            if counters.get("SQ_INSTS_LDS"):
+                counters["model_insts_over_counter"] = insts / counters["SQ_INSTS_LDS"]
+    return {"kernel": "mf_filter_kernel (permutohedral splat/blur/slice: %d bilateral lattices x %d label planes%s)" % (
+                B, C, "; the pixel-local Gaussian lattice is evaluated by the update kernel" if gflags_local
+                else " + the Gaussian lattice x %d planes x %d images" % (C, B)),
+            "bound": "lds", "achieved": lds_achieved, "peak": lds_peak, "unit": "GB/s",
+            "frac": lds_achieved / lds_peak, "traffic": traffic,
+            "lds_read_bytes_per_launch": rd + gauss_rd, "lds_write_bytes_per_launch": wr + gauss_wr,
+            "lds_bytes_gaussian_workgroups": gauss_rd + gauss_wr,
+            "lds_wave_instructions_model": insts,
+            "lds_peak_read_gbs": rate_r, "lds_peak_write_gbs": rate_w,
+            "us_per_launch": per_launch_s * 1e6, "launches": filt_n,
+            "us_per_launch_event_bracket": raw_launch_us, "event_bracket_overhead_us": ev_overhead_ms * 1e3,
+            "workgroups_with_lds_work": groups_b * B + (0 if gflags_local else groups_g * B), "cus": 256,
+            "lds_counters_per_launch": counters,
+            "hbm_model": {"alg_bytes_per_launch": alg_bytes, "gbs": alg_bytes / per_launch_s / 1e9,
+                          "frac_of_8TBs": alg_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                          "note": "SURVEY 8d stage-streamed bytes / time: a labelled secondary, NOT a roofline — "
+                                  "the values stay in LDS, so this ratio exceeds 1"},
+            "hbm_gbs_from_pmc_traffic": (traffic / per_launch_s / 1e9) if traffic else None,
+            "lattice_M_gauss": mg, "lattice_M_bilateral_mean": float(np.mean(mb)), "splat_extras_bilateral_mean": float(np.mean(xb)),
+            "note": "achieved = modelled LDS bytes per launch / HIP-event time per launch (events on the launch stream, "
+                    "empty-bracket cost subtracted); traffic = HBM bytes per launch from the FETCH_SIZE/WRITE_SIZE passes"}
+
+
+def srg_roofline(ops, B, C, N, logits, images, labels, cues, ctx):
+    """the region-growing kernels on their own (north_star asks for their HBM rate too): one bracket around 20 calls"""
+    refined, _ = ops.crf_refine(ops.softmax_forward(logits), images, ctx=ctx, want_log=False)
+    for _ in range(3):
+        ops.srg_grow(labels, cues, refined)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.srg_grow(labels, cues, refined)
+    e1.record()
+    torch.cuda.synchronize()
+    srg_us = e0.elapsed_time(e1) / 20 * 1e3
+    pmc = (_load_json("r03_pmc_traffic.json") or _load_json("pmc_traffic.json") or {}).get("kernels", {})
+    srg_bytes = 16 * C * N * B                  # SURVEY 8d: cues + fp64 marginals in, seeds out, per image
+    tr = sum(v.get("hbm_bytes_per_launch", 0) for k, v in pmc.items() if "srg_" in k) or None
+    return {"kernel": "srg_classify_kernel + srg_grow_kernel (seeded region growing, %d images)" % B, "bound": "hbm",
+            "achieved": srg_bytes / (srg_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": srg_bytes / (srg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+            "alg_bytes_per_launch": srg_bytes, "us_per_launch": srg_us,
+            "note": "two dependent launches (pixel-parallel classification over the batch, then one workgroup per image for the "
+                    "growth): the time is two kernel boundaries plus one memory round trip each, not bandwidth"}
+
+
+def supervision_record(device, rank, B, steps, warmup, cpu=True, cpu_target_s=10.0):
+    """the supervision path on fixed fc8 logits: Softmax -> CRF -> SRG -> losses -> backward (dsrg_supervision_step)"""
+    from dsrg_amd import ops, synthetic as S
+    C, H, W = 21, 41, 41
+    N = H * W
+    batch_np = S.make_batch(1000 + rank, B)
+    d = lambda a: torch.from_numpy(a).to(device)                 # noqa: E731
+    logits, images, labels, cues = d(batch_np["logits"]), d(batch_np["images"]), d(batch_np["labels"]), d(batch_np["cues"])
+    ctx = ops.get_context(B, C, H, W)
+    for _ in range(warmup):
+        ops.supervision_step(logits, images, labels, cues, ctx=ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses, _, _ = ops.supervision_step(logits, images, labels, cues, ctx=ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nprof = max(3, min(steps, 20))
+    ctx.profile_start(nprof * 10 + 16)                           # the filter launches bracketed in a separate, untimed pass
+    for _ in range(nprof):
+        ops.supervision_step(logits, images, labels, cues, ctx=ctx)
+    torch.cuda.synchronize()
+    filt_ms, filt_n = ctx.profile_stop()
+    rec = {"metric": "images/sec DSRG supervision path only (softmax+CRF+SRG+losses+backward)",
+           "value": B * steps / dt, "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (thresholds and marginals f64)", "data": "synthetic",
+           "config": {"workload": "supervision path on fixed fc8 logits, 41x41x21, CRF 10 iterations scale 12", "per_gpu_batch": B},
+           "losses": [float(x) for x in losses.detach().cpu()],
+           "roofline": filter_roofline(ctx, B, C, N, filt_ms, filt_n, event_overhead_ms()) if filt_n else None,
+           "other_rooflines": [srg_roofline(ops, B, C, N, logits, images, labels, cues, ctx)]}
+    if cpu:
+        rec["cpu_baseline"] = cpu_baseline(batch_np, target_s=cpu_target_s)
+    return rec
 
 
 def fp32_leg(device, images, labels, cues, steps, warmup=3):
@@ -327,13 +475,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 16, 1 for --mode infer")
     ap.add_argument("--mode", choices=["train", "supervision", "train-f", "crf-fullres", "infer"], default="train",
-                    help="train = seed_mc train-s step (the headline metric); supervision = hot path on fixed logits; "
+                    help="train = seed_mc train-s step (the headline metric; on one GPU the line also carries bounded "
+                         "sub-records of the other quoted configurations under `modes`); supervision = hot path on fixed "
+                         "logits; infer = BASELINE.json configs[1]; crf-fullres = test-time CRF at image resolution; "
                          "train-f = stage-2 retrain step (no SRG/CRF inside; BASELINE.json configs[4] with "
                          "--backbone resnet101 --size 513)")
     ap.add_argument("--backbone", choices=["vgg16", "resnet101"], default="vgg16")
     ap.add_argument("--size", type=int, default=321)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the float32-backbone leg and the bf16/fp32 loss trajectories")
+    ap.add_argument("--no-modes", action="store_true", help="--mode train: skip the sub-records of the other configurations")
     ap.add_argument("--no-graph", action="store_true", help="--mode infer: launch the backbone forward eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket filter launches with HIP events")
     args = ap.parse_args()
@@ -356,14 +507,34 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
 
-    if args.batch is None:
-        args.batch = 1 if args.mode == "infer" else 16
-    if args.mode in ("crf-fullres", "infer"):
-        (run_crf_fullres if args.mode == "crf-fullres" else run_infer)(args, device, rank)
+    def finish():
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
-        return
+
+    cpu = not args.no_cpu_baseline and world == 1
+    if args.batch is None:
+        args.batch = 1 if args.mode == "infer" else 16
+    if args.mode == "crf-fullres":
+        rec = crf_fullres_record(device, args.steps, args.warmup, cpu=cpu, size=args.size)
+        if rank == 0:
+            print(json.dumps(rec))
+        return finish()
+    if args.mode == "infer":
+        rec = infer_record(device, rank, args.batch, args.steps, args.warmup, use_graph=not args.no_graph)
+        if rank == 0:
+            print(json.dumps(rec))
+        return finish()
+    if args.mode == "supervision":
+        rec = supervision_record(device, rank, args.batch, args.steps, args.warmup, cpu=cpu)
+        if rank == 0:
+            if cpu:
+                try:
+                    rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+                except Exception as e:                   # never let the extra baseline cost the bench line
+                    rec["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
+            print(json.dumps(rec))
+        return finish()
 
     from dsrg_amd import ops, synthetic as S
     from dsrg_amd.backbone import count_flops_per_image
@@ -390,10 +561,7 @@ def main():
     def one_step():
         if retrainer is not None:
             return retrainer.step(f_images, f_label).reshape(1)
-        if trainer is not None:
-            return trainer.step(images, labels, cues)
-        losses, _, _ = ops.supervision_step(logits_fixed, images, labels, cues, ctx=ctx)
-        return losses
+        return trainer.step(images, labels, cues)
 
     def barrier():
         if dist is not None:
@@ -403,187 +571,101 @@ def main():
     for _ in range(args.warmup):
         one_step()
     barrier()
-    profile = not args.no_profile and args.mode != "train-f"
-    if profile:
-        ctx.profile_start(args.steps * 10 + 16)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = one_step()
     barrier()
     dt = time.perf_counter() - t0
-    filt_ms, filt_n = ctx.profile_stop() if profile else (0.0, 0)
-    # a HIP-event bracket also times the event signalling itself: measure that on empty brackets (same stream) and
-    # take it off, so that the per-launch figure is the kernel's duration as rocprofv3 --kernel-trace sees it
-    ev_overhead_ms = 0.0
-    if profile:
-        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-        for _ in range(2):
-            for a, b in pairs:
-                a.record()
-                b.record()
-            torch.cuda.synchronize()
-        ev_overhead_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the dominant hot-path kernel inside the train step: a separate, untimed pass with every filter launch bracketed by HIP
+    # events on its launch stream (the brackets cost ~5 us each: they must not sit in the timed region)
+    filt_ms, filt_n, ev_overhead = 0.0, 0, 0.0
+    if args.mode == "train" and not args.no_profile:
+        nprof = max(3, min(args.steps, 10))
+        ctx.profile_start(nprof * 10 + 16)
+        for _ in range(nprof):
+            one_step()
+        torch.cuda.synchronize()
+        filt_ms, filt_n = ctx.profile_stop()
+        ev_overhead = event_overhead_ms()
+
     # supervision-only time per step on this rank (same inputs; untimed region)
     sup_ms = None
     if args.mode == "train":
-        lg = logits_fixed
         for _ in range(3):
-            ops.supervision_step(lg, images, labels, cues, ctx=ctx)
+            ops.supervision_step(logits_fixed, images, labels, cues, ctx=ctx)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            ops.supervision_step(lg, images, labels, cues, ctx=ctx)
+            ops.supervision_step(logits_fixed, images, labels, cues, ctx=ctx)
         e1.record()
         torch.cuda.synchronize()
         sup_ms = e0.elapsed_time(e1) / 10
 
-    # the region-growing kernel on its own (north_star asks for its HBM rate too): one bracket around 20 launches
-    srg_us = None
-    if args.mode != "train-f" and rank == 0:
-        refined, _ = ops.crf_refine(ops.softmax_forward(logits_fixed), images, ctx=ctx, want_log=False)
-        for _ in range(3):
-            ops.srg_grow(labels, cues, refined)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            ops.srg_grow(labels, cues, refined)
-        e1.record()
-        torch.cuda.synchronize()
-        srg_us = e0.elapsed_time(e1) / 20 * 1e3
-
     if rank == 0:
-        mg, mb = ctx.lattice_sizes(B) if args.mode != "train-f" else (0, [0])
-        alg_bytes = sum(filter_bytes(2, mg, C, N) + filter_bytes(5, m, C, N) for m in mb)   # one filter launch
-        roofline = None
-        if filt_n > 0:
-            raw_launch_us = filt_ms / filt_n * 1e3
-            per_launch_s = (filt_ms / filt_n - ev_overhead_ms) * 1e-3
-            achieved = alg_bytes / per_launch_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get("mf_filter_kernel_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            # The lattice values never leave LDS between splat and slice, so the roof that binds this kernel is LDS bandwidth,
-            # not HBM: bytes through LDS per launch from the instruction mix (two label planes per bilateral workgroup, 8-byte
-            # accesses; the Gaussian lattice is diagonal at this scale and touches no LDS), against the per-instruction rates of
-            # MI355X_MICROARCH.md (reads and writes have different rates: the peak is the byte-weighted blend).
-            cpw = 2 if B * ((C + 1) // 2) >= 64 else 1
-            groups = (C + cpw - 1) // cpw
-            rd = sum(lds_filter_traffic(5, m, N, cpw)[0] for m in mb) * groups
-            wr = sum(lds_filter_traffic(5, m, N, cpw)[1] for m in mb) * groups
-            r_rate, w_rate = (LDS_RATE_GBS["read_b64"], LDS_RATE_GBS["write_b64"]) if cpw == 2 else (LDS_RATE_GBS["read_b32"], LDS_RATE_GBS["write_b32"])
-            lds_peak = (rd + wr) / (rd / r_rate + wr / w_rate)
-            lds_achieved = (rd + wr) / per_launch_s / 1e9
-            counters = None
-            cpath = os.path.join(ROOT, "profiles", "r02_lds_counters.json")
-            if os.path.exists(cpath):
-                try:
-                    cj = json.load(open(cpath))
-                    ck = [v for k, v in cj.get("kernels", {}).items() if "mf_filter_kernel" in k]
-                    if ck:
-                        counters = {k: ck[0].get(k) for k in ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS",
-                                                               "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES", "lds_conflict_share",
-                                                               "avg_duration_us_under_pmc")}
-                        counters["collected_at_commit"] = cj.get("commit")
-                        if counters.get("SQ_LDS_IDX_ACTIVE") and counters.get("avg_duration_us_under_pmc"):
-                            counters["lds_array_busy_frac_at_2.4GHz"] = counters["SQ_LDS_IDX_ACTIVE"] / (
-                                256 * counters["avg_duration_us_under_pmc"] * 1e-6 * 2.4e9)
-                except Exception:
-                    counters = None
-            roofline = {"kernel": "mf_filter_kernel (permutohedral splat/blur/slice, %d lattices x %d label planes)" % (2 * B, C),
-                        "bound": "lds", "achieved": lds_achieved, "peak": lds_peak, "unit": "GB/s",
-                        "frac": lds_achieved / lds_peak, "traffic": traffic,
-                        "lds_read_bytes_per_launch": rd, "lds_write_bytes_per_launch": wr,
-                        "lds_peak_read_gbs": r_rate, "lds_peak_write_gbs": w_rate,
-                        "us_per_launch": per_launch_s * 1e6, "launches": filt_n,
-                        "us_per_launch_event_bracket": raw_launch_us, "event_bracket_overhead_us": ev_overhead_ms * 1e3,
-                        "workgroups_with_lds_work": groups * B, "cus": 256,
-                        "lds_counters_per_launch": counters,
-                        "hbm_model": {"alg_bytes_per_launch": alg_bytes, "gbs": achieved, "frac_of_8TBs": achieved / HBM_PEAK_GBS,
-                                      "note": "SURVEY 8d stage-streamed bytes / time: a labelled secondary, NOT a roofline — "
-                                              "the values stay in LDS, so this ratio exceeds 1"},
-                        "hbm_gbs_from_pmc_traffic": (traffic / per_launch_s / 1e9) if traffic else None,
-                        "lattice_M_gauss": mg, "lattice_M_bilateral_mean": float(np.mean(mb)),
-                        "note": "traffic = HBM bytes per launch from the FETCH_SIZE/WRITE_SIZE passes (profiles/pmc_traffic.json)"}
         total_images = B * world * args.steps
-        pmc = {}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("kernels", {})
-        except Exception:
-            pass
         other = []
-        if srg_us:
-            srg_bytes = 16 * C * N * B                  # cues + fp64 marginals in, seeds out, per image
-            other.append({"kernel": "srg_grow_kernel (seeded region growing, %d images)" % B, "bound": "hbm",
-                          "achieved": srg_bytes / (srg_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": srg_bytes / (srg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                          "traffic": pmc.get("dsrg::srg_grow_kernel", {}).get("hbm_bytes_per_launch"),
-                          "hbm_gbs_from_pmc_traffic": (pmc["dsrg::srg_grow_kernel"]["hbm_bytes_per_launch"] / (srg_us * 1e-6) / 1e9)
-                          if "dsrg::srg_grow_kernel" in pmc else None,
-                          "alg_bytes_per_launch": srg_bytes, "us_per_launch": srg_us,
-                          "note": "one workgroup per image; bounded by three dependent memory round trips, not bandwidth"})
         if args.mode == "train":
+            other.append(srg_roofline(ops, B, C, N, logits_fixed, images, labels, cues, ctx))
             tf = count_flops_per_image() * 3 * B * world * args.steps / dt / 1e12 / world
-            other.append({"kernel": "backbone convolutions (hipBLASLt / MIOpen / CK, MFMA bf16), whole step per GPU",
+            other.append({"kernel": "backbone convolutions (hipBLASLt / MIOpen / CK / own direct kernels, MFMA bf16), whole step per GPU",
                           "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
                           "traffic": None, "note": "3 x forward flops of the conv stack / step time (supervision, "
                                                    "pooling, optimizer included in the time)"})
         out = {
             "metric": "images/sec DSRG train step (VGG16 321x321, 21-class)" if args.mode == "train"
-                      else ("images/sec train-f retrain step (%s %dx%d, softmax loss on pseudo-labels)" % (args.backbone, args.size, args.size)
-                            if args.mode == "train-f" else
-                            "images/sec DSRG supervision path only (softmax+CRF+SRG+losses+backward)"),
+                      else "images/sec train-f retrain step (%s %dx%d, softmax loss on pseudo-labels)" % (args.backbone, args.size, args.size),
             "value": total_images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 backbone (fp32 master weights) + f32/f64 supervision path" if args.mode == "train" else
-                      ("bf16 backbone (fp32 master weights), f32 loss" if args.mode == "train-f" else "f32 (thresholds and marginals f64)")),
+                      "bf16 backbone (fp32 master weights), f32 loss"),
             "data": "synthetic",
             "config": {"workload": ("full seed_mc train-s step: VGG16-ASPP fwd+bwd + Softmax/CRF(10 it, scale 12)/"
                                     "SRG/BalancedSeedLoss/ConstrainLoss + SGD, 321x321 -> 41x41x21"
                                     if args.mode == "train" else
-                                    ("train-f step: %s fwd+bwd + Interp(1/8) + SoftmaxWithLoss + SGD(poly), %dx%d" % (
-                                        args.backbone, args.size, args.size) if args.mode == "train-f"
-                                     else "supervision path on fixed fc8 logits")),
+                                    "train-f step: %s fwd+bwd + Interp(1/8) + SoftmaxWithLoss + SGD(poly), %dx%d" % (
+                                        args.backbone, args.size, args.size)),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "baseline_config": "configs[2] (batch 16 on 1 GPU); configs[3] at 8 GPUs"},
             "losses": [float(x) for x in losses.detach().cpu()],
             "supervision_ms_per_step": sup_ms,
             "backbone_tflops": (count_flops_per_image() * 3 * B * world * args.steps / dt / 1e12) if args.mode == "train" else None,
-            "roofline": roofline,
+            "roofline": filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead) if filt_n else None,
             "other_rooflines": other,
         }
+        if args.mode == "train" and world == 1:
+            out["legs"] = {"bf16": {"value": out["value"], "ms_per_step": out["ms_per_step"], "steps": args.steps,
+                                    "dtype": out["dtype"], "backbone_tflops": out["backbone_tflops"],
+                                    "mfma_peak_tflops": 2500.0, "mfma_frac": out["backbone_tflops"] / 2500.0}}
         if args.mode == "train" and world == 1 and not args.no_fp32:
-            # the reference's backbone arithmetic is Caffe float32: the same step with a float32 backbone, and how far the two
-            # loss trajectories drift apart
+            # the reference's backbone arithmetic is Caffe float32: the same step with a float32 backbone, for the SAME number
+            # of timed steps, and how far the two loss trajectories drift apart
             del trainer
             torch.cuda.empty_cache()
-            n32 = max(5, args.steps // 4)
-            dt32, l32 = fp32_leg(device, images, labels, cues, n32)
+            dt32, l32 = fp32_leg(device, images, labels, cues, args.steps)
             tf32 = count_flops_per_image() * 3 * B / dt32 / 1e12
             out["value_fp32"] = B / dt32
             out["ms_per_step_fp32"] = dt32 * 1e3
-            out["fp32"] = {"steps": n32, "losses": l32, "backbone_tflops": tf32, "mfma_peak_tflops": 157.3,
-                           "mfma_frac": tf32 / 157.3, "dtype": "f32 backbone + f32/f64 supervision path",
-                           "note": "float32 is the reference's backbone precision; `value` is the bf16-autocast (fp32 master "
-                                   "weights, fp32 classifier heads) figure"}
+            out["legs"]["fp32"] = {"value": B / dt32, "ms_per_step": dt32 * 1e3, "steps": args.steps, "losses": l32,
+                                   "dtype": "f32 backbone + f32/f64 supervision path", "backbone_tflops": tf32,
+                                   "mfma_peak_tflops": 157.3, "mfma_frac": tf32 / 157.3,
+                                   "note": "float32 is the reference's backbone precision (Caffe): any comparison with the "
+                                           "reference quotes this leg; `value` is the bf16-autocast (fp32 master weights, fp32 "
+                                           "classifier heads) leg — the MI355X-native configuration"}
             try:
                 t16, t32, gap = loss_trajectories(device, images, labels, cues)
-                out["fp32"]["loss_trajectory_bf16"] = t16
-                out["fp32"]["loss_trajectory_fp32"] = t32
-                out["fp32"]["max_rel_loss_gap_20_steps"] = gap
+                out["legs"]["loss_trajectory_bf16"] = t16
+                out["legs"]["loss_trajectory_fp32"] = t32
+                out["legs"]["max_rel_loss_gap_20_steps"] = gap
             except Exception as e:                       # never let the comparison cost the bench line
-                out["fp32"]["loss_trajectory_error"] = str(e)[:200]
-        if world == 1 and not args.no_cpu_baseline:
+                out["legs"]["loss_trajectory_error"] = str(e)[:200]
+        if args.mode == "train" and world == 1 and cpu:
             out["cpu_baseline"] = cpu_baseline(batch_np)
             try:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
@@ -591,10 +673,25 @@ def main():
                 out["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
         else:
             out["cpu_baseline"] = None
+        if args.mode == "train" and world == 1 and not args.no_modes:
+            # the other quoted configurations, bounded, each with its own roofline and CPU baseline: driver-timed alongside
+            # the headline (BASELINE.json configs[1]; the hot path alone at 16 images and at one)
+            trainer = None
+            torch.cuda.empty_cache()
+            modes = {}
+            for name, fn in (("supervision", lambda: supervision_record(device, rank, 16, 200, 20, cpu=False)),
+                             ("supervision_b1", lambda: supervision_record(device, rank, 1, 200, 20, cpu=cpu, cpu_target_s=5.0)),
+                             ("infer_b1", lambda: infer_record(device, rank, 1, 200, 20)),
+                             ("crf_fullres", lambda: crf_fullres_record(device, 20, 5, cpu=cpu))):
+                try:
+                    modes[name] = fn()
+                except Exception as e:                   # a sub-record must never cost the headline line
+                    modes[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            if "supervision" in modes and isinstance(out.get("cpu_baseline"), dict):
+                modes["supervision"]["cpu_baseline"] = out["cpu_baseline"]      # same workload: the port on the same batch
+            out["modes"] = modes
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

@@ -9,7 +9,9 @@ import os
 import torch  # noqa: F401  — loaded first so libdsrg_hip.so binds to torch's libamdhip64.so.7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsrg_hip.so")
+# DSRG_LIB (tools only): another build of the same library next to the shipped one, e.g. libdsrg_hip.exp3.so from
+# `make -C dsrg_amd/csrc EXP=3 exp` — for A/B measurements of kernel variants on one box
+LIB_PATH = os.path.join(_HERE, os.environ.get("DSRG_LIB") or "libdsrg_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4
 
@@ -58,6 +60,7 @@ SIGNATURES = {
     "dsrg_crf_prepare_batch": (_i, [_vp, _i, _vp, _i, _i, ctypes.POINTER(CrfParams), _vp]),
     "dsrg_crf_meanfield_batch": (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(CrfParams), _vp, _vp]),
     "dsrg_ctx_lattice_sizes": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "dsrg_ctx_lattice_extras": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dsrg_ctx_lattice_dump": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsrg_ctx_read_refined": (_i, [_vp, _i, _vp, _vp]),
     "dsrg_ctx_lattice_norm": (_i, [_vp, _i, _i, _vp, _vp]),

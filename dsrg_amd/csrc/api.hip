@@ -270,6 +270,18 @@ extern "C" int dsrg_ctx_lattice_sizes(dsrg_ctx_t c, int B, int32_t *m_gauss, int
     return DSRG_OK;
 }
 
+// measurement: the number of splat entries beyond the first of their row ("extras", common.h) per lattice — with the vertex
+// counts what the LDS traffic model of bench.py needs
+extern "C" int dsrg_ctx_lattice_extras(dsrg_ctx_t c, int B, int32_t *x_gauss, int32_t *x_bil, void *stream) {
+    if (!c || B < 0 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (x_gauss) DSRG_HIP_CHECK(hipMemcpyAsync(x_gauss, c->Lg.nextra, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (x_bil && B > 0)
+        DSRG_HIP_CHECK(hipMemcpyAsync(x_bil, c->Lb.nextra, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    DSRG_HIP_CHECK(hipStreamSynchronize(s));
+    return DSRG_OK;
+}
+
 // introspection (tests): the lattice of image b (kind 1, bilateral) or the shared Gaussian lattice (kind 0) in the
 // reference's own form — keys in id order (HashTable::getKeys, permutohedral.cpp:296), per-pixel vertex ids and
 // barycentric weights pixel-major (offset_ / barycentric_, :272-274), blur neighbours per axis with -1 = none (:315-316)

@@ -65,6 +65,13 @@ struct LatticeView {
     uint16_t *row_start;   // [Mcap+2]   CSR of the splat: entries of vertex v (E < 65536 on this path)
     uint16_t *csr_pix;     // [(d+1)*N]  source pixel of each entry, entry order = reference splat order
     float *csr_w;          // [(d+1)*N]  weight of each entry
+    // the filter kernel's form of the splat: the first contributor of every vertex, vertex-indexed, and all further
+    // entries ("extras") as one compact list; the extras of row v are [row_start[v] - v, row_start[v+1] - v - 1)
+    uint16_t *first_pix;   // [Mcap]     source pixel of vertex v's first entry (0 for a vertex without entries)
+    float *first_w;        // [Mcap]     its weight (0 for a vertex without entries)
+    uint16_t *x_pix;       // [(d+1)*N]  source pixel of extra entry t
+    float *x_w;            // [(d+1)*N]  its weight
+    int *nextra;           // [1]        number of extras = E - (vertices with at least one entry)
     float *norm;           // [N]        1/sqrt(K 1 + 1e-20)
     // d = 2 only, valid when flag kLatticeLocal is set: every vertex has one contributor and the only blur neighbours of a
     // pixel's three corners are each other (the spatial kernel at training scale, sigma = 0.25 px).  Corners relabelled per

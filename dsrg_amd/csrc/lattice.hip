@@ -70,6 +70,8 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     uint16_t *csr_pix = L.csr_pix + (size_t)b * E;
     float *csr_w = L.csr_w + (size_t)b * E;
     float *norm = L.norm + (size_t)b * N;
+    uint16_t *first_pix = L.first_pix + (size_t)b * Mcap, *x_pix = L.x_pix + (size_t)b * E;
+    float *first_w = L.first_w + (size_t)b * Mcap, *x_w = L.x_w + (size_t)b * E;
     uint32_t *key_e = L.key_e + (size_t)b * Epad * KW;
     uint32_t *key_v = L.key_v + (size_t)b * Mcap * KW;
 
@@ -338,6 +340,10 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     // weights of the sorted entries: to HBM for the filter kernel, and (when it fits) to LDS for the
     // norm pass below
     float *wl = wl_in_lds ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(scan2) + 32 * 4) : csr_w;
+    // The filter kernel's view of the same lists: the FIRST contributor of every vertex, vertex-indexed (most rows have
+    // exactly one entry), and the remaining entries as one compact list — rows without entries are the SSE padding's
+    // phantom vertices, which were created last and therefore sit at the end of the id range, so the extras of row v start
+    // at row_start[v] - v.
     for (int pos = tid; pos < E; pos += kWG) {
         const int e = csr_e[pos];
         const int i = e / D1, r = e - i * D1;
@@ -345,6 +351,22 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         csr_pix[pos] = (uint16_t)i;
         csr_w[pos] = w;
         if (wl_in_lds) wl[pos] = w;
+        const int v = vid[(size_t)r * N + i];
+        const int start = v == 0 ? 0 : (int)cnt[v - 1];        // cnt[v] = END of row v
+        if (pos == start) { first_pix[v] = (uint16_t)i; first_w[v] = w; }
+        else { x_pix[pos - v - 1] = (uint16_t)i; x_w[pos - v - 1] = w; }
+    }
+    {
+        int nonempty = 0;
+        for (int v = tid; v < M; v += kWG) {
+            const int start = v == 0 ? 0 : (int)cnt[v - 1];
+            if ((int)cnt[v] == start) { first_pix[v] = 0; first_w[v] = 0.0f; }      // phantom vertex: contributes an exact 0
+            else nonempty++;
+        }
+        // workgroup sum of `nonempty`
+        int tot2;
+        (void)block_exclusive_scan(nonempty, scan2, &tot2);
+        if (tid == 0) L.nextra[b] = E - tot2;
     }
     __syncthreads();
     DSRG_STAMP(7);
@@ -673,10 +695,10 @@ __global__ __launch_bounds__(kWG) void lattice_local_kernel(LatticeView L) {
 // ---------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static void lattice_layout(int d, int N, int nlat, size_t off[17], size_t &total) {
+static void lattice_layout(int d, int N, int nlat, size_t off[22], size_t &total) {
     const int d1 = d + 1, Npad = (N + 3) / 4 * 4, Mcap = Npad * d1, E = N * d1, Epad = Npad * d1;
     const int KW = (d * 16 + 31) / 32;
-    size_t sz[16] = {
+    size_t sz[21] = {
         sizeof(int) * (size_t)nlat,                          // M
         sizeof(uint16_t) * (size_t)E * nlat,                 // vid
         sizeof(float) * (size_t)E * nlat,                    // bary
@@ -693,20 +715,25 @@ static void lattice_layout(int d, int N, int nlat, size_t off[17], size_t &total
         sizeof(unsigned long long) * (size_t)Mcap * nlat,     // ckeys_g
         d == 2 ? sizeof(float) * 4 * (size_t)N * nlat : 0,   // loc_a
         d == 2 ? sizeof(uint32_t) * (size_t)N * nlat : 0,    // loc_z
+        sizeof(uint16_t) * (size_t)Mcap * nlat,              // first_pix
+        sizeof(float) * (size_t)Mcap * nlat,                 // first_w
+        sizeof(uint16_t) * (size_t)E * nlat,                 // x_pix
+        sizeof(float) * (size_t)E * nlat,                    // x_w
+        sizeof(int) * (size_t)nlat,                          // nextra
     };
     size_t cur = 0;
-    for (int i = 0; i < 16; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
+    for (int i = 0; i < 21; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
     total = cur;
 }
 
 size_t lattice_bytes(int d, int N, int nlat) {
-    size_t off[17], total;
+    size_t off[22], total;
     lattice_layout(d, N, nlat, off, total);
     return total;
 }
 
 void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
-    size_t off[17], total;
+    size_t off[22], total;
     lattice_layout(d, N, nlat, off, total);
     unsigned char *p = static_cast<unsigned char *>(base);
     L.d = d; L.N = N; L.Mcap = ((N + 3) / 4 * 4) * (d + 1); L.nlat = nlat;
@@ -726,6 +753,11 @@ void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
     L.ckeys_g = reinterpret_cast<unsigned long long *>(p + off[13]);
     L.loc_a = d == 2 ? reinterpret_cast<float *>(p + off[14]) : nullptr;
     L.loc_z = d == 2 ? reinterpret_cast<uint32_t *>(p + off[15]) : nullptr;
+    L.first_pix = reinterpret_cast<uint16_t *>(p + off[16]);
+    L.first_w = reinterpret_cast<float *>(p + off[17]);
+    L.x_pix = reinterpret_cast<uint16_t *>(p + off[18]);
+    L.x_w = reinterpret_cast<float *>(p + off[19]);
+    L.nextra = reinterpret_cast<int *>(p + off[20]);
 }
 
 void lattice_feat_init(LatticeFeat &F, int d, int W, int H, float sx, float sy, float sr, float sg, float sb) {

@@ -17,7 +17,17 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "common.h"
+
+// compile-time experiments on the filter kernel: make EXP=n builds libdsrg_hip.expN.so next to the shipped library and the
+// tools select it with DSRG_LIB (A/B on one box).  Measured and adopted in round 3: blur gathers batched per group of 5
+// slots (-0.96 us per workgroup), product gathers batched (-0.14); measured and dropped: a workgroup barrier behind the q
+// loads (+0.3), the first row term of every slot batched (0.0), term-major row sums (+1.5), neighbour-word descriptors that
+// end at M (0.0).  profiles/r03_filter_ab.txt
+#ifndef DSRG_EXP
+#define DSRG_EXP 0
+#endif
 
 namespace dsrg {
 
@@ -68,6 +78,8 @@ __device__ __forceinline__ void pv_set(float4 &v, int c, float x) {
     if (c == 0) v.x = x; else if (c == 1) v.y = x; else if (c == 2) v.z = x; else v.w = x;
 }
 
+template <int V> using IC = std::integral_constant<int, V>;
+
 #define DSRG_STAMP(i_) do { if (dbg && tid == 0) dbg[(i_)] = wall_clock64(); } while (0)
 
 // one lattice (dimension D, index li of set L), planes [c0, c0+nc) of image b:
@@ -85,65 +97,26 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
     constexpr int NCH = (VPT + KC - 1) / KC;
     constexpr int RING = 3;
     const int tid = (int)threadIdx.x;
-    const int Mcap = L.Mcap, E = N * D1;
+    const int Mcap = L.Mcap;
     const float *norm = L.norm + (size_t)li * N;
 
-    const int M = L.M[li];
-    const int lat_flags = L.flags[li];
-    // slots k with k * kWG >= Mlim hold no vertex of this lattice: skipped when the guard is on
-    const int Mlim = (opts & kOptSlotGuard) ? M : (VPT * kWG);
     const uint32_t nb_bytes = sizeof(uint32_t) * (uint32_t)Mcap;
 
+#if DSRG_EXP & 8
+    const int M = L.M[li];
+    const int lat_flags = L.flags[li];
+    const int X = L.nextra[li];
+    asm volatile("" :: "s"(M), "s"(lat_flags), "s"(X));     // consumed (waited for) here, ahead of the vector loads
+#endif
     const rsrc_t r_rs = make_rsrc(L.row_start + (size_t)li * (Mcap + 2), sizeof(uint16_t) * (size_t)(Mcap + 2));
-    const rsrc_t r_cp = make_rsrc(L.csr_pix + (size_t)li * D1 * N, sizeof(uint16_t) * (size_t)D1 * N);
-    const rsrc_t r_cw = make_rsrc(L.csr_w + (size_t)li * D1 * N, sizeof(float) * (size_t)D1 * N);
+    const rsrc_t r_fp = make_rsrc(L.first_pix + (size_t)li * Mcap, sizeof(uint16_t) * (size_t)Mcap);
+    const rsrc_t r_fw = make_rsrc(L.first_w + (size_t)li * Mcap, sizeof(float) * (size_t)Mcap);
     const rsrc_t r_vid = make_rsrc(L.vid + (size_t)li * D1 * N, sizeof(uint16_t) * (size_t)D1 * N);
     const rsrc_t r_bary = make_rsrc(L.bary + (size_t)li * D1 * N, sizeof(float) * (size_t)D1 * N);
     const rsrc_t r_norm = make_rsrc(norm, sizeof(float) * (size_t)N);
     const rsrc_t r_q = make_rsrc(qb, sizeof(float) * (size_t)nc * N);
     const uint32_t *nb_base = L.nb + (size_t)li * D1 * Mcap;
     DSRG_STAMP(0);
-
-    if (lat_flags & 1) {
-        // Diagonal lattice: every simplex corner is private to its pixel and has no blur neighbour, so splat, blur and
-        // slice collapse to per-pixel arithmetic — evaluated here in the general path's operation
-        // order (products, 0 + p, val + 0.5*(0+0), ordered slice sum), hence bit-identical to it.
-        const float alpha = 1.0f / (1.0f + exp2f(-(float)D));
-        float nvs[PPT], bws[PPT][D1], qq[PPT][CPW];
-#pragma unroll
-        for (int p = 0; p < PPT; p++) {
-            nvs[p] = ld_f32(r_norm, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u));
-#pragma unroll
-            for (int r = 0; r < D1; r++)
-                bws[p][r] = ld_f32(r_bary, (uint32_t)tid * 4u, ((uint32_t)p * kWG + (uint32_t)r * (uint32_t)N) * 4u);
-#pragma unroll
-            for (int c = 0; c < CPW; c++)
-                qq[p][c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
-        }
-#pragma unroll
-        for (int p = 0; p < PPT; p++) {
-            const int i = tid + p * kWG;
-            if (i < N) {
-#pragma unroll
-                for (int c = 0; c < CPW; c++) {
-                    if (c < nc) {
-                        const float x = qq[p][c] * nvs[p];
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int r = 0; r < D1; r++) {
-                            float v = 0.0f + bws[p][r] * x;      // splat into an empty vertex
-                            v = v + 0.5f * (0.0f + 0.0f);        // d+1 blur passes without neighbours
-                            acc = acc + (bws[p][r] * alpha) * v; // slice
-                        }
-                        out[(size_t)c * N + i] = acc * nvs[p];
-                    }
-                }
-            }
-        }
-        DSRG_STAMP(11);
-        if (dbg && tid == 0) dbg[12] = (unsigned long long)M;
-        return;
-    }
 
     // ---- stage A: everything that does not depend on anything, in one burst
     float qv[PPT][CPW], nrm[PPT];
@@ -154,19 +127,31 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
         for (int c = 0; c < CPW; c++)
             qv[p][c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
     }
-    uint32_t epx[KC], rs0[KC], rs1[KC];
-    float ew[KC];
+    // splat, vertex-major: the first contributor (pixel, weight) of my vertices v_k = tid + k*1024 and their CSR rows
+    uint32_t fpx[KC], rs0[KC], rs1[KC];
+    float fw[KC];
+    auto load_rows = [&](int ch) {
 #pragma unroll
-    for (int k = 0; k < KC; k++) {             // splat entries e_k = tid + k*1024 and CSR rows of v_k
-        epx[k] = ld_u16(r_cp, (uint32_t)tid * 2u, (uint32_t)k * (kWG * 2u));
-        ew[k] = ld_f32(r_cw, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
-        rs0[k] = ld_u16(r_rs, (uint32_t)tid * 2u, (uint32_t)k * (kWG * 2u));
-    }
-    // row end = the next vertex's row start: the neighbouring lane holds it; only the last lane of a wave loads it
-    if ((tid & 63) == 63) {
+        for (int k = 0; k < KC; k++) {
+            const uint32_t sk = (uint32_t)(ch * KC + k);
+            fpx[k] = ld_u16(r_fp, (uint32_t)tid * 2u, sk * (kWG * 2u));
+            fw[k] = ld_f32(r_fw, (uint32_t)tid * 4u, sk * (kWG * 4u));
+            rs0[k] = ld_u16(r_rs, (uint32_t)tid * 2u, sk * (kWG * 2u));
+        }
+        // row end = the next vertex's row start: the neighbouring lane holds it; only the last lane of a wave loads it
+        if ((tid & 63) == 63) {
 #pragma unroll
-        for (int k = 0; k < KC; k++) rs1[k] = ld_u16(r_rs, (uint32_t)tid * 2u, (uint32_t)k * (kWG * 2u) + 2u);
-    }
+            for (int k = 0; k < KC; k++) rs1[k] = ld_u16(r_rs, (uint32_t)tid * 2u, (uint32_t)(ch * KC + k) * (kWG * 2u) + 2u);
+        }
+    };
+    auto finish_rows = [&]() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const uint32_t up = __shfl_down(rs0[k], 1, 64);
+            if ((tid & 63) != 63) rs1[k] = up;
+        }
+    };
+    load_rows(0);
     // neighbour words n1 | n2<<16 of my vertices: a ring of RING axes, fetched RING-1 passes ahead of
     // their use (a blur pass is shorter than one memory round trip)
     uint32_t nbw[DEEP ? RING : 1][KC];
@@ -177,10 +162,65 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
             nbw[j % RING][k] = ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
     };
     if constexpr (DEEP) load_axis(0);
+    finish_rows();
+
+    // the lattice's size, flags and extras count are consumed only here, behind the burst: a scalar round trip in front of
+    // the first vector load would add its latency to every workgroup's start
+#if !(DSRG_EXP & 8)
+    const int M = L.M[li];
+    const int lat_flags = L.flags[li];
+    const int X = L.nextra[li];              // entries beyond the first of their row
+#endif
+    // slots k with k * kWG >= Mlim hold no vertex of this lattice: skipped when the guard is on
+    const int Mlim = (opts & kOptSlotGuard) ? M : (VPT * kWG);
+    // the extras (entry-parallel: x_k = tid + k*1024 < X), through descriptors that end at X: slots beyond read 0 for free
+    const rsrc_t r_xp = make_rsrc(L.x_pix + (size_t)li * D1 * N, sizeof(uint16_t) * (size_t)X);
+    const rsrc_t r_xw = make_rsrc(L.x_w + (size_t)li * D1 * N, sizeof(float) * (size_t)X);
+    uint32_t xpx[KC];
+    float xw[KC];
+    auto load_extras = [&](int ch) {
 #pragma unroll
-    for (int k = 0; k < KC; k++) {
-        const uint32_t up = __shfl_down(rs0[k], 1, 64);
-        if ((tid & 63) != 63) rs1[k] = up;
+        for (int k = 0; k < KC; k++) {
+            if ((ch * KC + k) * kWG >= X) { xpx[k] = 0u; xw[k] = 0.0f; continue; }   // (workgroup-uniform)
+            xpx[k] = ld_u16(r_xp, (uint32_t)tid * 2u, (uint32_t)(ch * KC + k) * (kWG * 2u));
+            xw[k] = ld_f32(r_xw, (uint32_t)tid * 4u, (uint32_t)(ch * KC + k) * (kWG * 4u));
+        }
+    };
+
+    if (lat_flags & 1) {
+        // Diagonal lattice: every simplex corner is private to its pixel and has no blur neighbour, so splat, blur and
+        // slice collapse to per-pixel arithmetic — evaluated here in the general path's operation
+        // order (products, 0 + p, val + 0.5*(0+0), ordered slice sum), hence bit-identical to it.
+        const float alpha = 1.0f / (1.0f + exp2f(-(float)D));
+        float bws[PPT][D1];
+#pragma unroll
+        for (int p = 0; p < PPT; p++)
+#pragma unroll
+            for (int r = 0; r < D1; r++)
+                bws[p][r] = ld_f32(r_bary, (uint32_t)tid * 4u, ((uint32_t)p * kWG + (uint32_t)r * (uint32_t)N) * 4u);
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            const int i = tid + p * kWG;
+            if (i < N) {
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                    if (c < nc) {
+                        const float x = qv[p][c] * nrm[p];
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < D1; r++) {
+                            float v = 0.0f + bws[p][r] * x;      // splat into an empty vertex
+                            v = v + 0.5f * (0.0f + 0.0f);        // d+1 blur passes without neighbours
+                            acc = acc + (bws[p][r] * alpha) * v; // slice
+                        }
+                        out[(size_t)c * N + i] = acc * nrm[p];
+                    }
+                }
+            }
+        }
+        DSRG_STAMP(11);
+        if (dbg && tid == 0) dbg[12] = (unsigned long long)M;
+        return;
     }
 
     // in = Q * norm   (pairwise.cpp:66)
@@ -194,106 +234,130 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
             inq[i] = x;
         }
     }
+    load_extras(0);                          // behind the input planes: nothing the first barrier waits for queues behind them
     __syncthreads();
     DSRG_STAMP(1);
 
-    // ---- splat (permutohedral.cpp:545-553), two steps that keep the reference's accumulation order
-    // without a dependent global load: (1) entry-parallel products w_e * in[pixel_e] into LDS (the
-    // entries are sorted by vertex, then by the reference's visiting order); (2) vertex-parallel
-    // ordered sums over each vertex's contiguous row of products.  `prod` aliases `val`: the sums
-    // wait in registers until every row has been read.
+    // ---- splat (permutohedral.cpp:545-553) in the reference's accumulation order without a dependent global load and
+    // without float atomics.  Vertex v's value is the ordered sum of its row of (pixel, weight) entries (sorted by the
+    // reference's visiting order at build time).  Most rows hold ONE entry: that first term is formed vertex-parallel,
+    // straight from the input planes (0 + w * in[pixel]); only the further entries ("extras", X of them) go through an
+    // entry-parallel products pass into LDS and are then added row by row, in order.  `prod` aliases the first value buffer.
     vec_t *prod = val;
     vec_t sacc[VPT];
-    const bool single = DEEP && (lat_flags & 4);
-    if (single) {
-        // every vertex has exactly one contributor (M == E; e.g. the Gaussian lattice at training scale): entry e is vertex
-        // e's only term, so the splat is values[v] = 0 + w_v * in[pixel_v] — no products pass, no row sums
+    // LDS gathers go out in batches of slots with ONE workgroup-uniform guard per batch (a guard per slot serialises the
+    // gathers: +0.96 us per workgroup).  Batches of 5, 4 and 1 slots: a 41x41 lattice has 10 slots of 1024 vertices and
+    // typically 7 800 - 8 900 of them, so the last slot is empty and the one before partly
+    constexpr int GS = 5, kG1 = KC < 5 ? KC : 5, kG2 = KC < 9 ? KC : 9;
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
-            const vec_t x = inq[min((int)epx[k], N - 1)];
+    for (int ch = 0; ch < NCH; ch++) {
+        if (ch > 0) load_extras(ch);
 #pragma unroll
-            for (int c = 0; c < CPW; c++) pv_set(sacc[k], c, 0.0f + ew[k] * pv_get(x, c));
+        for (int k0 = 0; k0 < KC; k0 += GS) {
+            if ((ch * KC + k0) * kWG < X) {
+                vec_t xin[GS];
+#pragma unroll
+                for (int g = 0; g < GS; g++)
+                    if (k0 + g < KC) xin[g] = inq[min((int)xpx[k0 + g], N - 1)];           // gathers in flight together
+#pragma unroll
+                for (int g = 0; g < GS; g++) {
+                    if (k0 + g < KC) {
+                        const int x = tid + (ch * KC + k0 + g) * kWG;
+                        vec_t p;
+#pragma unroll
+                        for (int c = 0; c < CPW; c++) pv_set(p, c, xw[k0 + g] * pv_get(xin[g], c));
+                        if (x < X) prod[x] = p;
+                    }
+                }
+            }
         }
-        if constexpr (DEEP) { if (1 < D1) load_axis(1); }
-        if constexpr (DEEP) { if (2 < D1) load_axis(2); }
-        DSRG_STAMP(2);
-        DSRG_STAMP(3);
-    } else {
+    }
+    // first terms (they read the input planes, like the products above: same phase)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        if (ch > 0) { load_rows(ch); finish_rows(); }
+        auto first_group = [&](auto k0c, auto k1c) {
+            constexpr int k0 = decltype(k0c)::value, G = decltype(k1c)::value - k0;
+            if constexpr (G > 0) {
+                if (ch * KC + k0 < VPT && (ch * KC + k0) * kWG < Mlim) {
+                    vec_t xin[G];
+#pragma unroll
+                    for (int g = 0; g < G; g++) xin[g] = inq[min((int)fpx[k0 + g], N - 1)];
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        if (ch * KC + k0 + g < VPT) {
+#pragma unroll
+                            for (int c = 0; c < CPW; c++)
+                                pv_set(sacc[ch * KC + k0 + g], c, 0.0f + fw[k0 + g] * pv_get(xin[g], c));
+                        }
+                    }
+                }
+            }
+        };
+        first_group(IC<0>{}, IC<kG1>{});
+        first_group(IC<kG1>{}, IC<kG2>{});
+        first_group(IC<kG2>{}, IC<KC>{});
+    }
+    if constexpr (DEEP) { if (1 < D1) load_axis(1); }
+    DSRG_STAMP(2);
+    if (X > 0) {                                         // (workgroup-uniform) some row has more than one entry
+        __syncthreads();                                 // the products are in place
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {
-            if (ch > 0) {
+            if (NCH > 1) { load_rows(ch); finish_rows(); }
+            // extras of row v: [rs0 - v, rs1 - v - 1) — every row before a non-empty row is non-empty
+            uint32_t t0[KC], t1[KC];
 #pragma unroll
-                for (int k = 0; k < KC; k++) {
-                    epx[k] = ld_u16(r_cp, (uint32_t)tid * 2u, (uint32_t)(ch * KC + k) * (kWG * 2u));
-                    ew[k] = ld_f32(r_cw, (uint32_t)tid * 4u, (uint32_t)(ch * KC + k) * (kWG * 4u));
-                }
+            for (int k = 0; k < KC; k++) {
+                const int v = tid + (ch * KC + k) * kWG;
+                t0[k] = rs0[k] - (uint32_t)v;
+                t1[k] = (v < M && rs1[k] > rs0[k]) ? rs1[k] - (uint32_t)v - 1u : t0[k];
             }
 #pragma unroll
             for (int k = 0; k < KC; k++) {
-                const int e = tid + (ch * KC + k) * kWG;
-                if (e < E) {
-                    const vec_t x = inq[min((int)epx[k], N - 1)];
-                    vec_t p;
+                if (ch * KC + k < VPT && (ch * KC + k) * kWG < Mlim) {
+                    float s[CPW];
 #pragma unroll
-                    for (int c = 0; c < CPW; c++) pv_set(p, c, ew[k] * pv_get(x, c));
-                    prod[e] = p;
+                    for (int c = 0; c < CPW; c++) s[c] = pv_get(sacc[ch * KC + k], c);
+                    for (uint32_t t = t0[k]; t < t1[k]; t++) {
+                        const vec_t p = prod[t];
+#pragma unroll
+                        for (int c = 0; c < CPW; c++) s[c] = s[c] + pv_get(p, c);
+                    }
+#pragma unroll
+                    for (int c = 0; c < CPW; c++) pv_set(sacc[ch * KC + k], c, s[c]);
                 }
             }
         }
-        if constexpr (DEEP) { if (1 < D1) load_axis(1); }   // the entry registers are free now
-        __syncthreads();
-        DSRG_STAMP(2);
-        {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ch++) {
-                if (ch > 0) {
-#pragma unroll
-                    for (int k = 0; k < KC; k++) {
-                        const uint32_t so = (uint32_t)(ch * KC + k) * (kWG * 2u);
-                        rs0[k] = ld_u16(r_rs, (uint32_t)tid * 2u, so);
-                        rs1[k] = ld_u16(r_rs, (uint32_t)tid * 2u, so + 2u);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < KC; k++) {
-                    if (ch * KC + k < VPT) {
-                        const int v = tid + (ch * KC + k) * kWG;
-                        float s[CPW];
-#pragma unroll
-                        for (int c = 0; c < CPW; c++) s[c] = 0.0f;
-                        const uint32_t t1 = (v < M) ? rs1[k] : rs0[k];
-                        for (uint32_t t = rs0[k]; t < t1; t++) {
-                            const vec_t p = prod[t];
-#pragma unroll
-                            for (int c = 0; c < CPW; c++) s[c] = s[c] + pv_get(p, c);
-                        }
-#pragma unroll
-                        for (int c = 0; c < CPW; c++) pv_set(sacc[ch * KC + k], c, s[c]);
-                    }
-                }
-            }
-        }
-        DSRG_STAMP(3);
-        if constexpr (DEEP) { if (2 < D1) load_axis(2); }
     }
-    __syncthreads();                                     // every row of products (or every input value) has been consumed
-    // two value buffers when the region holds them (the input planes are dead by now): an axis then gathers from one and
-    // writes the other — one barrier per axis instead of two
+    DSRG_STAMP(3);
+    if constexpr (DEEP) { if (2 < D1) load_axis(2); }
+    // Two value buffers when the region holds them (the input planes are dead after this phase): an axis then gathers from
+    // one and writes the other — one barrier per axis instead of two.  The first values go to the SECOND buffer when the
+    // products fit inside the first: nobody reads that memory in this phase, so no barrier is needed in front of the writes.
     const int vstride = (M + 2) & ~1;
     const bool pingpong = 2 * vstride <= lds_elems;
-    vec_t *cur = val, *nxt = pingpong ? val + vstride : val;
+    const bool direct = pingpong && X <= vstride && 2 * vstride + N <= lds_elems;   // (the input planes end the region)
+    vec_t *cur = direct ? val + vstride : val, *nxt = pingpong ? (direct ? val : val + vstride) : val;
+    if (!direct) __syncthreads();                        // every row of products (and every input value) has been consumed
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const int v = tid + k * kWG;
-        if (v < M) cur[v] = sacc[k];
+        if (k * kWG < Mlim && v < M) cur[v] = sacc[k];
     }
-    {                                                   // zero sentinel = "no neighbour" (permutohedral.cpp:561-562): slot M;
-        vec_t z;                                        // slot 0's reader is every out-of-range neighbour word, whose
-#pragma unroll                                          // vertex (v >= M) is never written back
+    {                                                   // zero sentinel = "no neighbour" (permutohedral.cpp:561-562): slot M
+        vec_t z;
+#pragma unroll
         for (int c = 0; c < CPW; c++) pv_set(z, c, 0.0f);
-        if (tid == 0) { cur[M] = z; nxt[M] = z; }
+        if (tid == 0) { cur[M] = z; if (!direct) nxt[M] = z; }
     }
     __syncthreads();
+    if (direct && tid == 0) {                           // the first buffer's sentinel: the products there are dead now
+        vec_t z;
+#pragma unroll
+        for (int c = 0; c < CPW; c++) pv_set(z, c, 0.0f);
+        nxt[M] = z;
+    }
     DSRG_STAMP(4);
 
     // ---- blur along the d+1 lattice axes (permutohedral.cpp:556-569): Jacobi per axis — new values
@@ -313,23 +377,34 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
                 for (int k = 0; k < KC; k++)
                     nbw[0][k] = ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)(ch * KC + k) * (kWG * 4u));
             }
+            auto blur_group = [&](auto k0c, auto k1c) {
+                constexpr int k0 = decltype(k0c)::value, G = decltype(k1c)::value - k0;
+                if constexpr (G > 0) {
+                    if (ch * KC + k0 < VPT && (ch * KC + k0) * kWG < Mlim) {
+                        vec_t x1[G], x2[G];
 #pragma unroll
-            for (int k = 0; k < KC; k++) {
-                if (ch * KC + k < VPT && (ch * KC + k) * kWG < Mlim) {
-                    // (the words of the unused tail v >= M point at the zero sentinel or read 0: no test needed, the
-                    // result of such a slot is never stored)
-                    const uint32_t word = nbw[DEEP ? j % RING : 0][k];
-                    const int n1 = (int)(word & 0xffffu), n2 = (int)(word >> 16);
-                    const vec_t x1 = cur[n1], x2 = cur[n2];
+                        for (int g = 0; g < G; g++) {
+                            const uint32_t word = nbw[DEEP ? j % RING : 0][k0 + g];
+                            x1[g] = cur[(int)(word & 0xffffu)];
+                            x2[g] = cur[(int)(word >> 16)];
+                        }
 #pragma unroll
-                    for (int c = 0; c < CPW; c++) {
-                        float s = pv_get(x1, c) + pv_get(x2, c);
-                        s = 0.5f * s;
-                        pv_set(sacc[ch * KC + k], c, pv_get(sacc[ch * KC + k], c) + s);
+                        for (int g = 0; g < G; g++) {
+                            if (ch * KC + k0 + g < VPT) {
+#pragma unroll
+                                for (int c = 0; c < CPW; c++) {
+                                    float s = pv_get(x1[g], c) + pv_get(x2[g], c);
+                                    s = 0.5f * s;
+                                    pv_set(sacc[ch * KC + k0 + g], c, pv_get(sacc[ch * KC + k0 + g], c) + s);
+                                }
+                            }
+                        }
                     }
-                    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the LDS gathers in flight
                 }
-            }
+            };
+            blur_group(IC<0>{}, IC<kG1>{});
+            blur_group(IC<kG1>{}, IC<kG2>{});
+            blur_group(IC<kG2>{}, IC<KC>{});
         }
         if constexpr (DEEP) { if (j + RING < D1) load_axis(j + RING); }     // this axis' ring slot is free
         // slice corners, one and two passes ahead of their use and after the last ring fetch: half of them per axis (all 24
@@ -501,9 +576,13 @@ __global__ __launch_bounds__(kUpdParts * kUpdPix) void mf_update_split_kernel(
     __shared__ float ev[CT][kUpdPix];                      // e, then q per (label, pixel)
     __shared__ float pm[kUpdParts][kUpdPix];               // partial column maxima
     const int px = threadIdx.x & (kUpdPix - 1), part = threadIdx.x >> 6;
-    const int idx = blockIdx.x * kUpdPix + px;
-    const bool live = idx < B * N;
-    const int b = live ? idx / N : 0, i = live ? idx - b * N : 0;
+    // XCD-affine block map (blockIdx % 8 = the XCD, as in the filter launch): the tiles of image b run on XCD b % 8, the one
+    // whose L2 holds the messages the filter workgroups of that image just wrote and from which they will read the marginals
+    const int ntile = (N + kUpdPix - 1) / kUpdPix;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b_map = xcd + 8 * (slot / ntile), i_map = (slot % ntile) * kUpdPix + px;
+    const bool live = b_map < B && i_map < N;
+    const int b = live ? b_map : 0, i = live ? i_map : 0;
     const size_t base = (size_t)b * C * N + i;
     constexpr int LPT = (CT + kUpdParts - 1) / kUpdParts;
     const bool local = USE_MSGS && loc.flags && (*loc.flags & kLatticeLocal);      // workgroup-uniform
@@ -630,7 +709,7 @@ static int dispatch_vpt(const FilterArgs &a, int nblocks, size_t lds, int vpt, h
 
 static int launch_update(const float *neg_unary, const MeanfieldBufs &buf, const UpdLocal &loc, float wg, float wb,
                          int use_msgs, float *q_out, double *refined, float *logq, int B, int C, int N, hipStream_t stream) {
-    const int blocks = (B * N + kUpdPix - 1) / kUpdPix;
+    const int blocks = 8 * ((N + kUpdPix - 1) / kUpdPix) * ((B + 7) / 8);
 #define DSRG_UPDS(CT_, UM_)                                                                                               \
     hipLaunchKernelGGL((mf_update_split_kernel<CT_, UM_>), dim3(blocks), dim3(kUpdParts * kUpdPix), 0, stream, neg_unary,     \
                        buf.msg_g, buf.q, buf.msg_b, wg, wb, q_out, refined, logq, B, C, N, loc)
@@ -653,7 +732,7 @@ static int plan_filter(const LatticeView &Lg, const LatticeView &Lb, const Meanf
     if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= nlabels <= %d required", kMaxLabels);
     const int N = Lb.N;
     const int vs_b = (Lb.Mcap + 1 + 3) & ~3, vs_g = (Lg.Mcap + 1 + 3) & ~3;
-    const size_t kLds = 150 * 1024;
+    const size_t kLds = 157 * 1024;          // of the CU's 160 KB; the kernel has no static LDS
     auto lds_for = [&](int cpw_b, int cpw_g) {
         const size_t lb = (size_t)cpw_b * ((size_t)vs_b + N) * sizeof(float);
         const size_t lg = (size_t)cpw_g * ((size_t)vs_g + N) * sizeof(float);

@@ -63,6 +63,13 @@ class Context(object):
         check(_lib.lib().dsrg_ctx_lattice_sizes(self._h, B, ctypes.byref(mg), mb, _stream()))
         return mg.value, [mb[i] for i in range(B)]
 
+    def lattice_extras(self, B):
+        """(X_gaussian, [X_bilateral per image]): splat entries beyond the first of their vertex (bench.py's LDS model)"""
+        xg = ctypes.c_int32(0)
+        xb = (ctypes.c_int32 * max(B, 1))()
+        check(_lib.lib().dsrg_ctx_lattice_extras(self._h, B, ctypes.byref(xg), xb, _stream()))
+        return xg.value, [xb[i] for i in range(B)]
+
     def lattice_dump(self, kind, b=0):
         """One lattice in the reference's own form (tests): kind 0 = Gaussian, 1 = bilateral lattice of image b.
         -> dict(M, keys (M,d) int16, vid (N,d+1) int32, bary (N,d+1) f32, n1 / n2 (d+1,M) int32 with -1 = none)."""

@@ -135,6 +135,10 @@ int dsrg_crf_meanfield_batch(dsrg_ctx_t ctx, int B, const float *neg_unary_dev,
 int dsrg_ctx_lattice_sizes(dsrg_ctx_t ctx, int B, int32_t *m_gauss_host, int32_t *m_bilateral_host,
                            void *stream);
 
+/* measurement: per lattice, the number of splat entries beyond the first entry of their vertex (the part of the splat that
+ * goes through LDS products; bench.py's LDS traffic model).  Host arrays as for dsrg_ctx_lattice_sizes; synchronises. */
+int dsrg_ctx_lattice_extras(dsrg_ctx_t ctx, int B, int32_t *x_gauss_host, int32_t *x_bilateral_host, void *stream);
+
 /* introspection for the parity tests: one lattice as the reference holds it.  kind 0 = the Gaussian lattice (b = 0),
  * kind 1 = the bilateral lattice of image b of the last refine / prepare / meanfield / supervision call.
  *   keys_host [M*d] int16   vertex keys in id order          (HashTable::getKeys, CRF/src/permutohedral.cpp:296-297)
