@@ -63,8 +63,7 @@ struct LatticeView {
     uint32_t *nb;          // [(d+1)*Mcap] blur neighbours along axis j: n1 | n2<<16; M (the zero sentinel slot) = none, and
                            //               so is every word of the unused tail v >= M
     uint16_t *row_start;   // [Mcap+2]   CSR of the splat: entries of vertex v (E < 65536 on this path)
-    uint16_t *csr_pix;     // [(d+1)*N]  source pixel of each entry, entry order = reference splat order
-    float *csr_w;          // [(d+1)*N]  weight of each entry
+    float *csr_w;          // [(d+1)*N]  weight of each entry, entry order = reference splat order (the norm pass reads it)
     // the filter kernel's form of the splat: the first contributor of every vertex, vertex-indexed, and all further
     // entries ("extras") as one compact list; the extras of row v are [row_start[v] - v, row_start[v+1] - v - 1)
     uint16_t *first_pix;   // [Mcap]     source pixel of vertex v's first entry (0 for a vertex without entries)

@@ -39,6 +39,16 @@ template <> struct CompactKey<5> {
     }
 };
 
+// the packed key (embed.h: 16-bit fields biased by 0x8000) back from its compact form — valid whenever make() was (12-bit range)
+__device__ __forceinline__ void unpack_compact(uint32_t (&w)[1], uint32_t c) { w[0] = c; }
+__device__ __forceinline__ void unpack_compact(uint32_t (&w)[3], unsigned long long c) {
+    const uint32_t f0 = (uint32_t)(c & 0xFFFu), f1 = (uint32_t)((c >> 12) & 0xFFFu), f2 = (uint32_t)((c >> 24) & 0xFFFu);
+    const uint32_t f3 = (uint32_t)((c >> 36) & 0xFFFu), f4 = (uint32_t)((c >> 48) & 0xFFFu);
+    w[0] = (f0 + 0x7800u) | ((f1 + 0x7800u) << 16);
+    w[1] = (f2 + 0x7800u) | ((f3 + 0x7800u) << 16);
+    w[2] = f4 + 0x7800u;
+}
+
 constexpr int kBuildVPT = 32;   // largest instantiation: Mcap <= 32*1024 (vertices / entries per thread)
 
 void *g_build_dbg = nullptr;     // tools only: 16 u64 phase timestamps per lattice (dsrg_debug_set_build_trace)
@@ -67,7 +77,6 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     float *bary = L.bary + (size_t)b * D1 * N;
     uint32_t *nb = L.nb + (size_t)b * D1 * Mcap;
     uint16_t *row_start = L.row_start + (size_t)b * (Mcap + 2);
-    uint16_t *csr_pix = L.csr_pix + (size_t)b * E;
     float *csr_w = L.csr_w + (size_t)b * E;
     float *norm = L.norm + (size_t)b * N;
     uint16_t *first_pix = L.first_pix + (size_t)b * Mcap, *x_pix = L.x_pix + (size_t)b * E;
@@ -90,9 +99,14 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
 #pragma unroll
             for (int q = 0; q < KW; q++) key_e[((size_t)i * D1 + r) * KW + q] = keys[r][q];
             if (i < N) bary[(size_t)r * N + i] = bc[r];
+            // the entry's key in compact form stays in LDS (the region becomes the per-VERTEX key array in phase 3): the
+            // probes of phase 2 then never leave the CU
+            if (lds_keys) ckeys[(size_t)i * D1 + r] = CompactKey<D>::make(keys[r]);
         }
     }
-    __syncthreads();
+    const int compact_ok = (D == 2) ? 1 : !__syncthreads_or(key12_bad);    // (also the phase barrier)
+    if (D == 2) __syncthreads();
+    const bool fast_keys = lds_keys && compact_ok;
     DSRG_STAMP(1);
 
     // ---- phase 2: deduplicate keys (open addressing, linear probing, table in LDS).  A slot ends up
@@ -102,6 +116,37 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     constexpr uint32_t kEmpty = 0xFFFFu;
     constexpr int EPT = VPT;                              // entries per thread (Epad <= Mcap)
     uint16_t hs[EPT];                                     // slot of my k-th entry
+    if (fast_keys) {
+        ckey_t mine_k[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; k++) mine_k[k] = ckeys[min(tid + k * kWG, Epad - 1)];      // all reads in flight together
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int e = tid + k * kWG;
+            hs[k] = 0;
+            if (e < Epad) {
+                uint32_t w[KW];
+                unpack_compact(w, mine_k[k]);
+                uint32_t h = hash_key<KW>(w) & mask;                 // the same hash the neighbour search computes
+                for (;;) {
+                    const uint32_t sh = (h & 1u) * 16u;
+                    const uint32_t cur = *reinterpret_cast<volatile uint32_t *>(&tabw[h >> 1]);
+                    const uint32_t half = (cur >> sh) & 0xFFFFu;
+                    const uint32_t mine = (cur & ~(0xFFFFu << sh)) | ((uint32_t)e << sh);
+                    if (half == kEmpty) {
+                        if (atomicCAS(&tabw[h >> 1], cur, mine) == cur) break;
+                        continue;                          // the word changed under us: look again
+                    }
+                    if (ckeys[half] == mine_k[k]) {
+                        if ((uint32_t)e < half && atomicCAS(&tabw[h >> 1], cur, mine) != cur) continue;
+                        break;
+                    }
+                    h = (h + 1) & mask;
+                }
+                hs[k] = (uint16_t)h;
+            }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
         const int e = tid + k * kWG;
@@ -128,9 +173,8 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
             hs[k] = (uint16_t)h;
         }
     }
-    const int compact_ok = (D == 2) ? 1 : !__syncthreads_or(key12_bad);    // (also the phase barrier)
-    if (D == 2) __syncthreads();
-    const bool fast_keys = lds_keys && compact_ok;
+    }
+    __syncthreads();
     DSRG_STAMP(2);
 
     // ---- phase 3: vertex ids in first-occurrence order — exactly the ids the reference's hash table
@@ -150,6 +194,12 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
                 atomicOr(&bm[e >> 5], 1u << (e & 31));
             }
         }
+        // the keys of my first-occurrence entries leave the entry-indexed array before it is overwritten vertex-indexed
+        ckey_t first_key[EPT];
+        if (fast_keys) {
+#pragma unroll
+            for (int k = 0; k < EPT; k++) first_key[k] = ckeys[min(tid + k * kWG, Epad - 1)];
+        }
         __syncthreads();
         // exclusive prefix of the per-word popcounts (nwords <= 1024 for Epad <= 32768)
         const int myc = tid < nwords ? __popc(bm[tid]) : 0;
@@ -162,10 +212,11 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
             if ((isfirst >> k) & 1u) {
                 const uint32_t id = wp[e >> 5] + (uint32_t)__popc(bm[e >> 5] & ((1u << (e & 31)) - 1u));
                 uint32_t w[KW];
-                load_key<KW>(w, key_e + (size_t)e * KW);
+                if (fast_keys) unpack_compact(w, first_key[k]);
+                else load_key<KW>(w, key_e + (size_t)e * KW);
 #pragma unroll
                 for (int t = 0; t < KW; t++) key_v[(size_t)id * KW + t] = w[t];
-                if (fast_keys) ckeys[id] = CompactKey<D>::make(w);
+                if (fast_keys) ckeys[id] = first_key[k];
                 tab[hs[k]] = (uint16_t)id;
             }
         }
@@ -348,7 +399,6 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         const int e = csr_e[pos];
         const int i = e / D1, r = e - i * D1;
         const float w = bary[(size_t)r * N + i];
-        csr_pix[pos] = (uint16_t)i;
         csr_w[pos] = w;
         if (wl_in_lds) wl[pos] = w;
         const int v = vid[(size_t)r * N + i];
@@ -357,16 +407,20 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
         else { x_pix[pos - v - 1] = (uint16_t)i; x_w[pos - v - 1] = w; }
     }
     {
-        int nonempty = 0;
+        // rows without entries (the phantom vertices) form the tail of the id range: the first of them gives the number of
+        // vertices with entries, hence the number of extras
+        int *first_empty = scan2;                              // (the scan scratch is free here)
+        if (tid == 0) *first_empty = M;
+        __syncthreads();
         for (int v = tid; v < M; v += kWG) {
             const int start = v == 0 ? 0 : (int)cnt[v - 1];
-            if ((int)cnt[v] == start) { first_pix[v] = 0; first_w[v] = 0.0f; }      // phantom vertex: contributes an exact 0
-            else nonempty++;
+            if ((int)cnt[v] == start) {                        // phantom vertex: contributes an exact 0
+                first_pix[v] = 0; first_w[v] = 0.0f;
+                atomicMin(first_empty, v);
+            }
         }
-        // workgroup sum of `nonempty`
-        int tot2;
-        (void)block_exclusive_scan(nonempty, scan2, &tot2);
-        if (tid == 0) L.nextra[b] = E - tot2;
+        __syncthreads();
+        if (tid == 0) L.nextra[b] = E - *first_empty;
     }
     __syncthreads();
     DSRG_STAMP(7);
@@ -704,7 +758,7 @@ static void lattice_layout(int d, int N, int nlat, size_t off[22], size_t &total
         sizeof(float) * (size_t)E * nlat,                    // bary
         sizeof(uint32_t) * (size_t)d1 * Mcap * nlat,         // nb
         sizeof(uint16_t) * (size_t)(Mcap + 2) * nlat,        // row_start
-        sizeof(uint16_t) * (size_t)E * nlat,                 // csr_pix
+        0,                                                   // (unused slot)
         sizeof(float) * (size_t)E * nlat,                    // csr_w
         sizeof(float) * (size_t)N * nlat,                    // norm
         sizeof(uint32_t) * (size_t)Epad * KW * nlat,         // key_e
@@ -742,7 +796,6 @@ void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
     L.bary = reinterpret_cast<float *>(p + off[2]);
     L.nb = reinterpret_cast<uint32_t *>(p + off[3]);
     L.row_start = reinterpret_cast<uint16_t *>(p + off[4]);
-    L.csr_pix = reinterpret_cast<uint16_t *>(p + off[5]);
     L.csr_w = reinterpret_cast<float *>(p + off[6]);
     L.norm = reinterpret_cast<float *>(p + off[7]);
     L.key_e = reinterpret_cast<uint32_t *>(p + off[8]);

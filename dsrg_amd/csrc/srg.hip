@@ -10,6 +10,7 @@
 // simultaneous flood fill from the cue pixels through equal-label 8-neighbours,
 // followed by the reference's exclusion rule — integer work, bit-exact.
 #include <math.h>
+#include <type_traits>
 #include "common.h"
 
 namespace dsrg {
@@ -38,6 +39,25 @@ __device__ __forceinline__ Mask128 m_fill(Mask128 m, Mask128 s) {
     return m_or(m_fill_up(m, s), m_rev(m_fill_up(m_rev(m), m_rev(s))));
 }
 __device__ __forceinline__ Mask128 m_dilate3(Mask128 a) { return m_or(a, m_or(m_shl1(a), m_shr1(a))); }
+// maps up to 64 pixels wide (the training sizes): one word per row
+struct Mask64 { unsigned long long lo; };
+__device__ __forceinline__ Mask64 m_or(Mask64 a, Mask64 b) { return {a.lo | b.lo}; }
+__device__ __forceinline__ Mask64 m_and(Mask64 a, Mask64 b) { return {a.lo & b.lo}; }
+__device__ __forceinline__ bool m_eq(Mask64 a, Mask64 b) { return a.lo == b.lo; }
+__device__ __forceinline__ Mask64 m_fill_up(Mask64 m, Mask64 s) { return {(((m.lo + s.lo) ^ m.lo) & m.lo) | s.lo}; }
+__device__ __forceinline__ Mask64 m_fill(Mask64 m, Mask64 s) {
+    const unsigned long long mr = __brevll(m.lo), sr = __brevll(s.lo);
+    return {m_fill_up(m, s).lo | __brevll((((mr + sr) ^ mr) & mr) | sr)};
+}
+__device__ __forceinline__ Mask64 m_dilate3(Mask64 a) { return {a.lo | (a.lo << 1) | (a.lo >> 1)}; }
+__device__ __forceinline__ Mask64 m_shfl(Mask64 a, int src_lane) { return {(unsigned long long)__shfl((long long)a.lo, src_lane, 64)}; }
+__device__ __forceinline__ Mask64 m_zero(Mask64) { return {0ull}; }
+__device__ __forceinline__ Mask128 m_zero(Mask128) { return {0ull, 0ull}; }
+__device__ __forceinline__ Mask64 m_from(Mask128 a, Mask64) { return {a.lo}; }
+__device__ __forceinline__ Mask128 m_from(Mask128 a, Mask128) { return a; }
+__device__ __forceinline__ Mask128 m_to128(Mask64 a) { return {a.lo, 0ull}; }
+__device__ __forceinline__ Mask128 m_to128(Mask128 a) { return a; }
+
 __device__ __forceinline__ Mask128 m_shfl(Mask128 a, int src_lane) {
     Mask128 r;
     r.lo = (unsigned long long)__shfl((long long)a.lo, src_lane, 64);
@@ -164,40 +184,41 @@ __global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W, c
         // absorbs its two neighbouring rows' members (dilated by one pixel, i.e. incl. diagonals),
         // restricted to its own label mask and closed along the row's runs; neighbours travel by
         // lane shuffles, state stays in registers, convergence is a wave vote — no barrier inside.
-        constexpr int RPL = 2;                                                    // rows per lane (H <= 128)
-        if (H <= 64 * RPL) {
+        // A component of height h needs ~h iterations, so an iteration is kept short: one 64-bit word per row and one row
+        // per lane when the map allows (41x41: a quarter of the 128x128 form's work per iteration)
+        auto grow = [&](auto mask_tag, auto rpl_tag) {
+            using M_t = decltype(mask_tag);
+            constexpr int RPL = decltype(rpl_tag)::value;
             for (int c = 1 + wave; c <= C; c += nwaves) {
                 if (!((present[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u)) continue;       // workgroup-uniform
-                Mask128 M[RPL], G[RPL];
+                M_t M[RPL], G[RPL];
 #pragma unroll
                 for (int k = 0; k < RPL; k++) {
                     const int y = lane + 64 * k;
-                    M[k] = (y < H) ? Mm[(size_t)c * H + y] : Mask128{0ull, 0ull};
-                    G[k] = (y < H) ? m_fill(M[k], Gm[(size_t)c * H + y]) : Mask128{0ull, 0ull};
+                    M[k] = (y < H) ? m_from(Mm[(size_t)c * H + y], M_t{}) : m_zero(M_t{});
+                    G[k] = (y < H) ? m_fill(M[k], m_from(Gm[(size_t)c * H + y], M_t{})) : m_zero(M_t{});
                 }
                 for (;;) {
                     bool changed = false;
-                    Mask128 up[RPL], dn[RPL];                                      // members of rows y-1 and y+1
+                    M_t up[RPL], dn[RPL];                                          // members of rows y-1 and y+1
 #pragma unroll
                     for (int k = 0; k < RPL; k++) {
-                        const Mask128 a = m_shfl(G[k], (lane + 63) & 63);         // from lane-1 (row y-1), wraps
-                        const Mask128 z = m_shfl(G[k], (lane + 1) & 63);          // from lane+1 (row y+1), wraps
-                        up[k] = a;
-                        dn[k] = z;
+                        up[k] = m_shfl(G[k], (lane + 63) & 63);                    // from lane-1 (row y-1), wraps
+                        dn[k] = m_shfl(G[k], (lane + 1) & 63);                     // from lane+1 (row y+1), wraps
                     }
                     // lane 0's row above is row 64k-1 = lane 63 of chunk k-1; lane 63's row below is lane 0 of chunk k+1
 #pragma unroll
                     for (int k = RPL - 1; k >= 0; k--) {
-                        if (lane == 0) up[k] = (k > 0) ? up[k - 1] : Mask128{0ull, 0ull};
+                        if (lane == 0) up[k] = (k > 0) ? up[k - 1] : m_zero(M_t{});
                     }
 #pragma unroll
                     for (int k = 0; k < RPL; k++) {
-                        if (lane == 63) dn[k] = (k + 1 < RPL) ? dn[k + 1] : Mask128{0ull, 0ull};
+                        if (lane == 63) dn[k] = (k + 1 < RPL) ? dn[k + 1] : m_zero(M_t{});
                     }
 #pragma unroll
                     for (int k = 0; k < RPL; k++) {
-                        const Mask128 add = m_and(m_dilate3(m_or(up[k], dn[k])), M[k]);
-                        const Mask128 g1 = m_fill(M[k], m_or(G[k], add));
+                        const M_t add = m_and(m_dilate3(m_or(up[k], dn[k])), M[k]);
+                        const M_t g1 = m_fill(M[k], m_or(G[k], add));
                         if (!m_eq(g1, G[k])) { G[k] = g1; changed = true; }
                     }
                     if (!__any(changed)) break;
@@ -205,10 +226,14 @@ __global__ __launch_bounds__(kSrgWG) void srg_grow_kernel(int C, int H, int W, c
 #pragma unroll
                 for (int k = 0; k < RPL; k++) {
                     const int y = lane + 64 * k;
-                    if (y < H) Gm[(size_t)c * H + y] = G[k];
+                    if (y < H) Gm[(size_t)c * H + y] = m_to128(G[k]);
                 }
             }
-        }
+        };
+        if (W <= 64 && H <= 64) grow(Mask64{}, std::integral_constant<int, 1>{});
+        else if (W <= 64) grow(Mask64{}, std::integral_constant<int, 2>{});
+        else if (H <= 64) grow(Mask128{}, std::integral_constant<int, 1>{});
+        else grow(Mask128{}, std::integral_constant<int, 2>{});
         __syncthreads();
         for (int p = tid; p < N; p += kSrgWG) {
             const int y = p / W, x = p - y * W;
