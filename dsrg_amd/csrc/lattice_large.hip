@@ -10,6 +10,7 @@
 // Build-time sorting/scanning uses hipCUB (DeviceRadixSort / DeviceScan): plumbing, once per image.
 #include <math.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include "common.h"
 #include "embed.h"
 
@@ -23,8 +24,16 @@ struct LargeLattice {
     uint32_t *key_e, *table, *slot_e, *first, *scanned, *key_v, *vid, *nb1, *nb2;
     uint32_t *ent_vid, *ent_idx, *srt_vid, *srt_idx, *cnt, *row_start, *csr_pix;
     float *bary, *csr_w, *norm;
-    int *M;
+    int *M;                  // [0] vertex count, [1] number of splat segments T, [2] number of multi-segment vertices
+    // splat work units: a vertex's row of entries is cut into segments of at most kSplatSeg entries (rows are heavy-tailed at
+    // image resolution: median 13 entries, maximum ~400 — one lane group per ROW made the longest row the kernel's duration)
+    uint32_t *seg_start;     // [M+1] first segment of vertex v (exclusive scan of max(1, ceil(len / kSplatSeg)))   (aliases `first`)
+    uint32_t *seg_cnt;       // [M+1] scan input                                                                (aliases `scanned`)
+    uint32_t *seg_v;         // [T]   vertex of segment s                                                      (aliases `slot_e`)
+    uint32_t *multi_v;       // [..]  vertices with more than one segment, any order                           (aliases `ent_vid`)
+    int T_host, nmulti_host;
 };
+constexpr int kSplatSeg = 64;
 
 // ---------------------------------------------------------------------------------------------
 template <int D>
@@ -132,6 +141,25 @@ __global__ void lg_csr_kernel(LargeLattice L, int D1) {
     L.csr_w[pos] = L.bary[(size_t)r * L.N + i];
 }
 
+// ---- splat segments: per vertex max(1, ceil(len / kSplatSeg)) units
+__global__ void lg_seg_count_kernel(LargeLattice L) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = *L.M;
+    if (v > L.Mcap) return;
+    if (v >= M) { L.seg_cnt[v] = 0u; return; }
+    const uint32_t len = L.row_start[v + 1] - L.row_start[v];
+    L.seg_cnt[v] = len <= (uint32_t)kSplatSeg ? 1u : (len + kSplatSeg - 1) / kSplatSeg;
+}
+__global__ void lg_seg_fill_kernel(LargeLattice L) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = *L.M;
+    if (v == 0) { L.M[1] = (int)L.seg_start[M]; }
+    if (v >= M) return;
+    const uint32_t s0 = L.seg_start[v], s1 = L.seg_start[v + 1];
+    for (uint32_t q = s0; q < s1; q++) L.seg_v[q] = (uint32_t)v;
+    if (s1 - s0 > 1u) L.multi_v[atomicAdd(reinterpret_cast<unsigned int *>(&L.M[2]), 1u)] = (uint32_t)v;
+}
+
 // ---- one-channel filter with Permutohedral::seqCompute semantics (permutohedral.cpp:476-527) for the
 // normalisation vector (pairwise.cpp:44,54-57)
 __global__ void lg_splat1_kernel(LargeLattice L, float *__restrict__ val) {
@@ -139,8 +167,19 @@ __global__ void lg_splat1_kernel(LargeLattice L, float *__restrict__ val) {
     const int M = *L.M;
     if (v == 0) val[M] = 0.0f;
     if (v >= M) return;
+    // rows are heavy-tailed (up to hundreds of entries): the loads do not depend on the sum, so eight are in flight per step
+    // while the additions keep the reference's order
     float s = 0.0f;
-    for (uint32_t pos = L.row_start[v]; pos < L.row_start[v + 1]; pos++) s = s + L.csr_w[pos] * 1.0f;
+    const uint32_t p1 = L.row_start[v + 1];
+    uint32_t pos = L.row_start[v];
+    for (; pos + 8 <= p1; pos += 8) {
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) w[u] = L.csr_w[pos + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s = s + w[u] * 1.0f;
+    }
+    for (; pos < p1; pos++) s = s + L.csr_w[pos] * 1.0f;
     val[v] = s;
 }
 __global__ void lg_blur1_kernel(LargeLattice L, int j, const float *__restrict__ a, float *__restrict__ b) {
@@ -168,7 +207,9 @@ __global__ void lg_norm_kernel(LargeLattice L, int D1, const float *__restrict__
 // one wave per vertex, lanes = channels: ordered accumulation of the vertex's row of (pixel, weight) entries
 __global__ __launch_bounds__(256) void lg_update_kernel(int N, int C, int CP, const float *__restrict__ neg_unary,
                                                         const float *__restrict__ t_g, const float *__restrict__ t_b,
-                                                        int use_msgs, float *__restrict__ q) {
+                                                        int use_msgs, float *__restrict__ q, const float *__restrict__ norm_b,
+                                                        const float *__restrict__ norm_g, float *__restrict__ qn_b,
+                                                        float *__restrict__ qn_g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *row = reinterpret_cast<float *>(smem);            // [256][CP+1]
     const int P = CP + 1;
@@ -192,63 +233,132 @@ __global__ __launch_bounds__(256) void lg_update_kernel(int N, int C, int CP, co
         for (int c = C; c < CP; c++) r[c] = 0.0f;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < nelem; k += 256) q[i0 * CP + k] = row[(k / CP) * P + (k % CP)];
+    for (int k = threadIdx.x; k < nelem; k += 256) {
+        const float v = row[(k / CP) * P + (k % CP)];
+        q[i0 * CP + k] = v;
+        // the splat's input, in = Q * norm (pairwise.cpp:66), formed once per pixel here instead of once per gather there
+        qn_b[i0 * CP + k] = v * norm_b[i0 + k / CP];
+        qn_g[i0 * CP + k] = v * norm_g[i0 + k / CP];
+    }
 }
 // label-fastest [N][C] (host layout of DenseCRFWrapper) <-> padded rows [N][CP]
+// XCD-aware work map.  Consecutive workgroups go to the 8 XCDs round-robin and each XCD has its own 4 MB L2 (cold at every
+// kernel start), so work item w of `total` is handed to the workgroup whose XCD owns the contiguous eighth that contains it:
+// vertex ids are first-occurrence order = image order, so an eighth of the vertices (or pixels) is an image strip, and the
+// ~9 entries that gather a pixel's row (or the ~30 pixels that gather a vertex's row) meet in ONE L2 instead of eight.
+// Returns the first unit of block `b` (units per block `per_block`), or -1 when the block is padding.
+__device__ __forceinline__ long long xcd_strip_first(unsigned b, size_t total, unsigned per_block, size_t *strip_end) {
+    const unsigned x = b & 7u, s = b >> 3;
+    const size_t per_xcd = ((total + 7) / 8 + per_block - 1) / per_block * per_block;    // units per XCD, whole blocks
+    const size_t first = (size_t)x * per_xcd + (size_t)s * per_block;
+    const size_t end = min((size_t)(x + 1) * per_xcd, total);
+    *strip_end = end;
+    return first < end ? (long long)first : -1;
+}
+__host__ __device__ static inline unsigned xcd_strip_blocks(size_t total, unsigned per_block) {
+    const size_t per_xcd = ((total + 7) / 8 + per_block - 1) / per_block;               // blocks per XCD
+    return (unsigned)(8 * per_xcd);
+}
+
 // ---- both lattices in one launch (the mean-field loop is a chain of short dependent launches: 14 -> 8 per iteration) ----
 // Splat: ordered sum of weight * (in * norm) over the vertex's entry list (pairwise.cpp:66, permutohedral.cpp:529-545);
 // blur: x + 0.5 (n1 + n2) per axis, Jacobi (:547-565); slice: barycentric gather * alpha, * norm, * -w (:567-589,
 // pairwise.cpp:72-79); update: -unary - gaussian - bilateral, expAndNormalize (densecrf.cpp:98-131).
-__device__ __forceinline__ void lg_splat_row(const LargeLattice &L, int v, int lane, int CP, const float *__restrict__ in,
-                                             float *__restrict__ val) {
-    const uint32_t p0 = L.row_start[v], p1 = L.row_start[v + 1];
+// One segment of vertex v's row: the ordered sum of weight * in over entries [p0, p1), in = Q * norm — at most kSplatSeg of them.
+// A row is a chain of dependent gathers (entry -> pixel -> value): eight entries per round, the (pixel, weight) words of the
+// NEXT round fetched while this round's gathers are in flight (a round costs one memory round trip, not two); the tail rides
+// in the same 8-wide code with weight 0 (s + 0 * x = s exactly).
+__device__ __forceinline__ float lg_splat_segment(const LargeLattice &L, uint32_t p0, uint32_t p1, int lane, int CP,
+                                                  const float *__restrict__ in) {
     float s = 0.0f;
-    uint32_t pos = p0;
-    // a row is a chain of dependent gathers (entry -> pixel -> value): eight entries in flight per round trip (rows hold
-    // ~25 entries on average at image resolution, hundreds in flat regions)
-    for (; pos + 8 <= p1; pos += 8) {
-        uint32_t px[8];
-        float w[8], x[8], nv[8];
+    constexpr int U = 8;
+    uint32_t px[U];
+    float w[U];
+    auto load_idx = [&](uint32_t pos, uint32_t (&px_)[U], float (&w_)[U]) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) { px[u] = L.csr_pix[pos + u]; w[u] = L.csr_w[pos + u]; }
+        for (int u = 0; u < U; u++) {
+            const uint32_t q = min(pos + (uint32_t)u, p1 - 1u);          // clamped: always a valid entry of this segment
+            px_[u] = L.csr_pix[q];
+            const float wq = L.csr_w[q];
+            w_[u] = (pos + (uint32_t)u < p1) ? wq : 0.0f;
+        }
+    };
+    if (p1 > p0) load_idx(p0, px, w);
+    for (uint32_t pos = p0; pos < p1; pos += U) {
+        float x[U];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { x[u] = in[(size_t)px[u] * CP + lane]; nv[u] = L.norm[px[u]]; }
+        for (int u = 0; u < U; u++) x[u] = in[(size_t)px[u] * CP + lane];        // in = Q * norm, formed by the update kernel
+        uint32_t npx[U];
+        float nw[U];
+        const bool more = pos + U < p1;
+        if (more) load_idx(pos + U, npx, nw);
 #pragma unroll
-        for (int u = 0; u < 8; u++) s = s + w[u] * (x[u] * nv[u]);
+        for (int u = 0; u < U; u++) s = s + w[u] * x[u];
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; u++) { px[u] = npx[u]; w[u] = nw[u]; }
+        }
     }
-    for (; pos + 4 <= p1; pos += 4) {
-        uint32_t px[4];
-        float w[4], x[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { px[u] = L.csr_pix[pos + u]; w[u] = L.csr_w[pos + u]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) x[u] = in[(size_t)px[u] * CP + lane] * L.norm[px[u]];
-#pragma unroll
-        for (int u = 0; u < 4; u++) s = s + w[u] * x[u];
-    }
-    for (; pos < p1; pos++) {
-        const uint32_t px = L.csr_pix[pos];
-        s = s + L.csr_w[pos] * (in[(size_t)px * CP + lane] * L.norm[px]);
-    }
-    val[(size_t)v * CP + lane] = s;
+    return s;
+}
+// unit `u` of a lattice's splat: segment u < T, or the zero row (u == T).  A vertex with ONE segment (rows of up to kSplatSeg
+// entries: the reference's accumulation order, exactly) writes its value; longer rows write per-segment partial sums that
+// lg_combine_kernel adds up in segment order (deterministic; differs from the strictly sequential sum by reassociation only).
+__device__ __forceinline__ void lg_splat_unit(const LargeLattice &L, size_t u, int lane, int CP, const float *__restrict__ in,
+                                              float *__restrict__ val, float *__restrict__ part) {
+    const int M = L.M[0], T = L.M[1];
+    if (u == (size_t)T) { val[(size_t)M * CP + lane] = 0.0f; return; }
+    const uint32_t v = L.seg_v[u];
+    const uint32_t s0 = L.seg_start[v], K = L.seg_start[v + 1] - s0;
+    const uint32_t r0 = L.row_start[v], r1 = L.row_start[v + 1];
+    const uint32_t p0 = r0 + ((uint32_t)u - s0) * (uint32_t)kSplatSeg, p1 = min(p0 + (uint32_t)kSplatSeg, r1);
+    const float sum = lg_splat_segment(L, p0, p1, lane, CP, in);
+    if (K == 1u) val[(size_t)v * CP + lane] = sum; else part[u * CP + lane] = sum;
 }
 // One group of LPV lanes (the power of two >= CP, at most a wave) per vertex: with 21 labels padded to 24 a whole wave
 // per vertex would idle 40 of its 64 lanes.  No cross-lane traffic, so the groups of a wave are independent.
 // vertex groups [0, Mb] belong to the bilateral lattice (row Mb = its zero row), the following Mg+1 to the Gaussian one
 __global__ __launch_bounds__(256) void lg_splat2_kernel(LargeLattice Lb, LargeLattice Lg, int CP, int lpv_shift,
-                                                         const float *__restrict__ in, float *__restrict__ val_b,
-                                                         float *__restrict__ val_g) {
+                                                         const float *__restrict__ in_b, const float *__restrict__ in_g,
+                                                         float *__restrict__ val_b, float *__restrict__ val_g,
+                                                         float *__restrict__ part_b, float *__restrict__ part_g) {
     const int lane = threadIdx.x & ((1 << lpv_shift) - 1);
-    int v = blockIdx.x * (blockDim.x >> lpv_shift) + (threadIdx.x >> lpv_shift);
     if (lane >= CP) return;
-    const int Mb = *Lb.M, Mg = *Lg.M;
-    if (v <= Mb) {
-        if (v == Mb) val_b[(size_t)Mb * CP + lane] = 0.0f; else lg_splat_row(Lb, v, lane, CP, in, val_b);
-        return;
+    const int Tb = Lb.M[1], Tg = Lg.M[1];
+    const unsigned upb = blockDim.x >> lpv_shift;                 // units per workgroup
+    // per XCD: first its strip of the bilateral lattice's segments, then its strip of the Gaussian lattice's (the same image strip)
+    const unsigned nb_b = xcd_strip_blocks((size_t)Tb + 1, upb) / 8;
+    const unsigned x = blockIdx.x & 7u, sl = blockIdx.x >> 3;
+    size_t end;
+    if (sl < nb_b) {
+        const long long f = xcd_strip_first(x | (sl << 3), (size_t)Tb + 1, upb, &end);
+        const size_t u = (size_t)f + (threadIdx.x >> lpv_shift);
+        if (f < 0 || u >= end) return;
+        lg_splat_unit(Lb, u, lane, CP, in_b, val_b, part_b);
+    } else {
+        const long long f = xcd_strip_first(x | ((sl - nb_b) << 3), (size_t)Tg + 1, upb, &end);
+        const size_t u = (size_t)f + (threadIdx.x >> lpv_shift);
+        if (f < 0 || u >= end) return;
+        lg_splat_unit(Lg, u, lane, CP, in_g, val_g, part_g);
     }
-    v -= Mb + 1;
-    if (v > Mg) return;
-    if (v == Mg) val_g[(size_t)Mg * CP + lane] = 0.0f; else lg_splat_row(Lg, v, lane, CP, in, val_g);
+}
+// the vertices whose row was cut into several segments: value = ((p_0 + p_1) + p_2) + ...
+__global__ __launch_bounds__(256) void lg_combine_kernel(LargeLattice Lb, LargeLattice Lg, int CP, int lpv_shift,
+                                                          float *__restrict__ val_b, float *__restrict__ val_g,
+                                                          const float *__restrict__ part_b, const float *__restrict__ part_g) {
+    const int lane = threadIdx.x & ((1 << lpv_shift) - 1);
+    if (lane >= CP) return;
+    size_t i = (size_t)blockIdx.x * (blockDim.x >> lpv_shift) + (threadIdx.x >> lpv_shift);
+    const int nb = Lb.M[2], ng = Lg.M[2];
+    const LargeLattice *L = &Lb;
+    float *val = val_b;
+    const float *part = part_b;
+    if (i >= (size_t)nb) { i -= nb; if (i >= (size_t)ng) return; L = &Lg; val = val_g; part = part_g; }
+    const uint32_t v = L->multi_v[i];
+    const uint32_t s0 = L->seg_start[v], s1 = L->seg_start[v + 1];
+    float acc = part[(size_t)s0 * CP + lane];
+    for (uint32_t q = s0 + 1; q < s1; q++) acc = acc + part[(size_t)q * CP + lane];
+    val[(size_t)v * CP + lane] = acc;
 }
 __device__ __forceinline__ void lg_blur_elem(const LargeLattice &L, int M, size_t v, int q, int CP4, int j,
                                              const float4 *__restrict__ a, float4 *__restrict__ b) {
@@ -287,16 +397,24 @@ __device__ __forceinline__ float4 lg_slice_elem(const LargeLattice &L, int D1, s
     o.x = neg_w * (acc.x * nv); o.y = neg_w * (acc.y * nv); o.z = neg_w * (acc.z * nv); o.w = neg_w * (acc.w * nv);
     return o;
 }
-// slice both lattices, subtract the messages from -unary (Gaussian first) and renormalise: 256 pixels per workgroup
+// slice both lattices, subtract the messages from -unary (Gaussian first) and renormalise.  kSlicePix pixels per 256-thread
+// workgroup (403 workgroups of 256 pixels left the chip at 6 waves per CU: latency-bound gathers); the fp64-rounded exps run
+// over all threads (pixel x label), the column maximum and the label-order sum per pixel.
+constexpr int kSlicePix = 64;
 __global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, LargeLattice Lg, int C, int CP,
                                                               const float4 *__restrict__ val_b, const float4 *__restrict__ val_g,
                                                               float neg_wb, float neg_wg, const float *__restrict__ neg_unary,
-                                                              float *__restrict__ q_out) {
+                                                              float *__restrict__ q_out, float *__restrict__ qn_b,
+                                                              float *__restrict__ qn_g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *row = reinterpret_cast<float *>(smem);            // [256][CP+1]
+    float *row = reinterpret_cast<float *>(smem);            // [kSlicePix][CP+1]
     const int P = CP + 1, CP4 = CP / 4, N = Lb.N;
-    const size_t i0 = (size_t)blockIdx.x * 256;
-    const int npix = (int)min((size_t)256, (size_t)N - i0);
+    float *mxs = row + kSlicePix * P;                        // [kSlicePix] column maxima
+    size_t strip_end;
+    const long long first = xcd_strip_first(blockIdx.x, (size_t)N, kSlicePix, &strip_end);     // pixel strips per XCD
+    if (first < 0) return;
+    const size_t i0 = (size_t)first;
+    const int npix = (int)min((size_t)kSlicePix, strip_end - i0);
     for (int k = threadIdx.x; k < npix * CP4; k += 256) {
         const int pl = k / CP4, q4 = k - pl * CP4;
         const size_t i = i0 + pl;
@@ -310,17 +428,33 @@ __global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, L
         { float v = nu.w; v = v - tg.w; v = v - tb.w; r[3] = v; }
     }
     __syncthreads();
-    if ((int)threadIdx.x < npix) {
-        float *r = row + threadIdx.x * P;
+    if ((int)threadIdx.x < npix) {                            // expAndNormalize (densecrf.cpp:98-106): column maximum
+        const float *r = row + threadIdx.x * P;
         float mx = -INFINITY;
         for (int c = 0; c < C; c++) mx = fmaxf(mx, r[c]);
+        mxs[threadIdx.x] = mx;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < npix * C; k += 256) {      // exp of every (pixel, label)
+        const int pl = k / C, c = k - pl * C;
+        float *r = row + pl * P;
+        r[c] = exp_cr(r[c] - mxs[pl]);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < npix) {                            // label-order sum, division
+        float *r = row + threadIdx.x * P;
         float sum = 0.0f;
-        for (int c = 0; c < C; c++) { const float e = exp_cr(r[c] - mx); r[c] = e; sum = sum + e; }
+        for (int c = 0; c < C; c++) sum = sum + r[c];
         for (int c = 0; c < C; c++) r[c] = r[c] / sum;
         for (int c = C; c < CP; c++) r[c] = 0.0f;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < npix * CP; k += 256) q_out[i0 * CP + k] = row[(k / CP) * P + (k % CP)];
+    for (int k = threadIdx.x; k < npix * CP; k += 256) {
+        const float v = row[(k / CP) * P + (k % CP)];
+        q_out[i0 * CP + k] = v;
+        qn_b[i0 * CP + k] = v * Lb.norm[i0 + k / CP];      // in = Q * norm (pairwise.cpp:66) for the next splat
+        qn_g[i0 * CP + k] = v * Lg.norm[i0 + k / CP];
+    }
 }
 
 __global__ void lg_pad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out, int negate) {
@@ -354,8 +488,11 @@ struct LargeCrf {
     void *arena;
     void *cub_tmp; size_t cub_bytes;
     float *neg_unary, *q;                  // [N][CP]
+    float *qn_b, *qn_g;                    // [N][CP] q * norm of the bilateral / Gaussian kernel: the splat inputs
     float *val_a, *val_b;                  // ping-pong [(Mb+1) + (Mg+1)][CP], grown on demand: bilateral rows first
     size_t val_rows;
+    float *part;                           // per-segment partial sums of the splat [T_b + T_g][CP], grown on demand
+    size_t part_rows;
     float *val1_a, *val1_b;                // one-channel buffers for the norm pass [Mcap+1]
     unsigned char *im;                     // [N][3]
     int32_t *lab;
@@ -395,8 +532,20 @@ static size_t large_lattice_carve(LargeLattice &L, unsigned char *p, int d, int 
     L.bary = (float *)take(sizeof(float) * (size_t)L.E);
     L.csr_w = (float *)take(sizeof(float) * (size_t)L.E);
     L.norm = (float *)take(sizeof(float) * (size_t)N);
-    L.M = (int *)take(sizeof(int));
+    L.M = (int *)take(sizeof(int) * 4);
+    L.seg_start = L.first; L.seg_cnt = L.scanned; L.seg_v = L.slot_e; L.multi_v = L.key_e;        // dead once lg_vid_kernel has run
+    L.T_host = L.nmulti_host = 0;
     return off;
+}
+
+// Stable sort of the (vertex id, entry index) pairs = the splat's per-vertex gather lists.  rocPRIM's default dispatch takes
+// its MERGE sort for up to 2^20 four-byte keys (device_radix_sort.hpp: `size <= merge_sort_limit && sizeof(key) > 2`) — 29
+// launches of 5.7 us per lattice at 321x321; the keys here have 14-16 significant bits, i.e. two Onesweep passes, so the
+// limit is set to 0 (hipCUB's wrapper cannot pass a config).
+static hipError_t lg_sort_pairs(void *tmp, size_t &bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                                int n, int begin_bit, int end_bit, hipStream_t s) {
+    using config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+    return rocprim::radix_sort_pairs<config>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, s);
 }
 
 int large_crf_create(int W, int H, int C, LargeCrf **out) {
@@ -410,12 +559,12 @@ int large_crf_create(int W, int H, int C, LargeCrf **out) {
     const size_t sg = large_lattice_carve(tmp, nullptr, 2, N), sb = large_lattice_carve(tmp, nullptr, 5, N);
     const int Emax = N * 6, Mcap5 = ((N + 3) / 4 * 4) * 6;
     size_t cb1 = 0, cb2 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cb1, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+    (void)lg_sort_pairs(nullptr, cb1, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                        (uint32_t *)nullptr, Emax, 0, 32, (hipStream_t)0);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cb2, (uint32_t *)nullptr, (uint32_t *)nullptr, Mcap5 + 1, (hipStream_t)0);
     c->cub_bytes = cb1 > cb2 ? cb1 : cb2;
     const size_t rows = sizeof(float) * (size_t)N * c->CP;
-    const size_t total = sg + sb + al(c->cub_bytes) + 2 * al(rows) + 2 * al(sizeof(float) * (size_t)(Mcap5 + 1)) +
+    const size_t total = sg + sb + al(c->cub_bytes) + 4 * al(rows) + 2 * al(sizeof(float) * (size_t)(Mcap5 + 1)) +
                          al((size_t)N * 3) + al(sizeof(int32_t) * (size_t)N) + al(sizeof(float) * (size_t)N * C);
     hipError_t e = hipMalloc(&c->arena, total);
     if (e != hipSuccess) { delete c; return set_error(DSRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); }
@@ -425,6 +574,8 @@ int large_crf_create(int W, int H, int C, LargeCrf **out) {
     c->cub_tmp = p; p += al(c->cub_bytes);
     c->neg_unary = (float *)p; p += al(rows);
     c->q = (float *)p; p += al(rows);
+    c->qn_b = (float *)p; p += al(rows);
+    c->qn_g = (float *)p; p += al(rows);
     c->val1_a = (float *)p; p += al(sizeof(float) * (size_t)(Mcap5 + 1));
     c->val1_b = (float *)p; p += al(sizeof(float) * (size_t)(Mcap5 + 1));
     c->im = p; p += al((size_t)N * 3);
@@ -441,6 +592,7 @@ void large_crf_destroy(LargeCrf *c) {
     if (c->arena) (void)hipFree(c->arena);
     if (c->val_a) (void)hipFree(c->val_a);
     if (c->val_b) (void)hipFree(c->val_b);
+    if (c->part) (void)hipFree(c->part);
     delete c;
 }
 
@@ -458,17 +610,27 @@ static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipSt
     hipLaunchKernelGGL(lg_assign_kernel<D>, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
     hipLaunchKernelGGL(lg_vid_kernel, dim3(blocks_for(L.E, T)), dim3(T), 0, s, L, D1);
     DSRG_LAUNCH_CHECK();
-    DSRG_HIP_CHECK(hipMemcpyAsync(&L.M_host, L.M, sizeof(int), hipMemcpyDeviceToHost, s));
-    DSRG_HIP_CHECK(hipStreamSynchronize(s));                      // M sizes the remaining launches
+    // CSR row starts and the splat segments, on worst-case grids (M is still on the device): the arrays they alias (first,
+    // scanned, slot_e, key_e) are dead from here on
+    bytes = c->cub_bytes;
+    DSRG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, bytes, L.cnt, L.row_start, L.Mcap + 1, s));
+    DSRG_HIP_CHECK(hipMemsetAsync(L.M + 1, 0, sizeof(int) * 2, s));
+    hipLaunchKernelGGL(lg_seg_count_kernel, dim3(blocks_for((size_t)L.Mcap + 1, T)), dim3(T), 0, s, L);
+    bytes = c->cub_bytes;
+    DSRG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, bytes, L.seg_cnt, L.seg_start, L.Mcap + 1, s));
+    hipLaunchKernelGGL(lg_seg_fill_kernel, dim3(blocks_for((size_t)L.Mcap + 1, T)), dim3(T), 0, s, L);
+    DSRG_LAUNCH_CHECK();
+    int mtn[3] = {0, 0, 0};
+    DSRG_HIP_CHECK(hipMemcpyAsync(mtn, L.M, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
+    DSRG_HIP_CHECK(hipStreamSynchronize(s));                      // M and the segment count size the remaining launches
+    L.M_host = mtn[0]; L.T_host = mtn[1]; L.nmulti_host = mtn[2];
     const int M = L.M_host;
     hipLaunchKernelGGL(lg_neigh_kernel<D>, dim3(blocks_for(M, T)), dim3(T), 0, s, L);
     int bits = 1;
     while ((1ll << bits) < (long long)M + 1) bits++;
     bytes = c->cub_bytes;
-    DSRG_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp, bytes, L.ent_vid, L.srt_vid, L.ent_idx, L.srt_idx,
+    DSRG_HIP_CHECK(lg_sort_pairs(c->cub_tmp, bytes, L.ent_vid, L.srt_vid, L.ent_idx, L.srt_idx,
                                                       L.E, 0, bits, s));
-    bytes = c->cub_bytes;
-    DSRG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, bytes, L.cnt, L.row_start, M + 1, s));
     hipLaunchKernelGGL(lg_csr_kernel, dim3(blocks_for(L.E, T)), dim3(T), 0, s, L, D1);
     // norm = 1/sqrt(K 1 + 1e-20)
     hipLaunchKernelGGL(lg_splat1_kernel, dim3(blocks_for(M, T)), dim3(T), 0, s, L, c->val1_a);
@@ -533,18 +695,32 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
         if (e != hipSuccess) return set_error(DSRG_ERR_NOMEM, "hipMalloc of lattice values failed: %s", hipGetErrorString(e));
         c->val_rows = need;
     }
+    const int Tb = c->Lb.T_host, Tg = c->Lg.T_host, nmulti = c->Lb.nmulti_host + c->Lg.nmulti_host;
+    const size_t need_part = (size_t)Tb + (size_t)Tg + 1;
+    if (need_part > c->part_rows) {
+        if (c->part) (void)hipFree(c->part);
+        c->part = nullptr; c->part_rows = 0;
+        hipError_t e = hipMalloc(&c->part, sizeof(float) * need_part * CP);
+        if (e != hipSuccess) return set_error(DSRG_ERR_NOMEM, "hipMalloc of splat partials failed: %s", hipGetErrorString(e));
+        c->part_rows = need_part;
+    }
     const int T = 256;
     const size_t upd_lds = sizeof(float) * 256 * (size_t)(CP + 1);
     hipLaunchKernelGGL(lg_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), upd_lds, s, c->N, c->C, CP, c->neg_unary,
-                       nullptr, nullptr, 0, c->q);
+                       nullptr, nullptr, 0, c->q, c->Lb.norm, c->Lg.norm, c->qn_b, c->qn_g);
     int lpv_shift = 3;
     while ((1 << lpv_shift) < CP && lpv_shift < 6) lpv_shift++;
     const size_t g_off = ((size_t)Mb + 1) * CP;                          // Gaussian rows follow the bilateral ones
     for (int it = 0; it < n_iters; it++) {
         const bool timed = c->prof.active && c->prof.used < c->prof.cap;      // the dominant kernel of this path (dsrg_crf_profile_*)
         if (timed) DSRG_HIP_CHECK(hipEventRecord(c->prof.start[c->prof.used], s));
-        hipLaunchKernelGGL(lg_splat2_kernel, dim3(blocks_for(need, 256 >> lpv_shift)), dim3(256), 0, s, c->Lb, c->Lg, CP,
-                           lpv_shift, c->q, c->val_a, c->val_a + g_off);
+        hipLaunchKernelGGL(lg_splat2_kernel,
+                           dim3(xcd_strip_blocks((size_t)Tb + 1, 256 >> lpv_shift) + xcd_strip_blocks((size_t)Tg + 1, 256 >> lpv_shift)),
+                           dim3(256), 0, s, c->Lb, c->Lg, CP, lpv_shift, c->qn_b, c->qn_g, c->val_a, c->val_a + g_off, c->part,
+                           c->part + (size_t)Tb * CP);
+        if (nmulti > 0)
+            hipLaunchKernelGGL(lg_combine_kernel, dim3(blocks_for((size_t)nmulti, 256 >> lpv_shift)), dim3(256), 0, s, c->Lb, c->Lg, CP,
+                               lpv_shift, c->val_a, c->val_a + g_off, c->part, c->part + (size_t)Tb * CP);
         if (timed) { DSRG_HIP_CHECK(hipEventRecord(c->prof.stop[c->prof.used], s)); c->prof.used++; }
         float *a = c->val_a, *b = c->val_b;
         for (int j = 0; j < 6; j++) {
@@ -554,9 +730,10 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
             float *t = a; a = b; b = t;
         }
         // after 6 swaps the bilateral result is back in val_a; the Gaussian one stopped after 3 swaps, in val_b
-        hipLaunchKernelGGL(lg_slice_update_kernel, dim3(blocks_for(c->N, T)), dim3(T), upd_lds, s, c->Lb, c->Lg, c->C, CP,
+        hipLaunchKernelGGL(lg_slice_update_kernel, dim3(xcd_strip_blocks((size_t)c->N, kSlicePix)), dim3(T),
+                           sizeof(float) * (kSlicePix * (size_t)(CP + 1) + kSlicePix), s, c->Lb, c->Lg, c->C, CP,
                            (const float4 *)c->val_a, (const float4 *)(c->val_b + g_off), -prm->w_bilateral,
-                           -prm->w_gaussian, c->neg_unary, c->q);
+                           -prm->w_gaussian, c->neg_unary, c->q, c->qn_b, c->qn_g);
     }
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
