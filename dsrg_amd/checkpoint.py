@@ -194,18 +194,37 @@ def load_layers(net, layers, rename=None, strict_shapes=True):
     return copied
 
 
+def _report_copied(net, path, copied, n_source):
+    """Caffe logs "Ignoring source layer ..." and starts from the filler values silently only for layers it names; a file that
+    fills NOTHING is almost certainly the wrong file (or names layers the other framework's way) — refuse it, and say which
+    target layers stayed at their initial values otherwise."""
+    import warnings
+    if not copied:
+        raise ValueError("%s: none of its %d layers matches a layer of %s by name — training would start from the random "
+                         "initialisation (for nets other than VGG16ASPP the layer names are the torch module paths)" % (
+                             path, n_source, type(net).__name__))
+    missing = sorted(set(caffe_layer_map(net)) - set(copied))
+    if missing:
+        warnings.warn("%s fills %d layers of %s; %d keep their initial values: %s" % (
+            path, len(copied), type(net).__name__, len(missing), ", ".join(missing[:12]) + (" ..." if len(missing) > 12 else "")))
+    return copied
+
+
 def load_weights(net, path, rename=None):
     """--weights: .caffemodel (by layer name), .npz ("<layer>/<blob index>"), or a torch file (state_dict or a snapshot
-    written by save_snapshot; loaded non-strictly by key, like Caffe by name).  -> names copied"""
+    written by save_snapshot; loaded non-strictly by key, like Caffe by name).  -> names copied.  A file that matches no
+    layer raises; layers left at their initial values are reported by a warning."""
     if path.endswith(".caffemodel"):
-        return load_layers(net, read_caffemodel(path), rename)
+        layers = read_caffemodel(path)
+        return _report_copied(net, path, load_layers(net, layers, rename), len(layers))
     if path.endswith(".npz"):
         z = np.load(path)
         layers = {}
         for key in z.files:
             name, idx = key.rsplit("/", 1)
             layers.setdefault(name, {})[int(idx)] = z[key]
-        return load_layers(net, {n: [d[i] for i in sorted(d)] for n, d in layers.items()}, rename)
+        return _report_copied(net, path, load_layers(net, {n: [d[i] for i in sorted(d)] for n, d in layers.items()}, rename),
+                              len(layers))
     sd = torch.load(path, map_location="cpu", weights_only=True)
     sd = sd.get("net", sd)
     own = net.state_dict()
@@ -213,6 +232,8 @@ def load_weights(net, path, rename=None):
     for k, v in use.items():
         if tuple(v.shape) != tuple(own[k].shape):
             raise ValueError("%s: source shape %s does not match %s" % (k, tuple(v.shape), tuple(own[k].shape)))
+    if not use:
+        raise ValueError("%s: none of its %d tensors matches a parameter of %s by name" % (path, len(sd), type(net).__name__))
     net.load_state_dict(use, strict=False)
     return sorted(use)
 
@@ -233,9 +254,10 @@ def _is_rank0():
 
 
 def save_snapshot(trainer, prefix):
-    """Caffe's Solver::Snapshot: `<prefix>_iter_<N>.caffemodel` (weights, readable by the reference's tools and by
-    load_weights) + `<prefix>_iter_<N>.solverstate.pt` (weights, momentum history, iteration).  Rank 0 writes.
-    -> (caffemodel path, solverstate path)"""
+    """Caffe's Solver::Snapshot: `<prefix>_iter_<N>.caffemodel` (weights; for VGG16ASPP with the reference's layer names and
+    blob order, i.e. readable by the reference's tools — other nets are written with their torch module paths as layer names
+    and are readable by load_weights only) + `<prefix>_iter_<N>.solverstate.pt` (weights, momentum history, iteration).
+    Rank 0 writes; every rank returns after the files exist (barrier).  -> (caffemodel path, solverstate path)"""
     it = trainer.opt.iter
     model_path, state_path = "%s_iter_%d.caffemodel" % (prefix, it), "%s_iter_%d.solverstate.pt" % (prefix, it)
     if _is_rank0():
@@ -247,6 +269,9 @@ def save_snapshot(trainer, prefix):
         torch.save({"net": {k: v.detach().cpu() for k, v in trainer.net.state_dict().items()},
                     "opt": trainer.opt.state_dict(), "iter": it}, tmp)
         os.replace(tmp, state_path)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()                                   # a rank that loads the snapshot right away must find it
     return model_path, state_path
 
 

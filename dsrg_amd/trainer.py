@@ -73,12 +73,14 @@ class CaffeSGD(object):
                 b.copy_(sb.to(b.device, b.dtype))
             g["buf_lr"] = sg["buf_lr"]
         self.iter = int(st["iter"])
-        self.base_lr = st.get("base_lr", self.base_lr)
+        # base_lr is NOT restored: Caffe's Solver::Restore takes the iteration and the history from the snapshot and the
+        # learning-rate policy from the solver prototxt, so a run resumed with another rate uses the new one (the history
+        # B = V / lr is rescaled at the next step through buf_lr)
 
 
 class DSRGTrainer(object):
     def __init__(self, device, world_size=1, seed=0, amp_dtype=torch.bfloat16, channels_last=True,
-                 loss_fn=None, net=None, ddp=None, weights=None, snapshot=None):
+                 loss_fn=None, net=None, ddp=None, weights=None, snapshot=None, bucket_cap_mb=32):
         """loss_fn(logits, images, labels, cues) -> (total, losses); defaults to the HIP supervision
         path.  (Tests inject a torch loss to exercise the data-parallel plumbing on CPU/gloo.)
         weights: `train.py --weights` (run.sh:5: ../../vgg16_20M_mc.caffemodel) — a .caffemodel / .npz / torch file
@@ -104,7 +106,7 @@ class DSRGTrainer(object):
         if (world_size > 1) if ddp is None else ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             # 151.5 MB of fp32 gradients per step; 32 MB buckets -> 5 all-reduces overlapped with backward
-            self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=32,
+            self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=bucket_cap_mb,
                              gradient_as_bucket_view=True)
         self.opt = CaffeSGD(net.caffe_param_groups())
         if snapshot is not None:
@@ -120,8 +122,20 @@ class DSRGTrainer(object):
         from .checkpoint import load_snapshot
         return load_snapshot(self, state_path)
 
+    def reduce_losses(self, losses):
+        """the logging all-reduce of SURVEY 8e: `losses` of step() are this rank's shard means; their mean over ranks is the
+        global-batch loss (both losses are means over images and the shards are equal).  One 8-byte all-reduce, outside the
+        gradient path; a single process returns its input."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return losses
+        out = losses.detach().clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        return out / dist.get_world_size()
+
     def step(self, images, labels, cues):
-        """images (B,3,321,321) f32 mean-subtracted, labels (B,1,1,21), cues (B,21,41,41) -> losses[2]"""
+        """images (B,3,321,321) f32 mean-subtracted, labels (B,1,1,21), cues (B,21,41,41) -> losses[2] (this rank's shard;
+        reduce_losses() gives the global-batch figure for logging)"""
         self.opt.zero_grad()
         x = images.contiguous(memory_format=torch.channels_last) if self.channels_last else images
         if self.overlap_build:

@@ -61,31 +61,64 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
+    # a bucket cap of ~1 KB splits TinyNet's 14 tensors over several buckets, as 32 MB does with the 37.9 M parameters of VGG16
     tr = DSRGTrainer(torch.device("cpu"), world_size=world, seed=0, amp_dtype=None, channels_last=False,
-                     loss_fn=torch_loss, net=TinyNet())
+                     loss_fn=torch_loss, net=TinyNet(), bucket_cap_mb=0.001)
+    # the overlap of the gradient all-reduce with backward, observed: a communication hook (the default all-reduce, plus a
+    # log line) fires per bucket as soon as the bucket's gradients exist; the first layer's weight gradient is the LAST thing
+    # backward computes, so bucket events in front of it are all-reduces issued while backward was still running
+    events = []
+
+    def hook(state, bucket):
+        events.append("bucket")
+        return dist.all_reduce(bucket.buffer().div_(world), async_op=True).get_future().then(lambda f: f.value()[0])
+    tr.model.register_comm_hook(None, hook)
+    tr.net.features[0].weight.register_hook(lambda g: events.append("first_layer_grad"))
     images, labels, cues = make_data(4)
     sh = slice(rank * 2, rank * 2 + 2)                       # rank r takes images [2r, 2r+2)
+    shard_losses, reduced = [], []
     for _ in range(3):
-        tr.step(images[sh], labels[sh], cues[sh])
-    torch.save([p.detach().clone() for p in tr.net.parameters()], os.path.join(out_dir, "w%d.pt" % rank))
+        events.append("step")
+        l = tr.step(images[sh], labels[sh], cues[sh])
+        shard_losses.append(l.clone())
+        reduced.append(tr.reduce_losses(l))                  # the 8-byte logging all-reduce
+    torch.save({"w": [p.detach().clone() for p in tr.net.parameters()], "events": events, "shard": shard_losses,
+                "reduced": reduced}, os.path.join(out_dir, "w%d.pt" % rank))
     dist.destroy_process_group()
 
 
 def test_two_rank_gloo_equals_single_process_global_batch(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    w0 = torch.load(os.path.join(str(tmp_path), "w0.pt"))
-    w1 = torch.load(os.path.join(str(tmp_path), "w1.pt"))
+    r0 = torch.load(os.path.join(str(tmp_path), "w0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "w1.pt"))
+    w0, w1 = r0["w"], r1["w"]
     for a, b in zip(w0, w1):
         assert torch.equal(a, b)                             # replicas stay in lock step
     torch.manual_seed(0)
     tr = DSRGTrainer(torch.device("cpu"), world_size=1, seed=0, amp_dtype=None, channels_last=False,
                      loss_fn=torch_loss, net=TinyNet())
     images, labels, cues = make_data(4)
-    for _ in range(3):
-        tr.step(images, labels, cues)
+    global_losses = [tr.step(images, labels, cues).clone() for _ in range(3)]
     for a, b in zip(w0, tr.net.parameters()):
         assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6)
+    # the logging all-reduce: the mean of the two shard losses = the global-batch loss of the single process, on both ranks
+    for it in range(3):
+        assert torch.allclose(r0["reduced"][it], r1["reduced"][it])
+        assert torch.allclose(r0["reduced"][it], (r0["shard"][it] + r1["shard"][it]) / 2)
+        assert torch.allclose(r0["reduced"][it], global_losses[it], rtol=1e-5, atol=1e-6)
+    assert tr.reduce_losses(global_losses[0]) is global_losses[0]            # a single process: no collective
+    # bucketed all-reduce overlapped with backward: from the second step on (DDP sizes its buckets from the order in which
+    # the gradients became ready in the first) there are several buckets per step, and all but the last are issued before
+    # backward has produced the first layer's gradient
+    for r in (r0, r1):
+        steps = " ".join(r["events"]).split("step")[1:]
+        assert len(steps) == 3
+        for st in steps[1:]:
+            ev = st.split()
+            assert ev.count("first_layer_grad") == 1 and ev.count("bucket") >= 2, ev
+            assert ev[:ev.index("first_layer_grad")].count("bucket") >= 1, ev
+            assert ev[-1] == "bucket", ev
 
 
 def test_caffe_sgd_matches_hand_computation():

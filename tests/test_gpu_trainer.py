@@ -151,17 +151,32 @@ dist.init_process_group("nccl", device_id=device)
 b = S.make_batch(51, 4)
 d = lambda a: torch.from_numpy(a).to(device)
 images, labels, cues = d(b["images"]), d(b["labels"]), d(b["cues"])
+events = []
 def run(ddp):
     tr = DSRGTrainer(device, world_size=dist.get_world_size(), seed=9, ddp=ddp)
-    out = [[float(v) for v in tr.step(images, labels, cues)] for _ in range(3)]
+    if ddp:
+        # the default all-reduce as a communication hook that also logs: one call per gradient bucket, issued by DDP while
+        # backward is still running; the first convolution's weight gradient is the last one backward produces
+        world = dist.get_world_size()
+        def hook(state, bucket):
+            events.append("bucket")
+            return dist.all_reduce(bucket.buffer().div_(world), async_op=True).get_future().then(lambda f: f.value()[0])
+        tr.model.register_comm_hook(None, hook)
+        next(tr.net.parameters()).register_hook(lambda g: events.append("first_layer_grad"))
+    out = []
+    for _ in range(3):
+        events.append("step")
+        l = tr.step(images, labels, cues)
+        out.append([float(v) for v in tr.reduce_losses(l)])
     torch.cuda.synchronize()
     return out, [p.detach().clone() for p in tr.net.parameters()]
 l_ddp, w_ddp = run(True)
+ddp_events = list(events)
 l_one, w_one = run(False)
 t = torch.ones(1, device=device); dist.all_reduce(t)
 same_w = all(torch.allclose(a, b, rtol=1e-6, atol=1e-9) for a, b in zip(w_ddp, w_one))
 print("DDPRESULT " + json.dumps({"ddp": l_ddp, "one": l_one, "same_weights": bool(same_w), "allreduce": float(t.item()),
-                                 "backend": dist.get_backend()}))
+                                 "backend": dist.get_backend(), "events": ddp_events}))
 dist.destroy_process_group()
 """
 
@@ -186,6 +201,14 @@ def test_config4_ddp_rccl_single_rank(tmp_path):
     assert np.allclose(res["ddp"], res["one"], rtol=1e-5, atol=1e-6), res
     assert res["same_weights"]
     assert np.isfinite(res["ddp"]).all()
+    # 151.5 MB of fp32 gradients in 32 MB buckets: from the second step on (DDP sizes the buckets from the first step's
+    # gradient order) at least five all-reduces per step, all but the last issued before backward has reached conv1_1
+    steps = " ".join(res["events"]).split("step")[1:]
+    assert len(steps) == 3
+    for st in steps[1:]:
+        ev = st.split()
+        assert ev.count("bucket") >= 5 and ev.count("first_layer_grad") == 1, ev
+        assert ev[:ev.index("first_layer_grad")].count("bucket") >= 3, ev
 
 
 def test_config5_retrain_step_resnet101_513():
