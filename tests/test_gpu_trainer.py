@@ -201,13 +201,14 @@ def test_config4_ddp_rccl_single_rank(tmp_path):
     assert np.allclose(res["ddp"], res["one"], rtol=1e-5, atol=1e-6), res
     assert res["same_weights"]
     assert np.isfinite(res["ddp"]).all()
-    # 151.5 MB of fp32 gradients in 32 MB buckets: from the second step on (DDP sizes the buckets from the first step's
-    # gradient order) at least five all-reduces per step, all but the last issued before backward has reached conv1_1
+    # 151.5 MB of fp32 gradients in 32 MB buckets (a bucket closes once it exceeds the cap): from the second step on (DDP
+    # sizes the buckets from the first step's gradient order) four or five all-reduces per step, all but the last issued
+    # before backward has reached conv1_1
     steps = " ".join(res["events"]).split("step")[1:]
     assert len(steps) == 3
     for st in steps[1:]:
         ev = st.split()
-        assert ev.count("bucket") >= 5 and ev.count("first_layer_grad") == 1, ev
+        assert ev.count("bucket") >= 4 and ev.count("first_layer_grad") == 1, ev
         assert ev[:ev.index("first_layer_grad")].count("bucket") >= 3, ev
 
 
