@@ -24,7 +24,8 @@
 // tools select it with DSRG_LIB (A/B on one box).  Measured and adopted in round 3: blur gathers batched per group of 5
 // slots (-0.96 us per workgroup), product gathers batched (-0.14); measured and dropped: a workgroup barrier behind the q
 // loads (+0.3), the first row term of every slot batched (0.0), term-major row sums (+1.5), neighbour-word descriptors that
-// end at M (0.0).  profiles/r03_filter_ab.txt
+// end at M (0.0), LDS-only barriers (0.0).  Adopted later: the extras' index words and the first axis' neighbour words
+// issued behind the first barrier (-0.6, -0.2).  profiles/r03_filter_ab.txt
 #ifndef DSRG_EXP
 #define DSRG_EXP 0
 #endif
@@ -161,7 +162,6 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
         for (int k = 0; k < KC; k++)
             nbw[j % RING][k] = ld_u32(r_nb, (uint32_t)tid * 4u, (uint32_t)k * (kWG * 4u));
     };
-    if constexpr (DEEP) load_axis(0);
     finish_rows();
 
     // the lattice's size, flags and extras count are consumed only here, behind the burst: a scalar round trip in front of
@@ -237,6 +237,9 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
     load_extras(0);                          // behind the input planes: nothing the first barrier waits for queues behind them
     __syncthreads();
     DSRG_STAMP(1);
+    // the first axis' neighbour words are not needed before the first blur pass: issued behind the input planes' barrier,
+    // they no longer queue in the L1 ahead of other waves' q loads (-0.44 us on the way to that barrier)
+    if constexpr (DEEP) load_axis(0);
 
     // ---- splat (permutohedral.cpp:545-553) in the reference's accumulation order without a dependent global load and
     // without float atomics.  Vertex v's value is the ordered sum of its row of (pixel, weight) entries (sorted by the
