@@ -190,9 +190,10 @@ def crf_fullres_record(device, steps, warmup, cpu=True, size=321):
         blur_ms, blur_n = crf.profile_stop()
         mg, mb = crf.lattice_size(0), crf.lattice_size(1)
         N = H * W
-        # SURVEY 8d, the splat stage of filter(d, M) for both lattices in one launch: the marginals in (4 C N, read once), the
-        # (vertex, weight) pair of every (pixel, corner) entry (8 (d+1) N per lattice), the lattice rows out (4 C M per lattice)
-        alg_per_launch = 4 * C * N + 8 * (6 + 3) * N + 4 * C * (mb + mg)
+        # SURVEY 8d, the splat stage of filter(d, M) for both lattices in one launch: the input planes in = Q * norm of each
+        # kernel (two arrays of 4 C N, each read once — the update kernel forms them, lattice_large.hip), the (pixel, weight)
+        # pair of every (pixel, corner) entry (8 (d+1) N per lattice), the lattice rows out (4 C M per lattice)
+        alg_per_launch = 2 * 4 * C * N + 8 * (6 + 3) * N + 4 * C * (mb + mg)
         out_sizes.append(dict(H=H, W=W, images_per_s=steps / dt, ms_per_image=dt / steps * 1e3, M_gauss=mg, M_bil=mb,
                               splat_us_per_launch_event_bracket=blur_ms / max(blur_n, 1) * 1e3, splat_launches=blur_n,
                               alg_bytes_per_splat_launch=alg_per_launch,
@@ -204,7 +205,8 @@ def crf_fullres_record(device, steps, warmup, cpu=True, size=321):
     tj = _load_json("r03_pmc_traffic_fullres.json") or _load_json("pmc_traffic_fullres.json") or {}
     traffic = tj.get("lg_splat2_kernel_bytes_per_launch")
     achieved = head["alg_bytes_per_splat_launch"] / per_launch_s / 1e9
-    roofline = {"kernel": "lg_splat2_kernel (permutohedral splat of both lattices: per-vertex ordered gather lists, values in HBM/L2)",
+    roofline = {"kernel": "lg_splat2_kernel + lg_combine_kernel (permutohedral splat of both lattices: per-vertex ordered gather lists cut "
+                          "into segments of 64 entries, values in HBM/L2)",
                 "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": head["alg_bytes_per_splat_launch"], "us_per_launch": per_launch_s * 1e6,
@@ -487,6 +489,7 @@ def main():
     ap.add_argument("--no-modes", action="store_true", help="--mode train: skip the sub-records of the other configurations")
     ap.add_argument("--no-graph", action="store_true", help="--mode infer: launch the backbone forward eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket filter launches with HIP events")
+    ap.add_argument("--sub", action="store_true", help="(internal) a sub-record of the default run: short CPU baseline, one core only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -526,9 +529,9 @@ def main():
             print(json.dumps(rec))
         return finish()
     if args.mode == "supervision":
-        rec = supervision_record(device, rank, args.batch, args.steps, args.warmup, cpu=cpu)
+        rec = supervision_record(device, rank, args.batch, args.steps, args.warmup, cpu=cpu, cpu_target_s=5.0 if args.sub else 10.0)
         if rank == 0:
-            if cpu:
+            if cpu and not args.sub:
                 try:
                     rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
                 except Exception as e:                   # never let the extra baseline cost the bench line
@@ -675,19 +678,28 @@ def main():
             out["cpu_baseline"] = None
         if args.mode == "train" and world == 1 and not args.no_modes:
             # the other quoted configurations, bounded, each with its own roofline and CPU baseline: driver-timed alongside
-            # the headline (BASELINE.json configs[1]; the hot path alone at 16 images and at one)
+            # the headline (BASELINE.json configs[1]; the hot path alone at 16 images and at one).  Each runs
+            # in a fresh process (this one keeps its GPU context but is idle): measured inside this process, after the
+            # float32 leg, the launch-bound batch-1 inference came out 13 % slower than on its own.
+            import subprocess
             trainer = None
             torch.cuda.empty_cache()
             modes = {}
-            for name, fn in (("supervision", lambda: supervision_record(device, rank, 16, 200, 20, cpu=False)),
-                             ("supervision_b1", lambda: supervision_record(device, rank, 1, 200, 20, cpu=cpu, cpu_target_s=5.0)),
-                             ("infer_b1", lambda: infer_record(device, rank, 1, 200, 20)),
-                             ("crf_fullres", lambda: crf_fullres_record(device, 20, 5, cpu=cpu))):
+            base = [sys.executable, os.path.abspath(__file__)]
+            nocpu = [] if cpu else ["--no-cpu-baseline"]
+            for name, argv in (("supervision", ["--mode", "supervision", "--batch", "16", "--steps", "200", "--warmup", "20", "--no-cpu-baseline"]),
+                               ("supervision_b1", ["--mode", "supervision", "--batch", "1", "--steps", "200", "--warmup", "20", "--sub"] + nocpu),
+                               ("infer_b1", ["--mode", "infer", "--batch", "1", "--steps", "300", "--warmup", "30"]),
+                               ("crf_fullres", ["--mode", "crf-fullres", "--steps", "20", "--warmup", "5"] + nocpu)):
                 try:
-                    modes[name] = fn()
+                    r = subprocess.run(base + argv, capture_output=True, text=True, timeout=420)
+                    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    if r.returncode != 0 or not lines:
+                        raise RuntimeError("rc %d: %s" % (r.returncode, r.stderr[-300:]))
+                    modes[name] = json.loads(lines[-1])
                 except Exception as e:                   # a sub-record must never cost the headline line
                     modes[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-            if "supervision" in modes and isinstance(out.get("cpu_baseline"), dict):
+            if "error" not in modes["supervision"] and isinstance(out.get("cpu_baseline"), dict):
                 modes["supervision"]["cpu_baseline"] = out["cpu_baseline"]      # same workload: the port on the same batch
             out["modes"] = modes
         print(json.dumps(out))

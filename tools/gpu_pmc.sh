@@ -21,6 +21,11 @@ for w in $WHAT; do
     fr_fetch) run fr_fetch "FETCH_SIZE" pmc_workload_fullres.py ;;
     fr_write) run fr_write "WRITE_SIZE" pmc_workload_fullres.py ;;
     fr_l2) run fr_l2 "TCC_HIT_sum TCC_MISS_sum" pmc_workload_fullres.py ;;
+    train_mfma)
+      rm -rf /tmp/pmc_train_mfma
+      timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/pmc_train_mfma -o train_mfma -- python $ROOT/bench.py --steps 6 --warmup 6 --no-fp32 --no-cpu-baseline --no-modes --no-profile > $ROOT/$OUT/train_mfma.log 2>&1
+      f=$(find /tmp/pmc_train_mfma -name "*counter_collection.csv" | head -1)
+      [ -n "$f" ] && cp $f $ROOT/$OUT/train_mfma_counter_collection.csv && echo "train_mfma: $(wc -l < $f) rows" ;;
   esac
 done
 cd $ROOT

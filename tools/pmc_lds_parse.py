@@ -14,6 +14,7 @@ import sys
 from collections import defaultdict
 
 CUS = 256
+XCDS = 8
 
 
 def main(path, out, commit=""):
@@ -39,7 +40,10 @@ def main(path, out, commit=""):
         if "SQ_LDS_IDX_ACTIVE" in e and e["SQ_LDS_IDX_ACTIVE"] > 0:
             e["lds_conflict_share"] = e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"]
             if "GRBM_GUI_ACTIVE" in e and e["GRBM_GUI_ACTIVE"] > 0:
-                e["lds_array_busy_frac"] = e["SQ_LDS_IDX_ACTIVE"] / (e["GRBM_GUI_ACTIVE"] * CUS)
+                # GRBM_GUI_ACTIVE comes summed over the 8 XCDs: cycles of ONE clock domain = value / 8
+                e["lds_array_busy_frac"] = e["SQ_LDS_IDX_ACTIVE"] / (e["GRBM_GUI_ACTIVE"] / XCDS * CUS)
+            if e.get("avg_duration_us_under_pmc"):
+                e["lds_array_busy_frac_at_2.4GHz"] = e["SQ_LDS_IDX_ACTIVE"] / (CUS * e["avg_duration_us_under_pmc"] * 1e-6 * 2.4e9)
         res["kernels"][k] = e
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, e in sorted(res["kernels"].items()):
