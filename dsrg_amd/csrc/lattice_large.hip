@@ -32,8 +32,10 @@ struct LargeLattice {
     uint32_t *seg_v;         // [T]   vertex of segment s                                                      (aliases `slot_e`)
     uint32_t *multi_v;       // [..]  vertices with more than one segment, any order                           (aliases `ent_vid`)
     int T_host, nmulti_host;
+    int seg_len;             // entries per splat segment
 };
 constexpr int kSplatSeg = 64;
+
 
 // ---------------------------------------------------------------------------------------------
 template <int D>
@@ -148,7 +150,7 @@ __global__ void lg_seg_count_kernel(LargeLattice L) {
     if (v > L.Mcap) return;
     if (v >= M) { L.seg_cnt[v] = 0u; return; }
     const uint32_t len = L.row_start[v + 1] - L.row_start[v];
-    L.seg_cnt[v] = len <= (uint32_t)kSplatSeg ? 1u : (len + kSplatSeg - 1) / kSplatSeg;
+    L.seg_cnt[v] = len <= (uint32_t)L.seg_len ? 1u : (len + L.seg_len - 1) / L.seg_len;
 }
 __global__ void lg_seg_fill_kernel(LargeLattice L) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,7 +313,7 @@ __device__ __forceinline__ void lg_splat_unit(const LargeLattice &L, size_t u, i
     const uint32_t v = L.seg_v[u];
     const uint32_t s0 = L.seg_start[v], K = L.seg_start[v + 1] - s0;
     const uint32_t r0 = L.row_start[v], r1 = L.row_start[v + 1];
-    const uint32_t p0 = r0 + ((uint32_t)u - s0) * (uint32_t)kSplatSeg, p1 = min(p0 + (uint32_t)kSplatSeg, r1);
+    const uint32_t p0 = r0 + ((uint32_t)u - s0) * (uint32_t)L.seg_len, p1 = min(p0 + (uint32_t)L.seg_len, r1);
     const float sum = lg_splat_segment(L, p0, p1, lane, CP, in);
     if (K == 1u) val[(size_t)v * CP + lane] = sum; else part[u * CP + lane] = sum;
 }
@@ -516,8 +518,9 @@ static size_t large_lattice_carve(LargeLattice &L, unsigned char *p, int d, int 
     L.key_e = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Epad * KW);
     L.table = (uint32_t *)take(sizeof(uint32_t) * (size_t)cap);
     L.slot_e = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Epad);
-    L.first = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Epad);
-    L.scanned = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Epad);
+    // (+2: the same arrays later hold seg_start / seg_cnt, Mcap + 1 = Epad + 1 entries)
+    L.first = (uint32_t *)take(sizeof(uint32_t) * ((size_t)L.Epad + 2));
+    L.scanned = (uint32_t *)take(sizeof(uint32_t) * ((size_t)L.Epad + 2));
     L.key_v = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.Mcap * KW);
     L.vid = (uint32_t *)take(sizeof(uint32_t) * (size_t)L.E);
     L.nb1 = (uint32_t *)take(sizeof(uint32_t) * (size_t)d1 * L.Mcap);
@@ -535,6 +538,7 @@ static size_t large_lattice_carve(LargeLattice &L, unsigned char *p, int d, int 
     L.M = (int *)take(sizeof(int) * 4);
     L.seg_start = L.first; L.seg_cnt = L.scanned; L.seg_v = L.slot_e; L.multi_v = L.key_e;        // dead once lg_vid_kernel has run
     L.T_host = L.nmulti_host = 0;
+    L.seg_len = kSplatSeg;
     return off;
 }
 
