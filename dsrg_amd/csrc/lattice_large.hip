@@ -362,12 +362,24 @@ __global__ __launch_bounds__(256) void lg_combine_kernel(LargeLattice Lb, LargeL
     for (uint32_t q = s0 + 1; q < s1; q++) acc = acc + part[(size_t)q * CP + lane];
     val[(size_t)v * CP + lane] = acc;
 }
-__device__ __forceinline__ void lg_blur_elem(const LargeLattice &L, int M, size_t v, int q, int CP4, int j,
+// seq: <= 2 label planes take Permutohedral::seqCompute's arithmetic (permutohedral.cpp:476-527 via :600-601): the blur is
+// summed in double (the literal 0.5) and the slice multiplies (w * value) * alpha
+__device__ __forceinline__ float lg_blur_seq(float x0, float x1, float x2) {
+    const float s = x1 + x2;
+    return (float)((double)x0 + 0.5 * (double)s);
+}
+__device__ __forceinline__ void lg_blur_elem(const LargeLattice &L, int M, size_t v, int q, int CP4, int j, int seq,
                                              const float4 *__restrict__ a, float4 *__restrict__ b) {
     if (v == (size_t)M) { b[(size_t)M * CP4 + q] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
     const uint32_t n1 = L.nb1[(size_t)j * L.Mcap + v], n2 = L.nb2[(size_t)j * L.Mcap + v];
     const float4 x0 = a[v * CP4 + q], x1 = a[(size_t)n1 * CP4 + q], x2 = a[(size_t)n2 * CP4 + q];
     float4 o;
+    if (seq) {
+        o.x = lg_blur_seq(x0.x, x1.x, x2.x); o.y = lg_blur_seq(x0.y, x1.y, x2.y);
+        o.z = lg_blur_seq(x0.z, x1.z, x2.z); o.w = lg_blur_seq(x0.w, x1.w, x2.w);
+        b[v * CP4 + q] = o;
+        return;
+    }
     { float s = x1.x + x2.x; s = 0.5f * s; o.x = x0.x + s; }
     { float s = x1.y + x2.y; s = 0.5f * s; o.y = x0.y + s; }
     { float s = x1.z + x2.z; s = 0.5f * s; o.z = x0.z + s; }
@@ -375,23 +387,31 @@ __device__ __forceinline__ void lg_blur_elem(const LargeLattice &L, int M, size_
     b[v * CP4 + q] = o;
 }
 // axis j of the bilateral lattice and, while j < 3, of the Gaussian lattice
-__global__ void lg_blur2_kernel(LargeLattice Lb, LargeLattice Lg, int CP4, int j, const float4 *__restrict__ ab,
+__global__ void lg_blur2_kernel(LargeLattice Lb, LargeLattice Lg, int CP4, int j, int seq, const float4 *__restrict__ ab,
                                 float4 *__restrict__ bb, const float4 *__restrict__ ag, float4 *__restrict__ bg) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int Mb = *Lb.M, Mg = *Lg.M;
     size_t v = idx / CP4;
     const int q = (int)(idx - v * CP4);
-    if (v <= (size_t)Mb) { lg_blur_elem(Lb, Mb, v, q, CP4, j, ab, bb); return; }
+    if (v <= (size_t)Mb) { lg_blur_elem(Lb, Mb, v, q, CP4, j, seq, ab, bb); return; }
     v -= (size_t)Mb + 1;
-    if (j < 3 && v <= (size_t)Mg) lg_blur_elem(Lg, Mg, v, q, CP4, j, ag, bg);
+    if (j < 3 && v <= (size_t)Mg) lg_blur_elem(Lg, Mg, v, q, CP4, j, seq, ag, bg);
 }
-__device__ __forceinline__ float4 lg_slice_elem(const LargeLattice &L, int D1, size_t i, int q, int CP4,
+__device__ __forceinline__ float4 lg_slice_elem(const LargeLattice &L, int D1, size_t i, int q, int CP4, int seq,
                                                 const float4 *__restrict__ val, float neg_w) {
     const float alpha = 1.0f / (1.0f + exp2f(-(float)(D1 - 1)));
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = 0; r < D1; r++) {
-        const float w = L.bary[(size_t)r * L.N + i] * alpha;
         const float4 x = val[(size_t)L.vid[(size_t)r * L.N + i] * CP4 + q];
+        if (seq) {
+            const float w0 = L.bary[(size_t)r * L.N + i];
+            { float t = w0 * x.x; t = t * alpha; acc.x = acc.x + t; }
+            { float t = w0 * x.y; t = t * alpha; acc.y = acc.y + t; }
+            { float t = w0 * x.z; t = t * alpha; acc.z = acc.z + t; }
+            { float t = w0 * x.w; t = t * alpha; acc.w = acc.w + t; }
+            continue;
+        }
+        const float w = L.bary[(size_t)r * L.N + i] * alpha;
         acc.x = acc.x + w * x.x; acc.y = acc.y + w * x.y; acc.z = acc.z + w * x.z; acc.w = acc.w + w * x.w;
     }
     const float nv = L.norm[i];
@@ -420,8 +440,8 @@ __global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, L
     for (int k = threadIdx.x; k < npix * CP4; k += 256) {
         const int pl = k / CP4, q4 = k - pl * CP4;
         const size_t i = i0 + pl;
-        const float4 tg = lg_slice_elem(Lg, 3, i, q4, CP4, val_g, neg_wg);
-        const float4 tb = lg_slice_elem(Lb, 6, i, q4, CP4, val_b, neg_wb);
+        const float4 tg = lg_slice_elem(Lg, 3, i, q4, CP4, C <= 2, val_g, neg_wg);
+        const float4 tb = lg_slice_elem(Lb, 6, i, q4, CP4, C <= 2, val_b, neg_wb);
         const float4 nu = reinterpret_cast<const float4 *>(neg_unary)[i * CP4 + q4];
         float *r = row + pl * P + q4 * 4;
         { float v = nu.x; v = v - tg.x; v = v - tb.x; r[0] = v; }
@@ -730,7 +750,7 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
         for (int j = 0; j < 6; j++) {
             const size_t rows = j < 3 ? need : (size_t)Mb + 1;
             hipLaunchKernelGGL(lg_blur2_kernel, dim3(blocks_for(rows * CP4, 256)), dim3(256), 0, s, c->Lb, c->Lg, CP4, j,
-                               (const float4 *)a, (float4 *)b, (const float4 *)(a + g_off), (float4 *)(b + g_off));
+                               c->C <= 2 ? 1 : 0, (const float4 *)a, (float4 *)b, (const float4 *)(a + g_off), (float4 *)(b + g_off));
             float *t = a; a = b; b = t;
         }
         // after 6 swaps the bilateral result is back in val_a; the Gaussian one stopped after 3 swaps, in val_b

@@ -39,6 +39,8 @@ namespace dsrg {
 enum : int {
     kOptLocalGauss = 1,   // a pixel-local Gaussian lattice is evaluated by the update kernel: its units exit at once
     kOptSlotGuard = 2,    // skip a thread's vertex slots beyond the lattice's actual size (workgroup-uniform test)
+    kOptSeq = 4,          // <= 2 label planes: Permutohedral::seqCompute's arithmetic (permutohedral.cpp:476-527 via :600-601) — blur
+                          // summed in double, slice as (w * value) * alpha.  Set by plan_filter, one-plane workgroups only
 };
 struct FilterArgs {
     LatticeView Lg, Lb;      // Gaussian (shared by all images, nlat==1) and bilateral (per image)
@@ -173,6 +175,7 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #endif
     // slots k with k * kWG >= Mlim hold no vertex of this lattice: skipped when the guard is on
     const int Mlim = (opts & kOptSlotGuard) ? M : (VPT * kWG);
+    const bool seq = (opts & kOptSeq) != 0;
     // the extras (entry-parallel: x_k = tid + k*1024 < X), through descriptors that end at X: slots beyond read 0 for free
     const rsrc_t r_xp = make_rsrc(L.x_pix + (size_t)li * D1 * N, sizeof(uint16_t) * (size_t)X);
     const rsrc_t r_xw = make_rsrc(L.x_w + (size_t)li * D1 * N, sizeof(float) * (size_t)X);
@@ -211,7 +214,8 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
                         for (int r = 0; r < D1; r++) {
                             float v = 0.0f + bws[p][r] * x;      // splat into an empty vertex
                             v = v + 0.5f * (0.0f + 0.0f);        // d+1 blur passes without neighbours
-                            acc = acc + (bws[p][r] * alpha) * v; // slice
+                            if (CPW == 1 && (opts & kOptSeq)) { float t = bws[p][r] * v; t = t * alpha; acc = acc + t; }
+                            else acc = acc + (bws[p][r] * alpha) * v; // slice
                         }
                         out[(size_t)c * N + i] = acc * nrm[p];
                     }
@@ -397,8 +401,13 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #pragma unroll
                                 for (int c = 0; c < CPW; c++) {
                                     float s = pv_get(x1[g], c) + pv_get(x2[g], c);
-                                    s = 0.5f * s;
-                                    pv_set(sacc[ch * KC + k0 + g], c, pv_get(sacc[ch * KC + k0 + g], c) + s);
+                                    if (CPW == 1 && seq) {       // new = old + 0.5 * (n1 + n2) with a double literal
+                                        pv_set(sacc[ch * KC + k0 + g], c,
+                                               (float)((double)pv_get(sacc[ch * KC + k0 + g], c) + 0.5 * (double)s));
+                                    } else {
+                                        s = 0.5f * s;
+                                        pv_set(sacc[ch * KC + k0 + g], c, pv_get(sacc[ch * KC + k0 + g], c) + s);
+                                    }
                                 }
                             }
                         }
@@ -457,10 +466,15 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
             for (int c = 0; c < CPW; c++) acc[c] = 0.0f;
 #pragma unroll
             for (int r = 0; r < D1; r++) {
-                const float w = sw[p][r] * alpha;
                 const vec_t x = cur[min(sv[p][r], (uint32_t)M)];
+                if (CPW == 1 && seq) {
 #pragma unroll
-                for (int c = 0; c < CPW; c++) acc[c] = acc[c] + w * pv_get(x, c);
+                    for (int c = 0; c < CPW; c++) { float t = sw[p][r] * pv_get(x, c); t = t * alpha; acc[c] = acc[c] + t; }
+                } else {
+                    const float w = sw[p][r] * alpha;
+#pragma unroll
+                    for (int c = 0; c < CPW; c++) acc[c] = acc[c] + w * pv_get(x, c);
+                }
             }
 #pragma unroll
             for (int c = 0; c < CPW; c++)
@@ -744,8 +758,8 @@ static int plan_filter(const LatticeView &Lg, const LatticeView &Lb, const Meanf
     // planes per block: bilateral 2 (8-byte LDS gathers) and Gaussian 4 (16-byte) when LDS holds them and
     // the batch is large enough to still fill the chip; otherwise narrower blocks
     int cpw_b = 1, cpw_g = 1;
-    if (lds_for(2, 4) <= kLds && (size_t)B * ((C + 1) / 2) >= 64) { cpw_b = 2; cpw_g = 4; }
-    else if (lds_for(1, 2) <= kLds) { cpw_b = 1; cpw_g = 2; }
+    if (lds_for(2, 4) <= kLds && (size_t)B * ((C + 1) / 2) >= 64 && C > 2) { cpw_b = 2; cpw_g = 4; }
+    else if (lds_for(1, 2) <= kLds && C > 2) { cpw_b = 1; cpw_g = 2; }
     else if (lds_for(1, 1) > 158 * 1024) return set_error(DSRG_ERR_UNSUPPORTED, "lattice does not fit LDS");
     const int vpt = (Lb.Mcap + kWG - 1) / kWG;
     const int ppt_tab = vpt <= 4 ? 1 : vpt <= 10 ? 2 : vpt <= 16 ? 3 : vpt <= 25 ? 5 : 6;
@@ -765,6 +779,7 @@ static int plan_filter(const LatticeView &Lg, const LatticeView &Lb, const Meanf
     // host knows the lattice to be pixel-local (then the update kernel forms that message)
     a.groups_g = (C + cpw_g - 1) / cpw_g;
     a.opts = filter_opts();
+    if (C <= 2) a.opts = (a.opts & ~kOptLocalGauss) | kOptSeq;     // the reference switches arithmetic at value_size <= 2
     const bool drop_gauss = gauss_local && (a.opts & kOptLocalGauss);
     a.nunits = a.nblk_b + (drop_gauss ? 0 : a.groups_g * B);
     a.dbg = reinterpret_cast<unsigned long long *>(g_filter_dbg);

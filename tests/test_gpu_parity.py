@@ -260,12 +260,14 @@ def test_filter_variants_are_bit_identical(ops, O, B, C, HW, scale):
 
 
 @pytest.mark.parametrize("kind,scale,HW,C", [("smooth", 12.0, (41, 41), 21), ("noise", 12.0, (41, 41), 21), ("smooth", 12.0, (65, 65), 21),
-                                             ("dark_corner", 12.0, (41, 41), 5), ("noise", 1.0, (24, 31), 7), ("smooth", 3.0, (17, 40), 4)])
+                                             ("dark_corner", 12.0, (41, 41), 5), ("noise", 1.0, (24, 31), 7), ("smooth", 3.0, (17, 40), 4),
+                                             ("noise", 12.0, (28, 5), 1), ("smooth", 12.0, (41, 41), 2), ("noise", 1.0, (33, 20), 2)])
 def test_single_filter_application_and_norm_vs_oracle(ops, O, kind, scale, HW, C):
     """a7 / a9 without the softmax contraction of ten iterations: the normalisation vector of DenseKernel::initLattice
     (pairwise.cpp:40-62) and ONE application of DenseKernel::filter (pairwise.cpp:63-80: x norm, Permutohedral::compute
     permutohedral.cpp:529-604, x norm) on both lattices, HIP against the oracle.  The arithmetic and its order are the
-    oracle's, so the results are compared to 2 ulp (observed: bit-equal)."""
+    oracle's, so the results are compared to 2 ulp (observed: bit-equal).  One and two label planes take the reference's
+    seqCompute arithmetic (permutohedral.cpp:476-527 via :600-601): blur summed in double, slice as (w * value) * alpha."""
     H, W = HW
     B, N = 2, H * W
     rng = np.random.default_rng(hash((kind, H, W, C)) % 2 ** 31)
