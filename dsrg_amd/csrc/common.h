@@ -120,6 +120,7 @@ struct Profiler {
 int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C,
                      const float *neg_unary, float wg, float wb, int n_iters, float *q_out,
                      double *refined_out, float *logq_out, bool gauss_local, hipStream_t stream, Profiler *prof = nullptr);
+int launch_lattice_norm_pass(const LatticeView &L, int nlat, hipStream_t stream);      // meanfield.hip; d = 5 lattices
 int launch_filter_once(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C, int kind,
                        const float *q_in, float *out, bool gauss_local, hipStream_t stream);
 

@@ -246,7 +246,8 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
             for (int q = tid; q < M; q += kWG) kg[q] = ckeys[q];
         }
         const int any_bad = __syncthreads_or(key_range_bad);
-        if (tid == 0) L.flags[b] = (any_bad ? 2 : 0) | (fast_keys ? 8 : 0);
+        // bit 0 ("diagonal": no vertex shared, no blur neighbour) is set on trust here and cleared by the neighbour search
+        if (tid == 0) L.flags[b] = (any_bad ? 2 : 0) | (fast_keys ? 8 : 0) | (M == E ? 1 : 0);
     } else {
     // ---- phase 5: blur neighbours (permutohedral.cpp:303-318): 2(d+1) hash look-ups per vertex,
         // advanced together one probe per round.  With the compact keys resident in LDS a probe is two
@@ -513,9 +514,9 @@ __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int c
     const uint32_t mask = (uint32_t)cap - 1u;
     constexpr uint32_t kEmpty = 0xFFFFu;
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
-    uint32_t *tabw = reinterpret_cast<uint32_t *>(smem);
     ckey_t *ckeys = reinterpret_cast<ckey_t *>(smem + (size_t)cap * 2);
     const bool fast_keys = lds_keys && (L.flags[b] & 8);
+    uint32_t *tabw = reinterpret_cast<uint32_t *>(smem);
     const uint32_t *tg = L.tab_g + (size_t)b * (cap / 2);
     for (int q = tid; q < cap / 2; q += kWG) tabw[q] = tg[q];
     if (fast_keys) {
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int c
         for (int q = tid; q < M; q += kWG) ckeys[q] = kg[q];
     }
     __syncthreads();
+    int has_nb = 0;
     const uint32_t *key_v = L.key_v + (size_t)b * Mcap * KW;
     uint32_t *nb = L.nb + (size_t)b * D1 * Mcap;
     const int chunk = (M + kNeighSplit - 1) / kNeighSplit;
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int c
                 }
             }
 #pragma unroll
-            for (int j = 0; j < D1; j++) word[j] |= found[j] << (half * 16);
+            for (int j = 0; j < D1; j++) { word[j] |= found[j] << (half * 16); has_nb |= (found[j] != (uint32_t)M); }
         }
 #pragma unroll
         for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = word[j];
@@ -599,6 +601,7 @@ __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int c
 #pragma unroll
         for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = (uint32_t)M | ((uint32_t)M << 16);
     }
+    if (__syncthreads_or(has_nb) && tid == 0) atomicAnd(&L.flags[b], ~1);     // some vertex has a neighbour: not diagonal
 }
 
 // Split build, stage 3: norm = 1/sqrt(K 1 + 1e-20) (pairwise.cpp:44,54-57) through
@@ -870,10 +873,15 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
             if (rc) return rc;                                                                                \
             hipLaunchKernelGGL((lattice_neigh_kernel<D_>), dim3(nlat * kNeighSplit), dim3(kWG), neigh_lds, stream, L, \
                                cap, (int)lds_keys);                                                           \
-            const size_t norm_lds = (size_t)(L.Mcap + 1) * 4;                                                 \
-            rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_norm_kernel<D_, V_>), norm_lds, granted_m); \
-            if (rc) return rc;                                                                                \
-            hipLaunchKernelGGL((lattice_norm_kernel<D_, V_>), dim3(nlat), dim3(kWG), norm_lds, stream, L);     \
+            if (D_ == 5) {   /* the filter kernel over a plane of ones (meanfield.hip) */                      \
+                rc = launch_lattice_norm_pass(L, nlat, stream);                                               \
+                if (rc) return rc;                                                                            \
+            } else {                                                                                          \
+                const size_t norm_lds = (size_t)(L.Mcap + 1) * 4;                                             \
+                rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_norm_kernel<D_, V_>), norm_lds, granted_m); \
+                if (rc) return rc;                                                                            \
+                hipLaunchKernelGGL((lattice_norm_kernel<D_, V_>), dim3(nlat), dim3(kWG), norm_lds, stream, L); \
+            }                                                                                                 \
         }                                                                                                     \
     } while (0)
 #define DSRG_BUILD_V(D_)                                                                                      \

@@ -41,6 +41,8 @@ enum : int {
     kOptSlotGuard = 2,    // skip a thread's vertex slots beyond the lattice's actual size (workgroup-uniform test)
     kOptSeq = 4,          // <= 2 label planes: Permutohedral::seqCompute's arithmetic (permutohedral.cpp:476-527 via :600-601) — blur
                           // summed in double, slice as (w * value) * alpha.  Set by plan_filter, one-plane workgroups only
+    kOptNormPass = 8,     // the build's normalisation pass (pairwise.cpp:44,54-57): the input is a plane of ones, no norm is
+                          // applied, and out = 1/sqrt(K 1 + 1e-20) is the lattice's norm vector.  With kOptSeq, one plane
 };
 struct FilterArgs {
     LatticeView Lg, Lb;      // Gaussian (shared by all images, nlat==1) and bilateral (per image)
@@ -87,7 +89,7 @@ template <int V> using IC = std::integral_constant<int, V>;
 
 // one lattice (dimension D, index li of set L), planes [c0, c0+nc) of image b:
 //   out[c][i] = norm[i] * (K (norm . q[c]))[i]
-template <int CPW, int VPT, int PPT, int D>
+template <int CPW, int VPT, int PPT, int D, bool SEQ>
 __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, const float *__restrict__ qb,
                                                float *__restrict__ out, int nc, int N,
                                                typename PlaneVec<CPW>::type *val,
@@ -129,6 +131,15 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #pragma unroll
         for (int c = 0; c < CPW; c++)
             qv[p][c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
+    }
+    const bool norm_pass = SEQ && (opts & kOptNormPass);
+    if (norm_pass) {                          // (the loads above hit valid memory — q aliases the norm vector — and are dropped)
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            nrm[p] = 1.0f;
+#pragma unroll
+            for (int c = 0; c < CPW; c++) qv[p][c] = 1.0f;
+        }
     }
     // splat, vertex-major: the first contributor (pixel, weight) of my vertices v_k = tid + k*1024 and their CSR rows
     uint32_t fpx[KC], rs0[KC], rs1[KC];
@@ -175,7 +186,8 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #endif
     // slots k with k * kWG >= Mlim hold no vertex of this lattice: skipped when the guard is on
     const int Mlim = (opts & kOptSlotGuard) ? M : (VPT * kWG);
-    const bool seq = (opts & kOptSeq) != 0;
+    constexpr bool seq = SEQ;                 // kOptSeq arithmetic: its own instantiation (a runtime test cost the
+                                              // one-plane workgroups of a lone image 1 us per launch)
     // the extras (entry-parallel: x_k = tid + k*1024 < X), through descriptors that end at X: slots beyond read 0 for free
     const rsrc_t r_xp = make_rsrc(L.x_pix + (size_t)li * D1 * N, sizeof(uint16_t) * (size_t)X);
     const rsrc_t r_xw = make_rsrc(L.x_w + (size_t)li * D1 * N, sizeof(float) * (size_t)X);
@@ -214,10 +226,10 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
                         for (int r = 0; r < D1; r++) {
                             float v = 0.0f + bws[p][r] * x;      // splat into an empty vertex
                             v = v + 0.5f * (0.0f + 0.0f);        // d+1 blur passes without neighbours
-                            if (CPW == 1 && (opts & kOptSeq)) { float t = bws[p][r] * v; t = t * alpha; acc = acc + t; }
+                            if (SEQ) { float t = bws[p][r] * v; t = t * alpha; acc = acc + t; }
                             else acc = acc + (bws[p][r] * alpha) * v; // slice
                         }
-                        out[(size_t)c * N + i] = acc * nrm[p];
+                        out[(size_t)c * N + i] = norm_pass ? (float)(1.0 / sqrt((double)acc + 1e-20)) : acc * nrm[p];
                     }
                 }
             }
@@ -401,7 +413,7 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #pragma unroll
                                 for (int c = 0; c < CPW; c++) {
                                     float s = pv_get(x1[g], c) + pv_get(x2[g], c);
-                                    if (CPW == 1 && seq) {       // new = old + 0.5 * (n1 + n2) with a double literal
+                                    if (seq) {       // new = old + 0.5 * (n1 + n2) with a double literal
                                         pv_set(sacc[ch * KC + k0 + g], c,
                                                (float)((double)pv_get(sacc[ch * KC + k0 + g], c) + 0.5 * (double)s));
                                     } else {
@@ -467,7 +479,7 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 #pragma unroll
             for (int r = 0; r < D1; r++) {
                 const vec_t x = cur[min(sv[p][r], (uint32_t)M)];
-                if (CPW == 1 && seq) {
+                if (seq) {
 #pragma unroll
                     for (int c = 0; c < CPW; c++) { float t = sw[p][r] * pv_get(x, c); t = t * alpha; acc[c] = acc[c] + t; }
                 } else {
@@ -478,7 +490,7 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
             }
 #pragma unroll
             for (int c = 0; c < CPW; c++)
-                if (c < nc) out[(size_t)c * N + i] = acc[c] * nrm[p];
+                if (c < nc) out[(size_t)c * N + i] = norm_pass ? (float)(1.0 / sqrt((double)acc[c] + 1e-20)) : acc[c] * nrm[p];
         }
     }
     DSRG_STAMP(11);
@@ -489,7 +501,7 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 // bilateral ones (CPW_B planes of one image: 6 axes, M ~ 2-6 N vertices, the long ones), then the Gaussian ones (CPW_G planes
 // of one image through the lattice all images share: 3 axes), handed out by the hardware dispatcher (a software unit queue
 // was measured and lost, profiles/r02_filter_queue_ab.txt).
-template <int CPW_B, int CPW_G, int VPT_B, int PPT>
+template <int CPW_B, int CPW_G, int VPT_B, int PPT, bool SEQ>
 __global__ __launch_bounds__(kWG) void mf_filter_kernel(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int VPT_G = (VPT_B + 1) / 2;                 // Mcap_gauss = Mcap_bilateral / 2
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(kWG) void mf_filter_kernel(FilterArgs a) {
         vec_t *val = reinterpret_cast<vec_t *>(smem);                      // value buffer(s), label-interleaved
         vec_t *inq = reinterpret_cast<vec_t *>(smem + a.lds_bytes) - a.N;  // [N] at the end of the region
         const size_t o = ((size_t)b * a.C + c0) * a.N;
-        filter_lattice<CPW_B, VPT_B, PPT, 5>(a.Lb, b, a.q + o, a.msg_b + o, nc, a.N, val, inq, dbg,
+        filter_lattice<CPW_B, VPT_B, PPT, 5, SEQ>(a.Lb, b, a.q + o, a.msg_b + o, nc, a.N, val, inq, dbg,
                                              a.lds_bytes / (int)sizeof(vec_t), a.opts);
     } else {
         using vec_t = typename PlaneVec<CPW_G>::type;
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(kWG) void mf_filter_kernel(FilterArgs a) {
         vec_t *val = reinterpret_cast<vec_t *>(smem);
         vec_t *inq = reinterpret_cast<vec_t *>(smem + a.lds_bytes) - a.N;
         const size_t o = ((size_t)b * a.C + c0) * a.N;
-        filter_lattice<CPW_G, VPT_G, PPT, 2>(a.Lg, 0, a.q + o, a.msg_g + o, nc, a.N, val, inq, dbg ? dbg + 16 : nullptr,
+        filter_lattice<CPW_G, VPT_G, PPT, 2, SEQ>(a.Lg, 0, a.q + o, a.msg_g + o, nc, a.N, val, inq, dbg ? dbg + 16 : nullptr,
                                              a.lds_bytes / (int)sizeof(vec_t), a.opts);
     }
 }
@@ -701,26 +713,26 @@ static int filter_opts() {
     return g_filter_opts;
 }
 
-template <int CPW_B, int CPW_G, int VPT_B, int PPT>
+template <int CPW_B, int CPW_G, int VPT_B, int PPT, bool SEQ>
 static int launch_filter(const FilterArgs &a, int nblocks, size_t lds, hipStream_t stream, Profiler *prof) {
     static LdsGrant granted;
-    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mf_filter_kernel<CPW_B, CPW_G, VPT_B, PPT>), lds, granted);
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mf_filter_kernel<CPW_B, CPW_G, VPT_B, PPT, SEQ>), lds, granted);
     if (rc) return rc;
     const bool timed = prof && prof->active && prof->used < prof->cap;
     if (timed) DSRG_HIP_CHECK(hipEventRecord(prof->start[prof->used], stream));
-    hipLaunchKernelGGL((mf_filter_kernel<CPW_B, CPW_G, VPT_B, PPT>), dim3(nblocks), dim3(kWG), lds, stream, a);
+    hipLaunchKernelGGL((mf_filter_kernel<CPW_B, CPW_G, VPT_B, PPT, SEQ>), dim3(nblocks), dim3(kWG), lds, stream, a);
     DSRG_LAUNCH_CHECK();
     if (timed) { DSRG_HIP_CHECK(hipEventRecord(prof->stop[prof->used], stream)); prof->used++; }
     return DSRG_OK;
 }
 
-template <int CPW_B, int CPW_G>
+template <int CPW_B, int CPW_G, bool SEQ = false>
 static int dispatch_vpt(const FilterArgs &a, int nblocks, size_t lds, int vpt, hipStream_t stream, Profiler *prof) {
-    if (vpt <= 4) return launch_filter<CPW_B, CPW_G, 4, 1>(a, nblocks, lds, stream, prof);
-    if (vpt <= 10) return launch_filter<CPW_B, CPW_G, 10, 2>(a, nblocks, lds, stream, prof);
-    if (vpt <= 16) return launch_filter<CPW_B, CPW_G, 16, 3>(a, nblocks, lds, stream, prof);
-    if (vpt <= 25) return launch_filter<CPW_B, CPW_G, 25, 5>(a, nblocks, lds, stream, prof);
-    if (vpt <= 32) return launch_filter<CPW_B, CPW_G, 32, 6>(a, nblocks, lds, stream, prof);
+    if (vpt <= 4) return launch_filter<CPW_B, CPW_G, 4, 1, SEQ>(a, nblocks, lds, stream, prof);
+    if (vpt <= 10) return launch_filter<CPW_B, CPW_G, 10, 2, SEQ>(a, nblocks, lds, stream, prof);
+    if (vpt <= 16) return launch_filter<CPW_B, CPW_G, 16, 3, SEQ>(a, nblocks, lds, stream, prof);
+    if (vpt <= 25) return launch_filter<CPW_B, CPW_G, 25, 5, SEQ>(a, nblocks, lds, stream, prof);
+    if (vpt <= 32) return launch_filter<CPW_B, CPW_G, 32, 6, SEQ>(a, nblocks, lds, stream, prof);
     return set_error(DSRG_ERR_UNSUPPORTED, "lattice too large for the LDS-resident filter (vpt=%d)", vpt);
 }
 
@@ -798,6 +810,7 @@ static int plan_filter(const LatticeView &Lg, const LatticeView &Lb, const Meanf
     return DSRG_OK;
 }
 static int run_filter(const FilterPlan &P, hipStream_t stream, Profiler *prof) {
+    if (P.a.opts & kOptSeq) return dispatch_vpt<1, 1, true>(P.a, P.nblocks, P.lds, P.vpt, stream, prof);
     if (P.cpw_b == 2) return dispatch_vpt<2, 4>(P.a, P.nblocks, P.lds, P.vpt, stream, prof);
     if (P.cpw_g == 2) return dispatch_vpt<1, 2>(P.a, P.nblocks, P.lds, P.vpt, stream, prof);
     return dispatch_vpt<1, 1>(P.a, P.nblocks, P.lds, P.vpt, stream, prof);
@@ -826,6 +839,35 @@ int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const Meanfie
         if (rc) return rc;
     }
     return DSRG_OK;
+}
+
+// The normalisation vectors of nlat freshly built d = 5 lattices, norm = 1/sqrt(K 1 + 1e-20) (pairwise.cpp:44,54-57), as one
+// launch of the filter kernel over a plane of ones: one workgroup per lattice, one plane, seqCompute arithmetic (value_size
+// 1).  Replaces the build's own single-purpose pass for these lattices (23 -> 11 us at 41x41).
+int launch_lattice_norm_pass(const LatticeView &L, int nlat, hipStream_t stream) {
+    FilterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Lg = L; a.Lb = L;
+    a.q = L.norm; a.msg_b = L.norm; a.msg_g = L.norm;     // q is never used (ones); the Gaussian half of the grid is empty
+    a.B = nlat; a.C = 1; a.N = L.N;
+    a.groups_b = 1; a.groups_g = 0;
+    a.lat_stride = nlat < 8 ? 8 : (nlat & ~7);
+    a.nblk_xcd = a.lat_stride;
+    a.nblk_b = a.nblk_xcd + (nlat > a.lat_stride ? nlat - a.lat_stride : 0);
+    a.nunits = a.nblk_b;
+    a.opts = (filter_opts() & kOptSlotGuard) | kOptSeq | kOptNormPass;
+    a.dbg = nullptr;
+    const size_t kLds = 157 * 1024;
+    const int vs = (L.Mcap + 1 + 3) & ~3;
+    size_t lds = ((size_t)vs + L.N) * sizeof(float);
+    size_t want = (size_t)2 * ((size_t)L.Mcap + 2) * sizeof(float);
+    if (want > kLds) want = kLds;
+    if (want > lds) lds = want;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 158 * 1024) return set_error(DSRG_ERR_UNSUPPORTED, "lattice does not fit LDS");
+    a.lds_bytes = (int)lds;
+    const int vpt = (L.Mcap + kWG - 1) / kWG;
+    return dispatch_vpt<1, 1, true>(a, a.nunits, lds, vpt, stream, nullptr);
 }
 
 // One application of one normalised kernel (DenseKernel::filter, pairwise.cpp:63-80) to caller-supplied planes — the parity
