@@ -200,6 +200,23 @@ __device__ __forceinline__ float ld_f32(rsrc_t r, uint32_t voff, uint32_t soff =
 __device__ __forceinline__ uint32_t ld_u16(rsrc_t r, uint32_t voff, uint32_t soff = 0) {
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
 }
+// Copy nbytes (a multiple of 16 readable at src, 16-byte aligned on both sides) into LDS with a 1024-thread workgroup: U
+// 16-byte loads per thread and round, all in flight before the first LDS store of the round.
+template <int U>
+__device__ __forceinline__ void stage16_to_lds(unsigned char *dst, const void *src, uint32_t nbytes, int tid) {
+    using v4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rsrc_t(), 0, 0, 0));
+    const rsrc_t r = make_rsrc(src, nbytes);
+    for (uint32_t base = 0; base < nbytes; base += 1024u * 16u * U) {
+        v4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)tid * 16u, base + (uint32_t)u * (1024u * 16u), 0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t off = base + (uint32_t)u * (1024u * 16u) + (uint32_t)tid * 16u;
+            if (off < nbytes) *reinterpret_cast<v4 *>(dst + off) = x[u];
+        }
+    }
+}
 
 #endif
 

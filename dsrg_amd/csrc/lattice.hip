@@ -499,35 +499,43 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
 }
 
 // ---------------------------------------------------------------------------------
-// Split build, stage 2: blur neighbours (permutohedral.cpp:303-318) with kNeighSplit workgroups per
+// Split build, stage 2: blur neighbours (permutohedral.cpp:303-318) with nsplit workgroups per
 // lattice.  Each workgroup reloads the hash table (and the compact keys) into LDS and resolves the
 // 2(d+1) look-ups of its share of the vertices; probes never leave LDS when the compact keys exist.
-constexpr int kNeighSplit = 8;
+// nsplit >= ceil(Mcap / 1024): no thread gets a second vertex (41x41: with 8 workgroups a chunk of 1038 sent every workgroup
+// round its loop twice for 14 threads' sake)
 
 template <int D>
-__global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int cap, int lds_keys) {
+__global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int cap, int lds_keys, int nsplit,
+                                                            unsigned long long *dbg) {
+#define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[64 * 16 + (size_t)blockIdx.x * 8 + (i_)] = wall_clock64(); } while (0)
+    DSRG_STAMP(0);
     constexpr int D1 = D + 1, KW = KeyWords<D>::value;
     using ckey_t = typename CompactKey<D>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x / kNeighSplit, part = blockIdx.x % kNeighSplit, tid = threadIdx.x;
+    const int b = blockIdx.x / nsplit, part = blockIdx.x % nsplit, tid = threadIdx.x;
     const int Mcap = L.Mcap, M = L.M[b];
     const uint32_t mask = (uint32_t)cap - 1u;
     constexpr uint32_t kEmpty = 0xFFFFu;
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
     ckey_t *ckeys = reinterpret_cast<ckey_t *>(smem + (size_t)cap * 2);
     const bool fast_keys = lds_keys && (L.flags[b] & 8);
-    uint32_t *tabw = reinterpret_cast<uint32_t *>(smem);
-    const uint32_t *tg = L.tab_g + (size_t)b * (cap / 2);
-    for (int q = tid; q < cap / 2; q += kWG) tabw[q] = tg[q];
+    // staging from a cold L2: every load of a round in flight before its first LDS store (element loops of 4 / 8 bytes per
+    // thread and trip took 9 + 8 dependent round trips)
+    stage16_to_lds<4>(smem, L.tab_g + (size_t)b * (cap / 2), (uint32_t)cap * 2u, tid);
     if (fast_keys) {
         const ckey_t *kg = reinterpret_cast<const ckey_t *>(L.ckeys_g) + (size_t)b * Mcap;
-        for (int q = tid; q < M; q += kWG) ckeys[q] = kg[q];
+        if ((reinterpret_cast<uintptr_t>(kg) & 15) == 0)
+            stage16_to_lds<5>(reinterpret_cast<unsigned char *>(ckeys), kg, ((uint32_t)M * (uint32_t)sizeof(ckey_t) + 15u) & ~15u, tid);
+        else
+            for (int q = tid; q < M; q += kWG) ckeys[q] = kg[q];
     }
     __syncthreads();
+    DSRG_STAMP(1);
     int has_nb = 0;
     const uint32_t *key_v = L.key_v + (size_t)b * Mcap * KW;
     uint32_t *nb = L.nb + (size_t)b * D1 * Mcap;
-    const int chunk = (M + kNeighSplit - 1) / kNeighSplit;
+    const int chunk = (M + nsplit - 1) / nsplit;
     const int v_end = min(M, (part + 1) * chunk);
     for (int v = part * chunk + tid; v < v_end; v += kWG) {
         uint32_t w[KW];
@@ -591,17 +599,21 @@ __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int c
             }
 #pragma unroll
             for (int j = 0; j < D1; j++) { word[j] |= found[j] << (half * 16); has_nb |= (found[j] != (uint32_t)M); }
+            DSRG_STAMP(2 + half);
         }
 #pragma unroll
         for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = word[j];
     }
     // the unused tail of every axis points at the sentinel too (consumers need no v < M test on the words)
-    const int tail = Mcap - M, tchunk = (tail + kNeighSplit - 1) / kNeighSplit;
+    const int tail = Mcap - M, tchunk = (tail + nsplit - 1) / nsplit;
     for (int v = M + part * tchunk + tid; v < min(Mcap, M + (part + 1) * tchunk); v += kWG) {
 #pragma unroll
         for (int j = 0; j < D1; j++) nb[(size_t)j * Mcap + v] = (uint32_t)M | ((uint32_t)M << 16);
     }
+    DSRG_STAMP(4);
     if (__syncthreads_or(has_nb) && tid == 0) atomicAnd(&L.flags[b], ~1);     // some vertex has a neighbour: not diagonal
+    DSRG_STAMP(5);
+#undef DSRG_STAMP
 }
 
 // Split build, stage 3: norm = 1/sqrt(K 1 + 1e-20) (pairwise.cpp:44,54-57) through
@@ -859,8 +871,12 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
     unsigned long long *dbg = L.d == 5 ? reinterpret_cast<unsigned long long *>(g_build_dbg) : nullptr;
     // split the build over more workgroups (neighbour search x8 per lattice) when the hash table and the
     // compact keys fit one workgroup's LDS next to each other
-    const size_t neigh_lds = (size_t)cap * 2 + (lds_keys ? (size_t)L.Mcap * (L.d == 5 ? 8 : 4) : 0);
+    const size_t neigh_lds = (size_t)cap * 2 + (lds_keys ? (((size_t)L.Mcap * (L.d == 5 ? 8 : 4) + 15) & ~(size_t)15) : 0);
     const int split = (neigh_lds <= 150 * 1024 && L.Mcap <= 16 * kWG) ? 1 : 0;
+    // at least ceil(Mcap / 1024) so that no thread gets a second vertex; beyond that as many as keep one round of
+    // workgroups on the chip (the search is issue-bound: hashing and probing 12 neighbour keys per vertex)
+    int nsplit = vpt < 8 ? 8 : vpt;
+    if (240 / nlat > nsplit) nsplit = 240 / nlat < 32 ? 240 / nlat : 32;
 #define DSRG_BUILD(D_, V_)                                                                                    \
     do {                                                                                                      \
         static LdsGrant granted, granted_n, granted_m;                                                         \
@@ -871,8 +887,8 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
         if (split) {                                                                                          \
             rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_neigh_kernel<D_>), neigh_lds, granted_n); \
             if (rc) return rc;                                                                                \
-            hipLaunchKernelGGL((lattice_neigh_kernel<D_>), dim3(nlat * kNeighSplit), dim3(kWG), neigh_lds, stream, L, \
-                               cap, (int)lds_keys);                                                           \
+            hipLaunchKernelGGL((lattice_neigh_kernel<D_>), dim3(nlat * nsplit), dim3(kWG), neigh_lds, stream, L,    \
+                               cap, (int)lds_keys, nsplit, dbg);                                              \
             if (D_ == 5) {   /* the filter kernel over a plane of ones (meanfield.hip) */                      \
                 rc = launch_lattice_norm_pass(L, nlat, stream);                                               \
                 if (rc) return rc;                                                                            \

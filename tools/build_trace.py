@@ -13,14 +13,15 @@ ctx = ops.get_context(B, 21, 41, 41)
 for _ in range(3):
     ops.supervision_step(logits, images, labels, cues, ctx=ctx)
 torch.cuda.synchronize()
-buf = torch.zeros(64 * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(64 * 16 + 1024 * 8, dtype=torch.int64, device="cuda")
 L = _lib.lib()
 L.dsrg_debug_set_build_trace.argtypes = [ctypes.c_void_p]
 L.dsrg_debug_set_build_trace(ctypes.c_void_p(buf.data_ptr()))
 ops.supervision_step(logits, images, labels, cues, ctx=ctx)
 torch.cuda.synchronize()
 L.dsrg_debug_set_build_trace(None)
-t = buf.cpu().numpy().reshape(64, 16)[:B]
+raw = buf.cpu().numpy()
+t = raw[:64 * 16].reshape(64, 16)[:B]
 names = ["embed", "insert", "ids", "vid+neigh", "csr count/scan", "csr fill/sort", "csr write", "norm splat", "norm blur", "norm slice"]
 prev = t[:, 0]
 for i, nm in enumerate(names):
@@ -28,4 +29,14 @@ for i, nm in enumerate(names):
     print("  %-15s mean %7.2f  max %7.2f us" % (nm, dt.mean(), dt.max()))
     prev = t[:, i + 1]
 print("  total mean %.2f max %.2f us;  M:" % (((t[:, 10] - t[:, 0]) / 100.0).mean(), ((t[:, 10] - t[:, 0]) / 100.0).max()), ctx.lattice_sizes(B))
+nt = raw[64 * 16:].reshape(1024, 8)
+nt = nt[nt[:, 0] > 0]
+if len(nt):
+    print("lattice_neigh_kernel: %d workgroups, start spread %.2f us (wave 0 of each workgroup)" % (len(nt), (nt[:, 0].max() - nt[:, 0].min()) / 100.0))
+    prev = nt[:, 0]
+    for i, nm in enumerate(["stage table+keys", "n1 look-ups", "n2 look-ups", "stores+tail", "flag"]):
+        dt = (nt[:, i + 1] - prev) / 100.0
+        print("  %-17s mean %7.2f  max %7.2f us" % (nm, dt.mean(), dt.max()))
+        prev = nt[:, i + 1]
+    print("  first start -> last end %.2f us" % ((nt[:, 5].max() - nt[:, 0].min()) / 100.0))
 sys.stdout.flush(); os._exit(0)
