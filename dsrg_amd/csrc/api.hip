@@ -167,8 +167,8 @@ static int check_params(const dsrg_crf_params *p) {
     return DSRG_OK;
 }
 
-// build the lattices for B images from im_u8 (B,N,3)
-static int crf_build(dsrg_ctx_t c, int B, const unsigned char *im_u8, const dsrg_crf_params *prm, hipStream_t s) {
+// build the lattices for B images (colours: a (B,N,3) uint8 image, or the net's float images resampled on the fly)
+static int crf_build(dsrg_ctx_t c, int B, const LatticeColours &col, const dsrg_crf_params *prm, hipStream_t s) {
     LatticeFeat Fg, Fb;
     lattice_feat_init(Fg, 2, c->W, c->H, prm->theta_gamma_x, prm->theta_gamma_y, 1.f, 1.f, 1.f);
     lattice_feat_init(Fb, 5, c->W, c->H, prm->theta_alpha_x, prm->theta_alpha_y, prm->theta_beta_r,
@@ -176,7 +176,7 @@ static int crf_build(dsrg_ctx_t c, int B, const unsigned char *im_u8, const dsrg
     int rc;
     // the Gaussian lattice depends only on (W,H,theta_gamma): build once, reuse across calls
     if (!c->gauss_valid || memcmp(&Fg, &c->Fg_built, sizeof(Fg)) != 0) {
-        rc = launch_lattice_build(c->Lg, Fg, nullptr, 1, s);
+        rc = launch_lattice_build(c->Lg, Fg, LatticeColours(), 1, s);
         if (rc) return rc;
         c->Fg_built = Fg;
         c->gauss_valid = true;
@@ -193,15 +193,22 @@ static int crf_build(dsrg_ctx_t c, int B, const unsigned char *im_u8, const dsrg
             c->gauss_local = (fl & kLatticeLocal) ? 1 : 0;
         }
     }
-    return launch_lattice_build(c->Lb, Fb, im_u8, B, s);
+    return launch_lattice_build(c->Lb, Fb, col, B, s);
 }
 
-// build lattices for B images from im_u8 (B,N,3), then run the mean field
-static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,
+static LatticeColours colours_u8(const unsigned char *im_u8) { LatticeColours c; c.im_u8 = im_u8; return c; }
+// the net's mean-subtracted float images, resampled to the map inside the embedding kernel (pylayers.py:70-75); the uint8
+// image lands in the context's im_u8 as before
+static LatticeColours colours_float(dsrg_ctx_t c, const float *images, int img_h, int img_w) {
+    LatticeColours col; col.images = images; col.Hi = img_h; col.Wi = img_w; col.im_out = c->im_u8; return col;
+}
+
+// build lattices for B images (unless prepared), then run the mean field
+static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const LatticeColours &col,
                    const dsrg_crf_params *prm, float *q_out, double *refined, float *logq, hipStream_t s,
                    bool prepared = false) {
     if (!prepared) {
-        int rc = crf_build(c, B, im_u8, prm, s);
+        int rc = crf_build(c, B, col, prm, s);
         if (rc) return rc;
     }
     return launch_meanfield(c->Lg, c->Lb, c->mf, B, c->C, neg_unary, prm->w_gaussian, prm->w_bilateral,
@@ -216,9 +223,7 @@ extern "C" int dsrg_crf_prepare_batch(dsrg_ctx_t c, int B, const float *images, 
     int rc = check_params(prm);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = launch_prepare_images(images, B, img_h, img_w, c->H, c->W, c->im_u8, s);   // pylayers.py:70-75
-    if (rc) return rc;
-    rc = crf_build(c, B, c->im_u8, prm, s);
+    rc = crf_build(c, B, colours_float(c, images, img_h, img_w), prm, s);             // pylayers.py:70-75 inside
     if (rc) return rc;
     c->prepared_B = B;
     c->prepared_prm = *prm;
@@ -242,13 +247,8 @@ extern "C" int dsrg_crf_refine_batch(dsrg_ctx_t c, int B, float *probs, const fl
     }
     rc = launch_clip_min(probs, (size_t)B * c->C * c->N, s);                    // pylayers.py:67
     if (rc) return rc;
-    if (!prepared) {
-        rc = launch_prepare_images(images, B, img_h, img_w, c->H, c->W, c->im_u8, s);   // pylayers.py:70-75
-        if (rc) return rc;
-    } else {
-        c->prepared_B = 0;                                                        // consumed
-    }
-    return crf_run(c, B, probs, c->im_u8, prm, nullptr, refined, logq, s, prepared);    // CRF.py:28: -(-unary) = probs
+    if (prepared) c->prepared_B = 0;                                              // consumed
+    return crf_run(c, B, probs, colours_float(c, images, img_h, img_w), prm, nullptr, refined, logq, s, prepared);    // CRF.py:28: -(-unary) = probs
 }
 
 extern "C" int dsrg_crf_meanfield_batch(dsrg_ctx_t c, int B, const float *neg_unary, const unsigned char *im_u8,
@@ -257,7 +257,7 @@ extern "C" int dsrg_crf_meanfield_batch(dsrg_ctx_t c, int B, const float *neg_un
     if (B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "batch %d outside 1..%d", B, c->maxB);
     int rc = check_params(prm);
     if (rc) return rc;
-    return crf_run(c, B, neg_unary, im_u8, prm, q, nullptr, nullptr, static_cast<hipStream_t>(stream));
+    return crf_run(c, B, neg_unary, colours_u8(im_u8), prm, q, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dsrg_ctx_lattice_sizes(dsrg_ctx_t c, int B, int32_t *m_gauss, int32_t *m_bil, void *stream) {
@@ -525,13 +525,9 @@ extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, c
     // the unclipped blob has no other reader (A.3: both losses read it after the CRF layer ran)
     int rc = launch_softmax_fwd(B, C, N, logits, c->probs, s, kMinProb);
     if (rc) return rc;
-    if (!prepared) {
-        rc = launch_prepare_images(images, B, img_h, img_w, c->H, c->W, c->im_u8, s);   // pylayers.py:70-75
-        if (!rc) rc = crf_run(c, B, c->probs, c->im_u8, prm, nullptr, c->refined, c->logq, s);    // CRF (once)
-    } else {
-        rc = crf_run(c, B, c->probs, c->im_u8, prm, nullptr, c->refined, c->logq, s, true);
-        c->prepared_B = 0;                                                         // consumed
-    }
+    // CRF (once); the images are resampled (pylayers.py:70-75) by the lattices' embedding kernel
+    rc = crf_run(c, B, c->probs, colours_float(c, images, img_h, img_w), prm, nullptr, c->refined, c->logq, s, prepared);
+    if (prepared) c->prepared_B = 0;                                               // consumed
     if (rc) return rc;
     rc = launch_srg(B, C, c->H, c->W, labels, cues, c->refined, th1, th2, c->seeds, c->srg_code, s);    // DSRG
     if (rc) return rc;

@@ -83,6 +83,18 @@ struct LatticeView {
     uint32_t *key_v;       // [Mcap*KW]  packed key of every vertex
     uint32_t *tab_g;       // [cap/2]    hash table (16-bit slots) handed from the build to the neighbour kernel
     unsigned long long *ckeys_g;   // [Mcap]   compact vertex keys, likewise
+    unsigned long long *ckeys_e;   // [Epad]   compact keys of every entry, handed from the embedding kernel to the build
+    int *embed_bad;        // [32]       per workgroup of the embedding kernel: bit 0 a coordinate beyond the short range,
+                           //            bit 1 beyond the 12-bit compact range
+};
+
+// where the colours of the bilateral lattices' pixels come from: a (nlat, N, 3) uint8 image, or the mean-subtracted float
+// images of the net resampled to the map (pylayers.py:70-75) on the fly — the uint8 image is then also written to im_out
+struct LatticeColours {
+    const unsigned char *im_u8 = nullptr;
+    const float *images = nullptr;
+    int Hi = 0, Wi = 0;
+    unsigned char *im_out = nullptr;
 };
 
 struct LatticeFeat {
@@ -97,8 +109,8 @@ size_t lattice_bytes(int d, int N, int nlat);
 void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat);
 void lattice_feat_init(LatticeFeat &F, int d, int W, int H, float sx, float sy, float sr, float sg, float sb);
 
-// builds `nlat` lattices (im = nullptr for the Gaussian, (nlat, N, 3) uint8 for the bilateral)
-int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsigned char *im, int nlat,
+// builds `nlat` lattices (no colours for the Gaussian)
+int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const LatticeColours &col, int nlat,
                          hipStream_t stream);
 bool lattice_supported(int d, int N);
 
@@ -126,8 +138,6 @@ int launch_filter_once(const LatticeView &Lg, const LatticeView &Lb, const Meanf
 
 // ---- pointwise / prep ----------------------------------------------------------------
 int launch_clip_min(float *p, size_t n, hipStream_t stream);
-int launch_prepare_images(const float *images, int B, int Hi, int Wi, int H, int W, unsigned char *im_u8,
-                          hipStream_t stream);
 
 int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream, float floor_at = 0.0f);
 int launch_softmax_bwd(int B, int C, int HW, const float *x, const float *g, float *dx, hipStream_t stream);

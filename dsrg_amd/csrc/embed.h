@@ -7,6 +7,34 @@
 
 namespace dsrg {
 
+// zoom(order=1) of a mean-subtracted (B,3,Hi,Wi) image to the (H,W) map with the (in-1)/(out-1) mapping, + mean pixel,
+// np.round, astype(ubyte) (pylayers.py:70-75, CRF.py:32): the three channels of map pixel p of image b, packed r | g<<8 | b<<16
+__device__ __forceinline__ uint32_t map_pixel_rgb(const float *__restrict__ images, int b, int Hi, int Wi, int H, int W, int p) {
+    const int y = p / W, x = p - y * W;
+    const double mean_pixel[3] = {104.0, 117.0, 123.0};
+    const double sy = H > 1 ? (double)y * (double)(Hi - 1) / (double)(H - 1) : 0.0;
+    const double sx = W > 1 ? (double)x * (double)(Wi - 1) / (double)(W - 1) : 0.0;
+    const int y0 = (int)floor(sy), x0 = (int)floor(sx);
+    const double fy = sy - y0, fx = sx - x0;
+    const int y1 = y0 + 1 < Hi ? y0 + 1 : y0, x1 = x0 + 1 < Wi ? x0 + 1 : x0;
+    uint32_t out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float *pl = images + ((size_t)b * 3 + ch) * Hi * Wi;
+        double v;
+        if (fy == 0.0 && fx == 0.0) v = (double)pl[(size_t)y0 * Wi + x0];
+        else {
+            const double a = (1.0 - fy) * (double)pl[(size_t)y0 * Wi + x0] + fy * (double)pl[(size_t)y1 * Wi + x0];
+            const double c = (1.0 - fy) * (double)pl[(size_t)y0 * Wi + x1] + fy * (double)pl[(size_t)y1 * Wi + x1];
+            v = (1.0 - fx) * a + fx * c;
+        }
+        const float vf = (float)v;
+        const double r = rint((double)vf + mean_pixel[ch]);      // half-even, like np.round
+        out |= (uint32_t)(unsigned char)(long long)r << (8 * ch);
+    }
+    return out;
+}
+
 template <int D> struct KeyWords { static constexpr int value = (D * 16 + 31) / 32; };
 
 template <int KW> __device__ __forceinline__ uint32_t hash_key(const uint32_t (&w)[KW]) {
@@ -87,9 +115,10 @@ __device__ __forceinline__ int block_exclusive_scan(int x, int *scratch, int *to
 // (CRF/src/permutohedral.cpp:191-275) in the reference's fp32 operation order; features per
 // DenseCRF2D::addPairwiseGaussian/Bilateral (CRF/src/densecrf.cpp:61-81).  im: (N,3) uint8 of this image.
 // returns bit 0: a coordinate beyond +-32000, bit 1: a coordinate beyond the 12-bit compact range.
+// (the colour of pixel i is handed in: callers fetch it ahead of time)
 template <int D>
-__device__ __forceinline__ int embed_pixel(const LatticeFeat &F, int i, int N, const unsigned char *im,
-                                           uint32_t (&keys)[D + 1][KeyWords<D>::value], float (&bc_out)[D + 1]) {
+__device__ __forceinline__ int embed_pixel_rgb(const LatticeFeat &F, int i, int N, float pr, float pg, float pb,
+                                               uint32_t (&keys)[D + 1][KeyWords<D>::value], float (&bc_out)[D + 1]) {
     constexpr int D1 = D + 1;
     const float invdplus1 = 1.0f / (float)D1;      // permutohedral.cpp:148
     const float dplus1 = (float)D1;                // :149
@@ -101,10 +130,9 @@ __device__ __forceinline__ int embed_pixel(const LatticeFeat &F, int i, int N, c
         f[0] = (float)x / F.sx;
         f[1] = (float)y / F.sy;
         if constexpr (D == 5) {
-            const unsigned char *px = im + (size_t)i * 3;
-            f[2] = (float)px[0] / F.sr;
-            f[3] = (float)px[1] / F.sg;
-            f[4] = (float)px[2] / F.sb;
+            f[2] = pr / F.sr;
+            f[3] = pg / F.sg;
+            f[4] = pb / F.sb;
         }
     }
     float elevated[D1], rem0[D1], rank[D1];
@@ -175,6 +203,16 @@ __device__ __forceinline__ int embed_pixel(const LatticeFeat &F, int i, int N, c
         bc_out[r] = bc[r];
     }
     return bad;
+}
+template <int D>
+__device__ __forceinline__ int embed_pixel(const LatticeFeat &F, int i, int N, const unsigned char *im,
+                                           uint32_t (&keys)[D + 1][KeyWords<D>::value], float (&bc_out)[D + 1]) {
+    float pr = 0.0f, pg = 0.0f, pb = 0.0f;
+    if (D == 5 && i < N) {
+        const unsigned char *px = im + (size_t)i * 3;
+        pr = (float)px[0]; pg = (float)px[1]; pb = (float)px[2];
+    }
+    return embed_pixel_rgb<D>(F, i, N, pr, pg, pb, keys, bc_out);
 }
 
 }  // namespace dsrg

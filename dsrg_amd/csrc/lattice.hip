@@ -53,9 +53,51 @@ constexpr int kBuildVPT = 32;   // largest instantiation: Mcap <= 32*1024 (verti
 
 void *g_build_dbg = nullptr;     // tools only: 16 u64 phase timestamps per lattice (dsrg_debug_set_build_trace)
 
+// ---------------------------------------------------------------------------------
+// Stage 0 of the build: embed every pixel (incl. the SSE zero padding) -> simplex keys + barycentric weights
+// (Permutohedral::init, permutohedral.cpp:185-259), one pixel per thread over the whole chip.  Inside the single-workgroup
+// build this was 11 of 60 us: ~800 instructions per pixel on one CU.  With float images the colour is the on-the-fly
+// resampling of CRFLayer (pylayers.py:70-75), which saves that kernel too.
+constexpr int kEmbedWG = 256;
+template <int D>
+__global__ __launch_bounds__(kEmbedWG) void lattice_embed_kernel(LatticeView L, LatticeFeat F, LatticeColours col) {
+    constexpr int D1 = D + 1, KW = KeyWords<D>::value;
+    using ckey_t = typename CompactKey<D>::type;
+    const int b = blockIdx.y, i = blockIdx.x * kEmbedWG + threadIdx.x;
+    const int N = L.N, Npad = (N + 3) & ~3, Epad = Npad * D1;
+    int bad = 0;
+    if (i < Npad) {
+        uint32_t c = 0;
+        if (D == 5 && i < N) {
+            if (col.images) {
+                c = map_pixel_rgb(col.images, b, col.Hi, col.Wi, F.H, F.W, i);
+                unsigned char *o = col.im_out + ((size_t)b * N + i) * 3;
+                o[0] = (unsigned char)c; o[1] = (unsigned char)(c >> 8); o[2] = (unsigned char)(c >> 16);
+            } else {
+                const unsigned char *px = col.im_u8 + ((size_t)b * N + i) * 3;
+                c = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+            }
+        }
+        uint32_t keys[D1][KW];
+        float bc[D1];
+        bad = embed_pixel_rgb<D>(F, i, N, (float)(c & 0xFFu), (float)((c >> 8) & 0xFFu), (float)((c >> 16) & 0xFFu), keys, bc);
+        uint32_t *key_e = L.key_e + ((size_t)b * Epad + (size_t)i * D1) * KW;
+        ckey_t *ck = reinterpret_cast<ckey_t *>(L.ckeys_e) + (size_t)b * Epad + (size_t)i * D1;
+        float *bary = L.bary + (size_t)b * D1 * N;
+#pragma unroll
+        for (int r = 0; r <= D; r++) {
+#pragma unroll
+            for (int q = 0; q < KW; q++) key_e[r * KW + q] = keys[r][q];
+            if (i < N) bary[(size_t)r * N + i] = bc[r];
+            ck[r] = CompactKey<D>::make(keys[r]);
+        }
+    }
+    const int any = __syncthreads_or(bad & 1) | (__syncthreads_or(bad & 2) ? 2 : 0);
+    if (threadIdx.x == 0) L.embed_bad[(size_t)b * 32 + blockIdx.x] = any;
+}
+
 template <int D, int VPT>   // VPT >= ceil(Mcap / 1024): vertices (and entries) per thread
-__global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, LatticeFeat F,
-                                                              const unsigned char *__restrict__ im, int cap,
+__global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int cap,
                                                               int wl_in_lds, int lds_keys, int split, unsigned long long *dbg) {
 #define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + (i_)] = wall_clock64(); } while (0)
     DSRG_STAMP(0);
@@ -71,7 +113,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     int *scan_scratch = reinterpret_cast<int *>(smem + (size_t)cap * 2);  // [32]
     uint32_t *bm = reinterpret_cast<uint32_t *>(smem + (size_t)cap * 2 + 32 * 4);   // [Epad/32 + 1] first-occurrence bitmap
     uint32_t *wp = bm + (Epad / 32 + 1);                                  // [Epad/32 + 1] word prefix
-    ckey_t *ckeys = reinterpret_cast<ckey_t *>(smem + (((size_t)cap * 2 + 32 * 4 + 2 * (size_t)(Epad / 32 + 1) * 4 + 7) & ~(size_t)7));   // [Mcap]
+    ckey_t *ckeys = reinterpret_cast<ckey_t *>(smem + (((size_t)cap * 2 + 32 * 4 + 2 * (size_t)(Epad / 32 + 1) * 4 + 15) & ~(size_t)15));   // [Mcap]
 
     uint16_t *vid = L.vid + (size_t)b * D1 * N;
     float *bary = L.bary + (size_t)b * D1 * N;
@@ -85,24 +127,19 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     uint32_t *key_v = L.key_v + (size_t)b * Mcap * KW;
 
     for (int h = tid; h < cap / 2; h += kWG) tabw[h] = 0xFFFFFFFFu;
+    // ---- phase 1: the pixels were embedded by lattice_embed_kernel; its range flags, and the entries' compact keys into LDS
+    // (the region becomes the per-VERTEX key array in phase 3): the probes of phase 2 then never leave the CU
     int key_range_bad = 0, key12_bad = 0;
-
-    // ---- phase 1: embed every pixel (incl. the SSE zero padding) -> keys + weights
-    for (int i = tid; i < Npad; i += kWG) {
-        uint32_t keys[D1][KW];
-        float bc[D1];
-        int bad = embed_pixel<D>(F, i, N, im ? im + (size_t)b * N * 3 : nullptr, keys, bc);
-        key_range_bad |= bad & 1;
-        key12_bad |= (bad >> 1) & 1;
-#pragma unroll
-        for (int r = 0; r <= D; r++) {
-#pragma unroll
-            for (int q = 0; q < KW; q++) key_e[((size_t)i * D1 + r) * KW + q] = keys[r][q];
-            if (i < N) bary[(size_t)r * N + i] = bc[r];
-            // the entry's key in compact form stays in LDS (the region becomes the per-VERTEX key array in phase 3): the
-            // probes of phase 2 then never leave the CU
-            if (lds_keys) ckeys[(size_t)i * D1 + r] = CompactKey<D>::make(keys[r]);
-        }
+    if (tid < (Npad + kEmbedWG - 1) / kEmbedWG) {
+        const int f = L.embed_bad[(size_t)b * 32 + tid];
+        key_range_bad = f & 1; key12_bad = (f >> 1) & 1;
+    }
+    if (lds_keys) {
+        const ckey_t *ke = reinterpret_cast<const ckey_t *>(L.ckeys_e) + (size_t)b * Epad;
+        if ((reinterpret_cast<uintptr_t>(ke) & 15) == 0 && ((size_t)Epad * sizeof(ckey_t)) % 16 == 0)
+            stage16_to_lds<5>(reinterpret_cast<unsigned char *>(ckeys), ke, (uint32_t)((size_t)Epad * sizeof(ckey_t)), tid);
+        else
+            for (int q = tid; q < Epad; q += kWG) ckeys[q] = ke[q];
     }
     const int compact_ok = (D == 2) ? 1 : !__syncthreads_or(key12_bad);    // (also the phase barrier)
     if (D == 2) __syncthreads();
@@ -183,16 +220,16 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     int M;
     {
         const int nwords = Epad / 32 + 1;
-        for (int q = tid; q < nwords; q += kWG) bm[q] = 0;
-        __syncthreads();
+        if (tid == 0 && nwords - 1 >= EPT * (kWG / 32)) bm[nwords - 1] = 0;      // the one word no ballot below covers
         uint32_t isfirst = 0;
 #pragma unroll
         for (int k = 0; k < EPT; k++) {
+            // entries tid + k*1024: a wave's 64 lanes are 64 consecutive entries = two bitmap words, written whole
             const int e = tid + k * kWG;
-            if (e < Epad && (uint32_t)tab[hs[k]] == (uint32_t)e) {
-                isfirst |= 1u << k;
-                atomicOr(&bm[e >> 5], 1u << (e & 31));
-            }
+            const bool f = e < Epad && (uint32_t)tab[hs[k]] == (uint32_t)e;
+            isfirst |= (f ? 1u : 0u) << k;
+            const unsigned long long m = __ballot(f);
+            if ((tid & 31) == 0 && (e >> 5) < nwords) bm[e >> 5] = (tid & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
         }
         // the keys of my first-occurrence entries leave the entry-indexed array before it is overwritten vertex-indexed
         ckey_t first_key[EPT];
@@ -226,12 +263,15 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     DSRG_STAMP(3);
 
     // ---- phase 4: vertex id of every real (pixel, corner) entry
+    uint16_t ev[EPT];                                     // ... kept for the CSR passes below
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
         const int e = tid + k * kWG;
+        ev[k] = 0;
         if (e < E) {
             const int i = e / D1, r = e - i * D1;
-            vid[(size_t)r * N + i] = tab[hs[k]];
+            ev[k] = tab[hs[k]];
+            vid[(size_t)r * N + i] = ev[k];
         }
     }
 
@@ -350,10 +390,9 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     int *scan2 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(csr_e) + (((size_t)E * 2 + 15) & ~(size_t)15));
     for (int v = tid; v <= Mcap; v += kWG) cnt[v] = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += kWG) {
-        const int i = e / D1, r = e - i * D1;
-        atomicAdd(&cnt[vid[(size_t)r * N + i]], 1u);
-    }
+#pragma unroll
+    for (int k = 0; k < EPT; k++)
+        if (tid + k * kWG < E) atomicAdd(&cnt[ev[k]], 1u);
     __syncthreads();
     {
         const int per = (Mcap + kWG - 1) / kWG;
@@ -372,10 +411,10 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     }
     __syncthreads();
     DSRG_STAMP(5);
-    for (int e = tid; e < E; e += kWG) {
-        const int i = e / D1, r = e - i * D1;
-        uint32_t pos = atomicAdd(&cnt[vid[(size_t)r * N + i]], 1u);
-        csr_e[pos] = (uint16_t)e;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int e = tid + k * kWG;
+        if (e < E) csr_e[atomicAdd(&cnt[ev[k]], 1u)] = (uint16_t)e;
     }
     __syncthreads();
     for (int v = tid; v < M; v += kWG) {          // cnt[v] is now the END of segment v
@@ -396,16 +435,34 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, Latti
     // exactly one entry), and the remaining entries as one compact list — rows without entries are the SSE padding's
     // phantom vertices, which were created last and therefore sit at the end of the id range, so the extras of row v start
     // at row_start[v] - v.
-    for (int pos = tid; pos < E; pos += kWG) {
-        const int e = csr_e[pos];
-        const int i = e / D1, r = e - i * D1;
-        const float w = bary[(size_t)r * N + i];
-        csr_w[pos] = w;
-        if (wl_in_lds) wl[pos] = w;
-        const int v = vid[(size_t)r * N + i];
-        const int start = v == 0 ? 0 : (int)cnt[v - 1];        // cnt[v] = END of row v
-        if (pos == start) { first_pix[v] = (uint16_t)i; first_w[v] = w; }
-        else { x_pix[pos - v - 1] = (uint16_t)i; x_w[pos - v - 1] = w; }
+    {
+        // (the weight and the vertex of every sorted entry come back from global memory: all of a thread's loads in flight
+        // before the first use — one round trip instead of one per entry)
+        float pw[EPT];
+        uint16_t pv[EPT], pi[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int pos = tid + k * kWG;
+            const int e = pos < E ? csr_e[pos] : 0;
+            const int i = e / D1, r = e - i * D1;
+            pi[k] = (uint16_t)i;
+            pw[k] = bary[(size_t)r * N + i];
+            pv[k] = vid[(size_t)r * N + i];
+        }
+        const bool keep_csr_w = !(split && D == 5);            // its only reader is the d = 2 / unsplit norm pass
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int pos = tid + k * kWG;
+            if (pos < E) {
+                const float w = pw[k];
+                const int v = pv[k], i = pi[k];
+                if (keep_csr_w) csr_w[pos] = w;
+                if (wl_in_lds) wl[pos] = w;
+                const int start = v == 0 ? 0 : (int)cnt[v - 1];        // cnt[v] = END of row v
+                if (pos == start) { first_pix[v] = (uint16_t)i; first_w[v] = w; }
+                else { x_pix[pos - v - 1] = (uint16_t)i; x_w[pos - v - 1] = w; }
+            }
+        }
     }
     {
         // rows without entries (the phantom vertices) form the tail of the id range: the first of them gives the number of
@@ -767,13 +824,13 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 static void lattice_layout(int d, int N, int nlat, size_t off[22], size_t &total) {
     const int d1 = d + 1, Npad = (N + 3) / 4 * 4, Mcap = Npad * d1, E = N * d1, Epad = Npad * d1;
     const int KW = (d * 16 + 31) / 32;
-    size_t sz[21] = {
+    size_t sz[22] = {
         sizeof(int) * (size_t)nlat,                          // M
         sizeof(uint16_t) * (size_t)E * nlat,                 // vid
         sizeof(float) * (size_t)E * nlat,                    // bary
         sizeof(uint32_t) * (size_t)d1 * Mcap * nlat,         // nb
         sizeof(uint16_t) * (size_t)(Mcap + 2) * nlat,        // row_start
-        0,                                                   // (unused slot)
+        sizeof(unsigned long long) * (size_t)Epad * nlat,    // ckeys_e
         sizeof(float) * (size_t)E * nlat,                    // csr_w
         sizeof(float) * (size_t)N * nlat,                    // norm
         sizeof(uint32_t) * (size_t)Epad * KW * nlat,         // key_e
@@ -789,9 +846,10 @@ static void lattice_layout(int d, int N, int nlat, size_t off[22], size_t &total
         sizeof(uint16_t) * (size_t)E * nlat,                 // x_pix
         sizeof(float) * (size_t)E * nlat,                    // x_w
         sizeof(int) * (size_t)nlat,                          // nextra
+        sizeof(int) * 32 * (size_t)nlat,                     // embed_bad
     };
     size_t cur = 0;
-    for (int i = 0; i < 21; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
+    for (int i = 0; i < 22; i++) { off[i] = cur; cur += align_up(sz[i], 256); }
     total = cur;
 }
 
@@ -815,6 +873,8 @@ void lattice_carve(LatticeView &L, void *base, int d, int N, int nlat) {
     L.norm = reinterpret_cast<float *>(p + off[7]);
     L.key_e = reinterpret_cast<uint32_t *>(p + off[8]);
     L.slot_e = reinterpret_cast<uint16_t *>(p + off[9]);
+    L.ckeys_e = reinterpret_cast<unsigned long long *>(p + off[5]);
+    L.embed_bad = reinterpret_cast<int *>(p + off[21]);
     L.key_v = reinterpret_cast<uint32_t *>(p + off[10]);
     L.flags = reinterpret_cast<int *>(p + off[11]);
     L.tab_g = reinterpret_cast<uint32_t *>(p + off[12]);
@@ -839,8 +899,8 @@ void lattice_feat_init(LatticeFeat &F, int d, int W, int H, float sx, float sy, 
 static size_t build_lds_bytes(int d, int N, bool with_wl = false, bool with_keys = false) {
     const int d1 = d + 1, Npad = (N + 3) / 4 * 4, Mcap = Npad * d1, E = N * d1, Epad = Npad * d1;
     const int cap = lattice_table_cap(Mcap);
-    size_t a = align_up((size_t)cap * 2 + 32 * 4 + 2 * (size_t)(Epad / 32 + 1) * 4, 8);
-    if (with_keys) a += (size_t)Mcap * (d == 5 ? 8 : 4);
+    size_t a = align_up((size_t)cap * 2 + 32 * 4 + 2 * (size_t)(Epad / 32 + 1) * 4, 16);
+    if (with_keys) a += align_up((size_t)Mcap * (d == 5 ? 8 : 4), 16);
     size_t b = align_up((size_t)(Mcap + 1) * 4, 16) + align_up((size_t)E * 2, 16) + 32 * 4;
     if (with_wl) b += (size_t)E * 4;
     return a > b ? a : b;
@@ -858,7 +918,7 @@ bool lattice_supported(int d, int N) {
     return true;
 }
 
-int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsigned char *im, int nlat,
+int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const LatticeColours &col, int nlat,
                          hipStream_t stream) {
     if (!lattice_supported(L.d, L.N))
         return set_error(DSRG_ERR_UNSUPPORTED,
@@ -877,12 +937,22 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const unsig
     // workgroups on the chip (the search is issue-bound: hashing and probing 12 neighbour keys per vertex)
     int nsplit = vpt < 8 ? 8 : vpt;
     if (240 / nlat > nsplit) nsplit = 240 / nlat < 32 ? 240 / nlat : 32;
+    {
+        const int Npad = (L.N + 3) & ~3;
+        const dim3 grid((Npad + kEmbedWG - 1) / kEmbedWG, nlat);
+        if (grid.x > 32) return set_error(DSRG_ERR_UNSUPPORTED, "map of %d pixels exceeds the embedding kernel's flag array", L.N);
+        if (L.d == 5 && !col.im_u8 && !(col.images && col.im_out))
+            return set_error(DSRG_ERR_INVALID, "bilateral lattices need an image");
+        if (L.d == 2) hipLaunchKernelGGL(lattice_embed_kernel<2>, grid, dim3(kEmbedWG), 0, stream, L, F, col);
+        else hipLaunchKernelGGL(lattice_embed_kernel<5>, grid, dim3(kEmbedWG), 0, stream, L, F, col);
+        DSRG_LAUNCH_CHECK();
+    }
 #define DSRG_BUILD(D_, V_)                                                                                    \
     do {                                                                                                      \
         static LdsGrant granted, granted_n, granted_m;                                                         \
         int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_build_kernel<D_, V_>), lds, granted); \
         if (rc) return rc;                                                                                    \
-        hipLaunchKernelGGL((lattice_build_kernel<D_, V_>), dim3(nlat), dim3(kWG), lds, stream, L, F, im, cap,  \
+        hipLaunchKernelGGL((lattice_build_kernel<D_, V_>), dim3(nlat), dim3(kWG), lds, stream, L, cap,         \
                            (int)wl_in_lds, (int)lds_keys, split, dbg);                                        \
         if (split) {                                                                                          \
             rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_neigh_kernel<D_>), neigh_lds, granted_n); \

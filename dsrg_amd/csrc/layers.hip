@@ -26,42 +26,6 @@ int launch_clip_min(float *p, size_t n, hipStream_t stream) {
     return DSRG_OK;
 }
 
-// zoom(order=1) to (H,W) with the (in-1)/(out-1) mapping, + mean pixel, np.round, astype(ubyte)
-// (pylayers.py:70-75, CRF.py:32).  images (B,3,Hi,Wi) f32 -> im (B,H*W,3) u8.
-__global__ void prepare_images_kernel(const float *__restrict__ images, int B, int Hi, int Wi, int H, int W,
-                                      unsigned char *__restrict__ im) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = H * W;
-    if (idx >= B * N) return;
-    const int b = idx / N, p = idx - b * N, y = p / W, x = p - y * W;
-    const double mean_pixel[3] = {104.0, 117.0, 123.0};
-    const double sy = H > 1 ? (double)y * (double)(Hi - 1) / (double)(H - 1) : 0.0;
-    const double sx = W > 1 ? (double)x * (double)(Wi - 1) / (double)(W - 1) : 0.0;
-    const int y0 = (int)floor(sy), x0 = (int)floor(sx);
-    const double fy = sy - y0, fx = sx - x0;
-    const int y1 = y0 + 1 < Hi ? y0 + 1 : y0, x1 = x0 + 1 < Wi ? x0 + 1 : x0;
-    for (int ch = 0; ch < 3; ch++) {
-        const float *pl = images + ((size_t)b * 3 + ch) * Hi * Wi;
-        double v;
-        if (fy == 0.0 && fx == 0.0) v = (double)pl[(size_t)y0 * Wi + x0];
-        else {
-            const double a = (1.0 - fy) * (double)pl[(size_t)y0 * Wi + x0] + fy * (double)pl[(size_t)y1 * Wi + x0];
-            const double c = (1.0 - fy) * (double)pl[(size_t)y0 * Wi + x1] + fy * (double)pl[(size_t)y1 * Wi + x1];
-            v = (1.0 - fx) * a + fx * c;
-        }
-        const float vf = (float)v;
-        const double r = rint((double)vf + mean_pixel[ch]);      // half-even, like np.round
-        im[((size_t)b * N + p) * 3 + ch] = (unsigned char)(long long)r;
-    }
-}
-int launch_prepare_images(const float *images, int B, int Hi, int Wi, int H, int W, unsigned char *im_u8,
-                          hipStream_t stream) {
-    const int threads = 256, blocks = (B * H * W + threads - 1) / threads;
-    hipLaunchKernelGGL(prepare_images_kernel, dim3(blocks), dim3(threads), 0, stream, images, B, Hi, Wi, H, W, im_u8);
-    DSRG_LAUNCH_CHECK();
-    return DSRG_OK;
-}
-
 // ---- SoftmaxLayer (pylayers.py:30-51) ----------------------------------------------------
 // forward: s = softmax_c(x); p = (s + 1e-4) / sum_c(s + 1e-4), fp32
 template <int CT>
