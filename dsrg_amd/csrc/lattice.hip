@@ -153,6 +153,9 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
     constexpr uint32_t kEmpty = 0xFFFFu;
     constexpr int EPT = VPT;                              // entries per thread (Epad <= Mcap)
     uint16_t hs[EPT];                                     // slot of my k-th entry
+    // (entry after entry: probing five entries of a thread together — table words, keys and CASes each in flight for all
+    // five — was measured at 21.4 instead of 12.6 us for this phase: every round costs the wave the work of all its lanes'
+    // pending entries, and failed CASes multiply)
     if (fast_keys) {
         ckey_t mine_k[EPT];
 #pragma unroll
@@ -464,6 +467,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
             }
         }
     }
+    DSRG_STAMP(11);
     {
         // rows without entries (the phantom vertices) form the tail of the id range: the first of them gives the number of
         // vertices with entries, hence the number of extras

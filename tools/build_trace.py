@@ -28,6 +28,9 @@ for i, nm in enumerate(names):
     dt = (t[:, i + 1] - prev) / 100.0
     print("  %-15s mean %7.2f  max %7.2f us" % (nm, dt.mean(), dt.max()))
     prev = t[:, i + 1]
+if (t[:, 11] > 0).all():
+    print("  (csr write: sorted entries -> first/extras lists %.2f us, phantom rows + extras count %.2f us)" % (
+        ((t[:, 11] - t[:, 6]) / 100.0).mean(), ((t[:, 7] - t[:, 11]) / 100.0).mean()))
 print("  total mean %.2f max %.2f us;  M:" % (((t[:, 10] - t[:, 0]) / 100.0).mean(), ((t[:, 10] - t[:, 0]) / 100.0).max()), ctx.lattice_sizes(B))
 nt = raw[64 * 16:].reshape(1024, 8)
 nt = nt[nt[:, 0] > 0]
