@@ -28,29 +28,52 @@ int launch_clip_min(float *p, size_t n, hipStream_t stream) {
 
 // ---- SoftmaxLayer (pylayers.py:30-51) ----------------------------------------------------
 // forward: s = softmax_c(x); p = (s + 1e-4) / sum_c(s + 1e-4), fp32
+// Four adjacent lanes share a pixel and split its labels (c = part, part + 4, ...): the fp64-rounded exps of a pixel no
+// longer queue up in one thread; the sums over the labels are formed in label order from shuffled terms (bit-identical
+// to one thread per pixel).
+constexpr int kSmParts = 4, kSmPix = 64;
 template <int CT>
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int C, int HW, const float *__restrict__ x,
-                                                          float *__restrict__ p, float floor_at) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * HW) return;
-    const int b = idx / HW, i = idx - b * HW;
+__global__ __launch_bounds__(kSmParts * kSmPix) void softmax_fwd_kernel(int B, int C, int HW, const float *__restrict__ x,
+                                                                         float *__restrict__ p, float floor_at) {
+    constexpr int P = kSmParts, LPP = (CT + P - 1) / P;
+    const int lane = threadIdx.x & 63, part = threadIdx.x & (P - 1), lane0 = lane & ~(P - 1);
+    const int idx = blockIdx.x * kSmPix + (threadIdx.x >> 2);
+    const bool live = idx < B * HW;
+    const int b = live ? idx / HW : 0, i = live ? idx - b * HW : 0;
     const size_t base = (size_t)b * C * HW + i;
-    float t[CT];
+    float t[LPP];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < CT; c++) t[c] = x[base + (size_t)min(c, C - 1) * HW];    // unconditional: all in flight
+    for (int k = 0; k < LPP; k++) t[k] = x[base + (size_t)min(part + k * P, C - 1) * HW];    // unconditional: all in flight
 #pragma unroll
-    for (int c = 0; c < CT; c++) { t[c] = (c < C) ? t[c] : -INFINITY; mx = fmaxf(mx, t[c]); }
+    for (int k = 0; k < LPP; k++) { t[k] = (part + k * P < C) ? t[k] : -INFINITY; mx = fmaxf(mx, t[k]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+#pragma unroll
+    for (int k = 0; k < LPP; k++) t[k] = exp_cr(t[k] - mx);
     float z = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++) { t[c] = exp_cr(t[c] - mx); z = (c < C) ? z + t[c] : z; }
+    for (int k = 0; k < LPP; k++)
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const float e = __shfl(t[k], lane0 + q, 64);
+            if (k * P + q < C) z = z + e;
+        }
     float z2 = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++) { t[c] = t[c] / z + kMinProb; z2 = (c < C) ? z2 + t[c] : z2; }
+    for (int k = 0; k < LPP; k++) t[k] = t[k] / z + kMinProb;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) p[base + (size_t)c * HW] = fmaxf(t[c] / z2, floor_at);     // floor_at = 0: the plain layer; 1e-4: the in-place
-}                                                                             // clip CRFLayer.forward applies next (pylayers.py:67)
+    for (int k = 0; k < LPP; k++)
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const float e = __shfl(t[k], lane0 + q, 64);
+            if (k * P + q < C) z2 = z2 + e;
+        }
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < LPP; k++)
+        if (part + k * P < C) p[base + (size_t)(part + k * P) * HW] = fmaxf(t[k] / z2, floor_at);   // floor_at = 0: the plain layer;
+}                                                      // 1e-4: the in-place clip CRFLayer.forward applies next (pylayers.py:67)
 // backward = T.grad(sum(probs*g), preds):  dx_j = s_j (g_j - sum_k s_k g_k) / Z,  Z = sum_c (s_c + 1e-4)
 template <int CT>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, const float *__restrict__ x,
@@ -84,7 +107,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, 
 }
 int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream, float floor_at) {
     if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
-    const int threads = 256, blocks = (B * HW + threads - 1) / threads;
+    const int threads = kSmParts * kSmPix, blocks = (B * HW + kSmPix - 1) / kSmPix;
     if (C <= 21) hipLaunchKernelGGL(softmax_fwd_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p, floor_at);
     else hipLaunchKernelGGL(softmax_fwd_kernel<kMaxLabels>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p, floor_at);
     DSRG_LAUNCH_CHECK();
@@ -288,10 +311,14 @@ __global__ __launch_bounds__(1024) void sup_stats_kernel(int C, int HW, const fl
     if (threadIdx.x == 0)
         for (int k = 0; k < 5; k++) stats[((size_t)b * kStatSplit + part) * 5 + k] = st[k];
 }
-// stage 2: per pixel: total gradient wrt the (clipped) softmax blob, then SoftmaxLayer.backward;
-// thread 0 of block 0 also finalises the two loss scalars in image order.
+// stage 2: per pixel: total gradient wrt the (clipped) softmax blob, then SoftmaxLayer.backward.  kGradParts adjacent lanes
+// share a pixel and split its labels (c = part, part + 4, ...): a thread per pixel walked 21 fp64-rounded exps, logs and
+// 105 loads alone, and 26 896 such threads fill a tenth of the chip (20.5 us).  Every sum over the labels is still formed in
+// label order (each lane of the pixel repeats it from shuffled terms), so the result is the one-thread result bit for bit.
+// Block 0 also finalises the two loss scalars: per-image terms in parallel, their sum in image order.
+constexpr int kGradParts = 4, kGradPix = 64;
 template <int CT>
-__global__ __launch_bounds__(256) void sup_grad_kernel(int B, int C, int HW, const float *__restrict__ logits,
+__global__ __launch_bounds__(kGradParts * kGradPix) void sup_grad_kernel(int B, int C, int HW, const float *__restrict__ logits,
                                                        const float *__restrict__ probs,
                                                        const float *__restrict__ seeds,
                                                        const float *__restrict__ logq,
@@ -299,70 +326,91 @@ __global__ __launch_bounds__(256) void sup_grad_kernel(int B, int C, int HW, con
                                                        const double *__restrict__ stats,
                                                        float *__restrict__ grad_logits,
                                                        float *__restrict__ losses) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0) {
-        double ls = 0.0, lc = 0.0;
-        for (int b = 0; b < B; b++) {
-            double st[5] = {0, 0, 0, 0, 0};
-            for (int part = 0; part < kStatSplit; part++)
-                for (int k = 0; k < 5; k++) st[k] += stats[((size_t)b * kStatSplit + part) * 5 + k];
-            const double dbg = st[0] > 1e-4 ? st[0] : 1e-4, dfg = st[1] > 1e-4 ? st[1] : 1e-4;
-            ls += -(st[2] / dbg) / B - (st[3] / dfg) / B;
-            lc += st[4];
-        }
-        losses[0] = (float)ls;
-        losses[1] = (float)(lc / ((double)B * (double)HW));
-    }
-    if (idx >= B * HW) return;
-    const int b = idx / HW, i = idx - b * HW;
+    constexpr int P = kGradParts, LPP = (CT + P - 1) / P;       // labels per part
+    const int lane = threadIdx.x & 63, part = threadIdx.x & (P - 1), lane0 = lane & ~(P - 1);
+    const int idx = blockIdx.x * kGradPix + (threadIdx.x >> 2);
+    const bool live = idx < B * HW;
+    const int b = live ? idx / HW : 0, i = live ? idx - b * HW : 0;
     const size_t base = (size_t)b * C * HW + i;
+    // loads first: everything this lane will need, unconditionally (clamped label index)
+    float s[LPP], pv[LPP], lq[LPP], sd[LPP];
+    double rf[LPP];
+#pragma unroll
+    for (int t = 0; t < LPP; t++) {
+        const size_t o = base + (size_t)min(part + t * P, C - 1) * HW;
+        s[t] = logits[o]; pv[t] = probs[o]; lq[t] = logq[o]; sd[t] = seeds[o]; rf[t] = refined[o];
+    }
     double cnt_bg = 0.0, cnt_fg = 0.0;
-    for (int part = 0; part < kStatSplit; part++) {
-        cnt_bg += stats[((size_t)b * kStatSplit + part) * 5 + 0];
-        cnt_fg += stats[((size_t)b * kStatSplit + part) * 5 + 1];
+    for (int sp = 0; sp < kStatSplit; sp++) {
+        cnt_bg += stats[((size_t)b * kStatSplit + sp) * 5 + 0];
+        cnt_fg += stats[((size_t)b * kStatSplit + sp) * 5 + 1];
+    }
+    if (blockIdx.x == 0) {
+        __shared__ double term_s[kGradParts * kGradPix], term_c[kGradParts * kGradPix];
+        double ls = 0.0, lc = 0.0;
+        for (int b0 = 0; b0 < B; b0 += kGradParts * kGradPix) {
+            const int bb = b0 + (int)threadIdx.x;
+            if (bb < B) {
+                double st[5] = {0, 0, 0, 0, 0};
+                for (int sp = 0; sp < kStatSplit; sp++)
+                    for (int k = 0; k < 5; k++) st[k] += stats[((size_t)bb * kStatSplit + sp) * 5 + k];
+                const double dbg = st[0] > 1e-4 ? st[0] : 1e-4, dfg = st[1] > 1e-4 ? st[1] : 1e-4;
+                term_s[threadIdx.x] = -(st[2] / dbg) / B - (st[3] / dfg) / B;
+                term_c[threadIdx.x] = st[4];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int k = 0; k < min(kGradParts * kGradPix, B - b0); k++) { ls += term_s[k]; lc += term_c[k]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            losses[0] = (float)ls;
+            losses[1] = (float)(lc / ((double)B * (double)HW));
+        }
     }
     const float dbg = (float)(cnt_bg > 1e-4 ? cnt_bg : 1e-4), dfg = (float)(cnt_fg > 1e-4 ? cnt_fg : 1e-4);
     const float inv = (float)(1.0 / ((double)B * (double)HW));
-    float s[CT], g[CT];
     float mx = -INFINITY;
-    // two passes over the labels, each with its loads issued unconditionally up front
 #pragma unroll
-    for (int c = 0; c < CT; c++) s[c] = logits[base + (size_t)min(c, C - 1) * HW];
+    for (int t = 0; t < LPP; t++) { s[t] = (part + t * P < C) ? s[t] : -INFINITY; mx = fmaxf(mx, s[t]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float g[LPP];
 #pragma unroll
-    for (int c = 0; c < CT; c++) { s[c] = (c < C) ? s[c] : -INFINITY; mx = fmaxf(mx, s[c]); }
-    float z = 0.0f;
-#pragma unroll
-    for (int c = 0; c < CT; c++) { s[c] = exp_cr(s[c] - mx); z = (c < C) ? z + s[c] : z; }
-    {
-        float pv[CT], lq[CT], sd[CT];
-        double rf[CT];
-#pragma unroll
-        for (int c = 0; c < CT; c++) {
-            const size_t o = base + (size_t)min(c, C - 1) * HW;
-            pv[c] = probs[o];
-            lq[c] = logq[o];
-            sd[c] = seeds[o];
-            rf[c] = refined[o];
-        }
-#pragma unroll
-        for (int c = 0; c < CT; c++) {
-            // BalancedSeedLoss.backward + ConstrainLoss.backward[0] + CRFLayer.backward(ConstrainLoss.backward[1])
-            float dp, dlq;
-            constrain_term(pv[c], lq[c], dp, dlq);
-            const float gseed = -sd[c] / (pv[c] * (c == 0 ? dbg : dfg) * (float)B);
-            const float gcrf = (float)((1.0 - rf[c]) * (double)(dlq * inv));
-            g[c] = gseed + dp * inv + gcrf;
-        }
+    for (int t = 0; t < LPP; t++) {
+        const int c = part + t * P;
+        s[t] = exp_cr(s[t] - mx);
+        // BalancedSeedLoss.backward + ConstrainLoss.backward[0] + CRFLayer.backward(ConstrainLoss.backward[1])
+        float dp, dlq;
+        constrain_term(pv[t], lq[t], dp, dlq);
+        const float gseed = -sd[t] / (pv[t] * (c == 0 ? dbg : dfg) * (float)B);
+        const float gcrf = (float)((1.0 - rf[t]) * (double)(dlq * inv));
+        g[t] = gseed + dp * inv + gcrf;
     }
+    float z = 0.0f;                                  // label-order sums: term c comes from lane part c % 4, slot c / 4
+#pragma unroll
+    for (int t = 0; t < LPP; t++)
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const float e = __shfl(s[t], lane0 + q, 64);
+            if (t * P + q < C) z = z + e;
+        }
     float Z = 0.0f, sg = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CT; c++) {
-        s[c] = s[c] / z;
-        if (c < C) { Z += s[c] + kMinProb; sg += s[c] * g[c]; }
-    }
+    for (int t = 0; t < LPP; t++) s[t] = s[t] / z;
 #pragma unroll
-    for (int c = 0; c < CT; c++)
-        if (c < C) grad_logits[base + (size_t)c * HW] = s[c] * (g[c] - sg) / Z;
+    for (int t = 0; t < LPP; t++)
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const float sv = __shfl(s[t], lane0 + q, 64), pr = __shfl(s[t] * g[t], lane0 + q, 64);
+            if (t * P + q < C) { Z += sv + kMinProb; sg += pr; }
+        }
+    if (!live) return;
+#pragma unroll
+    for (int t = 0; t < LPP; t++) {
+        const int c = part + t * P;
+        if (c < C) grad_logits[base + (size_t)c * HW] = s[t] * (g[t] - sg) / Z;
+    }
 }
 int launch_sup_loss_backward(int B, int C, int HW, const float *logits, const float *probs, const float *seeds,
                              const float *logq, const double *refined, double *stats, float *grad_logits,
@@ -370,7 +418,7 @@ int launch_sup_loss_backward(int B, int C, int HW, const float *logits, const fl
     if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
     hipLaunchKernelGGL(sup_stats_kernel, dim3(B * kStatSplit), dim3(1024), 0, stream, C, HW, probs, seeds, logq, stats);
     DSRG_LAUNCH_CHECK();
-    const int threads = 256, blocks = (B * HW + threads - 1) / threads;
+    const int threads = kGradParts * kGradPix, blocks = (B * HW + kGradPix - 1) / kGradPix;
     if (C <= 21)
         hipLaunchKernelGGL(sup_grad_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, logits, probs, seeds,
                            logq, refined, stats, grad_logits, losses);
