@@ -494,7 +494,11 @@ __global__ void im2col3x3_nhwc16_kernel(const uint4 *__restrict__ in, uint4 *__r
     const int yy = y + (tap / 3 - 1) * dil, xx = x + (tap % 3 - 1) * dil;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[(((size_t)b * H + yy) * W + xx) * C8 + c];
-    out[idx] = v;
+    // nontemporal: the patch matrix (248 MB for a 41x41x512 layer at batch 16) is far larger than the L2s and is read once by
+    // the GEMM that follows; keeping it out of them left the train step 1.5 % faster (1 200 -> 1 219 img/s)
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u4 *>(out) + idx);
 }
 // adjoint of the im2col above: out[b,y,x,:] = sum over the 9 taps of cols[(b, y - dy*dil, x - dx*dil), tap, :] for the source
 // pixels that exist (dy, dx in {-1,0,1}); cols is (B*H*W, 9*C) 2-byte bf16, sums in f32.  Used for the data gradient of a
