@@ -345,7 +345,8 @@ def filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead_ms):
     counters = None
     cj = _load_json("r03_lds_counters.json")
     if cj:
-        ck = [v for k, v in cj.get("kernels", {}).items() if "mf_filter_kernel" in k]
+        ck = sorted((v for k, v in cj.get("kernels", {}).items() if "mf_filter_kernel" in k),
+                    key=lambda v: -v.get("launches", 0))          # the loop's instantiation, not the build's norm pass
         if ck:
             counters = {k: ck[0].get(k) for k in ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS",
                                                   "SQ_WAVE_CYCLES", "lds_conflict_share", "avg_duration_us_under_pmc")}

@@ -206,13 +206,13 @@ static LatticeColours colours_float(dsrg_ctx_t c, const float *images, int img_h
 // build lattices for B images (unless prepared), then run the mean field
 static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const LatticeColours &col,
                    const dsrg_crf_params *prm, float *q_out, double *refined, float *logq, hipStream_t s,
-                   bool prepared = false) {
+                   bool prepared = false, bool q0_ready = false) {
     if (!prepared) {
         int rc = crf_build(c, B, col, prm, s);
         if (rc) return rc;
     }
     return launch_meanfield(c->Lg, c->Lb, c->mf, B, c->C, neg_unary, prm->w_gaussian, prm->w_bilateral,
-                            prm->n_iters, q_out, refined, logq, c->gauss_local == 1, s, &c->prof);
+                            prm->n_iters, q_out, refined, logq, c->gauss_local == 1, s, &c->prof, q0_ready);
 }
 
 extern "C" int dsrg_crf_prepare_batch(dsrg_ctx_t c, int B, const float *images, int img_h, int img_w,
@@ -523,10 +523,12 @@ extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, c
     const size_t nb = sizeof(float) * (size_t)B * C * N;
     // Softmax, with the in-place clip CRFLayer.forward applies to this blob next (pylayers.py:67) folded into the same pass:
     // the unclipped blob has no other reader (A.3: both losses read it after the CRF layer ran)
-    int rc = launch_softmax_fwd(B, C, N, logits, c->probs, s, kMinProb);
+    // ... and with the mean field's starting point Q0 = expAndNormalize(probs) (the unary energy is -probs, CRF.py:28)
+    const bool q0 = prm->n_iters > 0;
+    int rc = launch_softmax_fwd(B, C, N, logits, c->probs, s, kMinProb, q0 ? c->mf.q : nullptr);
     if (rc) return rc;
     // CRF (once); the images are resampled (pylayers.py:70-75) by the lattices' embedding kernel
-    rc = crf_run(c, B, c->probs, colours_float(c, images, img_h, img_w), prm, nullptr, c->refined, c->logq, s, prepared);
+    rc = crf_run(c, B, c->probs, colours_float(c, images, img_h, img_w), prm, nullptr, c->refined, c->logq, s, prepared, q0);
     if (prepared) c->prepared_B = 0;                                               // consumed
     if (rc) return rc;
     rc = launch_srg(B, C, c->H, c->W, labels, cues, c->refined, th1, th2, c->seeds, c->srg_code, s);    // DSRG

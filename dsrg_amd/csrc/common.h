@@ -131,7 +131,8 @@ struct Profiler {
 // the filter launches; without that knowledge they are launched and exit on the device-side flag)
 int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C,
                      const float *neg_unary, float wg, float wb, int n_iters, float *q_out,
-                     double *refined_out, float *logq_out, bool gauss_local, hipStream_t stream, Profiler *prof = nullptr);
+                     double *refined_out, float *logq_out, bool gauss_local, hipStream_t stream, Profiler *prof = nullptr,
+                     bool q0_ready = false);     // q0_ready: buf.q already holds Q0 = expAndNormalize(neg_unary) (n_iters > 0)
 int launch_lattice_norm_pass(const LatticeView &L, int nlat, hipStream_t stream);      // meanfield.hip; d = 5 lattices
 int launch_filter_once(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C, int kind,
                        const float *q_in, float *out, bool gauss_local, hipStream_t stream);
@@ -139,7 +140,9 @@ int launch_filter_once(const LatticeView &Lg, const LatticeView &Lb, const Meanf
 // ---- pointwise / prep ----------------------------------------------------------------
 int launch_clip_min(float *p, size_t n, hipStream_t stream);
 
-int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream, float floor_at = 0.0f);
+// q0 (optional): also write expAndNormalize(p), the mean field's starting point when the unary energy is -p (CRF.py:28)
+int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream, float floor_at = 0.0f,
+                       float *q0 = nullptr);
 int launch_softmax_bwd(int B, int C, int HW, const float *x, const float *g, float *dx, hipStream_t stream);
 int launch_crf_bwd(size_t n, const double *refined, const float *td, float *bd, hipStream_t stream);
 int launch_seed_loss(int B, int C, int HW, const float *p, const float *S, float *loss, float *grad,

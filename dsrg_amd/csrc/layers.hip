@@ -34,7 +34,8 @@ int launch_clip_min(float *p, size_t n, hipStream_t stream) {
 constexpr int kSmParts = 4, kSmPix = 64;
 template <int CT>
 __global__ __launch_bounds__(kSmParts * kSmPix) void softmax_fwd_kernel(int B, int C, int HW, const float *__restrict__ x,
-                                                                         float *__restrict__ p, float floor_at) {
+                                                                         float *__restrict__ p, float floor_at,
+                                                                         float *__restrict__ q0) {
     constexpr int P = kSmParts, LPP = (CT + P - 1) / P;
     const int lane = threadIdx.x & 63, part = threadIdx.x & (P - 1), lane0 = lane & ~(P - 1);
     const int idx = blockIdx.x * kSmPix + (threadIdx.x >> 2);
@@ -69,11 +70,35 @@ __global__ __launch_bounds__(kSmParts * kSmPix) void softmax_fwd_kernel(int B, i
             const float e = __shfl(t[k], lane0 + q, 64);
             if (k * P + q < C) z2 = z2 + e;
         }
-    if (!live) return;
+    // floor_at = 0: the plain layer; 1e-4: the in-place clip CRFLayer.forward applies next (pylayers.py:67)
+#pragma unroll
+    for (int k = 0; k < LPP; k++) t[k] = fmaxf(t[k] / z2, floor_at);
 #pragma unroll
     for (int k = 0; k < LPP; k++)
-        if (part + k * P < C) p[base + (size_t)(part + k * P) * HW] = fmaxf(t[k] / z2, floor_at);   // floor_at = 0: the plain layer;
-}                                                      // 1e-4: the in-place clip CRFLayer.forward applies next (pylayers.py:67)
+        if (live && part + k * P < C) p[base + (size_t)(part + k * P) * HW] = t[k];
+    if (q0) {
+        // the mean field's starting point Q0 = expAndNormalize(-unary) (densecrf.cpp:120; the unary energy is minus this blob,
+        // CRF.py:28) in mf_update_split_kernel's arithmetic: column maximum, fp64-rounded exp, label-order sum, division
+        float m2 = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < LPP; k++) m2 = fmaxf(m2, (part + k * P < C) ? t[k] : -INFINITY);
+        m2 = fmaxf(m2, __shfl_xor(m2, 1, 64));
+        m2 = fmaxf(m2, __shfl_xor(m2, 2, 64));
+#pragma unroll
+        for (int k = 0; k < LPP; k++) t[k] = exp_cr(((part + k * P < C) ? t[k] : -INFINITY) - m2);
+        float s2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LPP; k++)
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                const float e = __shfl(t[k], lane0 + q, 64);
+                if (k * P + q < C) s2 = s2 + e;
+            }
+#pragma unroll
+        for (int k = 0; k < LPP; k++)
+            if (live && part + k * P < C) q0[base + (size_t)(part + k * P) * HW] = t[k] / s2;
+    }
+}
 // backward = T.grad(sum(probs*g), preds):  dx_j = s_j (g_j - sum_k s_k g_k) / Z,  Z = sum_c (s_c + 1e-4)
 template <int CT>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, const float *__restrict__ x,
@@ -105,11 +130,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int C, int HW, 
     for (int c = 0; c < CT; c++)
         if (c < C) dx[base + (size_t)c * HW] = s[c] * (gg[c] - sg) / Z;
 }
-int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream, float floor_at) {
+int launch_softmax_fwd(int B, int C, int HW, const float *x, float *p, hipStream_t stream, float floor_at, float *q0) {
     if (C < 1 || C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "1 <= C <= %d required", kMaxLabels);
     const int threads = kSmParts * kSmPix, blocks = (B * HW + kSmPix - 1) / kSmPix;
-    if (C <= 21) hipLaunchKernelGGL(softmax_fwd_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p, floor_at);
-    else hipLaunchKernelGGL(softmax_fwd_kernel<kMaxLabels>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p, floor_at);
+    if (C <= 21) hipLaunchKernelGGL(softmax_fwd_kernel<21>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p, floor_at, q0);
+    else hipLaunchKernelGGL(softmax_fwd_kernel<kMaxLabels>, dim3(blocks), dim3(threads), 0, stream, B, C, HW, x, p, floor_at, q0);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

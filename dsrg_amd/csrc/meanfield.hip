@@ -818,7 +818,7 @@ static int run_filter(const FilterPlan &P, hipStream_t stream, Profiler *prof) {
 
 int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C,
                      const float *neg_unary, float wg, float wb, int n_iters, float *q_out,
-                     double *refined_out, float *logq_out, bool gauss_local, hipStream_t stream, Profiler *prof) {
+                     double *refined_out, float *logq_out, bool gauss_local, hipStream_t stream, Profiler *prof, bool q0_ready) {
     FilterPlan P;
     int rc = plan_filter(Lg, Lb, buf, B, C, gauss_local, P);
     if (rc) return rc;
@@ -826,10 +826,12 @@ int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const Meanfie
     loc.la = reinterpret_cast<const float4 *>(Lg.loc_a); loc.lz = Lg.loc_z;
     loc.flags = (P.a.opts & kOptLocalGauss) ? Lg.flags : nullptr;
     const int N = Lb.N;
-    // Q0 = expAndNormalize(-unary)   (densecrf.cpp:120)
-    rc = launch_update(neg_unary, buf, loc, wg, wb, 0, n_iters > 0 ? buf.q : q_out,
-                       n_iters > 0 ? nullptr : refined_out, n_iters > 0 ? nullptr : logq_out, B, C, N, stream);
-    if (rc) return rc;
+    // Q0 = expAndNormalize(-unary)   (densecrf.cpp:120); the fused step's softmax pass has written it already
+    if (!(q0_ready && n_iters > 0)) {
+        rc = launch_update(neg_unary, buf, loc, wg, wb, 0, n_iters > 0 ? buf.q : q_out,
+                           n_iters > 0 ? nullptr : refined_out, n_iters > 0 ? nullptr : logq_out, B, C, N, stream);
+        if (rc) return rc;
+    }
     for (int it = 0; it < n_iters; it++) {
         rc = run_filter(P, stream, prof);
         if (rc) return rc;

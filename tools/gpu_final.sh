@@ -20,6 +20,7 @@ python tools/rocpd_stats.py $OUT/sup_results.db 40 20 sup_grad_kernel > $OUT/sup
 python tools/rocpd_stats.py $OUT/fr_results.db 40 > $OUT/fullres_kernel_stats.txt 2>&1
 bash tools/gpu_pmc.sh $OUT/pmc sup_fetch sup_write sup_lds fr_fetch fr_write train_mfma
 for B in 16 1; do python tools/sup_graph_probe.py $B 2>&1 | grep -v amdgpu; done > $OUT/probe.txt
+{ timeout 400 python tools/parity_sweep.py 30; timeout 400 python tools/parity_sweep_crf.py 60; timeout 600 python tools/parity_sweep_shapes.py 40; } 2>&1 | grep -v amdgpu > $OUT/parity_sweeps.txt
 python tools/filter_trace.py 16 2>&1 | grep -v amdgpu > $OUT/filter_trace.txt
 python tools/build_trace.py 16 2>&1 | grep -v amdgpu > $OUT/build_trace.txt
-head -3 $OUT/train_kernel_stats.txt | cut -c1-200; cat $OUT/probe.txt
+head -3 $OUT/train_kernel_stats.txt | cut -c1-200; cat $OUT/probe.txt; tail -12 $OUT/parity_sweeps.txt
