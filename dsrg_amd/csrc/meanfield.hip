@@ -770,7 +770,11 @@ static int plan_filter(const LatticeView &Lg, const LatticeView &Lb, const Meanf
     // planes per block: bilateral 2 (8-byte LDS gathers) and Gaussian 4 (16-byte) when LDS holds them and
     // the batch is large enough to still fill the chip; otherwise narrower blocks
     int cpw_b = 1, cpw_g = 1;
-    if (lds_for(2, 4) <= kLds && (size_t)B * ((C + 1) / 2) >= 64 && C > 2) { cpw_b = 2; cpw_g = 4; }
+    // (with the Gaussian workgroups out of the launch, one-plane bilateral workgroups still make ONE round of MI355X's 256 CUs
+    // up to 12 images of 21 labels, and a one-plane workgroup is the shorter one: measured 14.1 / 14.3 us per launch at 8 / 12
+    // images against 16.8-17.4 / 16.3-16.5 with plane pairs)
+    const bool one_round_of_single_planes = gauss_local && (filter_opts() & kOptLocalGauss) && (size_t)B * C <= 256;
+    if (lds_for(2, 4) <= kLds && (size_t)B * ((C + 1) / 2) >= 64 && C > 2 && !one_round_of_single_planes) { cpw_b = 2; cpw_g = 4; }
     else if (lds_for(1, 2) <= kLds && C > 2) { cpw_b = 1; cpw_g = 2; }
     else if (lds_for(1, 1) > 158 * 1024) return set_error(DSRG_ERR_UNSUPPORTED, "lattice does not fit LDS");
     const int vpt = (Lb.Mcap + kWG - 1) / kWG;
