@@ -96,6 +96,126 @@ __global__ __launch_bounds__(kEmbedWG) void lattice_embed_kernel(LatticeView L, 
     if (threadIdx.x == 0) L.embed_bad[(size_t)b * 32 + blockIdx.x] = any;
 }
 
+// ---------------------------------------------------------------------------------
+// CSR of the splat, contributions in reference order (entry index ascending), and from it the filter kernel's first-term /
+// extras lists.  One 1024-thread workgroup per lattice; `ev` = the vertex id of the thread's entries tid + k*1024.  Runs
+// inside lattice_build_kernel when the build is one kernel, and as ONE EXTRA workgroup per lattice of the neighbour-search
+// launch when it is split: neither stage needs the other's result, and the single-workgroup build was 44 us with it.
+template <int D, int EPT>
+__device__ __forceinline__ void lattice_csr_phase(const LatticeView &L, int b, int M, unsigned char *smem,
+                                                  const uint16_t (&ev)[EPT], int wl_in_lds, int split,
+                                                  unsigned long long *dbg) {
+#define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[(size_t)b * 16 + (i_)] = wall_clock64(); } while (0)
+    constexpr int D1 = D + 1;
+    const int tid = threadIdx.x;
+    const int N = L.N, E = N * D1, Mcap = L.Mcap;
+    const uint16_t *vid = L.vid + (size_t)b * D1 * N;
+    const float *bary = L.bary + (size_t)b * D1 * N;
+    uint16_t *row_start = L.row_start + (size_t)b * (Mcap + 2);
+    float *csr_w = L.csr_w + (size_t)b * E;
+    uint16_t *first_pix = L.first_pix + (size_t)b * Mcap, *x_pix = L.x_pix + (size_t)b * E;
+    float *first_w = L.first_w + (size_t)b * Mcap, *x_w = L.x_w + (size_t)b * E;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                       // [Mcap+1]
+    uint16_t *csr_e = reinterpret_cast<uint16_t *>(smem + (((size_t)(Mcap + 1) * 4 + 15) & ~(size_t)15));   // [E]
+    int *scan2 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(csr_e) + (((size_t)E * 2 + 15) & ~(size_t)15));
+    for (int v = tid; v <= Mcap; v += kWG) cnt[v] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; k++)
+        if (tid + k * kWG < E) atomicAdd(&cnt[ev[k]], 1u);
+    __syncthreads();
+    {
+        const int per = (Mcap + kWG - 1) / kWG;
+        const int v0 = tid * per, v1 = min(v0 + per, M);
+        int local = 0;
+        for (int v = v0; v < v1; v++) local += (int)cnt[v];
+        int tot;
+        int run = block_exclusive_scan(local, scan2, &tot);
+        for (int v = v0; v < v1; v++) {
+            int c = (int)cnt[v];
+            cnt[v] = (uint32_t)run;
+            row_start[v] = (uint16_t)run;
+            run += c;
+        }
+        if (tid == 0) row_start[M] = (uint16_t)E;
+    }
+    __syncthreads();
+    DSRG_STAMP(5);
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int e = tid + k * kWG;
+        if (e < E) csr_e[atomicAdd(&cnt[ev[k]], 1u)] = (uint16_t)e;
+    }
+    __syncthreads();
+    for (int v = tid; v < M; v += kWG) {          // cnt[v] is now the END of segment v
+        const int s = v == 0 ? 0 : (int)cnt[v - 1], t = (int)cnt[v];
+        for (int a = s + 1; a < t; a++) {         // insertion sort, segments are short
+            uint16_t x = csr_e[a];
+            int c = a - 1;
+            while (c >= s && csr_e[c] > x) { csr_e[c + 1] = csr_e[c]; c--; }
+            csr_e[c + 1] = x;
+        }
+    }
+    __syncthreads();
+    DSRG_STAMP(6);
+    // weights of the sorted entries: to HBM for the filter kernel, and (when it fits) to LDS for the
+    // norm pass below
+    float *wl = wl_in_lds ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(scan2) + 32 * 4) : csr_w;
+    // The filter kernel's view of the same lists: the FIRST contributor of every vertex, vertex-indexed (most rows have
+    // exactly one entry), and the remaining entries as one compact list — rows without entries are the SSE padding's
+    // phantom vertices, which were created last and therefore sit at the end of the id range, so the extras of row v start
+    // at row_start[v] - v.
+    {
+        // (the weight and the vertex of every sorted entry come back from global memory: all of a thread's loads in flight
+        // before the first use — one round trip instead of one per entry)
+        float pw[EPT];
+        uint16_t pv[EPT], pi[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int pos = tid + k * kWG;
+            const int e = pos < E ? csr_e[pos] : 0;
+            const int i = e / D1, r = e - i * D1;
+            pi[k] = (uint16_t)i;
+            pw[k] = bary[(size_t)r * N + i];
+            pv[k] = vid[(size_t)r * N + i];
+        }
+        const bool keep_csr_w = !(split && D == 5);            // its only reader is the d = 2 / unsplit norm pass
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int pos = tid + k * kWG;
+            if (pos < E) {
+                const float w = pw[k];
+                const int v = pv[k], i = pi[k];
+                if (keep_csr_w) csr_w[pos] = w;
+                if (wl_in_lds) wl[pos] = w;
+                const int start = v == 0 ? 0 : (int)cnt[v - 1];        // cnt[v] = END of row v
+                if (pos == start) { first_pix[v] = (uint16_t)i; first_w[v] = w; }
+                else { x_pix[pos - v - 1] = (uint16_t)i; x_w[pos - v - 1] = w; }
+            }
+        }
+    }
+    DSRG_STAMP(11);
+    {
+        // rows without entries (the phantom vertices) form the tail of the id range: the first of them gives the number of
+        // vertices with entries, hence the number of extras
+        int *first_empty = scan2;                              // (the scan scratch is free here)
+        if (tid == 0) *first_empty = M;
+        __syncthreads();
+        for (int v = tid; v < M; v += kWG) {
+            const int start = v == 0 ? 0 : (int)cnt[v - 1];
+            if ((int)cnt[v] == start) {                        // phantom vertex: contributes an exact 0
+                first_pix[v] = 0; first_w[v] = 0.0f;
+                atomicMin(first_empty, v);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) L.nextra[b] = E - *first_empty;
+    }
+    __syncthreads();
+    DSRG_STAMP(7);
+#undef DSRG_STAMP
+}
+
 template <int D, int VPT>   // VPT >= ceil(Mcap / 1024): vertices (and entries) per thread
 __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int cap,
                                                               int wl_in_lds, int lds_keys, int split, unsigned long long *dbg) {
@@ -118,11 +238,8 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
     uint16_t *vid = L.vid + (size_t)b * D1 * N;
     float *bary = L.bary + (size_t)b * D1 * N;
     uint32_t *nb = L.nb + (size_t)b * D1 * Mcap;
-    uint16_t *row_start = L.row_start + (size_t)b * (Mcap + 2);
     float *csr_w = L.csr_w + (size_t)b * E;
     float *norm = L.norm + (size_t)b * N;
-    uint16_t *first_pix = L.first_pix + (size_t)b * Mcap, *x_pix = L.x_pix + (size_t)b * E;
-    float *first_w = L.first_w + (size_t)b * Mcap, *x_w = L.x_w + (size_t)b * E;
     uint32_t *key_e = L.key_e + (size_t)b * Epad * KW;
     uint32_t *key_v = L.key_v + (size_t)b * Mcap * KW;
 
@@ -387,105 +504,13 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
     }
     DSRG_STAMP(4);
 
-    // ---- phase 6: CSR of the splat, contributions in reference order (entry index ascending)
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                       // [Mcap+1]
+    // ---- phase 6: CSR of the splat (lattice_csr_phase).  In a split build it runs beside the neighbour search instead.
+    if (split) { DSRG_STAMP(10); return; }
+    lattice_csr_phase<D, EPT>(L, b, M, smem, ev, wl_in_lds, split, dbg);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                       // [Mcap+1] (now the END of every row)
     uint16_t *csr_e = reinterpret_cast<uint16_t *>(smem + (((size_t)(Mcap + 1) * 4 + 15) & ~(size_t)15));   // [E]
     int *scan2 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(csr_e) + (((size_t)E * 2 + 15) & ~(size_t)15));
-    for (int v = tid; v <= Mcap; v += kWG) cnt[v] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < EPT; k++)
-        if (tid + k * kWG < E) atomicAdd(&cnt[ev[k]], 1u);
-    __syncthreads();
-    {
-        const int per = (Mcap + kWG - 1) / kWG;
-        const int v0 = tid * per, v1 = min(v0 + per, M);
-        int local = 0;
-        for (int v = v0; v < v1; v++) local += (int)cnt[v];
-        int tot;
-        int run = block_exclusive_scan(local, scan2, &tot);
-        for (int v = v0; v < v1; v++) {
-            int c = (int)cnt[v];
-            cnt[v] = (uint32_t)run;
-            row_start[v] = (uint16_t)run;
-            run += c;
-        }
-        if (tid == 0) row_start[M] = (uint16_t)E;
-    }
-    __syncthreads();
-    DSRG_STAMP(5);
-#pragma unroll
-    for (int k = 0; k < EPT; k++) {
-        const int e = tid + k * kWG;
-        if (e < E) csr_e[atomicAdd(&cnt[ev[k]], 1u)] = (uint16_t)e;
-    }
-    __syncthreads();
-    for (int v = tid; v < M; v += kWG) {          // cnt[v] is now the END of segment v
-        const int s = v == 0 ? 0 : (int)cnt[v - 1], t = (int)cnt[v];
-        for (int a = s + 1; a < t; a++) {         // insertion sort, segments are short
-            uint16_t x = csr_e[a];
-            int c = a - 1;
-            while (c >= s && csr_e[c] > x) { csr_e[c + 1] = csr_e[c]; c--; }
-            csr_e[c + 1] = x;
-        }
-    }
-    __syncthreads();
-    DSRG_STAMP(6);
-    // weights of the sorted entries: to HBM for the filter kernel, and (when it fits) to LDS for the
-    // norm pass below
     float *wl = wl_in_lds ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(scan2) + 32 * 4) : csr_w;
-    // The filter kernel's view of the same lists: the FIRST contributor of every vertex, vertex-indexed (most rows have
-    // exactly one entry), and the remaining entries as one compact list — rows without entries are the SSE padding's
-    // phantom vertices, which were created last and therefore sit at the end of the id range, so the extras of row v start
-    // at row_start[v] - v.
-    {
-        // (the weight and the vertex of every sorted entry come back from global memory: all of a thread's loads in flight
-        // before the first use — one round trip instead of one per entry)
-        float pw[EPT];
-        uint16_t pv[EPT], pi[EPT];
-#pragma unroll
-        for (int k = 0; k < EPT; k++) {
-            const int pos = tid + k * kWG;
-            const int e = pos < E ? csr_e[pos] : 0;
-            const int i = e / D1, r = e - i * D1;
-            pi[k] = (uint16_t)i;
-            pw[k] = bary[(size_t)r * N + i];
-            pv[k] = vid[(size_t)r * N + i];
-        }
-        const bool keep_csr_w = !(split && D == 5);            // its only reader is the d = 2 / unsplit norm pass
-#pragma unroll
-        for (int k = 0; k < EPT; k++) {
-            const int pos = tid + k * kWG;
-            if (pos < E) {
-                const float w = pw[k];
-                const int v = pv[k], i = pi[k];
-                if (keep_csr_w) csr_w[pos] = w;
-                if (wl_in_lds) wl[pos] = w;
-                const int start = v == 0 ? 0 : (int)cnt[v - 1];        // cnt[v] = END of row v
-                if (pos == start) { first_pix[v] = (uint16_t)i; first_w[v] = w; }
-                else { x_pix[pos - v - 1] = (uint16_t)i; x_w[pos - v - 1] = w; }
-            }
-        }
-    }
-    DSRG_STAMP(11);
-    {
-        // rows without entries (the phantom vertices) form the tail of the id range: the first of them gives the number of
-        // vertices with entries, hence the number of extras
-        int *first_empty = scan2;                              // (the scan scratch is free here)
-        if (tid == 0) *first_empty = M;
-        __syncthreads();
-        for (int v = tid; v < M; v += kWG) {
-            const int start = v == 0 ? 0 : (int)cnt[v - 1];
-            if ((int)cnt[v] == start) {                        // phantom vertex: contributes an exact 0
-                first_pix[v] = 0; first_w[v] = 0.0f;
-                atomicMin(first_empty, v);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) L.nextra[b] = E - *first_empty;
-    }
-    __syncthreads();
-    DSRG_STAMP(7);
 
     if (!split) {
     // ---- phase 7: norm = 1/sqrt(K 1 + 1e-20)  (pairwise.cpp:44,54-57), one channel through
@@ -566,15 +591,29 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
 // nsplit >= ceil(Mcap / 1024): no thread gets a second vertex (41x41: with 8 workgroups a chunk of 1038 sent every workgroup
 // round its loop twice for 14 threads' sake)
 
-template <int D>
+template <int D, int VPT>
 __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int cap, int lds_keys, int nsplit,
                                                             unsigned long long *dbg) {
-#define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[64 * 16 + (size_t)blockIdx.x * 8 + (i_)] = wall_clock64(); } while (0)
-    DSRG_STAMP(0);
     constexpr int D1 = D + 1, KW = KeyWords<D>::value;
     using ckey_t = typename CompactKey<D>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x / nsplit, part = blockIdx.x % nsplit, tid = threadIdx.x;
+    const int b = blockIdx.x / (nsplit + 1), part = blockIdx.x % (nsplit + 1), tid = threadIdx.x;
+    if (part == nsplit) {
+        // the lattice's CSR workgroup (see lattice_csr_phase): the entries' vertex ids come back from the build's vid array
+        const int N = L.N, E = N * D1;
+        const uint16_t *vid = L.vid + (size_t)b * D1 * N;
+        uint16_t ev[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const int e = tid + k * kWG;
+            ev[k] = 0;
+            if (e < E) { const int i = e / D1, r = e - i * D1; ev[k] = vid[(size_t)r * N + i]; }
+        }
+        lattice_csr_phase<D, VPT>(L, b, L.M[b], smem, ev, 0, 1, dbg);
+        return;
+    }
+#define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[64 * 16 + ((size_t)b * nsplit + part) * 8 + (i_)] = wall_clock64(); } while (0)
+    DSRG_STAMP(0);
     const int Mcap = L.Mcap, M = L.M[b];
     const uint32_t mask = (uint32_t)cap - 1u;
     constexpr uint32_t kEmpty = 0xFFFFu;
@@ -935,7 +974,10 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const Latti
     unsigned long long *dbg = L.d == 5 ? reinterpret_cast<unsigned long long *>(g_build_dbg) : nullptr;
     // split the build over more workgroups (neighbour search x8 per lattice) when the hash table and the
     // compact keys fit one workgroup's LDS next to each other
-    const size_t neigh_lds = (size_t)cap * 2 + (lds_keys ? (((size_t)L.Mcap * (L.d == 5 ? 8 : 4) + 15) & ~(size_t)15) : 0);
+    // (the launch also carries one CSR workgroup per lattice: row counters [Mcap+1], sorted entries [E], scan scratch)
+    const size_t csr_lds = align_up((size_t)(L.Mcap + 1) * 4, 16) + align_up((size_t)L.N * (L.d + 1) * 2, 16) + 32 * 4;
+    const size_t search_lds = (size_t)cap * 2 + (lds_keys ? (((size_t)L.Mcap * (L.d == 5 ? 8 : 4) + 15) & ~(size_t)15) : 0);
+    const size_t neigh_lds = search_lds > csr_lds ? search_lds : csr_lds;
     const int split = (neigh_lds <= 150 * 1024 && L.Mcap <= 16 * kWG) ? 1 : 0;
     // at least ceil(Mcap / 1024) so that no thread gets a second vertex; beyond that as many as keep one round of
     // workgroups on the chip (the search is issue-bound: hashing and probing 12 neighbour keys per vertex)
@@ -959,9 +1001,9 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const Latti
         hipLaunchKernelGGL((lattice_build_kernel<D_, V_>), dim3(nlat), dim3(kWG), lds, stream, L, cap,         \
                            (int)wl_in_lds, (int)lds_keys, split, dbg);                                        \
         if (split) {                                                                                          \
-            rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_neigh_kernel<D_>), neigh_lds, granted_n); \
+            rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_neigh_kernel<D_, V_>), neigh_lds, granted_n); \
             if (rc) return rc;                                                                                \
-            hipLaunchKernelGGL((lattice_neigh_kernel<D_>), dim3(nlat * nsplit), dim3(kWG), neigh_lds, stream, L,    \
+            hipLaunchKernelGGL((lattice_neigh_kernel<D_, V_>), dim3(nlat * (nsplit + 1)), dim3(kWG), neigh_lds, stream, L, \
                                cap, (int)lds_keys, nsplit, dbg);                                              \
             if (D_ == 5) {   /* the filter kernel over a plane of ones (meanfield.hip) */                      \
                 rc = launch_lattice_norm_pass(L, nlat, stream);                                               \
