@@ -99,11 +99,13 @@ __global__ __launch_bounds__(kEmbedWG) void lattice_embed_kernel(LatticeView L, 
 // ---------------------------------------------------------------------------------
 // CSR of the splat, contributions in reference order (entry index ascending), and from it the filter kernel's first-term /
 // extras lists.  One 1024-thread workgroup per lattice; `ev` = the vertex id of the thread's entries tid + k*1024.  Runs
-// inside lattice_build_kernel when the build is one kernel, and as ONE EXTRA workgroup per lattice of the neighbour-search
-// launch when it is split: neither stage needs the other's result, and the single-workgroup build was 44 us with it.
+// inside lattice_build_kernel when the build is one kernel, and as EXTRA workgroups of the neighbour-search launch when it
+// is split: neither stage needs the other's result, and the single-workgroup build was 44 us with it.  There it is shared by
+// `nparts` workgroups per lattice: each counts and scans all rows (cheap) and fills, sorts and writes out the rows of its
+// range of vertices [M part / nparts, M (part + 1) / nparts).
 template <int D, int EPT>
 __device__ __forceinline__ void lattice_csr_phase(const LatticeView &L, int b, int M, unsigned char *smem,
-                                                  const uint16_t (&ev)[EPT], int wl_in_lds, int split,
+                                                  const uint16_t (&ev)[EPT], int wl_in_lds, int split, int part, int nparts,
                                                   unsigned long long *dbg) {
 #define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[(size_t)b * 16 + (i_)] = wall_clock64(); } while (0)
     constexpr int D1 = D + 1;
@@ -134,21 +136,25 @@ __device__ __forceinline__ void lattice_csr_phase(const LatticeView &L, int b, i
         for (int v = v0; v < v1; v++) {
             int c = (int)cnt[v];
             cnt[v] = (uint32_t)run;
-            row_start[v] = (uint16_t)run;
+            if (part == 0) row_start[v] = (uint16_t)run;
             run += c;
         }
-        if (tid == 0) row_start[M] = (uint16_t)E;
+        if (tid == 0 && part == 0) row_start[M] = (uint16_t)E;
     }
     __syncthreads();
-    DSRG_STAMP(5);
+    if (part == 0) DSRG_STAMP(5);
+    const int vlo = (int)((long long)M * part / nparts), vhi = (int)((long long)M * (part + 1) / nparts);
+    const int p0 = vlo < M ? (int)cnt[vlo] : E;       // start of my first row (cnt[v] = START of row v until the fill below)
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
         const int e = tid + k * kWG;
-        if (e < E) csr_e[atomicAdd(&cnt[ev[k]], 1u)] = (uint16_t)e;
+        if (e < E && (int)ev[k] >= vlo && (int)ev[k] < vhi) csr_e[atomicAdd(&cnt[ev[k]], 1u)] = (uint16_t)e;
     }
     __syncthreads();
-    for (int v = tid; v < M; v += kWG) {          // cnt[v] is now the END of segment v
-        const int s = v == 0 ? 0 : (int)cnt[v - 1], t = (int)cnt[v];
+    const int p1 = vhi > vlo ? (int)cnt[vhi - 1] : p0;   // end of my last row
+    for (int v = vlo + tid; v < vhi; v += kWG) {     // cnt[v] is now the END of segment v (for the rows of my range)
+        const int s = v == vlo ? p0 : (int)cnt[v - 1], t = (int)cnt[v];
         for (int a = s + 1; a < t; a++) {         // insertion sort, segments are short
             uint16_t x = csr_e[a];
             int c = a - 1;
@@ -157,7 +163,7 @@ __device__ __forceinline__ void lattice_csr_phase(const LatticeView &L, int b, i
         }
     }
     __syncthreads();
-    DSRG_STAMP(6);
+    if (part == 0) DSRG_STAMP(6);
     // weights of the sorted entries: to HBM for the filter kernel, and (when it fits) to LDS for the
     // norm pass below
     float *wl = wl_in_lds ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(scan2) + 32 * 4) : csr_w;
@@ -172,8 +178,8 @@ __device__ __forceinline__ void lattice_csr_phase(const LatticeView &L, int b, i
         uint16_t pv[EPT], pi[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; k++) {
-            const int pos = tid + k * kWG;
-            const int e = pos < E ? csr_e[pos] : 0;
+            const int pos = p0 + tid + k * kWG;
+            const int e = pos < p1 ? csr_e[pos] : 0;
             const int i = e / D1, r = e - i * D1;
             pi[k] = (uint16_t)i;
             pw[k] = bary[(size_t)r * N + i];
@@ -182,37 +188,38 @@ __device__ __forceinline__ void lattice_csr_phase(const LatticeView &L, int b, i
         const bool keep_csr_w = !(split && D == 5);            // its only reader is the d = 2 / unsplit norm pass
 #pragma unroll
         for (int k = 0; k < EPT; k++) {
-            const int pos = tid + k * kWG;
-            if (pos < E) {
+            const int pos = p0 + tid + k * kWG;
+            if (pos < p1) {
                 const float w = pw[k];
                 const int v = pv[k], i = pi[k];
                 if (keep_csr_w) csr_w[pos] = w;
                 if (wl_in_lds) wl[pos] = w;
-                const int start = v == 0 ? 0 : (int)cnt[v - 1];        // cnt[v] = END of row v
+                const int start = v == vlo ? p0 : (int)cnt[v - 1];     // cnt[v] = END of row v
                 if (pos == start) { first_pix[v] = (uint16_t)i; first_w[v] = w; }
                 else { x_pix[pos - v - 1] = (uint16_t)i; x_w[pos - v - 1] = w; }
             }
         }
     }
-    DSRG_STAMP(11);
+    if (part == 0) DSRG_STAMP(11);
     {
         // rows without entries (the phantom vertices) form the tail of the id range: the first of them gives the number of
         // vertices with entries, hence the number of extras
         int *first_empty = scan2;                              // (the scan scratch is free here)
         if (tid == 0) *first_empty = M;
         __syncthreads();
-        for (int v = tid; v < M; v += kWG) {
-            const int start = v == 0 ? 0 : (int)cnt[v - 1];
+        for (int v = vlo + tid; v < vhi; v += kWG) {
+            const int start = v == vlo ? p0 : (int)cnt[v - 1];
             if ((int)cnt[v] == start) {                        // phantom vertex: contributes an exact 0
                 first_pix[v] = 0; first_w[v] = 0.0f;
                 atomicMin(first_empty, v);
             }
         }
         __syncthreads();
-        if (tid == 0) L.nextra[b] = E - *first_empty;
+        // (several parts: the build kernel zeroed the word; the part that holds the first empty row supplies the maximum)
+        if (tid == 0) { if (nparts == 1) L.nextra[b] = E - *first_empty; else atomicMax(&L.nextra[b], E - *first_empty); }
     }
     __syncthreads();
-    DSRG_STAMP(7);
+    if (part == 0) DSRG_STAMP(7);
 #undef DSRG_STAMP
 }
 
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
         }
         const int any_bad = __syncthreads_or(key_range_bad);
         // bit 0 ("diagonal": no vertex shared, no blur neighbour) is set on trust here and cleared by the neighbour search
-        if (tid == 0) L.flags[b] = (any_bad ? 2 : 0) | (fast_keys ? 8 : 0) | (M == E ? 1 : 0);
+        if (tid == 0) { L.flags[b] = (any_bad ? 2 : 0) | (fast_keys ? 8 : 0) | (M == E ? 1 : 0); L.nextra[b] = 0; }
     } else {
     // ---- phase 5: blur neighbours (permutohedral.cpp:303-318): 2(d+1) hash look-ups per vertex,
         // advanced together one probe per round.  With the compact keys resident in LDS a probe is two
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
 
     // ---- phase 6: CSR of the splat (lattice_csr_phase).  In a split build it runs beside the neighbour search instead.
     if (split) { DSRG_STAMP(10); return; }
-    lattice_csr_phase<D, EPT>(L, b, M, smem, ev, wl_in_lds, split, dbg);
+    lattice_csr_phase<D, EPT>(L, b, M, smem, ev, wl_in_lds, split, 0, 1, dbg);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                       // [Mcap+1] (now the END of every row)
     uint16_t *csr_e = reinterpret_cast<uint16_t *>(smem + (((size_t)(Mcap + 1) * 4 + 15) & ~(size_t)15));   // [E]
     int *scan2 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(csr_e) + (((size_t)E * 2 + 15) & ~(size_t)15));
@@ -591,15 +598,16 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
 // nsplit >= ceil(Mcap / 1024): no thread gets a second vertex (41x41: with 8 workgroups a chunk of 1038 sent every workgroup
 // round its loop twice for 14 threads' sake)
 
+constexpr int kCsrParts = 2;      // CSR workgroups per lattice in the neighbour-search launch
 template <int D, int VPT>
 __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int cap, int lds_keys, int nsplit,
                                                             unsigned long long *dbg) {
     constexpr int D1 = D + 1, KW = KeyWords<D>::value;
     using ckey_t = typename CompactKey<D>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x / (nsplit + 1), part = blockIdx.x % (nsplit + 1), tid = threadIdx.x;
-    if (part == nsplit) {
-        // the lattice's CSR workgroup (see lattice_csr_phase): the entries' vertex ids come back from the build's vid array
+    const int b = blockIdx.x / (nsplit + kCsrParts), part = blockIdx.x % (nsplit + kCsrParts), tid = threadIdx.x;
+    if (part >= nsplit) {
+        // one of the lattice's CSR workgroups (see lattice_csr_phase): the entries' vertex ids come back from the build's vid array
         const int N = L.N, E = N * D1;
         const uint16_t *vid = L.vid + (size_t)b * D1 * N;
         uint16_t ev[VPT];
@@ -609,7 +617,7 @@ __global__ __launch_bounds__(kWG) void lattice_neigh_kernel(LatticeView L, int c
             ev[k] = 0;
             if (e < E) { const int i = e / D1, r = e - i * D1; ev[k] = vid[(size_t)r * N + i]; }
         }
-        lattice_csr_phase<D, VPT>(L, b, L.M[b], smem, ev, 0, 1, dbg);
+        lattice_csr_phase<D, VPT>(L, b, L.M[b], smem, ev, 0, 1, part - nsplit, kCsrParts, dbg);
         return;
     }
 #define DSRG_STAMP(i_) do { if (dbg && threadIdx.x == 0) dbg[64 * 16 + ((size_t)b * nsplit + part) * 8 + (i_)] = wall_clock64(); } while (0)
@@ -982,7 +990,7 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const Latti
     // at least ceil(Mcap / 1024) so that no thread gets a second vertex; beyond that as many as keep one round of
     // workgroups on the chip (the search is issue-bound: hashing and probing 12 neighbour keys per vertex)
     int nsplit = vpt < 8 ? 8 : vpt;
-    if (240 / nlat > nsplit) nsplit = 240 / nlat < 32 ? 240 / nlat : 32;
+    if (240 / nlat - kCsrParts > nsplit) nsplit = 240 / nlat - kCsrParts < 32 ? 240 / nlat - kCsrParts : 32;
     {
         const int Npad = (L.N + 3) & ~3;
         const dim3 grid((Npad + kEmbedWG - 1) / kEmbedWG, nlat);
@@ -1003,7 +1011,7 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const Latti
         if (split) {                                                                                          \
             rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&lattice_neigh_kernel<D_, V_>), neigh_lds, granted_n); \
             if (rc) return rc;                                                                                \
-            hipLaunchKernelGGL((lattice_neigh_kernel<D_, V_>), dim3(nlat * (nsplit + 1)), dim3(kWG), neigh_lds, stream, L, \
+            hipLaunchKernelGGL((lattice_neigh_kernel<D_, V_>), dim3(nlat * (nsplit + kCsrParts)), dim3(kWG), neigh_lds, stream, L, \
                                cap, (int)lds_keys, nsplit, dbg);                                              \
             if (D_ == 5) {   /* the filter kernel over a plane of ones (meanfield.hip) */                      \
                 rc = launch_lattice_norm_pass(L, nlat, stream);                                               \

@@ -162,7 +162,8 @@ def crf_refine(probs, images, scale_factor=12.0, maxiter=10, ctx=None, want_log=
 def crf_prepare(images, C, H, W, scale_factor=12.0, maxiter=10, ctx=None):
     """Image-dependent half of the CRF (image resampling + bilateral lattice build) on the current
     stream; a later supervision_step(..., prepared=True) on the same context skips it.  Lets a trainer
-    hide the lattice build under the backbone forward (side stream)."""
+    hide the lattice build under the backbone forward (side stream).  It overwrites the context's lattices: on a side
+    stream, order it behind the last mean field that reads them (`side.wait_stream(main)`, as DSRGTrainer.step does)."""
     _f32c(images, "images")
     B = images.shape[0]
     ctx = ctx or get_context(B, C, H, W)

@@ -119,7 +119,9 @@ int dsrg_crf_refine_batch(dsrg_ctx_t ctx, int B, float *probs_dev, const float *
 /* The image-dependent half of the CRF — resampling the images to (H,W) and building the bilateral
  * lattices (Permutohedral::init, CRF/src/permutohedral.cpp:140-321) — needs no network output, so a
  * trainer can run it on a side stream underneath the backbone forward.  After this call (and a
- * stream dependency set up by the caller) dsrg_supervision_step may be given images_dev = NULL. */
+ * stream dependency set up by the caller) dsrg_supervision_step may be given images_dev = NULL.
+ * The call overwrites the context's lattices: the caller also orders it BEHIND the last call that
+ * reads them (the previous step's mean field), e.g. side stream waits on the main stream first. */
 int dsrg_crf_prepare_batch(dsrg_ctx_t ctx, int B, const float *images_dev, int img_h, int img_w,
                            const dsrg_crf_params *params, void *stream);
 

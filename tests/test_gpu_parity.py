@@ -411,6 +411,7 @@ def test_prepared_lattices_on_side_stream(ops):
     from oracle import oracle as O
     probs = O.softmax_forward(b["logits"])
     r0, q0 = ops.crf_refine(dev(probs), args[1], ctx=ctx)
+    side.wait_stream(torch.cuda.current_stream())            # the call above still reads the context's lattices
     with torch.cuda.stream(side):
         ops.crf_prepare(args[1], 21, 41, 41, ctx=ctx)
     torch.cuda.current_stream().wait_stream(side)
