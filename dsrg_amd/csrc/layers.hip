@@ -311,7 +311,7 @@ __global__ __launch_bounds__(1024) void sup_stats_kernel(int C, int HW, const fl
     const float *pb = probs + (size_t)b * C * HW, *Sb = seeds + (size_t)b * C * HW, *lb = logq + (size_t)b * C * HW;
     double st[5] = {0, 0, 0, 0, 0};
     const int n = C * HW;
-    constexpr int U = 4;                        // elements per thread per batch of loads
+    constexpr int U = 5;                        // elements per thread per batch of loads: 8 x 1024 x 5 >= 21 x 41 x 41, ONE trip per image part (with 4, 7 % of the threads went round twice)
     for (int i0 = part * 1024 * U + threadIdx.x; i0 < n; i0 += kStatSplit * 1024 * U) {
         float s[U], p[U], q[U];
 #pragma unroll
