@@ -277,9 +277,10 @@ __global__ __launch_bounds__(kWG) void lattice_build_kernel(LatticeView L, int c
     constexpr uint32_t kEmpty = 0xFFFFu;
     constexpr int EPT = VPT;                              // entries per thread (Epad <= Mcap)
     uint16_t hs[EPT];                                     // slot of my k-th entry
-    // (entry after entry: probing five entries of a thread together — table words, keys and CASes each in flight for all
-    // five — was measured at 21.4 instead of 12.6 us for this phase: every round costs the wave the work of all its lanes'
-    // pending entries, and failed CASes multiply)
+    // (entry after entry.  Measured and dropped: probing five entries of a thread together — table words, keys and CASes
+    // each in flight for all five — 21.4 instead of 12.6 us for this phase (every round costs the wave the work of all its
+    // lanes' pending entries, and failed CASes multiply); every lane advancing through its own entries at its own pace, one
+    // probe step per loop trip — 15.2 us (the per-trip bookkeeping outweighs the shorter critical path))
     if (fast_keys) {
         ckey_t mine_k[EPT];
 #pragma unroll
