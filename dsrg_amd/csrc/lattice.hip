@@ -981,15 +981,15 @@ int launch_lattice_build(const LatticeView &L, const LatticeFeat &F, const Latti
     const size_t lds = build_lds_bytes(L.d, L.N, wl_in_lds, lds_keys);
     const int vpt = (L.Mcap + kWG - 1) / kWG;
     unsigned long long *dbg = L.d == 5 ? reinterpret_cast<unsigned long long *>(g_build_dbg) : nullptr;
-    // split the build over more workgroups (neighbour search x8 per lattice) when the hash table and the
-    // compact keys fit one workgroup's LDS next to each other
-    // (the launch also carries one CSR workgroup per lattice: row counters [Mcap+1], sorted entries [E], scan scratch)
+    // split the build over more workgroups (a second launch of nsplit neighbour-search and kCsrParts CSR workgroups per
+    // lattice) when the hash table and the compact keys fit one workgroup's LDS next to each other; a CSR workgroup needs
+    // the row counters [Mcap+1], the sorted entries [E] and the scan scratch
     const size_t csr_lds = align_up((size_t)(L.Mcap + 1) * 4, 16) + align_up((size_t)L.N * (L.d + 1) * 2, 16) + 32 * 4;
     const size_t search_lds = (size_t)cap * 2 + (lds_keys ? (((size_t)L.Mcap * (L.d == 5 ? 8 : 4) + 15) & ~(size_t)15) : 0);
     const size_t neigh_lds = search_lds > csr_lds ? search_lds : csr_lds;
     const int split = (neigh_lds <= 150 * 1024 && L.Mcap <= 16 * kWG) ? 1 : 0;
-    // at least ceil(Mcap / 1024) so that no thread gets a second vertex; beyond that as many as keep one round of
-    // workgroups on the chip (the search is issue-bound: hashing and probing 12 neighbour keys per vertex)
+    // at least ceil(Mcap / 1024) search workgroups so that no thread gets a second vertex; beyond that as many as keep the
+    // launch one round of workgroups on the chip (hashing and probing 12 neighbour keys is ~7 us of dependent work per wave)
     int nsplit = vpt < 8 ? 8 : vpt;
     if (240 / nlat - kCsrParts > nsplit) nsplit = 240 / nlat - kCsrParts < 32 ? 240 / nlat - kCsrParts : 32;
     {
