@@ -22,6 +22,7 @@ _DIRECT_C3 = _os.environ.get("DSRG_DIRECT_C3", "1") == "1"          # conv1_1 (3
 _FUSE_POOL = _os.environ.get("DSRG_FUSE_POOL", "1") == "1"           # pool1-3 inside the conv node: pool backward + ReLU mask + bias gradient in one pass
 _GEMM_1X1_BWD = _os.environ.get("DSRG_GEMM_1X1_BWD", "1") == "1"   # 1x1 layers (fc7): both gradients as hipBLASLt GEMMs (0: MIOpen/CK)
 _DIRECT_WGRAD = _os.environ.get("DSRG_DIRECT_WGRAD", "1") == "1"   # their weight gradients by the direct kernel too (0: MIOpen)
+_GEMM_DGRAD_MAX_MAP = int(_os.environ.get("DSRG_GEMM_DGRAD_MAX_MAP", "2048"))   # largest map (pixels) whose 3x3 data gradient is im2col(g) + GEMM
 _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
 
 
@@ -128,7 +129,7 @@ class _ConvFn(torch.autograd.Function):
         # data gradient of a 3x3 'same' convolution = the forward convolution of g with the flipped, transposed kernel:
         # the im2col + hipBLASLt route again (~1.2 PFLOP/s at the 41x41 stages against 550-630 TFLOP/s for CK's dgrad)
         gemm_dgrad = ctx.gemm and ctx.k == 3 and ctx.needs_input_grad[0] and g.dtype in (torch.bfloat16, torch.float32) \
-            and cout % 8 == 0 and x.shape[2] * x.shape[3] <= 2048    # larger maps: the im2col of g costs more than it saves (measured at 81x81)
+            and cout % 8 == 0 and x.shape[2] * x.shape[3] <= _GEMM_DGRAD_MAX_MAP    # larger maps: the im2col of g costs more than it saves (81x81, again with nontemporal im2col stores: 1 221 / 1 225 against 1 233 / 1 227 images/s)
         gx = None
         gemm_1x1 = _GEMM_1X1_BWD and ctx.gemm and ctx.k == 1 and g.dtype in (torch.bfloat16, torch.float32) and cout % 8 == 0 \
             and x.shape[1] % 8 == 0 and g.dtype == x.dtype
@@ -159,7 +160,7 @@ class _ConvFn(torch.autograd.Function):
         # since the hipBLASLt solutions are picked by TunableOp, the 512 -> 512 / 256 -> 512 layers too (round 2, A/B on one
         # box: 932.8 / 931.4 images/s with the 1024 threshold, 939.9 / 938.9 with 512, 934.1 / 932.4 with 256; the transposed
         # product g^T @ im2col(x) another +0.6 %)
-        gemm_wgrad = gemm_dgrad and x.shape[1] % 8 == 0 and cout >= _WGRAD_MIN_COUT
+        gemm_wgrad = gemm_dgrad and x.shape[2] * x.shape[3] <= 2048 and x.shape[1] % 8 == 0 and cout >= _WGRAD_MIN_COUT
         gw = None
         if gemm_1x1:
             x2d = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])       # NHWC memory of a channels_last activation
