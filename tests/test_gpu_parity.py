@@ -539,6 +539,33 @@ def test_fused_step_other_shapes_vs_oracle(ops, O, B, C, HW):
     _check_fused_step(ops, O, logits, images, labels, cues, "fused B=%d C=%d %dx%d" % (B, C, H, W))
 
 
+@pytest.mark.parametrize("seed", [50_002, 50_005, 50_011, 50_024, 50_027, 50_049, 50_054])
+def test_fused_step_random_shapes_vs_oracle(ops, O, seed):
+    """a slice of tools/parity_sweep_shapes.py in the suite: random batch, label count (2..96) and map size (2..65 a side),
+    images without background, cues of absent classes — the fused step against the oracle layer by layer.  (The sweep over
+    shapes, not data, is what found this round's allocation bug of the global-memory path.)"""
+    rng = np.random.default_rng(seed)
+    B, C = int(rng.integers(1, 7)), int(rng.choice([2, 3, 5, 21, 21, 21, 30, 64, 81, 96]))
+    H, W = int(rng.integers(2, 66)), int(rng.integers(2, 66))
+    size = 8 * (max(H, W) - 1) + 1
+    kind = ["smooth", "noise", "dark_corner"][seed % 3]
+    images = np.ascontiguousarray(S.make_images(rng, B, size=size, kind=kind)[:, :, :8 * (H - 1) + 1, :8 * (W - 1) + 1])
+    logits = S.make_logits(rng, B, C, H, W, gain=float(rng.uniform(2, 60)), sigma=float(rng.uniform(1, 8)))
+    labels = np.zeros((B, 1, 1, C), np.float32)
+    cues = np.zeros((B, C, H, W), np.float32)
+    for b in range(B):
+        pres = rng.choice(C, size=int(rng.integers(1, min(C, 7) + 1)), replace=False)
+        if rng.random() < 0.7:
+            pres[0] = 0
+        labels[b, 0, 0, np.unique(pres)] = 1.0
+        for c in rng.choice(C, size=min(C, len(pres) + 2), replace=False):
+            for _ in range(int(rng.integers(0, 4))):
+                h, w = int(rng.integers(1, max(2, H // 3 + 1))), int(rng.integers(1, max(2, W // 3 + 1)))
+                y, x = int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1))
+                cues[b, c, y:y + h, x:x + w] = 1.0
+    _check_fused_step(ops, O, logits, images, labels, cues, "fused random shape seed %d: B=%d C=%d %dx%d" % (seed, B, C, H, W))
+
+
 def test_unused_pylayers_vs_oracle(ops, O):
     """SeedLossLayer, ExpandLossLayer (sort-weighted pooling) and the evaluation histogram on the GPU"""
     rng = np.random.default_rng(11)
