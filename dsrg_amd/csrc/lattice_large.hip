@@ -54,24 +54,50 @@ __global__ void lg_embed_kernel(LargeLattice L, LatticeFeat F, const unsigned ch
     }
 }
 
+// For every lane of a wave: the lowest lane that holds the same value (itself when it is the first).  A wave's 64 consecutive
+// entries are ~10 neighbouring pixels whose simplices share most of their vertices, so a wave holds ~10 distinct keys: one
+// lane per key then goes to the table instead of 64 contending for the same few slots.  64 steps of readlane + compare.
+template <int KW>
+__device__ __forceinline__ int wave_first_lane_with_same(const uint32_t (&w)[KW], bool valid) {
+    const int lane = threadIdx.x & 63;
+    int leader = lane;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        bool same = __builtin_amdgcn_readlane((int)valid, j) != 0;
+#pragma unroll
+        for (int q = 0; q < KW; q++) same = same && ((uint32_t)__builtin_amdgcn_readlane((int)w[q], j) == w[q]);
+        if (same && !found && valid) { leader = j; found = true; }
+    }
+    return leader;
+}
+
 // open addressing, linear probing; a slot keeps the smallest entry index of its key (= first occurrence
-// in the reference's visiting order, permutohedral.cpp:261-276)
+// in the reference's visiting order, permutohedral.cpp:261-276).  Within a wave the first lane of every distinct key (it
+// holds the key's smallest entry index of the wave) inserts; the others take its slot.
 template <int D>
 __global__ void lg_insert_kernel(LargeLattice L) {
     constexpr int KW = KeyWords<D>::value;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L.Epad) return;
+    const bool valid = e < L.Epad;
     uint32_t w[KW];
-    load_key<KW>(w, L.key_e + (size_t)e * KW);
+#pragma unroll
+    for (int q = 0; q < KW; q++) w[q] = 0;
+    if (valid) load_key<KW>(w, L.key_e + (size_t)e * KW);
+    const int lane = threadIdx.x & 63;
+    const int leader = wave_first_lane_with_same<KW>(w, valid);
     const uint32_t mask = (uint32_t)L.cap - 1u;
     uint32_t h = hash_key<KW>(w) & mask;
-    for (;;) {
-        const uint32_t old = atomicCAS(&L.table[h], kEmptyL, (uint32_t)e);
-        if (old == kEmptyL) break;
-        if (key_eq<KW>(w, L.key_e + (size_t)old * KW)) { atomicMin(&L.table[h], (uint32_t)e); break; }
-        h = (h + 1) & mask;
+    if (valid && leader == lane) {
+        for (;;) {
+            const uint32_t old = atomicCAS(&L.table[h], kEmptyL, (uint32_t)e);
+            if (old == kEmptyL) break;
+            if (key_eq<KW>(w, L.key_e + (size_t)old * KW)) { atomicMin(&L.table[h], (uint32_t)e); break; }
+            h = (h + 1) & mask;
+        }
     }
-    L.slot_e[e] = h;
+    h = (uint32_t)__shfl((int)h, leader, 64);
+    if (valid) L.slot_e[e] = h;
 }
 
 __global__ void lg_first_kernel(LargeLattice L) {
@@ -94,15 +120,26 @@ __global__ void lg_assign_kernel(LargeLattice L) {
     }
 }
 
+// vertex id of every entry + row counts of the splat CSR: one atomic per distinct vertex of a wave (the first lane that
+// holds it adds the wave's count; ~26 entries share a vertex at 321x321)
 __global__ void lg_vid_kernel(LargeLattice L, int D1) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L.E) return;
-    const int i = e / D1, r = e - i * D1;
-    const uint32_t v = L.table[L.slot_e[e]];
-    L.vid[(size_t)r * L.N + i] = v;
-    L.ent_vid[e] = v;
-    L.ent_idx[e] = (uint32_t)e;
-    atomicAdd(&L.cnt[v], 1u);
+    const bool valid = e < L.E;
+    uint32_t v[1] = {0u};
+    if (valid) {
+        const int i = e / D1, r = e - i * D1;
+        v[0] = L.table[L.slot_e[e]];
+        L.vid[(size_t)r * L.N + i] = v[0];
+        L.ent_vid[e] = v[0];
+        L.ent_idx[e] = (uint32_t)e;
+    }
+    const int lane = threadIdx.x & 63;
+    const int leader = wave_first_lane_with_same<1>(v, valid);
+    // members of my group: lanes whose leader is me
+    uint32_t n = 0;
+#pragma unroll
+    for (int j = 0; j < 64; j++) n += (__builtin_amdgcn_readlane(valid ? leader : -1, j) == lane) ? 1u : 0u;
+    if (valid && leader == lane) atomicAdd(&L.cnt[v[0]], n);
 }
 
 // blur neighbours (permutohedral.cpp:303-318); M is the "no neighbour" id (row M of the values is zero)
