@@ -6,7 +6,9 @@ seeded region growing, seed + constrain losses, backward) -> backbone backward -
 16 images per GPU (BASELINE.json configs[2]; configs[3] at N=8).  Synthetic inputs are resident in HBM before the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode train|supervision|infer|crf-fullres|train-f]
-  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  N>1: python bench.py --gpus N re-executes itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+       --master-addr 127.0.0.1 ... bench.py --gpus N ...` (one rank per GPU over RCCL); started under that launcher
+       already (WORLD_SIZE set) it runs as a rank.  Fewer than N GPUs visible: one line saying so, exit status 1.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      — the dominant hot-path kernel (mean-field filter = permutohedral splat/blur/slice): modelled LDS bytes per
@@ -493,13 +495,30 @@ def main():
     ap.add_argument("--sub", action="store_true", help="(internal) a sub-record of the default run: short CPU baseline, one core only")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run
+        # (what the driver's own N>1 launch line does), same arguments, rendezvous on the loopback address
+        visible = torch.cuda.device_count()
+        if visible < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, visible))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
+    if args.gpus != world and (args.gpus > 1 or world > 1):
+        raise SystemExit("bench.py --gpus %d under a launcher with WORLD_SIZE=%d: start it with --nproc-per-node %d" % (
+            args.gpus, world, args.gpus))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -580,10 +599,12 @@ def main():
         losses = one_step()
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / args.steps * 1e3]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        ts = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(ts, torch.tensor([dt], dtype=torch.float64, device=device))
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in ts]
+        dt = max(float(t.item()) for t in ts)                     # the job's time is its slowest rank's
 
     # the dominant hot-path kernel inside the train step: a separate, untimed pass with every filter launch bracketed by HIP
     # events on its launch stream (the brackets cost ~5 us each: they must not sit in the timed region)
@@ -637,6 +658,8 @@ def main():
                                         args.backbone, args.size, args.size)),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "baseline_config": "configs[2] (batch 16 on 1 GPU); configs[3] at 8 GPUs"},
+            "rccl_ranks": dist.get_world_size() if dist is not None else 0,     # 0: no process group (plain single-GPU run)
+            "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms)},
             "losses": [float(x) for x in losses.detach().cpu()],
             "supervision_ms_per_step": sup_ms,
             "backbone_tflops": (count_flops_per_image() * 3 * B * world * args.steps / dt / 1e12) if args.mode == "train" else None,

@@ -45,11 +45,16 @@ struct dsrg_ctx_s {
                                  // -1 not read (built inside a stream capture): the kernels then test the flag themselves
 };
 
-namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; extern int g_filter_opts; }
+namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; extern int g_filter_opts; extern int g_igemm_variant; }
 // tests / tools only (not in the public header): option bits of the mean-field filter launch (meanfield.hip, kOpt*: 1 = a
 // pixel-local Gaussian lattice is evaluated by the update kernel, 2 = slot guard); -1 = back to the DSRG_FILTER_OPTS environment variable / the default (all on).  Every combination yields
 // bit-identical marginals (tests/test_gpu_parity.py).
-extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_opts(int opts) { dsrg::g_filter_opts = opts; }
+extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_opts(int opts) {
+    dsrg::g_filter_opts = opts < 0 ? -1 : (opts & 3);      // bits 4 and 8 (seqCompute arithmetic, norm pass) are the launcher's own
+}
+// tests / tools only: 1 = the implicit-GEMM convolution reads its LDS fragments one k-slice ahead (default), 0 = compiler-placed
+// reads, -1 = back to DSRG_IGEMM_VARIANT / the default; identical results
+extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_igemm_variant(int v) { dsrg::g_igemm_variant = v; }
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_build_trace(void *dev_buf) { dsrg::g_build_dbg = dev_buf; }
 // tools only (not in the public header): device buffer of 16 u64 per filter block receiving phase timestamps
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_trace(void *dev_buf) { dsrg::g_filter_dbg = dev_buf; }
@@ -460,6 +465,14 @@ extern "C" int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, co
                                         int W, int cin, int cout, int relu, void *stream) {
     if (!x_dev || !w_dev || !y_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
     return launch_conv3x3_direct(x_dev, w_dev, bias_dev, y_dev, B, H, W, cin, cout, relu, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_conv_igemm_supported(int cin, int cout, int ksize) { return conv_igemm_supported(cin, cout, ksize) ? 1 : 0; }
+extern "C" int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, const float *const *bias_dev,
+                                    void *const *y_dev, const int *dilation, int ngroups, int B, int H, int W, int cin, int cout,
+                                    int ksize, int relu, void *stream) {
+    if (!x_dev || !w_dev || !y_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "conv_igemm: bad arguments");
+    return launch_conv_igemm(x_dev, w_dev, bias_dev, y_dev, dilation, ngroups, B, H, W, cin, cout, ksize, relu,
+                             static_cast<hipStream_t>(stream));
 }
 extern "C" size_t dsrg_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
     return conv3x3_wgrad_workspace(B, H, W, cin, cout);

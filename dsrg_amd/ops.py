@@ -425,6 +425,54 @@ def conv3x3_wgrad(x, g):
     return gw
 
 
+def conv_igemm_supported(cin, cout, k):
+    """the channel counts / kernel sizes the implicit-GEMM convolution serves (cin % 64 == 0, cout % 256 == 0, k in (1, 3))"""
+    return bool(_lib.lib().dsrg_conv_igemm_supported(int(cin), int(cout), int(k)))
+
+
+def set_igemm_variant(v):
+    """tests / tools: 1 = LDS fragments read one k-slice ahead (default), 0 = compiler-placed reads, -1 = environment / default"""
+    _lib.lib().dsrg_debug_set_igemm_variant(int(v))
+
+
+def pack_conv_weight(weight, for_dgrad=False, dtype=torch.bfloat16):
+    """(cout, cin, k, k) kernel (any float dtype: the fp32 master weights are cast in the same copy) -> the layout
+    dsrg_conv_igemm_bf16 reads: (cout, cin / 64, k*k, 64), w_packed[o][cc][tap][c] = w[o][cc*64 + c][tap].  for_dgrad: the kernel
+    of the data gradient instead — flipped, channel axes swapped: (cin, cout / 64, k*k, 64)."""
+    k = weight.shape[2]
+    if for_dgrad:
+        weight = weight.flip(2, 3).transpose(0, 1) if k > 1 else weight.transpose(0, 1)
+    o, c = weight.shape[0], weight.shape[1]
+    out = torch.empty((o, c // 64, k * k, 64), dtype=dtype, device=weight.device)
+    out.copy_(weight.reshape(o, c // 64, 64, k * k).permute(0, 1, 3, 2))      # cast + permute in one pass
+    return out
+
+
+def conv_igemm(xs, packed, biases, dilations, ksize, relu):
+    """1 .. 4 convolutions of one geometry in one launch (the four ASPP branches): xs[g] (B,cin,H,W) bf16 channels_last,
+    packed[g] = pack_conv_weight(w_g), biases[g] (cout) f32 or None -> list of (B,cout,H,W) bf16 channels_last; fp32
+    accumulation, bias and ReLU fused, no im2col matrix"""
+    n = len(xs)
+    B, cin, H, W = xs[0].shape
+    cout = packed[0].shape[0]
+    cl = torch.channels_last
+    if not (1 <= n <= 4 and len(packed) == n and len(dilations) == n):
+        raise ValueError("conv_igemm: 1..4 groups")
+    for x, p in zip(xs, packed):
+        if not (x.is_cuda and x.dtype == torch.bfloat16 and tuple(x.shape) == (B, cin, H, W) and p.dtype == torch.bfloat16
+                and tuple(p.shape) == (cout, cin // 64, ksize * ksize, 64) and p.is_contiguous()):
+            raise ValueError("conv_igemm needs bf16 CUDA inputs of one shape and kernels packed by pack_conv_weight")
+    xs = [x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl) for x in xs]
+    bs = [None if b is None else _f32c(b, "bias") for b in (biases or [None] * n)]
+    ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xs[0].device, memory_format=cl) for _ in range(n)]
+    vp = ctypes.c_void_p * n
+    check(_lib.lib().dsrg_conv_igemm_bf16(vp(*[x.data_ptr() for x in xs]), vp(*[p.data_ptr() for p in packed]),
+                                          vp(*[None if b is None else b.data_ptr() for b in bs]),
+                                          vp(*[y.data_ptr() for y in ys]), (ctypes.c_int * n)(*[int(d) for d in dilations]),
+                                          n, B, H, W, cin, cout, ksize, int(bool(relu)), _stream()))
+    return ys
+
+
 def heads_forward(xs, weight, bias):
     """fc8-SEC_k + Eltwise SUM in float32: xs = list of <= 4 (B,K,H,W) bf16 channels_last activations, weight (n,O,K) f32,
     bias (n,O) f32 or None -> (B,O,H,W) float32, NCHW-contiguous (what the supervision path reads)."""

@@ -249,6 +249,19 @@ int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, const float *
 size_t dsrg_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout);
 int dsrg_conv3x3_wgrad_bf16(const void *x_dev, const void *g_dev, void *gw_dev, void *workspace_dev, size_t workspace_bytes,
                             int B, int H, int W, int cin, int cout, void *stream);
+/* Implicit-GEMM convolution for the wide layers (conv3_x, conv4_x, conv5_x, fc6_k, fc7_k of train-s.prototxt:161-736): 3x3
+ * with any dilation ('same' zero padding) or 1x1, stride 1, cin % 64 == 0, cout % 256 == 0, NHWC bf16 in and out, fp32
+ * accumulation, optional bias (cout f32) and ReLU in the epilogue; no im2col matrix is formed:
+ *   y[b,y,x,o] = relu?( bias[o] + sum_{dy,dx,c} w[o][dy+1][dx+1][c] * x[b,y+dy*dil,x+dx*dil,c] )
+ * Up to four independent problems of one geometry (the four ASPP branches) share a launch: x_dev, w_dev, bias_dev (may be
+ * NULL, entries may be NULL), y_dev and dilation are HOST arrays of ngroups entries.  w_dev[g]: the kernel packed as
+ * (cout, cin / 64, ksize * ksize, 64) bf16 — w_packed[o][cc][tap][c] = w[o][cc * 64 + c][tap / 3][tap % 3].  With the kernel
+ * flipped and its channel axes swapped the same call is the data gradient.  dsrg_conv_igemm_supported: 1 if the channel
+ * counts / kernel size are served, else 0 (the call then returns DSRG_ERR_UNSUPPORTED). */
+int dsrg_conv_igemm_supported(int cin, int cout, int ksize);
+int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, const float *const *bias_dev, void *const *y_dev,
+                         const int *dilation, int ngroups, int B, int H, int W, int cin, int cout, int ksize, int relu,
+                         void *stream);
 /* The four fc8-SEC_k 1x1 classifiers and their Eltwise SUM (train-s.prototxt:461-744) in one pass with float32 weights,
  * float32 accumulation and a float32 NCHW result: out[b][o][hw] = sum_k ( x_k[(b,hw)][:] . w[k][o][:] + bias[k][o] ).
  * x_dev: host array of n_branches (<= 4) device pointers to (B*HW, K) bf16 row-major (NHWC) activations; w_dev

@@ -1,0 +1,102 @@
+"""GPU (-m gpu): the implicit-GEMM convolution kernels of the backbone (csrc/conv_igemm.hip) against torch in fp32 on the
+same bf16-valued operands — backbone plumbing (train-s.prototxt:161-736 are Caffe Convolution layers; no oracle)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dsrg_amd import ops, _lib
+    _lib.require_gpu()
+    return ops
+
+
+def _case(B, H, W, cin, cout, k, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(B, cin, H, W, device="cuda", generator=g).bfloat16().contiguous(memory_format=CL)
+    w = (torch.randn(cout, cin, k, k, device="cuda", generator=g) * (2.0 / (cin * k * k)) ** 0.5).bfloat16()
+    b = torch.randn(cout, device="cuda", generator=g)
+    return x, w, b
+
+
+def _close(got, want, what):
+    err = (got.float() - want).abs().max()
+    assert err <= 0.01 * want.abs().max() + 1e-3, (what, float(err), float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,dil,relu,bias", [
+    (1, 5, 7, 64, 256, 3, 1, True, True),          # one partial tile, every border case
+    (1, 5, 7, 64, 256, 3, 9, False, False),        # dilation beyond the map: only the centre tap is inside
+    (2, 19, 23, 128, 256, 3, 2, True, True),       # several tiles, a ragged last one, two channel chunks
+    (1, 41, 41, 512, 512, 3, 2, True, True),       # conv5_x
+    (2, 41, 41, 512, 1024, 3, 12, True, True),     # fc6_2
+    (1, 41, 41, 1024, 512, 3, 6, False, False),    # its data gradient's shape
+    (2, 41, 41, 1024, 1024, 1, 1, True, True),     # fc7
+    (1, 81, 81, 256, 256, 3, 1, True, True),       # conv3_2
+    (3, 1, 1, 64, 256, 3, 1, True, True),
+])
+def test_igemm_conv_matches_torch(ops, B, H, W, cin, cout, k, dil, relu, bias):
+    x, w, b = _case(B, H, W, cin, cout, k, 5)
+    want = F.conv2d(x.float(), w.float(), b if bias else None, padding=dil * (k // 2), dilation=dil)
+    want = torch.relu(want) if relu else want
+    packed = ops.pack_conv_weight(w)
+    for variant in (1, 0):
+        ops.set_igemm_variant(variant)
+        (got,) = ops.conv_igemm([x], [packed], [b if bias else None], [dil], k, relu)
+        assert got.shape == want.shape and got.dtype == torch.bfloat16 and got.is_contiguous(memory_format=CL)
+        _close(got, want, "variant %d" % variant)
+        (again,) = ops.conv_igemm([x], [packed], [b if bias else None], [dil], k, relu)
+        assert torch.equal(got, again)                                               # deterministic
+    ops.set_igemm_variant(1)
+
+
+def test_igemm_packed_from_fp32_master_and_data_gradient(ops):
+    """pack_conv_weight casts the fp32 master weights in its one copy; with for_dgrad the same kernel is the data gradient"""
+    B, H, W, cin, cout, dil = 2, 13, 17, 256, 512, 2
+    x, w, _ = _case(B, H, W, cin, cout, 3, 7)
+    w32 = w.float() + 1e-4 * torch.randn_like(w.float())                             # not bf16-representable
+    assert torch.equal(ops.pack_conv_weight(w32), ops.pack_conv_weight(w32.bfloat16()))
+    g = torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL)
+    xr = x.float().requires_grad_(True)
+    F.conv2d(xr, w.float(), None, padding=dil, dilation=dil).backward(g.float())
+    (gx,) = ops.conv_igemm([g], [ops.pack_conv_weight(w, for_dgrad=True)], [None], [dil], 3, False)
+    assert gx.shape == x.shape
+    _close(gx, xr.grad, "dgrad")
+
+
+def test_igemm_four_branches_share_a_launch(ops):
+    """the ASPP form: four problems (own input, kernel, bias, dilation) in one launch == four launches"""
+    B, H, W, cin, cout = 1, 41, 41, 512, 1024
+    xs, ws, bs, dils = [], [], [], [6, 12, 18, 24]
+    for i in range(4):
+        x, w, b = _case(B, H, W, cin, cout, 3, 20 + i)
+        xs.append(x); ws.append(ops.pack_conv_weight(w)); bs.append(b)
+    together = ops.conv_igemm(xs, ws, bs, dils, 3, True)
+    for i in range(4):
+        (alone,) = ops.conv_igemm([xs[i]], [ws[i]], [bs[i]], [dils[i]], 3, True)
+        assert torch.equal(together[i], alone)
+    # same input for every branch (fc6_k all read pool5a)
+    shared = ops.conv_igemm([xs[0]] * 4, ws, bs, dils, 3, True)
+    want = torch.relu(F.conv2d(xs[0].float(), _unpack(ws[2]), bs[2], padding=18, dilation=18))
+    _close(shared[2], want, "shared input")
+
+
+def _unpack(p):
+    o, cc, taps, _ = p.shape
+    k = int(round(taps ** 0.5))
+    return p.float().permute(0, 1, 3, 2).reshape(o, cc * 64, k, k)
+
+
+def test_igemm_rejects_unsupported_shapes(ops):
+    from dsrg_amd._lib import DsrgError
+    assert ops.conv_igemm_supported(512, 1024, 3) and ops.conv_igemm_supported(1024, 1024, 1)
+    assert not ops.conv_igemm_supported(512, 128, 3) and not ops.conv_igemm_supported(96, 256, 3)
+    x = torch.zeros(1, 64, 4, 4, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=CL)
+    with pytest.raises(ValueError):
+        ops.conv_igemm([x], [torch.zeros(256, 1, 9, 64, device="cuda")], [None], [1], 3, False)      # float32 kernel
+    with pytest.raises(DsrgError):
+        ops.conv_igemm([x], [torch.zeros(128, 1, 9, 64, device="cuda", dtype=torch.bfloat16)], [None], [1], 3, False)

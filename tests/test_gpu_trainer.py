@@ -212,6 +212,88 @@ def test_config4_ddp_rccl_single_rank(tmp_path):
         assert ev[:ev.index("first_layer_grad")].count("bucket") >= 3, ev
 
 
+DDP2_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from dsrg_amd import synthetic as S
+from dsrg_amd.trainer import DSRGTrainer
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+device = torch.device("cuda", local)
+dist.init_process_group("nccl", device_id=device)
+b = S.make_batch(61, 2 * world)
+d = lambda a: torch.from_numpy(a).to(device)
+images, labels, cues = d(b["images"]), d(b["labels"]), d(b["cues"])
+sh = slice(2 * rank, 2 * rank + 2)                           # rank r takes images [2r, 2r+2) of the global batch
+def run(ddp, imgs, labs, cs):
+    tr = DSRGTrainer(device, world_size=world if ddp else 1, seed=9, ddp=ddp)
+    tr.net.eval()                                            # no dropout: the shards' masks would differ from the global batch's
+    w0 = [p.detach().clone() for p in tr.net.parameters()]
+    out = []
+    for _ in range(2):
+        out.append([float(v) for v in tr.reduce_losses(tr.step(imgs, labs, cs))] if ddp else [float(v) for v in tr.step(imgs, labs, cs)])
+    torch.cuda.synchronize()
+    return out, w0, [p.detach().clone() for p in tr.net.parameters()]
+l_ddp, w0, w_ddp = run(True, images[sh], labels[sh], cues[sh])
+# replicas in lock step: every rank's weights bit-equal to rank 0's
+flat = torch.cat([p.flatten() for p in w_ddp])
+ref = flat.clone(); dist.broadcast(ref, 0)
+same = torch.tensor([float(torch.equal(flat, ref))], device=device); dist.all_reduce(same, op=dist.ReduceOp.MIN)
+res = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "lockstep": float(same.item())}
+if rank == 0:
+    l_one, w0b, w_one = run(False, images, labels, cues)     # one process on the global batch
+    worst = 0.0
+    for a0, a, b_ in zip(w0, w_ddp, w_one):
+        upd = (b_ - a0).abs().max().item()
+        if upd > 0:
+            worst = max(worst, (a - b_).abs().max().item() / upd)
+    res.update({"ddp": l_ddp, "one": l_one, "worst_update_gap": worst})
+    print("DDP2RESULT " + json.dumps(res))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_config4_ddp_rccl_two_ranks(tmp_path):
+    """BASELINE configs[3] at the smallest world size that has a real exchange: two ranks over RCCL, each with its shard of a
+    4-image batch, two train steps; the replicas stay bit-equal and equal the single-process run on the global batch (both
+    losses are means over images, so averaged shard gradients are the global-batch gradient — up to the bf16 rounding of
+    each shard's weight-gradient GEMMs).  Needs two GPUs; bench.py --gpus 2 is exercised the same way."""
+    import json
+    import socket
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-rank RCCL step needs two")
+    script = tmp_path / "ddp2_worker.py"
+    script.write_text(DDP2_WORKER % {"root": ROOT})
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MIOPEN_FIND_MODE=os.environ.get("MIOPEN_FIND_MODE", "2"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("DDP2RESULT ")][-1][len("DDP2RESULT "):])
+    assert res["ranks"] == 2 and res["backend"] == "nccl" and res["lockstep"] == 1.0, res
+    assert np.allclose(res["ddp"], res["one"], rtol=2e-3, atol=1e-4), res
+    assert res["worst_update_gap"] < 0.05, res                # bf16 gradient GEMMs per shard vs per global batch
+    # and bench.py's own launcher: plain `python bench.py --gpus 2` must start both ranks and report them
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-profile"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 4
+
+
+def test_bench_gpus_beyond_the_visible_ones_fails_in_one_line():
+    """`python bench.py --gpus N` with fewer than N GPUs on the node: no traceback, one line naming the reason"""
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    err = [l for l in r.stderr.splitlines() if l.strip()]
+    assert "Traceback" not in r.stderr and err and "only %d GPU(s) visible" % (n - 1) in err[-1], r.stderr[-500:]
+
+
 def test_config5_retrain_step_resnet101_513():
     """BASELINE configs[4]: RetrainTrainer.step with the full ResNet-101 DeepLab (3,4,23,3) at 513x513, batch 2: the
     65x65 score map, a finite SoftmaxWithLoss (ignore 255) on the 1/8-shrunk label map, parameters move, poly rate"""
