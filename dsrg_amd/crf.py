@@ -104,36 +104,40 @@ class DenseCRF(object):
         return ms.value, n.value
 
 
-def CRF(image, unary, maxiter=10, scale_factor=1.0, color_factor=13):
-    """Mean-field inference in a fully connected CRF with Gaussian edge potentials.
+# the parameter contract of the reference's CRF() (CRF.py:27-35): Potts weights and kernel widths, divided by scale_factor
+_BILATERAL_W, _BILATERAL_XY, _GAUSS_W, _GAUSS_XY = 10, 80.0, 3, 3.0
 
-    image: (H,W,3) values in [0,256); unary: (H,W,M) — returns (H,W,M) float32 marginals.
-    Statement-for-statement the reference function (CRF.py:19-37) over the HIP object."""
+
+def _crf_object(width, height, labels, neg_unary, image, scale_factor, color_factor):
+    crf = DenseCRF(width, height, labels)
+    crf.set_unary_energy(neg_unary)
+    sxy_b, sxy_g = _BILATERAL_XY / scale_factor, _GAUSS_XY / scale_factor
+    crf.add_pairwise_energy(_BILATERAL_W, sxy_b, sxy_b, color_factor, color_factor, color_factor, _GAUSS_W, sxy_g, sxy_g, image)
+    return crf
+
+
+def CRF(image, unary, maxiter=10, scale_factor=1.0, color_factor=13):
+    """Mean-field inference in a fully connected CRF with Gaussian edge potentials — the reference's `krahenbuhl2013.CRF`
+    (CRF.py:4-37): image (H,W,3) with values in [0,256), unary (H,W,M) scores whose NEGATIVE is the unary energy ->
+    (H,W,M) float32 marginals after `maxiter` iterations; bilateral kernel 10 * k(80/s px, color_factor), spatial kernel
+    3 * k(3/s px)."""
     assert(image.shape[:2] == unary.shape[:2])
-    H, W = image.shape[:2]
-    nlables = unary.shape[2]
-    crf = DenseCRF(W, H, nlables)
-    crf.set_unary_energy(-unary.ravel().astype('float32'))
-    crf.add_pairwise_energy(10, 80 / scale_factor, 80 / scale_factor, color_factor, color_factor, color_factor,
-                            3, 3 / scale_factor, 3 / scale_factor, image.ravel().astype('ubyte'))
-    prediction = crf.inference(maxiter).reshape((H, W, nlables))
-    return prediction
+    height, width, labels = unary.shape
+    crf = _crf_object(width, height, labels, -unary.ravel().astype('float32'), image.ravel().astype('ubyte'), scale_factor,
+                      color_factor)
+    return crf.inference(maxiter).reshape((height, width, labels))
 
 
 def CRF_device(image, unary, maxiter=10, scale_factor=1.0, color_factor=13, want="marginals"):
     """`CRF()` for a device-resident caller: image (H,W,3) uint8 and unary (H,W,M) float32 CUDA tensors in, a CUDA tensor
     out — (H,W,M) float32 marginals, or with want="map" the (H,W) int32 arg-max labels — without a PCIe round trip.
-    Same statements as CRF() (CRF.py:19-37)."""
+    Same parameters as CRF() (CRF.py:19-37)."""
     import torch
     assert image.shape[:2] == unary.shape[:2]
-    H, W = image.shape[:2]
-    nlables = unary.shape[2]
+    H, W, labels = unary.shape
     if torch.cuda.current_stream(unary.device) != torch.cuda.default_stream(unary.device):
         torch.cuda.current_stream(unary.device).synchronize()     # the object API works on the null stream
-    crf = DenseCRF(W, H, nlables)
-    crf.set_unary_energy(-unary.to(torch.float32))
-    crf.add_pairwise_energy(10, 80 / scale_factor, 80 / scale_factor, color_factor, color_factor, color_factor,
-                            3, 3 / scale_factor, 3 / scale_factor, image)
+    crf = _crf_object(W, H, labels, -unary.to(torch.float32), image, scale_factor, color_factor)
     if want == "map":
         return crf.map(maxiter, out=torch.empty((H, W), dtype=torch.int32, device=unary.device))
-    return crf.inference(maxiter, out=torch.empty((H, W, nlables), dtype=torch.float32, device=unary.device))
+    return crf.inference(maxiter, out=torch.empty((H, W, labels), dtype=torch.float32, device=unary.device))

@@ -45,15 +45,15 @@ struct dsrg_ctx_s {
                                  // -1 not read (built inside a stream capture): the kernels then test the flag themselves
 };
 
-namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; extern int g_filter_opts; extern int g_igemm_variant; }
+namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; extern std::atomic<int> g_filter_opts; extern std::atomic<int> g_igemm_variant; }
 // tests / tools only (not in the public header): option bits of the mean-field filter launch (meanfield.hip, kOpt*: 1 = a
 // pixel-local Gaussian lattice is evaluated by the update kernel, 2 = slot guard); -1 = back to the DSRG_FILTER_OPTS environment variable / the default (all on).  Every combination yields
 // bit-identical marginals (tests/test_gpu_parity.py).
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_opts(int opts) {
     dsrg::g_filter_opts = opts < 0 ? -1 : (opts & 3);      // bits 4 and 8 (seqCompute arithmetic, norm pass) are the launcher's own
 }
-// tests / tools only: 1 = the implicit-GEMM convolution reads its LDS fragments one k-slice ahead (default), 0 = compiler-placed
-// reads, -1 = back to DSRG_IGEMM_VARIANT / the default; identical results
+// tests / tools only: pipeline of the implicit-GEMM convolution: 1 = two LDS stages of 64 reduction elements (default), 2 = a
+// ring of four stages of 32 with three steps in flight, -1 = back to DSRG_IGEMM_VARIANT / the default; identical results
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_igemm_variant(int v) { dsrg::g_igemm_variant = v; }
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_build_trace(void *dev_buf) { dsrg::g_build_dbg = dev_buf; }
 // tools only (not in the public header): device buffer of 16 u64 per filter block receiving phase timestamps

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/dsrg_hip.h"
 
 namespace dsrg {
@@ -21,22 +22,26 @@ int set_error(int code, const char *fmt, ...);
 // raise a kernel's dynamic-LDS limit (default 64 KiB) to `bytes`; `granted` caches what was set.
 // The limit is requested per need, not as a flat 160 KiB: static LDS (e.g. the variable behind
 // __syncthreads_or) counts against the same 160 KiB and an over-ask is rejected.
-struct LdsGrant { size_t bytes[16] = {0}; };       // per device (hipFuncSetAttribute acts on the current device)
-inline int ensure_dynamic_lds(const void *fn, size_t bytes, size_t &granted);
-inline int ensure_dynamic_lds(const void *fn, size_t bytes, LdsGrant &g) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { size_t none = 0; return ensure_dynamic_lds(fn, bytes, none); }
-    return ensure_dynamic_lds(fn, bytes, g.bytes[dev]);
-}
-inline int ensure_dynamic_lds(const void *fn, size_t bytes, size_t &granted) {
-    if (bytes <= granted) return DSRG_OK;
+// The cache is shared by every host thread that launches the kernel (function-static tables): entries are atomics, and a
+// race between two threads costs at most a repeated hipFuncSetAttribute with the larger of their sizes winning last —
+// hipFuncSetAttribute itself is thread-safe, and a launch never asks for more than its own thread has just reserved
+// because the value only ever grows (compare-and-swap to the maximum).
+struct LdsGrant { std::atomic<size_t> bytes[16]; LdsGrant() { for (auto &b : bytes) b.store(0, std::memory_order_relaxed); } };
+inline int ensure_dynamic_lds(const void *fn, size_t bytes, std::atomic<size_t> &granted) {
+    size_t have = granted.load(std::memory_order_acquire);
+    if (bytes <= have) return DSRG_OK;
     if (bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess)
             return set_error(DSRG_ERR_HIP, "cannot reserve %zu B of dynamic LDS: %s", bytes, hipGetErrorString(e));
     }
-    granted = bytes;
+    while (have < bytes && !granted.compare_exchange_weak(have, bytes, std::memory_order_release, std::memory_order_acquire)) {}
     return DSRG_OK;
+}
+inline int ensure_dynamic_lds(const void *fn, size_t bytes, LdsGrant &g) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { std::atomic<size_t> none(0); return ensure_dynamic_lds(fn, bytes, none); }
+    return ensure_dynamic_lds(fn, bytes, g.bytes[dev]);
 }
 
 constexpr int kWG = 1024;          // threads per workgroup of the lattice kernels (16 waves)

@@ -37,13 +37,28 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int kBM = 256, kBN = 256, kBK = 64;
-constexpr int kRow = kBK * 2;                              // bytes per LDS row
-constexpr int kStage = (kBM + kBN) * kRow;                 // 64 KB: pixel rows, then weight rows
+constexpr int kBM = 256, kBN = 256;
 constexpr int kOutRow = 128 * 2 + 16;                      // epilogue: a wave's 64 pixels x 128 channels, padded rows
 constexpr int kOutWave = 64 * kOutRow;
-constexpr size_t kLdsBytes = (size_t)(2 * kStage > 8 * kOutWave ? 2 * kStage : 8 * kOutWave);
 constexpr uint32_t kOob = 0x80000000u;                     // beyond any descriptor of this kernel: the load returns zeros
+
+// BK = reduction elements per K-step, NST = LDS stages.  (64, 2): one step in flight behind the one being multiplied;
+// (32, 4): a ring with three steps in flight (counted vmcnt: the DMA of steps s + 1, s + 2 stays in flight across the barrier of
+// step s) — same 128 KB of LDS, deeper prefetch, twice the barriers.
+template <int BK, int NST> struct ICfg {
+    static constexpr int ROW = BK * 2;                     // bytes per LDS row
+    static constexpr int CPR = ROW / 16;                   // 16-byte chunks per row (8 / 4)
+    static constexpr int RPI = 1024 / ROW;                 // rows one wave DMA instruction moves (8 / 16)
+    static constexpr int IPW = 256 / RPI / 8;              // DMA instructions per wave, tile and step (4 / 2)
+    static constexpr int STAGE = (kBM + kBN) * ROW;        // pixel rows, then weight rows (64 / 32 KB)
+    static constexpr int KS = BK / 16;                     // MFMA k-slices per step
+    static constexpr int SPC = 64 / BK;                    // steps per 64-channel chunk of a tap
+    static constexpr int AHEAD = NST - 1;
+    static constexpr size_t LDS = (size_t)(NST * STAGE > 8 * kOutWave ? NST * STAGE : 8 * kOutWave);
+    // chunk c of row r is stored at chunk position c ^ swz(r): the 16 rows a ds_read_b128 lane group touches then cover
+    // all 64 banks (rows of 128 B: 2 rows per 256-byte bank line -> 3 bits from r >> 1; rows of 64 B: 4 per line -> r >> 2)
+    __device__ static constexpr int swz(int r) { return BK == 64 ? (r >> 1) & 7 : (r >> 2) & 3; }
+};
 
 struct IgemmGroup {
     const uint16_t *x;      // (B, H, W, Cin) bf16
@@ -63,10 +78,16 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // v_cvt_pk_bf
     return *reinterpret_cast<uint32_t *>(&b);
 }
 
-// PREFETCH: the fragments of k-slice ks + 1 are read from LDS before the MFMAs of slice ks (order pinned by sched_barrier);
-// otherwise the compiler places the reads (it sinks each next to its first use)
-template <bool PREFETCH>
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+    // this wave's DMA up to the step about to be read has landed (N younger loads may still fly), then the workgroup barrier:
+    // everybody's has, and everybody is done reading the stage the next issue overwrites.  One asm statement with a memory
+    // clobber: neither LDS reads nor the DMA issue may move across it.
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BK, int NST>
 __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(IgemmArgs a) {
+    using C = ICfg<BK, NST>;
     extern __shared__ __attribute__((aligned(16))) unsigned char ig_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,17 +108,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(IgemmArgs a) {
     const IgemmGroup G = a.g[grp];
     const int taps = a.taps, Cin = a.Cin, W = a.W, H = a.H;
     const int ktot = taps * Cin;
-    const int nsteps = (Cin >> 6) * taps;
+    const int nsteps = (Cin >> 6) * taps * C::SPC;
 
     const rsrc_t rx = make_rsrc(G.x, (size_t)a.M * Cin * 2);
     const rsrc_t rw = make_rsrc(G.w, (size_t)a.Cout * ktot * 2);
 
-    // ---- DMA geometry: per K-step a wave moves rows [wv*32 + i*8, +8) of both tiles, i = 0..3; lane -> (row, 16-byte chunk)
-    uint32_t pbase[4], pvalid[4], wbase[4];
+    // ---- DMA geometry: per K-step a wave moves rows [wv*32 + i*RPI, +RPI) of both tiles; lane -> (row, 16-byte chunk)
+    uint32_t pbase[C::IPW], pvalid[C::IPW], wbase[C::IPW];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = wv * 32 + i * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);         // source chunk that lands at chunk position lane & 7
+    for (int i = 0; i < C::IPW; i++) {
+        const int r = wv * 32 + i * C::RPI + lane / C::CPR;
+        const int c = (lane % C::CPR) ^ C::swz(r);         // source chunk that lands at chunk position lane % CPR
         const int m = m0 + r;
         const bool in = m < a.M;
         const int mm = in ? m : 0;
@@ -121,20 +142,21 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(IgemmArgs a) {
     }
 
     auto issue = [&](int stage, int s) {
-        const int cc = s / taps, tap = s - cc * taps;
+        const int q = s / C::SPC, h = s - q * C::SPC;
+        const int cc = q / taps, tap = q - cc * taps;
         int dy = 0, dx = 0;
         if (taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-        const int toff = (dy * G.dil * W + dx * G.dil) * Cin * 2 + cc * kRow;          // wave-uniform
-        unsigned char *P = ig_lds + stage * kStage + wv * (32 * kRow);
-        unsigned char *Wt = P + kBM * kRow;
+        const int toff = (dy * G.dil * W + dx * G.dil) * Cin * 2 + cc * 128 + h * C::ROW;      // wave-uniform
+        unsigned char *P = ig_lds + stage * C::STAGE + wv * (32 * C::ROW);
+        unsigned char *Wt = P + kBM * C::ROW;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < C::IPW; i++) {
             const uint32_t vo = ((pvalid[i] >> tap) & 1u) ? pbase[i] + (uint32_t)toff : kOob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(P + i * (8 * kRow)), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(P + i * (C::RPI * C::ROW)), 16, vo, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Wt + i * (8 * kRow)), 16, wbase[i], (uint32_t)s * kRow, 0, 0);
+        for (int i = 0; i < C::IPW; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Wt + i * (C::RPI * C::ROW)), 16, wbase[i], (uint32_t)s * C::ROW, 0, 0);
     };
 
     f32x16 acc[4][2];
@@ -145,58 +167,50 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    // per-lane LDS read offsets: row l31 of a 32-row fragment, chunk (ks*2 + kgrp) ^ swizzle(row); the swizzle term
-    // ((row >> 1) & 7) depends on the lane only (fragment bases are multiples of 32 rows)
-    const int sw = (l31 >> 1) & 7;
-    const uint32_t rowoff = (uint32_t)l31 * kRow;
-    uint32_t choff[4];
+    // per-lane LDS read offsets: row l31 of a 32-row fragment, chunk (ks*2 + kgrp) ^ swizzle(row); the swizzle term depends on
+    // the lane only (fragment bases are multiples of 32 rows)
+    const int sw = C::swz(l31);
+    const uint32_t rowoff = (uint32_t)l31 * C::ROW;
+    uint32_t choff[C::KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) choff[ks] = rowoff + (uint32_t)(((ks * 2 + kgrp) ^ sw) << 4);
+    for (int ks = 0; ks < C::KS; ks++) choff[ks] = rowoff + (uint32_t)(((ks * 2 + kgrp) ^ sw) << 4);
 
-    issue(0, 0);
+#pragma unroll
+    for (int p = 0; p < C::AHEAD; p++)
+        if (p < nsteps) issue(p, p);
+    constexpr int LPS = 2 * C::IPW;                         // DMA instructions per wave and step
+    int stage = 0;
     for (int s = 0; s < nsteps; s++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of step s has landed
-        __syncthreads();                                    // ... everybody's has, and everybody is done with step s - 1
-        if (s + 1 < nsteps) issue((s + 1) & 1, s + 1);
-        const unsigned char *P = ig_lds + (s & 1) * kStage + wm * (64 * kRow);
-        const unsigned char *Wt = ig_lds + (s & 1) * kStage + kBM * kRow + wn * (128 * kRow);
-        if (PREFETCH) {
-            bf16x8 af[2][4], bfr[2][2];
+        // the steps behind s that are already on their way: min(AHEAD - 1, nsteps - 1 - s)
+        if (C::AHEAD >= 3 && s + 2 < nsteps) wait_vm_barrier<2 * LPS>();
+        else if (C::AHEAD >= 2 && s + 1 < nsteps) wait_vm_barrier<LPS>();
+        else wait_vm_barrier<0>();
+        if (s + C::AHEAD < nsteps) issue(stage == 0 ? NST - 1 : stage - 1, s + C::AHEAD);    // the stage step s - 1 was read from
+        const unsigned char *P = ig_lds + stage * C::STAGE + wm * (64 * C::ROW);
+        const unsigned char *Wt = ig_lds + stage * C::STAGE + kBM * C::ROW + wn * (128 * C::ROW);
+        // fragments of k-slice ks + 1 are read before the MFMAs of slice ks (order pinned by sched_barrier)
+        bf16x8 af[2][4], bfr[2][2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) af[0][i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * kRow) + choff[0]);
+        for (int i = 0; i < 4; i++) af[0][i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * C::ROW) + choff[0]);
 #pragma unroll
-            for (int j = 0; j < 2; j++) bfr[0][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * kRow) + choff[0]);
+        for (int j = 0; j < 2; j++) bfr[0][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[0]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                if (ks + 1 < 4) {
+        for (int ks = 0; ks < C::KS; ks++) {
+            if (ks + 1 < C::KS) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * kRow) + choff[(ks + 1) & 3]);
+                for (int i = 0; i < 4; i++) af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * C::ROW) + choff[(ks + 1) % C::KS]);
 #pragma unroll
-                    for (int j = 0; j < 2; j++) bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * kRow) + choff[(ks + 1) & 3]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 2; j++) bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[(ks + 1) % C::KS]);
             }
-        } else {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                bf16x8 af[4], bfr[2];
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * kRow) + choff[ks]);
-#pragma unroll
-                for (int j = 0; j < 2; j++) bfr[j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * kRow) + choff[ks]);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        stage = stage + 1 == NST ? 0 : stage + 1;
     }
     __syncthreads();                                        // every wave is done reading the last stage
 
@@ -244,10 +258,15 @@ bool conv_igemm_supported(int cin, int cout, int k) {
     return (k == 1 || k == 3) && cin >= 64 && cin % 64 == 0 && cout >= kBN && cout % kBN == 0;
 }
 
-int g_igemm_variant = -1;      // dsrg_debug_set_igemm_variant (tests / tools); -1 = DSRG_IGEMM_VARIANT or the default
+std::atomic<int> g_igemm_variant{-1};      // dsrg_debug_set_igemm_variant (tests / tools); -1 = DSRG_IGEMM_VARIANT or the default
 static int igemm_variant() {
-    if (g_igemm_variant < 0) { const char *e = getenv("DSRG_IGEMM_VARIANT"); g_igemm_variant = e ? atoi(e) : 1; }
-    return g_igemm_variant;
+    int v = g_igemm_variant.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("DSRG_IGEMM_VARIANT");
+        v = e ? atoi(e) : 1;
+        g_igemm_variant.store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
@@ -274,11 +293,17 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     a.tiles_n = cout / kBN;
     a.tiles_per_group = a.tiles_m * a.tiles_n;
     static LdsGrant grant[2];
-    const int variant = igemm_variant() ? 1 : 0;
-    const void *fn = variant ? reinterpret_cast<const void *>(&conv_igemm_kernel<true>) : reinterpret_cast<const void *>(&conv_igemm_kernel<false>);
-    if (int rc = ensure_dynamic_lds(fn, kLdsBytes, grant[variant])) return rc;
-    if (variant) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.tiles_per_group * ngroups), dim3(512), kLdsBytes, stream, a);
-    else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.tiles_per_group * ngroups), dim3(512), kLdsBytes, stream, a);
+    const int variant = igemm_variant() == 2 ? 1 : 0;       // 1: two stages of 64; 2: ring of four stages of 32
+    const dim3 grid(a.tiles_per_group * ngroups), block(512);
+    if (variant == 0) {
+        constexpr size_t lds = ICfg<64, 2>::LDS;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<64, 2>), lds, grant[0])) return rc;
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 2>), grid, block, lds, stream, a);
+    } else {
+        constexpr size_t lds = ICfg<32, 4>::LDS;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<32, 4>), lds, grant[1])) return rc;
+        hipLaunchKernelGGL((conv_igemm_kernel<32, 4>), grid, block, lds, stream, a);
+    }
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

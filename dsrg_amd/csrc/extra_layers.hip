@@ -10,14 +10,15 @@ namespace dsrg {
 static int reserve_lds(const void *fn, size_t bytes, LdsGrant &grant) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    size_t &granted = grant.bytes[dev];
-    if (bytes <= granted) return DSRG_OK;
+    std::atomic<size_t> &granted = grant.bytes[dev];
+    size_t have = granted.load(std::memory_order_acquire);
+    if (bytes <= have) return DSRG_OK;
     if (bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess)
             return set_error(DSRG_ERR_HIP, "cannot reserve %zu B of dynamic LDS: %s", bytes, hipGetErrorString(e));
     }
-    granted = bytes;
+    while (have < bytes && !granted.compare_exchange_weak(have, bytes, std::memory_order_release, std::memory_order_acquire)) {}
     return DSRG_OK;
 }
 

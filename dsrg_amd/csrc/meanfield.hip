@@ -706,13 +706,15 @@ __global__ __launch_bounds__(kUpdParts * kUpdPix) void mf_update_split_kernel(
 // ---------------------------------------------------------------------------------
 void *g_filter_dbg = nullptr;   // set through dsrg_debug_set_filter_trace (tools only)
 // tests / tools: kOpt* bits of the filter launch; -1 = from DSRG_FILTER_OPTS at first use (default: all on)
-int g_filter_opts = -1;
+std::atomic<int> g_filter_opts{-1};
 static int filter_opts() {
-    if (g_filter_opts < 0) {
+    int v = g_filter_opts.load(std::memory_order_relaxed);
+    if (v < 0) {                                   // any thread may resolve the default: they all compute the same value
         const char *e = getenv("DSRG_FILTER_OPTS");
-        g_filter_opts = e ? (atoi(e) & 3) : (kOptLocalGauss | kOptSlotGuard);
+        v = e ? (atoi(e) & 3) : (kOptLocalGauss | kOptSlotGuard);
+        g_filter_opts.store(v, std::memory_order_relaxed);
     }
-    return g_filter_opts;
+    return v;
 }
 
 template <int CPW_B, int CPW_G, int VPT_B, int PPT, bool SEQ>

@@ -206,76 +206,86 @@ class DSRGLayer(_Base):
         return seeds.cpu().numpy()
 
 
+def _open_cue_file(name):
+    """the localisation-cue dictionary of an AnnotationLayer: a pickle of {'<id>_labels': class ids, '<id>_cues': (3, K)
+    int array of (class, row, column) triplets on the 41x41 map}, written by Python 2 (hence latin1).  A relative name is
+    looked up where the reference keeps its cue files (pylayers.py:362-363), an absolute path is taken as it is."""
+    path = name if osp.isabs(name) else osp.join(osp.dirname(__file__), '../../training', 'localization_cues', name)
+    with open(path, 'rb') as f:
+        return pickle.load(f, encoding='latin1')
+
+
+def _mirror_rows(arr, picked):
+    """reverse the last axis of arr[i] for the picked i, in place"""
+    if picked.any():
+        arr[picked] = arr[picked][..., ::-1]
+
+
 class AnnotationLayer(_Base):
-    """pylayers.py:346-387: image ids -> labels (B,1,1,21), cues (B,21,41,41), images, with one
-    random horizontal flip per image applied to cues and image alike.  Pure data marshalling
-    (no arithmetic), done on the host exactly as in the reference.  The cue pickle
-    ('%i_labels' -> class ids, '%i_cues' -> (c,h,w) index triplets) is looked up relative to
-    this file like the reference does, or at the absolute path given in `cues`."""
+    """Drop-in for pylayers.py:346-387: image ids + images -> image-level labels (B,1,1,21), cue planes (B,21,41,41) and
+    the images, with one random horizontal mirror per image applied to cues and image alike.  Host-side marshalling only
+    (no arithmetic).  The mirror decisions come from `np.random.choice(2)`, one draw per image in batch order — the
+    reference's draws — so a seeded run reproduces the reference's flips (tests/golden/annotation_cases.npz)."""
+
+    num_classes, map_size = 21, 41
 
     def setup(self, bottom, top):
         if len(bottom) != 2:
             raise Exception("The layer needs two inputs!")
-        layer_params = yaml.safe_load(self.param_str)
-        if 'cues' not in layer_params:
-            layer_params['cues'] = 'localization_cues.pickle'
-        self._cue_name = layer_params['cues']
-        if 'mirror' not in layer_params:
-            layer_params['mirror'] = False
-        self.is_mirror = layer_params['mirror']
-        path = self._cue_name
-        if not osp.isabs(path):
-            path = osp.join(osp.dirname(__file__), '../../training', 'localization_cues', self._cue_name)
-        with open(path, 'rb') as f:
-            self.data_file = pickle.load(f, encoding='latin1')     # py2 cPickle files
+        prm = yaml.safe_load(self.param_str) or {}
+        self._cue_name = prm.get('cues', 'localization_cues.pickle')
+        self.is_mirror = prm.get('mirror', False)
+        self.data_file = _open_cue_file(self._cue_name)
 
     def reshape(self, bottom, top):
-        top[0].reshape(bottom[0].data.shape[0], 1, 1, 21)
-        top[1].reshape(bottom[0].data.shape[0], 21, 41, 41)
+        n = bottom[0].data.shape[0]
+        top[0].reshape(n, 1, 1, self.num_classes)
+        top[1].reshape(n, self.num_classes, self.map_size, self.map_size)
         top[2].reshape(*bottom[1].data.shape)
 
     def forward(self, bottom, top):
-        top[0].data[...] = 0.0
-        top[1].data[...] = 0.0
-        top[2].data[...] = bottom[1].data
-        for i, image_id in enumerate(bottom[0].data[...].ravel()):
-            labels_i = self.data_file['%i_labels' % image_id]
-            top[0].data[i, 0, 0, 0] = 1.0
-            top[0].data[i, 0, 0, labels_i] = 1.0
-            cues_i = self.data_file['%i_cues' % image_id]
-            top[1].data[i, cues_i[0], cues_i[1], cues_i[2]] = 1.0
+        ids = [int(v) for v in np.asarray(bottom[0].data).reshape(-1)]
+        n = len(ids)
+        present = np.zeros((n, self.num_classes), dtype=np.float32)
+        present[:, 0] = 1.0                                              # background is present in every image
+        planes = np.zeros((n, self.num_classes, self.map_size, self.map_size), dtype=np.float32)
+        mirrored = np.zeros(n, dtype=bool)
+        for row, image_id in enumerate(ids):
+            present[row, self.data_file['%i_labels' % image_id]] = 1.0
+            cls, ys, xs = self.data_file['%i_cues' % image_id]
+            planes[row, cls, ys, xs] = 1.0
             if self.is_mirror:
-                flip = np.random.choice(2) * 2 - 1
-                top[1].data[i, ...] = top[1].data[i, :, :, ::flip]
-                top[2].data[i, ...] = top[2].data[i, :, :, ::flip]
+                mirrored[row] = np.random.choice(2) == 0                 # the reference's step = choice * 2 - 1: -1 reverses
+        images = np.array(bottom[1].data, dtype=np.float32, copy=True)
+        _mirror_rows(planes, mirrored)
+        _mirror_rows(images, mirrored)
+        top[0].data[...] = present.reshape(n, 1, 1, self.num_classes)
+        top[1].data[...] = planes
+        top[2].data[...] = images
 
     def backward(self, top, prop_down, bottom):
         pass
 
 
 class AnnotationLayerCOCO(_Base):
-    """pylayers.py:387-507: a self-feeding data layer for the 81-class COCO variant.  `source` lists
-    `image_path label_path` pairs under `root`; every forward loads `batch_size` pairs, resizes the image to
-    `new_size` (bilinear, scipy zoom order 1 as the reference), RGB, mean-subtracted, CHW; the label PNG becomes
-    81 one-hot cue planes (ignore_label skipped) and the image-level label vector (1,1,81); one random horizontal
-    flip for image and cues alike; the list is reshuffled at every epoch end.  Host-side marshalling only.
-    Differences forced by the image: PIL instead of the absent OpenCV; `param_str` parsed with ast.literal_eval
-    instead of eval; the per-pixel Python loop over the label is one vectorised scatter."""
+    """Drop-in for pylayers.py:387-507: a self-feeding data layer for the 81-class COCO variant.  `source` lists
+    `image_path label_path` pairs under `root`; every forward emits `batch_size` of them: the image resized to `new_size`
+    (scipy zoom, order 1, as the reference), RGB, mean-subtracted, CHW; the label PNG as 81 one-hot cue planes (pixels of
+    `ignore_label` in none) and as the image-level label vector (1,1,81); one random horizontal mirror for image and cues
+    alike; the list is reshuffled whenever it has been walked through.  Host-side marshalling only.  Differences forced by
+    this image: PIL instead of the absent OpenCV; `param_str` parsed with ast.literal_eval instead of eval."""
 
     num_classes = 81
 
     def setup(self, bottom, top):
         import ast
-        layer_params = ast.literal_eval(self.param_str)
-        self.source = layer_params['source']
-        self.root_folder = layer_params['root']
-        self.batch_size = layer_params['batch_size']
-        self.is_mirror = layer_params.get('mirror', False)
-        self.mean = layer_params['mean']
-        self.new_h, self.new_w = layer_params['new_size']
-        self.ignore_label = layer_params.get('ignore_label', 255)
+        prm = ast.literal_eval(self.param_str)
+        self.source, self.root_folder, self.batch_size = prm['source'], prm['root'], prm['batch_size']
+        self.mean, (self.new_h, self.new_w) = prm['mean'], prm['new_size']
+        self.is_mirror = prm.get('mirror', False)
+        self.ignore_label = prm.get('ignore_label', 255)
         with open(self.source) as f:
-            self.indexlist = [line.strip().split() for line in f if line.strip()]
+            self.indexlist = [ln.split() for ln in f if ln.strip()]
         self._cur = 0
         top[0].reshape(self.batch_size, 1, 1, self.num_classes)
         top[1].reshape(self.batch_size, self.num_classes, self.new_h // 8 + 1, self.new_w // 8 + 1)
@@ -288,41 +298,31 @@ class AnnotationLayerCOCO(_Base):
         pass
 
     def forward(self, bottom, top):
-        for itt in range(self.batch_size):
-            im, label, image_label = self.load_next_image()
-            top[0].data[itt, ...] = image_label
-            top[1].data[itt, ...] = label
-            top[2].data[itt, ...] = im
+        for slot in range(self.batch_size):
+            top[2].data[slot, ...], top[1].data[slot, ...], top[0].data[slot, ...] = self.load_next_image()
 
     def load_next_image(self):
-        from random import shuffle
+        """-> (image (3,new_h,new_w), cue planes (81,h,w), image-level labels (1,1,81)) of the next list entry"""
+        import random
         from .data import _imread_bgr, _imread_gray
-        if self._cur == len(self.indexlist):
+        if self._cur >= len(self.indexlist):                               # an epoch is through: new order
+            random.shuffle(self.indexlist)
             self._cur = 0
-            shuffle(self.indexlist)
-        image_file_path, label_file_path = self.indexlist[self._cur]
-        image = _imread_bgr(self.root_folder + image_file_path)
-        label = _imread_gray(self.root_folder + label_file_path)
+        image_name, label_name = self.indexlist[self._cur]
         self._cur += 1
-        return self.preprocess(image, label)
+        return self.preprocess(_imread_bgr(self.root_folder + image_name), _imread_gray(self.root_folder + label_name))
 
     def preprocess(self, image, label):
         from scipy.ndimage import zoom
-        image = zoom(np.asarray(image).astype('float32'),
-                     (self.new_h / float(image.shape[0]), self.new_w / float(image.shape[1]), 1.0), order=1)
-        image = image[:, :, [2, 1, 0]]
-        image = image - self.mean
-        image = image.transpose([2, 0, 1])
-        h, w = label.shape
-        cues = np.zeros((self.num_classes, h, w), dtype=np.uint8)
-        ys, xs = np.nonzero(label != self.ignore_label)
-        cues[label[ys, xs], ys, xs] = 1
-        if self.is_mirror:
-            flip = np.random.choice(2) * 2 - 1
-            image = image[:, :, ::flip]
-            cues = cues[:, :, ::flip]
-        unique_inst = np.unique(label)
-        unique_inst = unique_inst[unique_inst != self.ignore_label]
-        image_label = np.zeros((1, 1, self.num_classes))
-        image_label[0, 0, unique_inst] = 1
-        return image, cues, image_label
+        bgr = np.asarray(image, dtype=np.float32)
+        bgr = zoom(bgr, (self.new_h / float(bgr.shape[0]), self.new_w / float(bgr.shape[1]), 1.0), order=1)
+        chw = np.transpose(bgr[:, :, ::-1] - self.mean, (2, 0, 1))        # BGR -> RGB, mean, channels first
+        kept = label != self.ignore_label
+        planes = np.zeros((self.num_classes,) + label.shape, dtype=np.uint8)
+        rows, cols = np.nonzero(kept)
+        planes[label[rows, cols], rows, cols] = 1                          # one scatter instead of the per-pixel loop
+        if self.is_mirror and np.random.choice(2) == 0:
+            chw, planes = chw[:, :, ::-1], planes[:, :, ::-1]
+        present = np.zeros((1, 1, self.num_classes))
+        present[0, 0, np.unique(label[kept])] = 1
+        return chw, planes, present

@@ -5,6 +5,7 @@ HIP kernels behind the C ABI (include/dsrg_hip.h).  Every function below names t
 reference routine it replaces.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -111,14 +112,18 @@ class Context(object):
 
 
 _CTX_CACHE = {}
+_CTX_LOCK = threading.Lock()
 
 
 def get_context(B, C, H, W):
-    key = (torch.cuda.current_device(), C, H, W)
-    ctx = _CTX_CACHE.get(key)
-    if ctx is None or ctx.max_batch < B:
-        ctx = Context(max(B, 1), C, H, W)
-        _CTX_CACHE[key] = ctx
+    """the cached workspace of (device, host thread, C, H, W): a context is used by one host thread at a time
+    (include/dsrg_hip.h), so every thread gets its own"""
+    key = (torch.cuda.current_device(), threading.get_ident(), C, H, W)
+    with _CTX_LOCK:
+        ctx = _CTX_CACHE.get(key)
+        if ctx is None or ctx.max_batch < B:
+            ctx = Context(max(B, 1), C, H, W)
+            _CTX_CACHE[key] = ctx
     return ctx
 
 
@@ -431,7 +436,8 @@ def conv_igemm_supported(cin, cout, k):
 
 
 def set_igemm_variant(v):
-    """tests / tools: 1 = LDS fragments read one k-slice ahead (default), 0 = compiler-placed reads, -1 = environment / default"""
+    """tests / tools: pipeline of conv_igemm: 1 = two LDS stages of 64 (default), 2 = ring of four stages of 32, -1 = environment /
+    default; identical results"""
     _lib.lib().dsrg_debug_set_igemm_variant(int(v))
 
 

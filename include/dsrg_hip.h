@@ -15,6 +15,11 @@
  *     entry points are stream-ordered and never synchronise the host
  *   - layouts: blobs are NCHW float32, C-contiguous, exactly like the Caffe
  *     blobs the reference's Python layers see (pylayers.py)
+ *   - threads: a handle (dsrg_ctx_t, dsrg_crf_t) is used by one host thread at a
+ *     time; different handles, and the handle-free entry points, may be called
+ *     from different host threads concurrently (the library's shared tables are
+ *     atomics; dsrg_last_error() is per thread).  Results do not depend on the
+ *     interleaving (tests/test_gpu_parity.py::test_four_host_threads_four_contexts)
  */
 #ifndef DSRG_HIP_H
 #define DSRG_HIP_H

@@ -951,3 +951,46 @@ def test_col2im_is_the_adjoint_of_im2col(ops):
         lhs = (ops.col2im3x3_nhwc(c, B, H, W, C, d).permute(0, 2, 3, 1).float() * x.float()).sum()
         rhs = (c.float() * ops.im2col3x3_nhwc(x, d).float()).sum()
         assert abs(lhs.item() - rhs.item()) <= 0.01 * max(1.0, abs(rhs.item())) + 0.02 * (c.float().abs().sum() * 2 ** -8).item() ** 0.5
+
+
+def test_four_host_threads_four_contexts(ops):
+    """include/dsrg_hip.h, "threads": different handles may be driven from different host threads at once.  Four threads,
+    each with its own context, stream, batch and map size (so that the kernels' shared dynamic-LDS tables are raced for
+    different sizes), run the fused step, a CRF and an SRG call six times; every result must equal the single-threaded run
+    of the same inputs bit for bit."""
+    import threading
+    shapes = [(3, 21, 41, 41), (2, 21, 65, 65), (1, 30, 33, 47), (4, 21, 41, 41)]
+    cases = []
+    for k, (B, C, H, W) in enumerate(shapes):
+        b = S.make_batch(700 + k, B, C=C, H=H, W=W, size=8 * (max(H, W) - 1) + 1)
+        cases.append({k_: dev(v) for k_, v in b.items()})
+
+    def work(k, out, reps):
+        torch.cuda.set_device(0)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            c = cases[k]
+            B, C, H, W = c["logits"].shape
+            ctx = ops.Context(B, C, H, W)
+            res = None
+            for _ in range(reps):
+                losses, grad, blobs = ops.supervision_step(c["logits"], c["images"], c["labels"], c["cues"], ctx=ctx, want_blobs=True)
+                refined, logq = ops.crf_refine(blobs["probs"].clone(), c["images"], ctx=ctx)
+                seeds = ops.srg_grow(c["labels"], c["cues"], refined)
+                res = [losses.clone(), grad.clone(), blobs["seeds"].clone(), refined.clone(), logq.clone(), seeds.clone()]
+            st.synchronize()
+            out[k] = [t.cpu() for t in res]
+
+    alone = {}
+    for k in range(4):
+        work(k, alone, 1)
+    together = {}
+    threads = [threading.Thread(target=work, args=(k, together, 6)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(together) == [0, 1, 2, 3]
+    for k in range(4):
+        for a, b in zip(alone[k], together[k]):
+            assert torch.equal(a, b), k

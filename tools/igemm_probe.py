@@ -55,7 +55,7 @@ def main():
         ("conv3_2 256->256 81x81", 81, 81, 256, 256, 3, [1]),
         ("conv3_1 128->256 81x81", 81, 81, 128, 256, 3, [1]),
     ]
-    print("%-28s %9s %9s %9s %9s | %8s %8s | %s" % ("layer", "igemm1", "igemm0", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
+    print("%-28s %9s %9s %9s %9s | %8s %8s | %s" % ("layer", "ig 64x2", "ig 32x4", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
     for name, H, W, cin, cout, k, dils in layers:
         n = len(dils)
         torch.manual_seed(1)
@@ -91,7 +91,7 @@ def main():
         for _ in range(args.rounds):
             ops.set_igemm_variant(1)
             t["ig1"].append(timed(run_ig, args.iters))
-            ops.set_igemm_variant(0)
+            ops.set_igemm_variant(2)
             t["ig0"].append(timed(run_ig, args.iters))
             t["old"].append(timed(run_old, args.iters))
             t["mm"].append(timed(run_mm, args.iters))
