@@ -85,6 +85,8 @@ SIGNATURES = {
     "dsrg_conv3x3_direct_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_conv_igemm_supported": (_i, [_i, _i, _i]),
     "dsrg_conv_igemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dsrg_conv_igemm_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "dsrg_conv_igemm_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_conv3x3_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dsrg_conv3x3_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "dsrg_heads_backward_chunks": (_i, [_i]),

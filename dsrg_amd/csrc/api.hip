@@ -474,6 +474,16 @@ extern "C" int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const 
     return launch_conv_igemm(x_dev, w_dev, bias_dev, y_dev, dilation, ngroups, B, H, W, cin, cout, ksize, relu,
                              static_cast<hipStream_t>(stream));
 }
+extern "C" size_t dsrg_conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int ksize) {
+    return conv_igemm_wgrad_workspace(ngroups, B, H, W, cin, cout, ksize);
+}
+extern "C" int dsrg_conv_igemm_wgrad_bf16(const void *const *x_dev, const void *const *g_dev, void *const *gw_dev, const int *dilation,
+                                          int ngroups, void *workspace_dev, size_t workspace_bytes, int B, int H, int W, int cin,
+                                          int cout, int ksize, int out_bf16, void *stream) {
+    if (!x_dev || !g_dev || !gw_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: bad arguments");
+    return launch_conv_igemm_wgrad(x_dev, g_dev, gw_dev, dilation, ngroups, workspace_dev, workspace_bytes, B, H, W, cin, cout, ksize,
+                                   out_bf16, static_cast<hipStream_t>(stream));
+}
 extern "C" size_t dsrg_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
     return conv3x3_wgrad_workspace(B, H, W, cin, cout);
 }

@@ -85,8 +85,10 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// (the body is a device function template behind two plain kernels: hipcc 7.2's HOST pass drops the stub of a kernel TEMPLATE
+// whose body calls a lambda that uses the template's constants — no diagnostic, an undefined symbol at load time)
 template <int BK, int NST>
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(IgemmArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
     using C = ICfg<BK, NST>;
     extern __shared__ __attribute__((aligned(16))) unsigned char ig_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -252,6 +254,202 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(IgemmArgs a) {
     }
 }
 
+
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_64x2(IgemmArgs a) { conv_igemm_body<64, 2>(a); }
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_32x4(IgemmArgs a) { conv_igemm_body<32, 4>(a); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolutions, again without an im2col matrix:
+//
+//   gw[n][tap][c] = sum over pixels m of  g[m][n] * x[pixel(m) + tap offset][c]
+//
+// A GEMM whose reduction runs over the pixels — the SLOW axis of both NHWC operands — so both MFMA operands are formed by
+// gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block and each lane
+// receives one channel's four pixels), exactly as the direct kernels' weight gradient does (conv_direct.hip), but with the
+// tiles DMA'd global -> LDS as in the forward kernel above:
+//   * output tile 256 channels of g x 256 columns (one tap, 256 channels of x), K-step = 64 pixels: two tiles of 64 rows x
+//     512 bytes per step; a DMA wave instruction moves 2 rows; the 64-byte piece (32 channels) p of row r is stored at piece
+//     position p ^ (r & 3) so that the four pixel rows of a transposing read hit four different bank quarters;
+//   * the x rows are the g rows' pixels shifted by the tile's tap (zero outside the map, per lane, by the descriptor's range
+//     check); (row, column) of a lane's pixels advance incrementally by 64 pixels per step — no division in the loop;
+//   * 9 * cin * cout / 65536 tiles are far fewer than CUs, so the pixel range is split over `ksplit` workgroups per tile
+//     (chosen by the launcher to fill whole rounds of the chip); each writes its fp32 partial tile, and a second kernel sums
+//     the partials in a fixed order (deterministic) into the gradient, laid out [n][tap][c] = a channels_last (cout, cin, k, k)
+//     tensor, in fp32 (the master weights' gradient needs no further cast) or bf16.
+struct WgradGroup {
+    const uint16_t *x;      // (B, H, W, Cin) bf16: the layer's input
+    const uint16_t *g;      // (B, H, W, Cout) bf16: gradient of its output
+    float *part;            // (ksplit, Cout, taps, Cin) f32 partials
+    int dil, pad_;
+};
+struct IgemmWgradArgs {
+    WgradGroup g[4];
+    int ngroups, B, H, W, Cin, Cout, taps, M, tiles_n, tiles_c, ksplit, kchunk, tiles_per_group;
+};
+constexpr int kWRow = 512;                                 // bytes per LDS row: 256 channels
+constexpr int kWTile = 64 * kWRow;                         // 64 pixels
+constexpr int kWStage = 2 * kWTile;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+__device__ __forceinline__ bf16x8 tr_frag8(lds_u8 *p) {    // pixels 0-3 and 4-7 of a lane's k-range: two transposing reads
+    bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<__attribute__((address_space(3))) bf16x4v *>(p));
+    bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<__attribute__((address_space(3))) bf16x4v *>(p + 4 * kWRow));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ig_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kgrp = lane >> 5, i16 = lane & 15, gq = lane >> 4;
+    const int wn = wv >> 2, wm = wv & 3;
+
+    int t;
+    {
+        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = id & 7, k = id >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    // all tiles of one pixel chunk are neighbours in t (they read the same rows of g and x): they share an XCD's L2
+    const int grp = t / a.tiles_per_group;
+    t -= grp * a.tiles_per_group;
+    const int tiles = a.tiles_n * a.tiles_c;
+    const int split = t / tiles;
+    t -= split * tiles;
+    const int tn = t / a.tiles_c, tc = t - tn * a.tiles_c;
+    const WgradGroup G = a.g[grp];
+    const int taps = a.taps, Cin = a.Cin, Cout = a.Cout, W = a.W, H = a.H;
+    const int ncb = Cin >> 8;                               // 256-channel blocks of x per tap
+    const int tap = tc / ncb, c0 = (tc - tap * ncb) << 8, n0 = tn << 8;
+    int dy = 0, dx = 0;
+    if (taps == 9) { dy = (tap / 3 - 1) * G.dil; dx = (tap % 3 - 1) * G.dil; }
+    const int mbeg = split * a.kchunk, mend = min(a.M, mbeg + a.kchunk);
+    const int nsteps = mend > mbeg ? (mend - mbeg + 63) >> 6 : 0;
+
+    const rsrc_t rx = make_rsrc(G.x, (size_t)a.M * Cin * 2);
+    const rsrc_t rg = make_rsrc(G.g, (size_t)a.M * Cout * 2);
+
+    // ---- DMA geometry: per step a wave moves rows [wv*8 + i*2, +2) of both tiles, i = 0..3; lane -> (row, 16-byte piece)
+    int pm[4], py[4], px[4];
+    uint32_t srcoff[4];                                     // byte offset of the lane's source piece inside a 512-byte row
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = wv * 8 + i * 2 + (lane >> 5);
+        const int q = lane & 31, p = (q >> 2) ^ (r & 3);    // 64-byte source piece that lands at piece position q >> 2
+        srcoff[i] = (uint32_t)(p * 64 + (q & 3) * 16);
+        const int m = mbeg + r;
+        pm[i] = m;
+        const int hw = H * W, mm = m < a.M ? m : 0;
+        const int rem = mm - (mm / hw) * hw;
+        py[i] = rem / W;
+        px[i] = rem - py[i] * W;
+    }
+    const int qW = 64 / W, rW = 64 - qW * W;                // a step advances every row by 64 pixels
+    const int tapoff = (dy * W + dx) * Cin * 2 + c0 * 2;
+
+    auto issue = [&](int stage) {
+        unsigned char *A = ig_lds + stage * kWStage + wv * (8 * kWRow);
+        unsigned char *Bt = A + kWTile;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool live = pm[i] < mend;
+            const uint32_t vo = live ? (uint32_t)pm[i] * (uint32_t)(Cout * 2) + (uint32_t)(n0 * 2) + srcoff[i] : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(A + i * (2 * kWRow)), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int yy = py[i] + dy, xx = px[i] + dx;
+            const bool live = pm[i] < mend && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const uint32_t vo = live ? (uint32_t)(pm[i] * (Cin * 2) + tapoff) + srcoff[i] : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(Bt + i * (2 * kWRow)), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                        // the next step's pixels
+            pm[i] += 64;
+            px[i] += rW;
+            py[i] += qW;
+            if (px[i] >= W) { px[i] -= W; py[i] += 1; }
+            while (py[i] >= H) py[i] -= H;
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // the address a lane supplies to a transposing read of fragment f (32 channels = one 64-byte piece), k-slice ks: pixel row
+    // ks*16 + kgrp*8 + i16/4 (the second read 4 rows further), piece f ^ (row & 3), channels (gq & 1)*16 + 4 (i16 & 3) .. + 3
+    const int swz = (i16 >> 2) & 3;
+    const uint32_t lane_off = (uint32_t)((kgrp * 8 + (i16 >> 2)) * kWRow + (gq & 1) * 32 + (i16 & 3) * 8);
+    uint32_t aoff[4], boff[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) aoff[i] = lane_off + (uint32_t)(((wn * 4 + i) ^ swz) * 64);
+#pragma unroll
+    for (int j = 0; j < 2; j++) boff[j] = lane_off + (uint32_t)(kWTile + ((wm * 2 + j) ^ swz) * 64);
+    lds_u8 *lds = (lds_u8 *)ig_lds;
+
+    if (nsteps > 0) issue(0);
+    for (int s = 0; s < nsteps; s++) {
+        wait_vm_barrier<0>();
+        if (s + 1 < nsteps) issue((s + 1) & 1);
+        lds_u8 *st = lds + (s & 1) * kWStage;
+        bf16x8 af[2][4], bfr[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[0][i] = tr_frag8(st + aoff[i]);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bfr[0][j] = tr_frag8(st + boff[j]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) af[(ks + 1) & 1][i] = tr_frag8(st + (ks + 1) * (16 * kWRow) + aoff[i]);
+#pragma unroll
+                for (int j = 0; j < 2; j++) bfr[(ks + 1) & 1][j] = tr_frag8(st + (ks + 1) * (16 * kWRow) + boff[j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // C[row = channel of g][col = channel of x]: lane holds column l31, rows (reg & 3) + 8 (reg >> 2) + 4 kgrp
+    float *pp = G.part + (size_t)split * ((size_t)Cout * taps * Cin);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int c = c0 + wm * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+                pp[((size_t)n * taps + tap) * Cin + c] = acc[i][j][r];
+            }
+        }
+}
+
+// gw[e] = sum over the splits of part[s][e], e over [n][tap][c], in split order; float4 per thread
+template <bool BF16_OUT>
+__global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(const float *part, void *gw, int ksplit, size_t n4) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    const float4 *p = reinterpret_cast<const float4 *>(part) + e;
+    float4 s = p[0];
+    for (int k = 1; k < ksplit; k++) {
+        const float4 v = p[(size_t)k * n4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (BF16_OUT) reinterpret_cast<uint2 *>(gw)[e] = make_uint2(pack2(s.x, s.y), pack2(s.z, s.w));
+    else reinterpret_cast<float4 *>(gw)[e] = s;
+}
+
 }  // namespace
 
 bool conv_igemm_supported(int cin, int cout, int k) {
@@ -297,14 +495,87 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     const dim3 grid(a.tiles_per_group * ngroups), block(512);
     if (variant == 0) {
         constexpr size_t lds = ICfg<64, 2>::LDS;
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<64, 2>), lds, grant[0])) return rc;
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 2>), grid, block, lds, stream, a);
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel_64x2), lds, grant[0])) return rc;
+        hipLaunchKernelGGL(conv_igemm_kernel_64x2, grid, block, lds, stream, a);
     } else {
         constexpr size_t lds = ICfg<32, 4>::LDS;
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<32, 4>), lds, grant[1])) return rc;
-        hipLaunchKernelGGL((conv_igemm_kernel<32, 4>), grid, block, lds, stream, a);
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel_32x4), lds, grant[1])) return rc;
+        hipLaunchKernelGGL(conv_igemm_kernel_32x4, grid, block, lds, stream, a);
     }
     DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+
+bool conv_igemm_wgrad_supported(int cin, int cout, int k) {
+    return (k == 1 || k == 3) && cin >= 256 && cin % 256 == 0 && cout >= 256 && cout % 256 == 0;
+}
+
+// pixel split of the weight-gradient launch: the number of workgroups per output tile that minimises
+// rounds of the chip x (K-steps per workgroup + a fixed cost per workgroup for prologue and the partial tile's write-out)
+static int wgrad_ksplit(long long M, int tiles, int cus) {
+    long long best_cost = -1;
+    int best = 1;
+    for (int ks = 1; ks <= 128; ks++) {
+        const long long chunk = ((M + ks - 1) / ks + 63) / 64 * 64;
+        if ((long long)(ks - 1) * chunk >= M) continue;                 // an empty last split
+        const long long steps = chunk / 64, rounds = ((long long)tiles * ks + cus - 1) / cus;
+        const long long cost = rounds * (steps + 8);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ks; }
+    }
+    return best;
+}
+
+size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k) {
+    if (!conv_igemm_wgrad_supported(cin, cout, k) || ngroups < 1 || ngroups > 4) return 0;
+    const long long M = (long long)B * H * W;
+    const int tiles = ngroups * (cout / 256) * (k * k * cin / 256);
+    const int ks = wgrad_ksplit(M, tiles, 256);
+    return (size_t)ngroups * ks * cout * k * k * cin * sizeof(float);
+}
+
+int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *const *gw, const int *dil, int ngroups, void *workspace,
+                            size_t workspace_bytes, int B, int H, int W, int cin, int cout, int k, int out_bf16, hipStream_t stream) {
+    if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: 1..4 groups");
+    if (!conv_igemm_wgrad_supported(cin, cout, k))
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm_wgrad: cin %% 256 == 0, cout %% 256 == 0, k in (1, 3) required (got %d, %d, %d)",
+                         cin, cout, k);
+    const long long M = (long long)B * H * W;
+    if (M <= 0 || M * cin * 2 >= 0x7fffffffLL || M * cout * 2 >= 0x7fffffffLL)
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm_wgrad: tensor too large for 32-bit buffer offsets");
+    const size_t need = conv_igemm_wgrad_workspace(ngroups, B, H, W, cin, cout, k);
+    if (!workspace || workspace_bytes < need) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: workspace of %zu bytes needed", need);
+    IgemmWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.M = (int)M;
+    a.tiles_n = cout / 256;
+    a.tiles_c = k * k * cin / 256;
+    a.ksplit = wgrad_ksplit(M, ngroups * a.tiles_n * a.tiles_c, 256);
+    a.kchunk = (int)(((M + a.ksplit - 1) / a.ksplit + 63) / 64 * 64);
+    a.tiles_per_group = a.tiles_n * a.tiles_c * a.ksplit;
+    const size_t per_group = (size_t)a.ksplit * cout * k * k * cin;
+    for (int q = 0; q < ngroups; q++) {
+        a.g[q].x = static_cast<const uint16_t *>(x[q]);
+        a.g[q].g = static_cast<const uint16_t *>(g[q]);
+        a.g[q].part = static_cast<float *>(workspace) + (size_t)q * per_group;
+        a.g[q].dil = dil ? dil[q] : 1;
+        if (!a.g[q].x || !a.g[q].g || !gw[q]) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: null pointer");
+    }
+    static LdsGrant grant;
+    constexpr size_t lds = 2 * kWStage;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_wgrad_kernel), lds, grant)) return rc;
+    hipLaunchKernelGGL(conv_igemm_wgrad_kernel, dim3(a.tiles_per_group * ngroups), dim3(512), lds, stream, a);
+    DSRG_LAUNCH_CHECK();
+    const size_t n4 = (size_t)cout * k * k * cin / 4;
+    for (int q = 0; q < ngroups; q++) {
+        if (out_bf16)
+            hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a.g[q].part, gw[q],
+                               a.ksplit, n4);
+        else
+            hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a.g[q].part, gw[q],
+                               a.ksplit, n4);
+        DSRG_LAUNCH_CHECK();
+    }
     return DSRG_OK;
 }
 

@@ -479,6 +479,41 @@ def conv_igemm(xs, packed, biases, dilations, ksize, relu):
     return ys
 
 
+_igemm_ws = {}
+
+
+def conv_igemm_wgrad(xs, gs, dilations, ksize, out_dtype=torch.float32):
+    """weight gradients of 1 .. 4 convolutions of one geometry in one launch: xs[g] (B,cin,H,W) the layer inputs and gs[g]
+    (B,cout,H,W) the output gradients, bf16 channels_last -> list of (cout,cin,k,k) channels_last tensors in float32 (the
+    master weights' gradient) or bf16; cin % 256 == 0, cout % 256 == 0; fp32 accumulation, deterministic, no im2col matrix"""
+    n = len(xs)
+    B, cin, H, W = xs[0].shape
+    cout = gs[0].shape[1]
+    cl = torch.channels_last
+    if not (1 <= n <= 4 and len(gs) == n and len(dilations) == n) or out_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("conv_igemm_wgrad: 1..4 groups, float32 or bfloat16 result")
+    for x, g in zip(xs, gs):
+        if not (x.is_cuda and x.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and tuple(x.shape) == (B, cin, H, W)
+                and tuple(g.shape) == (B, cout, H, W)):
+            raise ValueError("conv_igemm_wgrad needs bf16 CUDA tensors of one geometry")
+    xs = [x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl) for x in xs]
+    gs = [g if g.is_contiguous(memory_format=cl) else g.contiguous(memory_format=cl) for g in gs]
+    L = _lib.lib()
+    need = L.dsrg_conv_igemm_wgrad_workspace(n, B, H, W, cin, cout, ksize)
+    if need == 0:
+        raise ValueError("conv_igemm_wgrad: cin %% 256 == 0, cout %% 256 == 0, k in (1, 3) required (got %d, %d, %d)" % (cin, cout, ksize))
+    key = (xs[0].device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _igemm_ws.get(key)                                          # per-stream scratch, reused across layers and steps
+    if ws is None or ws.numel() < need:
+        ws = _igemm_ws[key] = torch.empty(need, dtype=torch.uint8, device=xs[0].device)
+    gws = [torch.empty((cout, cin, ksize, ksize), dtype=out_dtype, device=xs[0].device, memory_format=cl) for _ in range(n)]
+    vp = ctypes.c_void_p * n
+    check(L.dsrg_conv_igemm_wgrad_bf16(vp(*[x.data_ptr() for x in xs]), vp(*[g.data_ptr() for g in gs]),
+                                       vp(*[w.data_ptr() for w in gws]), (ctypes.c_int * n)(*[int(d) for d in dilations]), n,
+                                       _ptr(ws), ws.numel(), B, H, W, cin, cout, ksize, int(out_dtype == torch.bfloat16), _stream()))
+    return gws
+
+
 def heads_forward(xs, weight, bias):
     """fc8-SEC_k + Eltwise SUM in float32: xs = list of <= 4 (B,K,H,W) bf16 channels_last activations, weight (n,O,K) f32,
     bias (n,O) f32 or None -> (B,O,H,W) float32, NCHW-contiguous (what the supervision path reads)."""

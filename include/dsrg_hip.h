@@ -267,6 +267,17 @@ int dsrg_conv_igemm_supported(int cin, int cout, int ksize);
 int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, const float *const *bias_dev, void *const *y_dev,
                          const int *dilation, int ngroups, int B, int H, int W, int cin, int cout, int ksize, int relu,
                          void *stream);
+/* Weight gradient of the same convolutions, again without an im2col matrix (cin % 256 == 0, cout % 256 == 0, ksize 1 or 3):
+ *   gw[o][tap][c] = sum_{b,y,x} g[b,y,x,o] * x[b,y+dy*dil,x+dx*dil,c]      (zero padding; tap = 3 (dy+1) + dx+1)
+ * x_dev[g] (B,H,W,cin) and g_dev[g] (B,H,W,cout) NHWC bf16; gw_dev[g] (cout, ksize*ksize, cin) = the memory of a channels_last
+ * (cout, cin, ksize, ksize) tensor, float32 (out_bf16 = 0: the master weights' gradient, no cast behind it) or bf16; fp32
+ * accumulation; the pixel range is split over workgroups whose partial tiles are summed in a fixed order (deterministic).
+ * x_dev, g_dev, gw_dev, dilation: HOST arrays of ngroups (1..4) entries (the four ASPP branches in one launch).
+ * workspace_dev: dsrg_conv_igemm_wgrad_workspace(ngroups, B, H, W, cin, cout, ksize) bytes of device scratch (0 = unsupported). */
+size_t dsrg_conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int ksize);
+int dsrg_conv_igemm_wgrad_bf16(const void *const *x_dev, const void *const *g_dev, void *const *gw_dev, const int *dilation,
+                               int ngroups, void *workspace_dev, size_t workspace_bytes, int B, int H, int W, int cin, int cout,
+                               int ksize, int out_bf16, void *stream);
 /* The four fc8-SEC_k 1x1 classifiers and their Eltwise SUM (train-s.prototxt:461-744) in one pass with float32 weights,
  * float32 accumulation and a float32 NCHW result: out[b][o][hw] = sum_k ( x_k[(b,hw)][:] . w[k][o][:] + bias[k][o] ).
  * x_dev: host array of n_branches (<= 4) device pointers to (B*HW, K) bf16 row-major (NHWC) activations; w_dev

@@ -100,3 +100,42 @@ def test_igemm_rejects_unsupported_shapes(ops):
         ops.conv_igemm([x], [torch.zeros(256, 1, 9, 64, device="cuda")], [None], [1], 3, False)      # float32 kernel
     with pytest.raises(DsrgError):
         ops.conv_igemm([x], [torch.zeros(128, 1, 9, 64, device="cuda", dtype=torch.bfloat16)], [None], [1], 3, False)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,dil", [
+    (1, 5, 7, 256, 256, 3, 1),           # one K-step, every border case
+    (2, 19, 23, 256, 256, 3, 2),         # several steps, ragged split, map narrower than a step (64 pixels span 2-3 rows)
+    (1, 41, 41, 512, 512, 3, 2),         # conv5_x
+    (2, 41, 41, 512, 1024, 3, 12),       # fc6_2
+    (2, 41, 41, 1024, 1024, 1, 1),       # fc7
+    (1, 81, 81, 256, 256, 3, 1),         # conv3_2
+    (3, 1, 1, 256, 256, 3, 1),
+    (1, 3, 100, 256, 512, 3, 24),        # map wider than a step; dilation beyond the height
+])
+def test_igemm_weight_gradient_matches_torch(ops, B, H, W, cin, cout, k, dil):
+    x, w, _ = _case(B, H, W, cin, cout, k, 9)
+    g = torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL)
+    wr = w.float().requires_grad_(True)
+    F.conv2d(x.float(), wr, None, padding=dil * (k // 2), dilation=dil).backward(g.float())
+    (gw,) = ops.conv_igemm_wgrad([x], [g], [dil], k)
+    assert gw.shape == wr.shape and gw.dtype == torch.float32 and gw.is_contiguous(memory_format=CL)
+    err = (gw - wr.grad).abs().max()
+    assert err <= 2e-3 * wr.grad.abs().max() + 1e-4, (float(err), float(wr.grad.abs().max()))       # fp32 sums of exact products
+    (again,) = ops.conv_igemm_wgrad([x], [g], [dil], k)
+    assert torch.equal(gw, again)                                                    # deterministic
+    (gb,) = ops.conv_igemm_wgrad([x], [g], [dil], k, out_dtype=torch.bfloat16)
+    assert torch.equal(gb, gw.bfloat16())
+
+
+def test_igemm_weight_gradient_four_branches(ops):
+    B, H, W, cin, cout = 1, 41, 41, 512, 1024
+    x, _, _ = _case(B, H, W, cin, cout, 3, 31)
+    gs = [torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(4)]
+    dils = [6, 12, 18, 24]
+    together = ops.conv_igemm_wgrad([x] * 4, gs, dils, 3)
+    for i in range(4):
+        (alone,) = ops.conv_igemm_wgrad([x], [gs[i]], [dils[i]], 3)
+        assert (together[i] - alone).abs().max() <= 1e-4 * alone.abs().max()         # another pixel split: another summation order
+    wr = torch.zeros(cout, cin, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(x.float(), wr, None, padding=18, dilation=18).backward(gs[2].float())
+    assert (together[2] - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max() + 1e-4

@@ -101,6 +101,50 @@ def main():
         print("%-28s %9.1f %9.1f %9.1f %9.1f | %8.0f %8.0f | %.2e" % (
             name, med["ig1"], med["ig0"], med["old"], med["mm"], flops / min(med["ig1"], med["ig0"]) / 1e6,
             flops / med["old"] / 1e6, err), flush=True)
+    wgrad_probe(B, args.rounds, args.iters)
+
+
+def wgrad_probe(B, rounds, iters):
+    """the implicit weight gradient against im2col + g^T @ cols (what backbone._ConvFn.backward runs today)"""
+    layers = [("conv4_2 512->512", 41, 41, 512, 512, 3, [1]), ("conv4_1 256->512", 41, 41, 256, 512, 3, [1]),
+              ("fc6 512->1024 d12", 41, 41, 512, 1024, 3, [12]), ("fc6 x4 (one launch)", 41, 41, 512, 1024, 3, [6, 12, 18, 24]),
+              ("fc7 1024->1024 1x1", 41, 41, 1024, 1024, 1, [1]), ("fc7 x4 (one launch)", 41, 41, 1024, 1024, 1, [1] * 4),
+              ("conv3_2 256->256 81x81", 81, 81, 256, 256, 3, [1])]
+    print("%-28s %9s %9s %9s | %8s %8s | %s" % ("weight gradient", "igemm", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
+    for name, H, W, cin, cout, k, dils in layers:
+        n = len(dils)
+        torch.manual_seed(2)
+        xs = [torch.randn(B, cin, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(n)]
+        gs = [torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(n)]
+
+        def run_ig():
+            return ops.conv_igemm_wgrad(xs, gs, dils, k)
+
+        def cols_of(g_):
+            return ops.im2col3x3_nhwc(xs[g_].permute(0, 2, 3, 1), dils[g_]) if k == 3 else xs[g_].permute(0, 2, 3, 1).reshape(-1, cin)
+
+        def run_old():
+            return [torch.mm(gs[g_].permute(0, 2, 3, 1).reshape(-1, cout).t(), cols_of(g_)) for g_ in range(n)]
+        cols = [cols_of(g_) for g_ in range(n)]
+
+        def run_mm():
+            return [torch.mm(gs[g_].permute(0, 2, 3, 1).reshape(-1, cout).t(), cols[g_]) for g_ in range(n)]
+        want = run_old()[0].float().view(cout, k, k, cin).permute(0, 3, 1, 2)
+        got = run_ig()[0]
+        err = float((got - want).abs().max() / want.abs().max())
+        for fn in (run_ig, run_old, run_mm):
+            for _ in range(3):
+                fn()
+        torch.cuda.synchronize()
+        t = {"ig": [], "old": [], "mm": []}
+        for _ in range(rounds):
+            t["ig"].append(timed(run_ig, iters))
+            t["old"].append(timed(run_old, iters))
+            t["mm"].append(timed(run_mm, iters))
+        med = {k_: float(np.median(v)) for k_, v in t.items()}
+        flops = 2.0 * B * H * W * cin * k * k * cout * n
+        print("%-28s %9.1f %9.1f %9.1f | %8.0f %8.0f | %.2e" % (name, med["ig"], med["old"], med["mm"], flops / med["ig"] / 1e6,
+                                                                  flops / med["old"] / 1e6, err), flush=True)
 
 
 if __name__ == "__main__":
