@@ -24,6 +24,10 @@ _GEMM_1X1_BWD = _os.environ.get("DSRG_GEMM_1X1_BWD", "1") == "1"   # 1x1 layers 
 _DIRECT_WGRAD = _os.environ.get("DSRG_DIRECT_WGRAD", "1") == "1"   # their weight gradients by the direct kernel too (0: MIOpen)
 _GEMM_DGRAD_MAX_MAP = int(_os.environ.get("DSRG_GEMM_DGRAD_MAX_MAP", "2048"))   # largest map (pixels) whose 3x3 data gradient is im2col(g) + GEMM
 _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1) or im2col(x)^T @ g (0): same numbers, other solution
+# 3x3 layers with >= 256 output channels (conv3_x, conv4_x, conv5_x, fc6_k) through the implicit-GEMM kernels (csrc/conv_igemm.hip:
+# no im2col matrix in the forward, the data gradient or the weight gradient; the four fc6_k in one launch); "0": the im2col +
+# hipBLASLt route of rounds 1-3
+_IGEMM = _os.environ.get("DSRG_IGEMM", "1") == "1"
 
 
 def _im2col_gemm(x, weight, bias, dilation, relu, want_cols=False):
@@ -191,6 +195,93 @@ class _ConvFn(torch.autograd.Function):
         return (gx if gemm_dgrad else gx2), (gw if gemm_wgrad else gw2), (gb if fused else gb2), None, None, None, None, None
 
 
+class _IgemmConvFn(torch.autograd.Function):
+    """n convolutions of one geometry (n = 1, or the four ASPP branches) + bias (+ ReLU (+ Dropout) (+ the stride-2 max pool)):
+    apply(k, dils, relu, drop_p, pool, n, x_1..x_n, w_1..w_n, b_1..b_n).  k = 3 (conv3_x .. fc6_k): forward, data and weight
+    gradient by the implicit-GEMM kernels; k = 1 (fc7_k): forward and data gradient are plain hipBLASLt GEMMs over the NHWC
+    matrices (nothing to gather), the weight gradients of all branches one implicit-GEMM launch.
+    x: bf16 channels_last; w, b: the float32 master parameters — the kernel is cast to bf16 by the same copy that packs it
+    for the kernel, and the weight gradient comes back in float32, so autocast's per-layer casts both ways disappear.
+    Backward: ReLU / dropout mask + bias gradient in one fused pass (as _ConvFn), data gradients of all branches in one launch
+    (the same kernel on the flipped, transposed kernels), weight gradients in one launch."""
+
+    @staticmethod
+    def forward(ctx, k, dils, relu, drop_p, pool, n, *t):
+        from .ops import conv_igemm, pack_conv_weight
+        xs, ws, bs = t[:n], t[n:2 * n], t[2 * n:3 * n]
+        xs = [x if x.dtype == torch.bfloat16 else x.bfloat16() for x in xs]
+        if k == 3:
+            outs = conv_igemm(xs, [pack_conv_weight(w) for w in ws], [b.detach().float().contiguous() for b in bs], dils, 3, relu)
+        else:
+            outs = [_im2col_gemm(x, w.to(torch.bfloat16), b.to(torch.bfloat16), 1, relu) for x, w, b in zip(xs, ws, bs)]
+        if drop_p > 0.0:
+            outs = [torch.ops.aten.native_dropout(o, drop_p, True)[0] for o in outs]      # o = relu * mask / (1 - p)
+        code, pooled = None, None
+        if pool is not None:                                                             # n == 1 (conv3_3)
+            from .ops import maxpool3x3_fwd
+            pooled, code = maxpool3x3_fwd(outs[0], pool[0], pool[1])
+        ctx.save_for_backward(code, *xs, *ws, *(outs if relu else ()))
+        ctx.dils, ctx.relu, ctx.scale, ctx.pool, ctx.n, ctx.k = dils, relu, 1.0 / (1.0 - drop_p), pool, n, k
+        return tuple(outs) if pool is None else (pooled,)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        from .ops import (conv_igemm, conv_igemm_supported, conv_igemm_wgrad, pack_conv_weight, relu_bwd_bias, bias_grad,
+                          maxpool3x3_bwd_relu)
+        n = ctx.n
+        code, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        xs, ws, ys = saved[:n], saved[n:2 * n], saved[2 * n:]
+        cout, cin = ws[0].shape[0], ws[0].shape[1]
+        gms, gbs = [], []
+        for i, g in enumerate(gs):
+            if ctx.pool is not None:
+                gm, gb = maxpool3x3_bwd_relu(g, code, ys[i], ctx.pool[0])
+            elif ctx.relu:
+                gm, gb = relu_bwd_bias(g, ys[i], ctx.scale)
+            else:
+                gm = g.contiguous(memory_format=torch.channels_last)
+                gb = bias_grad(gm)
+            gms.append(gm); gbs.append(gb)
+        need_x = [ctx.needs_input_grad[6 + i] for i in range(n)]
+        gxs = [None] * n
+        if ctx.k == 1:
+            for i in range(n):
+                if need_x[i]:
+                    g2d = gms[i].permute(0, 2, 3, 1).reshape(-1, cout)
+                    B_, _, H_, W_ = xs[i].shape
+                    gxs[i] = torch.mm(g2d, ws[i].to(torch.bfloat16).reshape(cout, cin)).view(B_, H_, W_, cin).permute(0, 3, 1, 2)
+            gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 1)
+            return (None,) * 6 + tuple(gxs) + tuple(gws) + tuple(gbs)
+        if any(need_x):
+            if conv_igemm_supported(cout, cin, 3):
+                gxs = conv_igemm(gms, [pack_conv_weight(w, for_dgrad=True) for w in ws], None, ctx.dils, 3, False)
+            else:                                                                        # conv3_1: 128 input channels
+                for i in range(n):
+                    d = ctx.dils[i]
+                    gxs[i] = torch.ops.aten.convolution_backward(gms[i], xs[i], ws[i].to(torch.bfloat16), None, [1, 1], [d, d], [d, d],
+                                                                 False, [0, 0], 1, [True, False, False])[0]
+        if cin % 256 == 0:
+            gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 3)                           # float32, the parameters' own layout
+        else:
+            gws = []
+            for i in range(n):
+                d = ctx.dils[i]
+                gws.append(torch.ops.aten.convolution_backward(gms[i], xs[i], ws[i].to(torch.bfloat16), None, [1, 1], [d, d], [d, d],
+                                                               False, [0, 0], 1, [False, True, False])[1].float())
+        return (None,) * 6 + tuple(gx if nx else None for gx, nx in zip(gxs, need_x)) + tuple(gws) + tuple(gbs)
+
+
+def _igemm_route(conv, x):
+    """does this GemmConv2d call take the implicit-GEMM kernels: a 3x3 'same' convolution with bias on bf16 activations
+    (autocast), 64 | input channels, 256 | output channels"""
+    if not (_IGEMM and x.is_cuda and conv.gemm and conv.kernel_size == (3, 3) and conv.bias is not None and conv.groups == 1):
+        return False
+    if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
+        return False
+    from .ops import conv_igemm_supported
+    return conv_igemm_supported(conv.in_channels, conv.out_channels, 3)
+
+
 class GemmConv2d(nn.Conv2d):
     """nn.Conv2d (same parameters, same init, same state_dict) whose CUDA forward is im2col + GEMM, optionally
     with the following ReLU (`fuse_relu`) and Dropout (`fuse_dropout` = p, needs fuse_relu) fused; on the CPU it is the
@@ -212,6 +303,11 @@ class GemmConv2d(nn.Conv2d):
                 self.padding[0] == self.dilation[0] * (self.kernel_size[0] // 2):
             # the pool rides inside the node when its kernels apply: bf16 activations (autocast), 8 | channels, (channels / 8) | 256
             cout = self.out_channels
+            if _igemm_route(self, x):
+                in_node = pool is not None and _FUSE_POOL
+                (out,) = _IgemmConvFn.apply(3, [self.dilation[0]], self.fuse_relu, p, pool if in_node else None, 1, x, self.weight,
+                                            self.bias)
+                return out if pool is None or in_node else _pool3x3(out, pool[0], pool[1])
             in_node = pool is not None and _FUSE_POOL and cout % 8 == 0 and 256 % (cout // 8) == 0 and self.bias is not None and (
                 x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16))
             out = _ConvFn.apply(x, self.weight, self.bias, self.dilation[0], self.fuse_relu, self.gemm, p, pool if in_node else None)
@@ -363,11 +459,29 @@ class VGG16ASPP(nn.Module):
         score of magnitude 8-16 has a step of 0.06-0.125."""
         f = self.features(x)
         hs = []
-        for br in self.branches:
-            h = f
-            for m in list(br)[:-1]:
-                h = m(h)
-            hs.append(h)
+        fc6 = [br[0] for br in self.branches]
+        if len(fc6) <= 4 and all(_igemm_route(m, f) and m.stride == (1, 1) and m.padding == m.dilation for m in fc6):
+            # the four fc6_k (same input, own dilation) in one launch each way: 1696 tiles fill the chip where 424 leave a sixth idle
+            p = fc6[0].fuse_dropout if self.training else 0.0
+            n = len(fc6)
+            hs = list(_IgemmConvFn.apply(3, [m.dilation[0] for m in fc6], True, p, None, n, *([f] * n), *[m.weight for m in fc6],
+                                         *[m.bias for m in fc6]))
+            fc7 = [br[3] for br in self.branches]
+            if all(isinstance(m, GemmConv2d) and m.kernel_size == (1, 1) and m.fuse_relu and m.bias is not None and m.gemm
+                   and m.in_channels % 256 == 0 and m.out_channels % 256 == 0 for m in fc7):
+                # fc7_k: own input each, one launch for the four weight gradients
+                p7 = fc7[0].fuse_dropout if self.training else 0.0
+                hs = list(_IgemmConvFn.apply(1, [1] * n, True, p7, None, n, *hs, *[m.weight for m in fc7], *[m.bias for m in fc7]))
+            else:
+                for i, br in enumerate(self.branches):
+                    for m in list(br)[1:-1]:
+                        hs[i] = m(hs[i])
+        else:
+            for br in self.branches:
+                h = f
+                for m in list(br)[:-1]:
+                    h = m(h)
+                hs.append(h)
         heads = [br[-1] for br in self.branches]
         if hs[0].is_cuda and hs[0].dtype == torch.bfloat16 and len(hs) <= 4 and heads[0].out_channels <= 32 \
                 and heads[0].in_channels % 256 == 0:

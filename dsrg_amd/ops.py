@@ -450,7 +450,11 @@ def pack_conv_weight(weight, for_dgrad=False, dtype=torch.bfloat16):
         weight = weight.flip(2, 3).transpose(0, 1) if k > 1 else weight.transpose(0, 1)
     o, c = weight.shape[0], weight.shape[1]
     out = torch.empty((o, c // 64, k * k, 64), dtype=dtype, device=weight.device)
-    out.copy_(weight.reshape(o, c // 64, 64, k * k).permute(0, 1, 3, 2))      # cast + permute in one pass
+    if weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous():
+        # the net's parameters are channels_last: memory [o][tap][c] -> [o][c / 64][tap][64] is a strided view of it
+        out.copy_(weight.permute(0, 2, 3, 1).reshape(o, k * k, c // 64, 64).permute(0, 2, 1, 3))
+    else:
+        out.copy_(weight.reshape(o, c // 64, 64, k * k).permute(0, 1, 3, 2))  # cast + permute in one pass
     return out
 
 

@@ -139,3 +139,34 @@ def test_igemm_weight_gradient_four_branches(ops):
     wr = torch.zeros(cout, cin, 3, 3, device="cuda", requires_grad=True)
     F.conv2d(x.float(), wr, None, padding=18, dilation=18).backward(gs[2].float())
     assert (together[2] - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max() + 1e-4
+
+
+def test_backbone_igemm_route_matches_im2col_route():
+    """VGG16-ASPP forward + backward under bf16 autocast: the implicit-GEMM route (conv3_x .. fc6_k, fc7_k weight gradients)
+    against the im2col + hipBLASLt route of the earlier rounds on the same weights and input (dropout off): same scores and
+    parameter gradients up to bf16 rounding of intermediate activations"""
+    from dsrg_amd import backbone
+    torch.manual_seed(3)
+    net = backbone.VGG16ASPP(dropout=0.0).cuda().to(memory_format=CL)
+    x = torch.randn(2, 3, 161, 161, device="cuda").contiguous(memory_format=CL)
+    gout = None
+    res = {}
+    for route in (True, False):
+        backbone._IGEMM = route
+        try:
+            net.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(x)
+            if gout is None:
+                gout = torch.randn_like(y)
+            y.backward(gout)
+            res[route] = (y.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        finally:
+            backbone._IGEMM = True
+    ya, ga = res[True]
+    yb, gb = res[False]
+    assert ya.dtype == torch.float32 and (ya - yb).abs().max() <= 0.02 * yb.abs().max()
+    for n in ga:
+        assert ga[n].dtype == torch.float32 and ga[n].shape == gb[n].shape
+        rel = (ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-12)
+        assert rel <= 0.03, (n, float(rel))
