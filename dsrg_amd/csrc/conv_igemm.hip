@@ -70,6 +70,8 @@ struct IgemmGroup {
 struct IgemmArgs {
     IgemmGroup g[4];
     int ngroups, B, H, W, Cin, Cout, taps, relu, M, tiles_m, tiles_n, tiles_per_group;
+    int stagger;            // 1: waves 4-7 issue their DMA behind the first MFMA cluster of a step (their SIMD partners 0-3 issue
+                            // in front of theirs), so that no SIMD's matrix pipe waits for both of its waves to get through the issue code
 };
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
@@ -187,7 +189,9 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         if (C::AHEAD >= 3 && s + 2 < nsteps) wait_vm_barrier<2 * LPS>();
         else if (C::AHEAD >= 2 && s + 1 < nsteps) wait_vm_barrier<LPS>();
         else wait_vm_barrier<0>();
-        if (s + C::AHEAD < nsteps) issue(stage == 0 ? NST - 1 : stage - 1, s + C::AHEAD);    // the stage step s - 1 was read from
+        const bool more = s + C::AHEAD < nsteps, late = a.stagger && wv >= 4;
+        const int nstage = stage == 0 ? NST - 1 : stage - 1;                                  // the stage step s - 1 was read from
+        if (more && !late) issue(nstage, s + C::AHEAD);
         const unsigned char *P = ig_lds + stage * C::STAGE + wm * (64 * C::ROW);
         const unsigned char *Wt = ig_lds + stage * C::STAGE + kBM * C::ROW + wn * (128 * C::ROW);
         // fragments of k-slice ks + 1 are read before the MFMAs of slice ks (order pinned by sched_barrier)
@@ -211,6 +215,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0 && more && late) issue(nstage, s + C::AHEAD);
         }
         stage = stage + 1 == NST ? 0 : stage + 1;
     }
@@ -285,6 +290,7 @@ struct WgradGroup {
 struct IgemmWgradArgs {
     WgradGroup g[4];
     int ngroups, B, H, W, Cin, Cout, taps, M, tiles_n, tiles_c, ksplit, kchunk, tiles_per_group;
+    int stagger;            // as IgemmArgs::stagger
 };
 constexpr int kWRow = 512;                                 // bytes per LDS row: 256 channels
 constexpr int kWTile = 64 * kWRow;                         // 64 pixels
@@ -396,7 +402,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     if (nsteps > 0) issue(0);
     for (int s = 0; s < nsteps; s++) {
         wait_vm_barrier<0>();
-        if (s + 1 < nsteps) issue((s + 1) & 1);
+        const bool more = s + 1 < nsteps, late = a.stagger && wv >= 4;
+        if (more && !late) issue((s + 1) & 1);
         lds_u8 *st = lds + (s & 1) * kWStage;
         bf16x8 af[2][4], bfr[2][2];
 #pragma unroll
@@ -418,6 +425,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0 && more && late) issue((s + 1) & 1);
         }
     }
     // C[row = channel of g][col = channel of x]: lane holds column l31, rows (reg & 3) + 8 (reg >> 2) + 4 kgrp
@@ -491,7 +499,8 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     a.tiles_n = cout / kBN;
     a.tiles_per_group = a.tiles_m * a.tiles_n;
     static LdsGrant grant[2];
-    const int variant = igemm_variant() == 2 ? 1 : 0;       // 1: two stages of 64; 2: ring of four stages of 32
+    const int variant = igemm_variant() == 2 ? 1 : 0;       // 1, 3: two stages of 64; 2: ring of four stages of 32
+    a.stagger = igemm_variant() == 3;
     const dim3 grid(a.tiles_per_group * ngroups), block(512);
     if (variant == 0) {
         constexpr size_t lds = ICfg<64, 2>::LDS;
@@ -553,6 +562,7 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     a.ksplit = wgrad_ksplit(M, ngroups * a.tiles_n * a.tiles_c, 256);
     a.kchunk = (int)(((M + a.ksplit - 1) / a.ksplit + 63) / 64 * 64);
     a.tiles_per_group = a.tiles_n * a.tiles_c * a.ksplit;
+    a.stagger = igemm_variant() == 3;
     const size_t per_group = (size_t)a.ksplit * cout * k * k * cin;
     for (int q = 0; q < ngroups; q++) {
         a.g[q].x = static_cast<const uint16_t *>(x[q]);

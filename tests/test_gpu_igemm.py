@@ -141,32 +141,35 @@ def test_igemm_weight_gradient_four_branches(ops):
     assert (together[2] - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max() + 1e-4
 
 
-def test_backbone_igemm_route_matches_im2col_route():
-    """VGG16-ASPP forward + backward under bf16 autocast: the implicit-GEMM route (conv3_x .. fc6_k, fc7_k weight gradients)
-    against the im2col + hipBLASLt route of the earlier rounds on the same weights and input (dropout off): same scores and
-    parameter gradients up to bf16 rounding of intermediate activations"""
+def test_backbone_igemm_route_is_as_close_to_float32_as_the_im2col_route():
+    """VGG16-ASPP forward + backward (dropout off, same weights, input and score gradient): the implicit-GEMM route (conv3_x ..
+    fc6_k, fc7_k weight gradients) and the im2col + hipBLASLt route of the earlier rounds under bf16 autocast, each against the
+    float32 backbone.  bf16 activations make every parameter gradient noisy, the more the deeper the backward chain (a
+    relative distance of 2e-3 at fc8 grows to 0.8 at conv1_1 with default initialisation: tools/igemm_route_diag.py), so
+    the routes are not compared with each other: the new one must be no further from float32 than the old one."""
     from dsrg_amd import backbone
     torch.manual_seed(3)
     net = backbone.VGG16ASPP(dropout=0.0).cuda().to(memory_format=CL)
     x = torch.randn(2, 3, 161, 161, device="cuda").contiguous(memory_format=CL)
-    gout = None
-    res = {}
-    for route in (True, False):
-        backbone._IGEMM = route
-        try:
+    gout, res = None, {}
+    try:
+        for tag, route, amp in (("igemm", True, True), ("im2col", False, True), ("fp32", False, False)):
+            backbone._IGEMM = route
             net.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
                 y = net(x)
-            if gout is None:
-                gout = torch.randn_like(y)
+            gout = torch.randn_like(y) if gout is None else gout
             y.backward(gout)
-            res[route] = (y.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
-        finally:
-            backbone._IGEMM = True
-    ya, ga = res[True]
-    yb, gb = res[False]
-    assert ya.dtype == torch.float32 and (ya - yb).abs().max() <= 0.02 * yb.abs().max()
-    for n in ga:
-        assert ga[n].dtype == torch.float32 and ga[n].shape == gb[n].shape
-        rel = (ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-12)
-        assert rel <= 0.03, (n, float(rel))
+            res[tag] = (y.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+    finally:
+        backbone._IGEMM = True
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm().clamp_min(1e-20))      # noqa: E731
+    assert res["igemm"][0].dtype == torch.float32
+    assert rel(res["igemm"][0], res["fp32"][0]) <= 1.25 * rel(res["im2col"][0], res["fp32"][0]) + 1e-3
+    worse = []
+    for n, ref in res["fp32"][1].items():
+        a, b = res["igemm"][1][n], res["im2col"][1][n]
+        assert a.dtype == torch.float32 and a.shape == ref.shape
+        if rel(a, ref) > 1.3 * rel(b, ref) + 0.01:
+            worse.append((n, rel(a, ref), rel(b, ref)))
+    assert not worse, worse

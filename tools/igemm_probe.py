@@ -55,7 +55,7 @@ def main():
         ("conv3_2 256->256 81x81", 81, 81, 256, 256, 3, [1]),
         ("conv3_1 128->256 81x81", 81, 81, 128, 256, 3, [1]),
     ]
-    print("%-28s %9s %9s %9s %9s | %8s %8s | %s" % ("layer", "ig 64x2", "ig 32x4", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
+    print("%-28s %9s %9s %9s %9s | %8s %8s | %s" % ("layer", "ig 64x2", "ig stagger", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
     for name, H, W, cin, cout, k, dils in layers:
         n = len(dils)
         torch.manual_seed(1)
@@ -91,7 +91,7 @@ def main():
         for _ in range(args.rounds):
             ops.set_igemm_variant(1)
             t["ig1"].append(timed(run_ig, args.iters))
-            ops.set_igemm_variant(2)
+            ops.set_igemm_variant(3)
             t["ig0"].append(timed(run_ig, args.iters))
             t["old"].append(timed(run_old, args.iters))
             t["mm"].append(timed(run_mm, args.iters))
@@ -136,15 +136,18 @@ def wgrad_probe(B, rounds, iters):
             for _ in range(3):
                 fn()
         torch.cuda.synchronize()
-        t = {"ig": [], "old": [], "mm": []}
+        t = {"ig": [], "ig3": [], "old": [], "mm": []}
         for _ in range(rounds):
+            ops.set_igemm_variant(3)
+            t["ig3"].append(timed(run_ig, iters))
+            ops.set_igemm_variant(1)
             t["ig"].append(timed(run_ig, iters))
             t["old"].append(timed(run_old, iters))
             t["mm"].append(timed(run_mm, iters))
         med = {k_: float(np.median(v)) for k_, v in t.items()}
         flops = 2.0 * B * H * W * cin * k * k * cout * n
-        print("%-28s %9.1f %9.1f %9.1f | %8.0f %8.0f | %.2e" % (name, med["ig"], med["old"], med["mm"], flops / med["ig"] / 1e6,
-                                                                  flops / med["old"] / 1e6, err), flush=True)
+        print("%-28s %9.1f %9.1f %9.1f | %8.0f %8.0f | %.2e  (staggered %.1f)" % (name, med["ig"], med["old"], med["mm"], flops / med["ig"] / 1e6,
+                                                                  flops / med["old"] / 1e6, err, med["ig3"]), flush=True)
 
 
 if __name__ == "__main__":
