@@ -458,12 +458,16 @@ def fp32_leg(device, images, labels, cues, steps, warmup=3):
 
 
 def loss_trajectories(device, images, labels, cues, steps=20):
-    """bf16-autocast backbone vs float32 backbone: same initial weights, same dropout seeds, same batch, `steps` steps;
+    """bf16-autocast backbone vs float32 backbone: same initial weights, same batch, `steps` steps, Dropout off (the bf16 leg
+    draws its masks inside the convolutions' epilogues from a counter-based generator, the float32 leg from torch's: with
+    Dropout on the two trajectories would differ by their masks, not by their arithmetic);
     -> (bf16 totals, fp32 totals, max relative gap of the total loss)"""
+    from dsrg_amd.backbone import VGG16ASPP
     from dsrg_amd.trainer import DSRGTrainer
     out = []
     for amp in (torch.bfloat16, None):
-        tr = DSRGTrainer(device, amp_dtype=amp, seed=123)
+        torch.manual_seed(123)
+        tr = DSRGTrainer(device, amp_dtype=amp, seed=123, net=VGG16ASPP(dropout=0.0))
         tot = []
         for _ in range(steps):
             tot.append(tr.step(images, labels, cues))

@@ -28,6 +28,7 @@ _WGRAD_T = _os.environ.get("DSRG_WGRAD_T", "1") == "1"     # g^T @ im2col(x) (1)
 # no im2col matrix in the forward, the data gradient or the weight gradient; the four fc6_k in one launch); "0": the im2col +
 # hipBLASLt route of rounds 1-3
 _IGEMM = _os.environ.get("DSRG_IGEMM", "1") == "1"
+_FC7_IGEMM = _os.environ.get("DSRG_FC7_IGEMM", "1") == "1"   # fc7_k forward by the 1x1 implicit-GEMM launch when Dropout follows (mask fused)
 
 
 def _im2col_gemm(x, weight, bias, dilation, relu, want_cols=False):
@@ -207,21 +208,40 @@ class _IgemmConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, k, dils, relu, drop_p, pool, n, *t):
-        from .ops import conv_igemm, pack_conv_weight
+        from .ops import conv_igemm, conv_igemm_supported, pack_conv_weight_pair, dropout_seed
         xs, ws, bs = t[:n], t[n:2 * n], t[2 * n:3 * n]
         xs = [x if x.dtype == torch.bfloat16 else x.bfloat16() for x in xs]
+        packs_d = [None] * n
+        fb = [b.detach().float().contiguous() for b in bs]
+        # Dropout behind the ReLU rides in the implicit-GEMM epilogue (mask = f(seed, branch, position), p in steps of 1/256)
+        fused_drop = drop_p > 0.0 and relu and (k == 3 or _FC7_IGEMM)
+        scale = 1.0
+        if fused_drop:
+            scale = 256.0 / (256 - min(255, int(drop_p * 256.0 + 0.5)))
+        elif drop_p > 0.0:
+            scale = 1.0 / (1.0 - drop_p)
+        seed = dropout_seed() if fused_drop else 0
         if k == 3:
-            outs = conv_igemm(xs, [pack_conv_weight(w) for w in ws], [b.detach().float().contiguous() for b in bs], dils, 3, relu)
+            # both packed forms of every kernel from the float32 master in one pass each; the data-gradient form waits for backward
+            need_d = any(ctx.needs_input_grad[6:6 + n]) and conv_igemm_supported(ws[0].shape[0], ws[0].shape[1], 3)
+            packs = [pack_conv_weight_pair(w, True, need_d) for w in ws]
+            packs_d = [p[1] for p in packs]
+            outs = conv_igemm(xs, [p[0] for p in packs], fb, dils, 3, relu, drop_p if fused_drop else 0.0, seed)
+        elif fused_drop:
+            # fc7_k with Dropout behind it: one 1x1 implicit-GEMM launch for all branches with the mask in its epilogue beats four
+            # hipBLASLt GEMMs + four dropout passes
+            outs = conv_igemm(xs, [pack_conv_weight_pair(w, True, False)[0] for w in ws], fb, dils, 1, relu, drop_p, seed)
         else:
             outs = [_im2col_gemm(x, w.to(torch.bfloat16), b.to(torch.bfloat16), 1, relu) for x, w, b in zip(xs, ws, bs)]
-        if drop_p > 0.0:
+        if drop_p > 0.0 and not fused_drop:
             outs = [torch.ops.aten.native_dropout(o, drop_p, True)[0] for o in outs]      # o = relu * mask / (1 - p)
         code, pooled = None, None
         if pool is not None:                                                             # n == 1 (conv3_3)
             from .ops import maxpool3x3_fwd
             pooled, code = maxpool3x3_fwd(outs[0], pool[0], pool[1])
         ctx.save_for_backward(code, *xs, *ws, *(outs if relu else ()))
-        ctx.dils, ctx.relu, ctx.scale, ctx.pool, ctx.n, ctx.k = dils, relu, 1.0 / (1.0 - drop_p), pool, n, k
+        ctx.packs_d = packs_d                  # not an input or output of the node: kept outside save_for_backward
+        ctx.dils, ctx.relu, ctx.scale, ctx.pool, ctx.n, ctx.k = dils, relu, scale, pool, n, k
         return tuple(outs) if pool is None else (pooled,)
 
     @staticmethod
@@ -254,7 +274,8 @@ class _IgemmConvFn(torch.autograd.Function):
             return (None,) * 6 + tuple(gxs) + tuple(gws) + tuple(gbs)
         if any(need_x):
             if conv_igemm_supported(cout, cin, 3):
-                gxs = conv_igemm(gms, [pack_conv_weight(w, for_dgrad=True) for w in ws], None, ctx.dils, 3, False)
+                packs_d = [p if p is not None else pack_conv_weight(w, for_dgrad=True) for p, w in zip(ctx.packs_d, ws)]
+                gxs = conv_igemm(gms, packs_d, None, ctx.dils, 3, False)
             else:                                                                        # conv3_1: 128 input channels
                 for i in range(n):
                     d = ctx.dils[i]

@@ -52,8 +52,9 @@ namespace dsrg { extern void *g_filter_dbg; extern void *g_build_dbg; extern std
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_opts(int opts) {
     dsrg::g_filter_opts = opts < 0 ? -1 : (opts & 3);      // bits 4 and 8 (seqCompute arithmetic, norm pass) are the launcher's own
 }
-// tests / tools only: pipeline of the implicit-GEMM convolution: 1 = two LDS stages of 64 reduction elements (default), 2 = a
-// ring of four stages of 32 with three steps in flight, -1 = back to DSRG_IGEMM_VARIANT / the default; identical results
+// tests / tools only: pipeline of the implicit-GEMM convolution: 1 = two LDS stages of 64 reduction elements, every wave issuing
+// its DMA right behind the barrier; 3 (default) = the same with waves 4-7 issuing behind their first MFMA cluster; 2 = a ring of
+// four stages of 32 with three steps in flight; -1 = back to DSRG_IGEMM_VARIANT / the default; identical results
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_igemm_variant(int v) { dsrg::g_igemm_variant = v; }
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_build_trace(void *dev_buf) { dsrg::g_build_dbg = dev_buf; }
 // tools only (not in the public header): device buffer of 16 u64 per filter block receiving phase timestamps
@@ -469,10 +470,13 @@ extern "C" int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, co
 extern "C" int dsrg_conv_igemm_supported(int cin, int cout, int ksize) { return conv_igemm_supported(cin, cout, ksize) ? 1 : 0; }
 extern "C" int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, const float *const *bias_dev,
                                     void *const *y_dev, const int *dilation, int ngroups, int B, int H, int W, int cin, int cout,
-                                    int ksize, int relu, void *stream) {
+                                    int ksize, int relu, float dropout_p, unsigned long long dropout_seed, void *stream) {
     if (!x_dev || !w_dev || !y_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "conv_igemm: bad arguments");
-    return launch_conv_igemm(x_dev, w_dev, bias_dev, y_dev, dilation, ngroups, B, H, W, cin, cout, ksize, relu,
-                             static_cast<hipStream_t>(stream));
+    return launch_conv_igemm(x_dev, w_dev, bias_dev, y_dev, dilation, ngroups, B, H, W, cin, cout, ksize, relu, dropout_p,
+                             dropout_seed, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_pack_conv_weight_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, int ksize, void *stream) {
+    return launch_pack_conv_weight(w_dev, fwd_dev, dgrad_dev, cout, cin, ksize, static_cast<hipStream_t>(stream));
 }
 extern "C" size_t dsrg_conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int ksize) {
     return conv_igemm_wgrad_workspace(ngroups, B, H, W, cin, cout, ksize);

@@ -181,10 +181,12 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
                           int relu, hipStream_t stream);
 bool conv_igemm_supported(int cin, int cout, int k);
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
-                      int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, hipStream_t stream);
+                      int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
+                      hipStream_t stream);
 size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k);
 int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *const *gw, const int *dil, int ngroups, void *workspace,
                             size_t workspace_bytes, int B, int H, int W, int cin, int cout, int k, int out_bf16, hipStream_t stream);
+int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream);
 int heads_bwd_chunks(int M);
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
                      float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream);

@@ -72,7 +72,22 @@ struct IgemmArgs {
     int ngroups, B, H, W, Cin, Cout, taps, relu, M, tiles_m, tiles_n, tiles_per_group;
     int stagger;            // 1: waves 4-7 issue their DMA behind the first MFMA cluster of a step (their SIMD partners 0-3 issue
                             // in front of theirs), so that no SIMD's matrix pipe waits for both of its waves to get through the issue code
+    uint32_t drop_thresh;   // Dropout behind the ReLU, fused: keep an element iff its random byte >= drop_thresh (p = thresh / 256;
+    float drop_scale;       // 0 = no dropout), kept elements times drop_scale = 1 / (1 - p)
+    uint32_t seed_lo, seed_hi;
 };
+
+// the random bytes of the four consecutive channels starting at element 4 * e4 of a launch's output: a counter-based
+// generator (two rounds of the murmur3 finaliser over the element counter and the 64-bit seed) — every element's decision is a
+// pure function of (seed, position), so the mask needs no state, no extra pass and no storage (the backward pass reads it
+// off the sign of the output, as with torch's dropout kernel before)
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t dropout_bytes(uint32_t e4, uint32_t seed_lo, uint32_t seed_hi) {
+    return fmix32(fmix32(e4 ^ seed_lo) + seed_hi);
+}
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
     f32x2 v = {lo, hi};
@@ -226,6 +241,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
     const int nw = n0 + wn * 128;
     const rsrc_t rb = make_rsrc(G.bias, G.bias ? (size_t)a.Cout * 4 : 0);      // no bias: every load is out of range = 0
     const float floor_ = a.relu ? 0.0f : -__builtin_inff();                    // ReLU without a branch per value
+    const uint32_t seed_g = a.seed_lo + (uint32_t)grp * 0x9E3779B9u;              // every branch its own stream
     float bias_r[4][4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -245,6 +261,14 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
                 float v0 = acc[i][j][q * 4 + 0] + b4.x, v1 = acc[i][j][q * 4 + 1] + b4.y;
                 float v2 = acc[i][j][q * 4 + 2] + b4.z, v3 = acc[i][j][q * 4 + 3] + b4.w;
                 v0 = fmaxf(v0, floor_); v1 = fmaxf(v1, floor_); v2 = fmaxf(v2, floor_); v3 = fmaxf(v3, floor_);
+                if (a.drop_thresh) {                                             // uniform
+                    const uint32_t m = (uint32_t)(m0 + wm * 64 + j * 32 + l31);
+                    const uint32_t h = dropout_bytes((m * (uint32_t)a.Cout + (uint32_t)(nw + nl)) >> 2, seed_g, a.seed_hi);
+                    v0 = (h & 0xffu) >= a.drop_thresh ? v0 * a.drop_scale : 0.0f;
+                    v1 = ((h >> 8) & 0xffu) >= a.drop_thresh ? v1 * a.drop_scale : 0.0f;
+                    v2 = ((h >> 16) & 0xffu) >= a.drop_thresh ? v2 * a.drop_scale : 0.0f;
+                    v3 = (h >> 24) >= a.drop_thresh ? v3 * a.drop_scale : 0.0f;
+                }
                 *reinterpret_cast<uint2 *>(O + (j * 32 + l31) * kOutRow + nl * 2) = make_uint2(pack2(v0, v1), pack2(v2, v3));
             }
         }
@@ -458,6 +482,35 @@ __global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(const floa
     else reinterpret_cast<float4 *>(gw)[e] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Both packed forms of a kernel in one pass over the float32 master weights ([o][tap][c] = a channels_last (cout, cin, k, k)
+// parameter): the forward form fwd[o][c / 64][tap][64] and the data-gradient form dg[c][o / 64][T - tap][64] (the kernel
+// flipped, T = k*k - 1, and its channel axes swapped), both bf16.  One block per (64 outputs, 64 inputs, tap): the forward
+// form is the tile as it is read; the data-gradient form is its transpose, taken through LDS.
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float *w, uint16_t *fwd, uint16_t *dg, int cout, int cin, int taps) {
+    __shared__ uint16_t tile[64][64 + 4];
+    const int ob = blockIdx.x, cb = blockIdx.y, tap = blockIdx.z, t = threadIdx.x;
+    const int r = t >> 4, q = t & 15;                        // 16 rows x 16 float4 per pass
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int o = r + 16 * i;
+        const float4 v = *reinterpret_cast<const float4 *>(w + ((size_t)(ob * 64 + o) * taps + tap) * cin + cb * 64 + q * 4);
+        const uint2 pk = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+        if (fwd) *reinterpret_cast<uint2 *>(fwd + (((size_t)(ob * 64 + o) * (cin >> 6) + cb) * taps + tap) * 64 + q * 4) = pk;
+        *reinterpret_cast<uint2 *>(&tile[o][q * 4]) = pk;
+    }
+    if (!dg) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = r + 16 * i;                            // row of the transposed tile; q*4 .. q*4+3 = its outputs
+        const uint32_t lo = (uint32_t)tile[q * 4 + 0][c] | ((uint32_t)tile[q * 4 + 1][c] << 16);
+        const uint32_t hi = (uint32_t)tile[q * 4 + 2][c] | ((uint32_t)tile[q * 4 + 3][c] << 16);
+        *reinterpret_cast<uint2 *>(dg + (((size_t)(cb * 64 + c) * (cout >> 6) + ob) * taps + (taps - 1 - tap)) * 64 + q * 4) = make_uint2(lo, hi);
+    }
+}
+
 }  // namespace
 
 bool conv_igemm_supported(int cin, int cout, int k) {
@@ -469,14 +522,15 @@ static int igemm_variant() {
     int v = g_igemm_variant.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("DSRG_IGEMM_VARIANT");
-        v = e ? atoi(e) : 1;
+        v = e ? atoi(e) : 3;
         g_igemm_variant.store(v, std::memory_order_relaxed);
     }
     return v;
 }
 
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
-                      int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, hipStream_t stream) {
+                      int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
+                      hipStream_t stream) {
     if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm: 1..4 groups");
     if (!conv_igemm_supported(cin, cout, k))
         return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: cin %% 64 == 0, cout %% %d == 0, k in (1, 3) required (got %d, %d, %d)",
@@ -498,6 +552,11 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     a.tiles_m = (int)((M + kBM - 1) / kBM);
     a.tiles_n = cout / kBN;
     a.tiles_per_group = a.tiles_m * a.tiles_n;
+    if (drop_p < 0.0f || drop_p >= 1.0f) return set_error(DSRG_ERR_INVALID, "conv_igemm: 0 <= dropout probability < 1");
+    a.drop_thresh = (uint32_t)(drop_p * 256.0f + 0.5f);       // p is realised in steps of 1 / 256 (0.5 exactly)
+    if (a.drop_thresh > 255) a.drop_thresh = 255;
+    a.drop_scale = 256.0f / (float)(256 - (int)a.drop_thresh);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     static LdsGrant grant[2];
     const int variant = igemm_variant() == 2 ? 1 : 0;       // 1, 3: two stages of 64; 2: ring of four stages of 32
     a.stagger = igemm_variant() == 3;
@@ -586,6 +645,17 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
                                a.ksplit, n4);
         DSRG_LAUNCH_CHECK();
     }
+    return DSRG_OK;
+}
+
+
+int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream) {
+    if (!w || cout < 64 || cout % 64 || cin < 64 || cin % 64 || (k != 1 && k != 3))
+        return set_error(DSRG_ERR_INVALID, "pack_conv_weight: 64 | cout, 64 | cin, k in (1, 3) required (got %d, %d, %d)", cout, cin, k);
+    if (!fwd && !dgrad) return DSRG_OK;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cout / 64, cin / 64, k * k), dim3(256), 0, stream, w, static_cast<uint16_t *>(fwd),
+                       static_cast<uint16_t *>(dgrad), cout, cin, k * k);
+    DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
 

@@ -458,10 +458,25 @@ def pack_conv_weight(weight, for_dgrad=False, dtype=torch.bfloat16):
     return out
 
 
-def conv_igemm(xs, packed, biases, dilations, ksize, relu):
+def pack_conv_weight_pair(weight, want_fwd=True, want_dgrad=True):
+    """both packed forms of a float32 channels_last (cout, cin, k, k) parameter in one pass (cast included) ->
+    (pack_conv_weight(weight), pack_conv_weight(weight, for_dgrad=True)); an entry is None when not wanted.  Other dtypes /
+    layouts take the torch copies of pack_conv_weight."""
+    cout, cin, k, _ = weight.shape
+    if not (weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous(memory_format=torch.channels_last)
+            and cout % 64 == 0 and cin % 64 == 0 and k in (1, 3)):
+        return (pack_conv_weight(weight) if want_fwd else None, pack_conv_weight(weight, for_dgrad=True) if want_dgrad else None)
+    fwd = torch.empty((cout, cin // 64, k * k, 64), dtype=torch.bfloat16, device=weight.device) if want_fwd else None
+    dg = torch.empty((cin, cout // 64, k * k, 64), dtype=torch.bfloat16, device=weight.device) if want_dgrad else None
+    check(_lib.lib().dsrg_pack_conv_weight_f32(_ptr(weight.detach()), _ptr(fwd), _ptr(dg), cout, cin, k, _stream()))
+    return fwd, dg
+
+
+def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0):
     """1 .. 4 convolutions of one geometry in one launch (the four ASPP branches): xs[g] (B,cin,H,W) bf16 channels_last,
     packed[g] = pack_conv_weight(w_g), biases[g] (cout) f32 or None -> list of (B,cout,H,W) bf16 channels_last; fp32
-    accumulation, bias and ReLU fused, no im2col matrix"""
+    accumulation, bias, ReLU and (dropout_p > 0, multiples of 1/256) the Dropout behind it fused — the mask is a function of
+    (seed, branch, position) — no im2col matrix"""
     n = len(xs)
     B, cin, H, W = xs[0].shape
     cout = packed[0].shape[0]
@@ -479,8 +494,14 @@ def conv_igemm(xs, packed, biases, dilations, ksize, relu):
     check(_lib.lib().dsrg_conv_igemm_bf16(vp(*[x.data_ptr() for x in xs]), vp(*[p.data_ptr() for p in packed]),
                                           vp(*[None if b is None else b.data_ptr() for b in bs]),
                                           vp(*[y.data_ptr() for y in ys]), (ctypes.c_int * n)(*[int(d) for d in dilations]),
-                                          n, B, H, W, cin, cout, ksize, int(bool(relu)), _stream()))
+                                          n, B, H, W, cin, cout, ksize, int(bool(relu)), float(dropout_p),
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()))
     return ys
+
+
+def dropout_seed():
+    """a 63-bit seed for a fused dropout from torch's CPU generator (deterministic under torch.manual_seed, no device sync)"""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 _igemm_ws = {}

@@ -261,12 +261,20 @@ int dsrg_conv3x3_wgrad_bf16(const void *x_dev, const void *g_dev, void *gw_dev, 
  * Up to four independent problems of one geometry (the four ASPP branches) share a launch: x_dev, w_dev, bias_dev (may be
  * NULL, entries may be NULL), y_dev and dilation are HOST arrays of ngroups entries.  w_dev[g]: the kernel packed as
  * (cout, cin / 64, ksize * ksize, 64) bf16 — w_packed[o][cc][tap][c] = w[o][cc * 64 + c][tap / 3][tap % 3].  With the kernel
- * flipped and its channel axes swapped the same call is the data gradient.  dsrg_conv_igemm_supported: 1 if the channel
- * counts / kernel size are served, else 0 (the call then returns DSRG_ERR_UNSUPPORTED). */
+ * flipped and its channel axes swapped the same call is the data gradient.  dropout_p > 0: the Dropout layer behind the
+ * ReLU (train-s.prototxt: drop6_k, drop7_k) in the same epilogue — y = relu(..) * keep / (1 - p), keep a pure function of
+ * (dropout_seed, group, element position) from a counter-based generator, p realised in steps of 1/256; the backward pass
+ * reads both masks off the sign of y.  dsrg_conv_igemm_supported: 1 if the channel counts / kernel size are served, else 0
+ * (the call then returns DSRG_ERR_UNSUPPORTED). */
 int dsrg_conv_igemm_supported(int cin, int cout, int ksize);
 int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, const float *const *bias_dev, void *const *y_dev,
                          const int *dilation, int ngroups, int B, int H, int W, int cin, int cout, int ksize, int relu,
-                         void *stream);
+                         float dropout_p, unsigned long long dropout_seed, void *stream);
+/* The two packed forms dsrg_conv_igemm_bf16 reads, from the float32 master kernel in ONE pass (cast included): w_dev
+ * (cout, ksize*ksize, cin) f32 = the memory of a channels_last (cout, cin, ksize, ksize) parameter; fwd_dev (may be NULL):
+ * (cout, cin / 64, taps, 64) bf16 for the forward; dgrad_dev (may be NULL): (cin, cout / 64, taps, 64) bf16 for the data
+ * gradient (kernel flipped, channel axes swapped).  64 | cout, 64 | cin. */
+int dsrg_pack_conv_weight_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, int ksize, void *stream);
 /* Weight gradient of the same convolutions, again without an im2col matrix (cin % 256 == 0, cout % 256 == 0, ksize 1 or 3):
  *   gw[o][tap][c] = sum_{b,y,x} g[b,y,x,o] * x[b,y+dy*dil,x+dx*dil,c]      (zero padding; tap = 3 (dy+1) + dx+1)
  * x_dev[g] (B,H,W,cin) and g_dev[g] (B,H,W,cout) NHWC bf16; gw_dev[g] (cout, ksize*ksize, cin) = the memory of a channels_last

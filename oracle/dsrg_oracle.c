@@ -205,6 +205,110 @@ static void orc_lattice_init(orc_lattice *L, const float *feature, int d, int N)
     free(rem0); free(rank); free(bc); free(key);
 }
 
+/* Permutohedral::init, scalar variant (permutohedral.cpp:323-474) — the reference's second, independent formulation of the
+ * same lattice (what a build without SSE runs).  Restated here ONLY as a cross-check of the SSE restatement above
+ * (tests/test_oracle_golden.py): the two differ in how they round (ceil/floor comparison, ties go DOWN, instead of
+ * round-half-even), in `sum` being an int updated through a float (`:384`), in rank being short arithmetic, in the wrap-around
+ * term `1.0 + barycentric[d+1]` being evaluated in double (`:422`), and in the pixel loop not being padded to a multiple of
+ * four (no phantom origin vertices).  A transcription slip in either restatement breaks their agreement. */
+static void orc_lattice_init_scalar(orc_lattice *L, const float *feature, int d, int N) {
+    const int d1 = d + 1;
+    L->N = N; L->d = d;
+    L->offset = (int *)calloc((size_t)(N > 0 ? N : 1) * d1, sizeof(int));
+    L->bary = (float *)calloc((size_t)(N > 0 ? N : 1) * d1, sizeof(float));
+    orc_hash H;
+    orc_hash_init(&H, d, N * d1 + d1);
+
+    float *scale_factor = (float *)malloc(sizeof(float) * (d > 0 ? d : 1));
+    float *elevated = (float *)malloc(sizeof(float) * d1);
+    float *rem0 = (float *)malloc(sizeof(float) * d1);
+    float *barycentric = (float *)malloc(sizeof(float) * (d + 2));
+    short *rank = (short *)malloc(sizeof(short) * d1);
+    short *canonical = (short *)malloc(sizeof(short) * d1 * d1);
+    short *key = (short *)malloc(sizeof(short) * d1);
+
+    for (int i = 0; i <= d; i++) {                                      /* :345-350 */
+        for (int j = 0; j <= d - i; j++) canonical[i * d1 + j] = (short)i;
+        for (int j = d - i + 1; j <= d; j++) canonical[i * d1 + j] = (short)(i - d1);
+    }
+    float inv_std_dev = (float)(sqrt(2.0 / 3.0) * (double)d1);          /* :353 */
+    for (int i = 0; i < d; i++)                                         /* :355-356 */
+        scale_factor[i] = (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std_dev);
+
+    for (int k = 0; k < N; k++) {
+        const float *f = feature + (size_t)k * d;
+        float sm = 0;                                                   /* :364-370 */
+        for (int j = d; j > 0; j--) {
+            float cf = f[j - 1] * scale_factor[j - 1];
+            elevated[j] = sm - (float)j * cf;
+            sm += cf;
+        }
+        elevated[0] = sm;
+
+        float down_factor = 1.0f / (float)d1;                           /* :373-374 */
+        float up_factor = (float)d1;
+        int sum = 0;
+        for (int i = 0; i <= d; i++) {                                  /* :376-391 */
+            int rd2;
+            float v = down_factor * elevated[i];
+            float up = ceilf(v) * up_factor;
+            float down = floorf(v) * up_factor;
+            if (up - elevated[i] < elevated[i] - down) rd2 = (short)up;
+            else rd2 = (short)down;
+            rem0[i] = (float)rd2;
+            sum = (int)((float)sum + (float)rd2 * down_factor);        /* `sum += rd2*down_factor` with an int sum */
+        }
+        for (int i = 0; i <= d; i++) rank[i] = 0;                       /* :394-403 */
+        for (int i = 0; i < d; i++) {
+            double di = (double)(elevated[i] - rem0[i]);
+            for (int j = i + 1; j <= d; j++)
+                if (di < (double)(elevated[j] - rem0[j])) rank[i]++;
+                else rank[j]++;
+        }
+        for (int i = 0; i <= d; i++) {                                  /* :406-416 */
+            rank[i] = (short)(rank[i] + sum);
+            if (rank[i] < 0) { rank[i] = (short)(rank[i] + d1); rem0[i] += (float)d1; }
+            else if (rank[i] > d) { rank[i] = (short)(rank[i] - d1); rem0[i] -= (float)d1; }
+        }
+        for (int i = 0; i <= d + 1; i++) barycentric[i] = 0;            /* :419-426 */
+        for (int i = 0; i <= d; i++) {
+            float v = (elevated[i] - rem0[i]) * down_factor;
+            barycentric[d - rank[i]] += v;
+            barycentric[d - rank[i] + 1] -= v;
+        }
+        barycentric[0] = (float)((double)barycentric[0] + (1.0 + (double)barycentric[d + 1]));   /* :428, in double */
+
+        for (int remainder = 0; remainder <= d; remainder++) {         /* :431-437 */
+            for (int i = 0; i < d; i++)
+                key[i] = (short)(rem0[i] + (float)canonical[remainder * d1 + rank[i]]);
+            L->offset[(size_t)k * d1 + remainder] = orc_hash_find(&H, key, 1);
+            L->bary[(size_t)k * d1 + remainder] = barycentric[remainder];
+        }
+    }
+    const int M = H.filled;                                             /* :450-473 */
+    L->M = M;
+    L->n1 = (int *)malloc(sizeof(int) * (size_t)d1 * (M > 0 ? M : 1));
+    L->n2 = (int *)malloc(sizeof(int) * (size_t)d1 * (M > 0 ? M : 1));
+    short *n1 = (short *)malloc(sizeof(short) * d1);
+    short *n2 = (short *)malloc(sizeof(short) * d1);
+    for (int j = 0; j <= d; j++)
+        for (int i = 0; i < M; i++) {
+            const short *kk = H.keys + (size_t)i * d;
+            for (int k = 0; k < d; k++) { n1[k] = (short)(kk[k] - 1); n2[k] = (short)(kk[k] + 1); }
+            if (j < d) { n1[j] = (short)(kk[j] + d); n2[j] = (short)(kk[j] - d); }   /* j == d: a slot find() never reads */
+            L->n1[(size_t)j * M + i] = orc_hash_find(&H, n1, 0);
+            L->n2[(size_t)j * M + i] = orc_hash_find(&H, n2, 0);
+        }
+    L->keys = H.keys;
+    free(H.table);
+    free(n1); free(n2); free(scale_factor); free(elevated); free(rem0); free(barycentric); free(rank); free(canonical); free(key);
+}
+
+/* which formulation orc_kernel_init uses: 0 = the SSE path (what the reference's build runs; every parity test), 1 = the
+ * scalar path (cross-check only) */
+static int orc_lattice_path = 0;
+ORC_API void orc_set_lattice_path(int scalar) { orc_lattice_path = scalar ? 1 : 0; }
+
 /* Permutohedral::seqCompute (permutohedral.cpp:476-527), used when
  * value_size <= 2 (permutohedral.cpp:600-601).  Note the blur is evaluated in
  * double (the literal 0.5) and the slice multiplies (w*value)*alpha. */
@@ -309,7 +413,8 @@ typedef struct {
 } orc_kernel;
 
 static void orc_kernel_init(orc_kernel *K, const float *feature, int d, int N, float w) {
-    orc_lattice_init(&K->lat, feature, d, N);
+    if (orc_lattice_path) orc_lattice_init_scalar(&K->lat, feature, d, N);
+    else orc_lattice_init(&K->lat, feature, d, N);
     K->w = w;
     K->norm = (float *)malloc(sizeof(float) * N);
     float *ones = (float *)malloc(sizeof(float) * N);

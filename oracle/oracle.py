@@ -155,6 +155,22 @@ class DenseCRF(object):
         return out
 
 
+class lattice_path(object):
+    """context manager: lattices built inside use the reference's SCALAR Permutohedral::init (permutohedral.cpp:323-474)
+    instead of the SSE one (:140-321) — a cross-check of the two restatements, never used by a parity test"""
+
+    def __init__(self, scalar=True):
+        self.scalar = scalar
+
+    def __enter__(self):
+        lib().orc_set_lattice_path(int(bool(self.scalar)))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_lattice_path(0)
+        return False
+
+
 def CRF(image, unary, maxiter=10, scale_factor=1.0, color_factor=13):
     """Restatement of krahenbuhl2013.CRF (CRF/krahenbuhl2013/CRF.py:4-37)."""
     assert image.shape[:2] == unary.shape[:2]

@@ -173,3 +173,40 @@ def test_backbone_igemm_route_is_as_close_to_float32_as_the_im2col_route():
         if rel(a, ref) > 1.3 * rel(b, ref) + 0.01:
             worse.append((n, rel(a, ref), rel(b, ref)))
     assert not worse, worse
+
+
+def test_pack_kernel_matches_the_torch_copies(ops):
+    """dsrg_pack_conv_weight_f32: both packed forms in one pass == pack_conv_weight's strided torch copies, bit for bit"""
+    for cout, cin, k in [(256, 128, 3), (512, 512, 3), (1024, 512, 3), (1024, 1024, 1), (64, 64, 3)]:
+        w = torch.randn(cout, cin, k, k, device="cuda").contiguous(memory_format=CL)
+        fwd, dg = ops.pack_conv_weight_pair(w)
+        assert torch.equal(fwd, ops.pack_conv_weight(w)) and torch.equal(dg, ops.pack_conv_weight(w, for_dgrad=True))
+        only_f, none_d = ops.pack_conv_weight_pair(w, True, False)
+        assert none_d is None and torch.equal(only_f, fwd)
+
+
+def test_igemm_fused_dropout(ops):
+    """Dropout in the convolution's epilogue: every element is 0 or relu(conv) / (1 - p) (p in steps of 1/256), the kept
+    share is 1 - p, the mask is a function of (seed, branch, position) only, and 3x3 and 1x1 launches both carry it"""
+    for k, cin, cout, dil in [(3, 128, 512, 2), (1, 256, 256, 1)]:
+        x, w, b = _case(2, 41, 41, cin, cout, k, 40 + k)
+        packed = ops.pack_conv_weight(w)
+        (plain,) = ops.conv_igemm([x], [packed], [b], [dil], k, True)
+        for p in (0.5, 0.25):
+            (a1,) = ops.conv_igemm([x], [packed], [b], [dil], k, True, p, 1234)
+            (a2,) = ops.conv_igemm([x], [packed], [b], [dil], k, True, p, 1234)
+            (a3,) = ops.conv_igemm([x], [packed], [b], [dil], k, True, p, 1235)
+            assert torch.equal(a1, a2) and not torch.equal(a1, a3)
+            kept = a1 != 0
+            pos = plain > 0
+            assert not (kept & ~pos).any()                                           # nothing appears where the ReLU is off
+            share = float((kept & pos).sum()) / float(pos.sum())
+            assert abs(share - (1 - p)) < 0.01, share
+            want = (plain.float() / (1 - p)).bfloat16()                              # one rounding from the fp32 accumulator in both
+            diff = (a1.float() - want.float())[kept].abs()
+            assert (diff <= 0.008 * want.float()[kept].abs() + 1e-6).all()           # the plain output was itself rounded once
+            # masks of different branches differ
+            two = ops.conv_igemm([x, x], [packed, packed], [b, b], [dil, dil], k, True, p, 1234)
+            assert torch.equal(two[0], a1) and not torch.equal(two[1], a1)
+            both = ((two[0] != 0) & (two[1] != 0) & pos).sum().item() / pos.sum().item()
+            assert abs(both - (1 - p) ** 2) < 0.01                                   # independent
