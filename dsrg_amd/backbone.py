@@ -246,8 +246,8 @@ class _IgemmConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        from .ops import (conv_igemm, conv_igemm_supported, conv_igemm_wgrad, pack_conv_weight, relu_bwd_bias, bias_grad,
-                          maxpool3x3_bwd_relu)
+        from .ops import (conv_igemm, conv_igemm_supported, conv_igemm_wgrad, conv_igemm_wgrad_supported, pack_conv_weight,
+                          relu_bwd_bias, bias_grad, maxpool3x3_bwd_relu)
         n = ctx.n
         code, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         xs, ws, ys = saved[:n], saved[n:2 * n], saved[2 * n:]
@@ -276,12 +276,12 @@ class _IgemmConvFn(torch.autograd.Function):
             if conv_igemm_supported(cout, cin, 3):
                 packs_d = [p if p is not None else pack_conv_weight(w, for_dgrad=True) for p, w in zip(ctx.packs_d, ws)]
                 gxs = conv_igemm(gms, packs_d, None, ctx.dils, 3, False)
-            else:                                                                        # conv3_1: 128 input channels
+            else:                                                                        # input channels not a multiple of 128
                 for i in range(n):
                     d = ctx.dils[i]
                     gxs[i] = torch.ops.aten.convolution_backward(gms[i], xs[i], ws[i].to(torch.bfloat16), None, [1, 1], [d, d], [d, d],
                                                                  False, [0, 0], 1, [True, False, False])[0]
-        if cin % 256 == 0:
+        if conv_igemm_wgrad_supported(cin, cout, 3):
             gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 3)                           # float32, the parameters' own layout
         else:
             gws = []

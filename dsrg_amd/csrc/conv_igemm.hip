@@ -194,6 +194,8 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
 #pragma unroll
     for (int ks = 0; ks < C::KS; ks++) choff[ks] = rowoff + (uint32_t)(((ks * 2 + kgrp) ^ sw) << 4);
 
+    // an output-channel count of 128 (mod 256) leaves the upper half of the last n-tile empty: its waves (4-7) only move data
+    const bool active = n0 + wn * 128 < a.Cout;
 #pragma unroll
     for (int p = 0; p < C::AHEAD; p++)
         if (p < nsteps) issue(p, p);
@@ -204,9 +206,10 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         if (C::AHEAD >= 3 && s + 2 < nsteps) wait_vm_barrier<2 * LPS>();
         else if (C::AHEAD >= 2 && s + 1 < nsteps) wait_vm_barrier<LPS>();
         else wait_vm_barrier<0>();
-        const bool more = s + C::AHEAD < nsteps, late = a.stagger && wv >= 4;
+        const bool more = s + C::AHEAD < nsteps, late = a.stagger && wv >= 4 && active;
         const int nstage = stage == 0 ? NST - 1 : stage - 1;                                  // the stage step s - 1 was read from
         if (more && !late) issue(nstage, s + C::AHEAD);
+        if (active) {
         const unsigned char *P = ig_lds + stage * C::STAGE + wm * (64 * C::ROW);
         const unsigned char *Wt = ig_lds + stage * C::STAGE + kBM * C::ROW + wn * (128 * C::ROW);
         // fragments of k-slice ks + 1 are read before the MFMAs of slice ks (order pinned by sched_barrier)
@@ -232,9 +235,11 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0 && more && late) issue(nstage, s + C::AHEAD);
         }
+        }
         stage = stage + 1 == NST ? 0 : stage + 1;
     }
     __syncthreads();                                        // every wave is done reading the last stage
+    if (!active) return;
 
     // ---- epilogue: C[row = channel][col = pixel]; a lane holds channels (reg & 3) + 8 (reg >> 2) + 4 kgrp of pixel l31
     unsigned char *O = ig_lds + wv * kOutWave;
@@ -350,10 +355,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     const int tn = t / a.tiles_c, tc = t - tn * a.tiles_c;
     const WgradGroup G = a.g[grp];
     const int taps = a.taps, Cin = a.Cin, Cout = a.Cout, W = a.W, H = a.H;
-    const int ncb = Cin >> 8;                               // 256-channel blocks of x per tap
-    const int tap = tc / ncb, c0 = (tc - tap * ncb) << 8, n0 = tn << 8;
-    int dy = 0, dx = 0;
-    if (taps == 9) { dy = (tap / 3 - 1) * G.dil; dx = (tap % 3 - 1) * G.dil; }
+    // the 256 columns of a tile: one tap x 256 channels of x — or, for a 128-channel x (conv3_1), two taps x 128 channels
+    const bool two = Cin == 128;
+    const int ncb = two ? 1 : Cin >> 8;                     // 256-channel blocks of x per tap
+    const int tap = two ? 2 * tc : tc / ncb, c0 = two ? 0 : (tc - tap * ncb) << 8, n0 = tn << 8;
     const int mbeg = split * a.kchunk, mend = min(a.M, mbeg + a.kchunk);
     const int nsteps = mend > mbeg ? (mend - mbeg + 63) >> 6 : 0;
 
@@ -361,13 +366,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     const rsrc_t rg = make_rsrc(G.g, (size_t)a.M * Cout * 2);
 
     // ---- DMA geometry: per step a wave moves rows [wv*8 + i*2, +2) of both tiles, i = 0..3; lane -> (row, 16-byte piece)
-    int pm[4], py[4], px[4];
-    uint32_t srcoff[4];                                     // byte offset of the lane's source piece inside a 512-byte row
+    int pm[4], py[4], px[4], ldy[4], ldx[4], ltapoff[4];
+    uint32_t srcoff[4], xsrcoff[4];                         // byte offset of the lane's source piece inside a row of g / of x
+    bool ltap[4];                                           // the lane's tap exists (a two-tap tile may hold the tenth)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r = wv * 8 + i * 2 + (lane >> 5);
         const int q = lane & 31, p = (q >> 2) ^ (r & 3);    // 64-byte source piece that lands at piece position q >> 2
         srcoff[i] = (uint32_t)(p * 64 + (q & 3) * 16);
+        const int mytap = two ? tap + (p >> 2) : tap;       // pieces 4-7 of a two-tap tile belong to the second tap
+        xsrcoff[i] = two ? (uint32_t)((p & 3) * 64 + (q & 3) * 16) : srcoff[i];
+        ltap[i] = mytap < taps;
+        ldy[i] = taps == 9 ? (mytap / 3 - 1) * G.dil : 0;
+        ldx[i] = taps == 9 ? (mytap % 3 - 1) * G.dil : 0;
+        ltapoff[i] = (ldy[i] * W + ldx[i]) * Cin * 2 + c0 * 2;
         const int m = mbeg + r;
         pm[i] = m;
         const int hw = H * W, mm = m < a.M ? m : 0;
@@ -376,7 +388,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
         px[i] = rem - py[i] * W;
     }
     const int qW = 64 / W, rW = 64 - qW * W;                // a step advances every row by 64 pixels
-    const int tapoff = (dy * W + dx) * Cin * 2 + c0 * 2;
 
     auto issue = [&](int stage) {
         unsigned char *A = ig_lds + stage * kWStage + wv * (8 * kWRow);
@@ -389,9 +400,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int yy = py[i] + dy, xx = px[i] + dx;
-            const bool live = pm[i] < mend && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const uint32_t vo = live ? (uint32_t)(pm[i] * (Cin * 2) + tapoff) + srcoff[i] : kOob;
+            const int yy = py[i] + ldy[i], xx = px[i] + ldx[i];
+            const bool live = ltap[i] && pm[i] < mend && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const uint32_t vo = live ? (uint32_t)(pm[i] * (Cin * 2) + ltapoff[i]) + xsrcoff[i] : kOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(Bt + i * (2 * kWRow)), 16, vo, 0, 0, 0);
         }
 #pragma unroll
@@ -458,11 +469,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int c = c0 + wm * 64 + j * 32 + l31;
+            const int col = wm * 64 + j * 32 + l31;
+            const int etap = two ? tap + (col >> 7) : tap, c = two ? (col & 127) : c0 + col;
+            if (etap < taps) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-                pp[((size_t)n * taps + tap) * Cin + c] = acc[i][j][r];
+                for (int r = 0; r < 16; r++) {
+                    const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+                    pp[((size_t)n * taps + etap) * Cin + c] = acc[i][j][r];
+                }
             }
         }
 }
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float *w, u
 }  // namespace
 
 bool conv_igemm_supported(int cin, int cout, int k) {
-    return (k == 1 || k == 3) && cin >= 64 && cin % 64 == 0 && cout >= kBN && cout % kBN == 0;
+    return (k == 1 || k == 3) && cin >= 64 && cin % 64 == 0 && cout >= 128 && cout % 128 == 0;
 }
 
 std::atomic<int> g_igemm_variant{-1};      // dsrg_debug_set_igemm_variant (tests / tools); -1 = DSRG_IGEMM_VARIANT or the default
@@ -533,8 +547,8 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
                       hipStream_t stream) {
     if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm: 1..4 groups");
     if (!conv_igemm_supported(cin, cout, k))
-        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: cin %% 64 == 0, cout %% %d == 0, k in (1, 3) required (got %d, %d, %d)",
-                         kBN, cin, cout, k);
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: cin %% 64 == 0, cout %% 128 == 0, k in (1, 3) required (got %d, %d, %d)",
+                         cin, cout, k);
     const long long M = (long long)B * H * W;
     if (M <= 0 || M * cin * 2 >= 0x7fffffffLL || (long long)cout * k * k * cin * 2 >= 0x7fffffffLL || M * cout * 2 >= 0x7fffffff00LL)
         return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: tensor too large for 32-bit buffer offsets");
@@ -550,7 +564,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     }
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.relu = relu; a.M = (int)M;
     a.tiles_m = (int)((M + kBM - 1) / kBM);
-    a.tiles_n = cout / kBN;
+    a.tiles_n = (cout + kBN - 1) / kBN;
     a.tiles_per_group = a.tiles_m * a.tiles_n;
     if (drop_p < 0.0f || drop_p >= 1.0f) return set_error(DSRG_ERR_INVALID, "conv_igemm: 0 <= dropout probability < 1");
     a.drop_thresh = (uint32_t)(drop_p * 256.0f + 0.5f);       // p is realised in steps of 1 / 256 (0.5 exactly)
@@ -576,8 +590,9 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
 
 
 bool conv_igemm_wgrad_supported(int cin, int cout, int k) {
-    return (k == 1 || k == 3) && cin >= 256 && cin % 256 == 0 && cout >= 256 && cout % 256 == 0;
+    return (k == 1 || k == 3) && ((cin >= 256 && cin % 256 == 0) || (cin == 128 && k == 3)) && cout >= 256 && cout % 256 == 0;
 }
+static int wgrad_col_tiles(int cin, int k) { return cin == 128 ? (k * k + 1) / 2 : k * k * cin / 256; }
 
 // pixel split of the weight-gradient launch: the number of workgroups per output tile that minimises
 // rounds of the chip x (K-steps per workgroup + a fixed cost per workgroup for prologue and the partial tile's write-out)
@@ -597,7 +612,7 @@ static int wgrad_ksplit(long long M, int tiles, int cus) {
 size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k) {
     if (!conv_igemm_wgrad_supported(cin, cout, k) || ngroups < 1 || ngroups > 4) return 0;
     const long long M = (long long)B * H * W;
-    const int tiles = ngroups * (cout / 256) * (k * k * cin / 256);
+    const int tiles = ngroups * (cout / 256) * wgrad_col_tiles(cin, k);
     const int ks = wgrad_ksplit(M, tiles, 256);
     return (size_t)ngroups * ks * cout * k * k * cin * sizeof(float);
 }
@@ -606,7 +621,7 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
                             size_t workspace_bytes, int B, int H, int W, int cin, int cout, int k, int out_bf16, hipStream_t stream) {
     if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: 1..4 groups");
     if (!conv_igemm_wgrad_supported(cin, cout, k))
-        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm_wgrad: cin %% 256 == 0, cout %% 256 == 0, k in (1, 3) required (got %d, %d, %d)",
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm_wgrad: cin %% 256 == 0 (or 128 with k = 3), cout %% 256 == 0, k in (1, 3) required (got %d, %d, %d)",
                          cin, cout, k);
     const long long M = (long long)B * H * W;
     if (M <= 0 || M * cin * 2 >= 0x7fffffffLL || M * cout * 2 >= 0x7fffffffLL)
@@ -617,7 +632,7 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     memset(&a, 0, sizeof(a));
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.M = (int)M;
     a.tiles_n = cout / 256;
-    a.tiles_c = k * k * cin / 256;
+    a.tiles_c = wgrad_col_tiles(cin, k);
     a.ksplit = wgrad_ksplit(M, ngroups * a.tiles_n * a.tiles_c, 256);
     a.kchunk = (int)(((M + a.ksplit - 1) / a.ksplit + 63) / 64 * 64);
     a.tiles_per_group = a.tiles_n * a.tiles_c * a.ksplit;

@@ -507,6 +507,11 @@ def dropout_seed():
 _igemm_ws = {}
 
 
+def conv_igemm_wgrad_supported(cin, cout, k):
+    """the shapes conv_igemm_wgrad serves: 256 | cout, 256 | cin (or cin = 128 for a 3x3 kernel), k in (1, 3)"""
+    return _lib.lib().dsrg_conv_igemm_wgrad_workspace(1, 1, 8, 8, int(cin), int(cout), int(k)) > 0
+
+
 def conv_igemm_wgrad(xs, gs, dilations, ksize, out_dtype=torch.float32):
     """weight gradients of 1 .. 4 convolutions of one geometry in one launch: xs[g] (B,cin,H,W) the layer inputs and gs[g]
     (B,cout,H,W) the output gradients, bf16 channels_last -> list of (cout,cin,k,k) channels_last tensors in float32 (the
@@ -526,7 +531,7 @@ def conv_igemm_wgrad(xs, gs, dilations, ksize, out_dtype=torch.float32):
     L = _lib.lib()
     need = L.dsrg_conv_igemm_wgrad_workspace(n, B, H, W, cin, cout, ksize)
     if need == 0:
-        raise ValueError("conv_igemm_wgrad: cin %% 256 == 0, cout %% 256 == 0, k in (1, 3) required (got %d, %d, %d)" % (cin, cout, ksize))
+        raise ValueError("conv_igemm_wgrad: 256 | cin (or cin = 128, k = 3), 256 | cout, k in (1, 3) required (got %d, %d, %d)" % (cin, cout, ksize))
     key = (xs[0].device.index, torch.cuda.current_stream().cuda_stream)
     ws = _igemm_ws.get(key)                                          # per-stream scratch, reused across layers and steps
     if ws is None or ws.numel() < need:

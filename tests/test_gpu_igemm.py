@@ -38,6 +38,8 @@ def _close(got, want, what):
     (2, 41, 41, 1024, 1024, 1, 1, True, True),     # fc7
     (1, 81, 81, 256, 256, 3, 1, True, True),       # conv3_2
     (3, 1, 1, 64, 256, 3, 1, True, True),
+    (2, 27, 31, 256, 128, 3, 1, False, False),     # conv3_1's data gradient: half an n-tile (waves 4-7 only move data)
+    (1, 20, 20, 128, 384, 3, 2, True, True),       # one and a half n-tiles
 ])
 def test_igemm_conv_matches_torch(ops, B, H, W, cin, cout, k, dil, relu, bias):
     x, w, b = _case(B, H, W, cin, cout, k, 5)
@@ -94,12 +96,14 @@ def _unpack(p):
 def test_igemm_rejects_unsupported_shapes(ops):
     from dsrg_amd._lib import DsrgError
     assert ops.conv_igemm_supported(512, 1024, 3) and ops.conv_igemm_supported(1024, 1024, 1)
-    assert not ops.conv_igemm_supported(512, 128, 3) and not ops.conv_igemm_supported(96, 256, 3)
+    assert ops.conv_igemm_supported(256, 128, 3) and not ops.conv_igemm_supported(512, 64, 3) and not ops.conv_igemm_supported(96, 256, 3)
+    assert ops.conv_igemm_wgrad_supported(128, 256, 3) and not ops.conv_igemm_wgrad_supported(128, 256, 1)
+    assert not ops.conv_igemm_wgrad_supported(64, 256, 3) and not ops.conv_igemm_wgrad_supported(256, 128, 3)
     x = torch.zeros(1, 64, 4, 4, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=CL)
     with pytest.raises(ValueError):
         ops.conv_igemm([x], [torch.zeros(256, 1, 9, 64, device="cuda")], [None], [1], 3, False)      # float32 kernel
     with pytest.raises(DsrgError):
-        ops.conv_igemm([x], [torch.zeros(128, 1, 9, 64, device="cuda", dtype=torch.bfloat16)], [None], [1], 3, False)
+        ops.conv_igemm([x], [torch.zeros(64, 1, 9, 64, device="cuda", dtype=torch.bfloat16)], [None], [1], 3, False)
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,k,dil", [
@@ -111,6 +115,8 @@ def test_igemm_rejects_unsupported_shapes(ops):
     (1, 81, 81, 256, 256, 3, 1),         # conv3_2
     (3, 1, 1, 256, 256, 3, 1),
     (1, 3, 100, 256, 512, 3, 24),        # map wider than a step; dilation beyond the height
+    (2, 27, 31, 128, 256, 3, 1),         # conv3_1: two taps of 128 channels per column tile, the tenth "tap" of the last tile empty
+    (1, 81, 81, 128, 256, 3, 1),
 ])
 def test_igemm_weight_gradient_matches_torch(ops, B, H, W, cin, cout, k, dil):
     x, w, _ = _case(B, H, W, cin, cout, k, 9)
