@@ -152,6 +152,20 @@ def _load_json(name):
         return None
 
 
+def _counter_file(stem, kernel):
+    """the newest profiles/rNN_<stem>.json and whether it still describes `kernel`: the PMC passes run outside bench.py
+    (tools/gpu_pmc.sh) and their figures are replayed here — only while the kernel's sources hash to what the file was
+    collected against (dsrg_amd/provenance.py); -> (record or None, provenance dict for the bench line)"""
+    from dsrg_amd import provenance
+    for rnd in ("r04", "r03"):
+        rec = _load_json("%s_%s.json" % (rnd, stem))
+        if rec is not None:
+            src = provenance.check(rec, kernel)
+            src["file"] = "profiles/%s_%s.json" % (rnd, stem)
+            return (rec if src["match"] else None), src
+    return None, {"file": None, "match": False}
+
+
 def crf_fullres_record(device, steps, warmup, cpu=True, size=321):
     """SURVEY 8f-1, training/tools/test-ms.py:84-111: the test-time dense CRF at image resolution — log-probability unaries,
     scale_factor 1, 21 labels, 10 iterations — through krahenbuhl2013's object API with device pointers (dsrg_amd.crf.DenseCRF;
@@ -204,13 +218,14 @@ def crf_fullres_record(device, steps, warmup, cpu=True, size=321):
     ev_us = event_overhead_ms(torch.cuda.default_stream()) * 1e3
     head = out_sizes[0]
     per_launch_s = max(head["splat_us_per_launch_event_bracket"] - ev_us, 1e-3) * 1e-6
-    tj = _load_json("r03_pmc_traffic_fullres.json") or _load_json("pmc_traffic_fullres.json") or {}
-    traffic = tj.get("lg_splat2_kernel_bytes_per_launch")
+    tj, traffic_src = _counter_file("pmc_traffic_fullres", "fullres")
+    traffic = (tj or {}).get("lg_splat2_kernel_bytes_per_launch")
     achieved = head["alg_bytes_per_splat_launch"] / per_launch_s / 1e9
     roofline = {"kernel": "lg_splat2_kernel + lg_combine_kernel (permutohedral splat of both lattices: per-vertex ordered gather lists cut "
                           "into segments of 64 entries, values in HBM/L2)",
                 "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "alg_bytes_per_launch": head["alg_bytes_per_splat_launch"], "us_per_launch": per_launch_s * 1e6,
                 "us_per_launch_event_bracket": head["splat_us_per_launch_event_bracket"], "event_bracket_overhead_us": ev_us,
                 "launches": head["splat_launches"], "lattice_M_gauss": head["M_gauss"], "lattice_M_bilateral": head["M_bil"],
@@ -324,7 +339,7 @@ def filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead_ms):
     raw_launch_us = filt_ms / filt_n * 1e3
     per_launch_s = (filt_ms / filt_n - ev_overhead_ms) * 1e-3
     alg_bytes = sum(filter_bytes(2, mg, C, N) + filter_bytes(5, m, C, N) for m in mb)   # SURVEY 8d, one filter launch
-    cpw_b, cpw_g = (2, 4) if B * ((C + 1) // 2) >= 64 else (1, 2)
+    cpw_b, cpw_g, plan_wgs, plan_lds = ctx.filter_plan(B)      # what the launcher does, not a copy of its rules
     groups_b, groups_g = (C + cpw_b - 1) // cpw_b, (C + cpw_g - 1) // cpw_g
     rd = sum(lds_filter_traffic(5, m, x, N, cpw_b)[0] for m, x in zip(mb, xb)) * groups_b
     wr = sum(lds_filter_traffic(5, m, x, N, cpw_b)[1] for m, x in zip(mb, xb)) * groups_b
@@ -342,10 +357,10 @@ def filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead_ms):
     total = rd + wr + gauss_rd + gauss_wr
     lds_peak = total / t_peak
     lds_achieved = total / per_launch_s / 1e9
-    tj = _load_json("r03_pmc_traffic.json") or _load_json("pmc_traffic.json") or {}
-    traffic = tj.get("mf_filter_kernel_bytes_per_launch")
+    tj, traffic_src = _counter_file("pmc_traffic", "mf_filter_kernel")
+    traffic = (tj or {}).get("mf_filter_kernel_bytes_per_launch")       # None when the kernel changed after the PMC pass
     counters = None
-    cj = _load_json("r03_lds_counters.json")
+    cj, counters_src = _counter_file("lds_counters", "mf_filter_kernel")
     if cj:
         ck = sorted((v for k, v in cj.get("kernels", {}).items() if "mf_filter_kernel" in k),
                     key=lambda v: -v.get("launches", 0))          # the loop's instantiation, not the build's norm pass
@@ -362,7 +377,8 @@ def filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead_ms):
                 B, C, "; the pixel-local Gaussian lattice is evaluated by the update kernel" if gflags_local
                 else " + the Gaussian lattice x %d planes x %d images" % (C, B)),
             "bound": "lds", "achieved": lds_achieved, "peak": lds_peak, "unit": "GB/s",
-            "frac": lds_achieved / lds_peak, "traffic": traffic,
+            "frac": lds_achieved / lds_peak, "traffic": traffic, "traffic_source": traffic_src,
+            "lds_counters_source": counters_src,
             "lds_read_bytes_per_launch": rd + gauss_rd, "lds_write_bytes_per_launch": wr + gauss_wr,
             "lds_bytes_gaussian_workgroups": gauss_rd + gauss_wr,
             "lds_wave_instructions_model": insts,
@@ -370,6 +386,8 @@ def filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead_ms):
             "us_per_launch": per_launch_s * 1e6, "launches": filt_n,
             "us_per_launch_event_bracket": raw_launch_us, "event_bracket_overhead_us": ev_overhead_ms * 1e3,
             "workgroups_with_lds_work": groups_b * B + (0 if gflags_local else groups_g * B), "cus": 256,
+            "launch_plan": {"planes_per_bilateral_workgroup": cpw_b, "planes_per_gaussian_workgroup": cpw_g,
+                            "workgroups_in_grid": plan_wgs, "dynamic_lds_bytes": plan_lds},
             "lds_counters_per_launch": counters,
             "hbm_model": {"alg_bytes_per_launch": alg_bytes, "gbs": alg_bytes / per_launch_s / 1e9,
                           "frac_of_8TBs": alg_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS,
@@ -393,12 +411,13 @@ def srg_roofline(ops, B, C, N, logits, images, labels, cues, ctx):
     e1.record()
     torch.cuda.synchronize()
     srg_us = e0.elapsed_time(e1) / 20 * 1e3
-    pmc = (_load_json("r03_pmc_traffic.json") or _load_json("pmc_traffic.json") or {}).get("kernels", {})
+    pj, srg_src = _counter_file("pmc_traffic", "srg")
+    pmc = (pj or {}).get("kernels", {})
     srg_bytes = 16 * C * N * B                  # cues + fp64 marginals in, seeds out, per image
     tr = sum(v.get("hbm_bytes_per_launch", 0) for k, v in pmc.items() if "srg_" in k) or None
     return {"kernel": "srg_classify_kernel + srg_grow_kernel (seeded region growing, %d images)" % B, "bound": "hbm",
             "achieved": srg_bytes / (srg_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": srg_bytes / (srg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+            "frac": srg_bytes / (srg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": srg_src,
             "alg_bytes_per_launch": srg_bytes, "us_per_launch": srg_us,
             "note": "two dependent launches (pixel-parallel classification over the batch, then one workgroup per image for the "
                     "growth): the time is two kernel boundaries plus one memory round trip each, not bandwidth"}
@@ -683,6 +702,11 @@ def main():
             tf32 = count_flops_per_image() * 3 * B / dt32 / 1e12
             out["value_fp32"] = B / dt32
             out["ms_per_step_fp32"] = dt32 * 1e3
+            # the reference's backbone precision is float32 (Caffe): the figure any comparison WITH THE REFERENCE quotes, kept in
+            # fields the driver's record keeps (it drops keys it does not know)
+            out["config"]["fp32_backbone_images_per_s"] = B / dt32
+            out["config"]["fp32_backbone_ms_per_step"] = dt32 * 1e3
+            out["dtype"] += "; float32-backbone leg (the reference's precision) %.1f images/s" % (B / dt32)
             out["legs"]["fp32"] = {"value": B / dt32, "ms_per_step": dt32 * 1e3, "steps": args.steps, "losses": l32,
                                    "dtype": "f32 backbone + f32/f64 supervision path", "backbone_tflops": tf32,
                                    "mfma_peak_tflops": 157.3, "mfma_frac": tf32 / 157.3,

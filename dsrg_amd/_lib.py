@@ -61,6 +61,7 @@ SIGNATURES = {
     "dsrg_crf_meanfield_batch": (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(CrfParams), _vp, _vp]),
     "dsrg_ctx_lattice_sizes": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dsrg_ctx_lattice_extras": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "dsrg_ctx_filter_plan": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "dsrg_ctx_lattice_dump": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsrg_ctx_read_refined": (_i, [_vp, _i, _vp, _vp]),
     "dsrg_ctx_lattice_norm": (_i, [_vp, _i, _i, _vp, _vp]),

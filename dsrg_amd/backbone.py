@@ -299,6 +299,8 @@ def _igemm_route(conv, x):
         return False
     if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
         return False
+    if conv.out_channels < 256:                 # conv1_x / conv2_x: the direct kernels (weights in registers) serve the narrow layers
+        return False
     from .ops import conv_igemm_supported
     return conv_igemm_supported(conv.in_channels, conv.out_channels, 3)
 

@@ -257,21 +257,32 @@ def save_snapshot(trainer, prefix):
     """Caffe's Solver::Snapshot: `<prefix>_iter_<N>.caffemodel` (weights; for VGG16ASPP with the reference's layer names and
     blob order, i.e. readable by the reference's tools — other nets are written with their torch module paths as layer names
     and are readable by load_weights only) + `<prefix>_iter_<N>.solverstate.pt` (weights, momentum history, iteration).
-    Rank 0 writes; every rank returns after the files exist (barrier).  -> (caffemodel path, solverstate path)"""
+    COLLECTIVE under torch.distributed: every rank calls it (rank 0 writes, the others wait) and every rank returns after the
+    files exist — or every rank raises when rank 0 could not write them (its outcome is broadcast; a rank-0 failure never
+    leaves the others blocked in a barrier).  Calling it from rank 0 only (`if rank == 0: trainer.save()`) would hang rank 0 in
+    that broadcast: save on all ranks.  -> (caffemodel path, solverstate path)"""
+    import torch.distributed as dist
     it = trainer.opt.iter
     model_path, state_path = "%s_iter_%d.caffemodel" % (prefix, it), "%s_iter_%d.solverstate.pt" % (prefix, it)
+    err = None
     if _is_rank0():
-        d = os.path.dirname(model_path)
-        if d:
-            os.makedirs(d, exist_ok=True)
-        save_weights(trainer.net, model_path)
-        tmp = state_path + ".tmp"
-        torch.save({"net": {k: v.detach().cpu() for k, v in trainer.net.state_dict().items()},
-                    "opt": trainer.opt.state_dict(), "iter": it}, tmp)
-        os.replace(tmp, state_path)
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        dist.barrier()                                   # a rank that loads the snapshot right away must find it
+        try:
+            d = os.path.dirname(model_path)
+            if d:
+                os.makedirs(d, exist_ok=True)
+            save_weights(trainer.net, model_path)
+            tmp = state_path + ".tmp"
+            torch.save({"net": {k: v.detach().cpu() for k, v in trainer.net.state_dict().items()},
+                        "opt": trainer.opt.state_dict(), "iter": it}, tmp)
+            os.replace(tmp, state_path)
+        except Exception as e:                           # noqa: BLE001 - reported on every rank below
+            err = "%s: %s" % (type(e).__name__, e)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        box = [err]
+        dist.broadcast_object_list(box, src=0)          # also the barrier: a rank that loads the snapshot right away finds it
+        err = box[0]
+    if err is not None:
+        raise RuntimeError("snapshot %s not written (rank 0: %s)" % (state_path, err))
     return model_path, state_path
 
 

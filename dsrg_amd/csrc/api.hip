@@ -173,6 +173,20 @@ static int check_params(const dsrg_crf_params *p) {
     return DSRG_OK;
 }
 
+// the cached Gaussian lattice's kLatticeLocal flag, read back once per (shape, theta_gamma) — one host synchronisation of the
+// stream, on the first call after a rebuild that does not run inside a stream capture (documented in dsrg_hip.h)
+static int refresh_gauss_local(dsrg_ctx_t c, hipStream_t s) {
+    if (c->gauss_local != -1 || !c->gauss_valid) return DSRG_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+    if (cap != hipStreamCaptureStatusNone) return DSRG_OK;
+    int fl = 0;
+    DSRG_HIP_CHECK(hipMemcpyAsync(&fl, c->Lg.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    DSRG_HIP_CHECK(hipStreamSynchronize(s));
+    c->gauss_local = (fl & kLatticeLocal) ? 1 : 0;
+    return DSRG_OK;
+}
+
 // build the lattices for B images (colours: a (B,N,3) uint8 image, or the net's float images resampled on the fly)
 static int crf_build(dsrg_ctx_t c, int B, const LatticeColours &col, const dsrg_crf_params *prm, hipStream_t s) {
     LatticeFeat Fg, Fb;
@@ -190,15 +204,9 @@ static int crf_build(dsrg_ctx_t c, int B, const LatticeColours &col, const dsrg_
         // workgroups out of the grid when the lattice is pixel-local.  Not inside a stream capture (no host sync there):
         // the kernels then decide from the device-side flag and the launch merely carries workgroups that exit at once.
         c->gauss_local = -1;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
-        if (cap == hipStreamCaptureStatusNone) {
-            int fl = 0;
-            DSRG_HIP_CHECK(hipMemcpyAsync(&fl, c->Lg.flags, sizeof(int), hipMemcpyDeviceToHost, s));
-            DSRG_HIP_CHECK(hipStreamSynchronize(s));
-            c->gauss_local = (fl & kLatticeLocal) ? 1 : 0;
-        }
     }
+    // (the flag is read back lazily: here when the stream is not capturing, else by the first later call that is not)
+    if (int rc2 = refresh_gauss_local(c, s)) return rc2;
     return launch_lattice_build(c->Lb, Fb, col, B, s);
 }
 
@@ -216,6 +224,8 @@ static int crf_run(dsrg_ctx_t c, int B, const float *neg_unary, const LatticeCol
     if (!prepared) {
         int rc = crf_build(c, B, col, prm, s);
         if (rc) return rc;
+    } else if (int rc = refresh_gauss_local(c, s)) {        // built inside a capture earlier: learn the flag now
+        return rc;
     }
     return launch_meanfield(c->Lg, c->Lb, c->mf, B, c->C, neg_unary, prm->w_gaussian, prm->w_bilateral,
                             prm->n_iters, q_out, refined, logq, c->gauss_local == 1, s, &c->prof, q0_ready);
@@ -285,6 +295,19 @@ extern "C" int dsrg_ctx_lattice_extras(dsrg_ctx_t c, int B, int32_t *x_gauss, in
     if (x_bil && B > 0)
         DSRG_HIP_CHECK(hipMemcpyAsync(x_bil, c->Lb.nextra, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
     DSRG_HIP_CHECK(hipStreamSynchronize(s));
+    return DSRG_OK;
+}
+
+extern "C" int dsrg_ctx_filter_plan(dsrg_ctx_t c, int B, int32_t *planes_bilateral, int32_t *planes_gaussian, int32_t *workgroups,
+                                    int32_t *lds_bytes) {
+    if (!c || B < 1 || B > c->maxB) return set_error(DSRG_ERR_INVALID, "bad argument");
+    int out[4];
+    int rc = filter_plan_query(c->Lg, c->Lb, c->mf, B, c->C, c->gauss_local == 1, out);
+    if (rc) return rc;
+    if (planes_bilateral) *planes_bilateral = out[0];
+    if (planes_gaussian) *planes_gaussian = out[1];
+    if (workgroups) *workgroups = out[2];
+    if (lds_bytes) *lds_bytes = out[3];
     return DSRG_OK;
 }
 

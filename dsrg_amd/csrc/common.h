@@ -138,6 +138,8 @@ int launch_meanfield(const LatticeView &Lg, const LatticeView &Lb, const Meanfie
                      const float *neg_unary, float wg, float wb, int n_iters, float *q_out,
                      double *refined_out, float *logq_out, bool gauss_local, hipStream_t stream, Profiler *prof = nullptr,
                      bool q0_ready = false);     // q0_ready: buf.q already holds Q0 = expAndNormalize(neg_unary) (n_iters > 0)
+int filter_plan_query(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C, bool gauss_local,
+                      int out[4]);
 int launch_lattice_norm_pass(const LatticeView &L, int nlat, hipStream_t stream);      // meanfield.hip; d = 5 lattices
 int launch_filter_once(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C, int kind,
                        const float *q_in, float *out, bool gauss_local, hipStream_t stream);

@@ -817,6 +817,20 @@ static int plan_filter(const LatticeView &Lg, const LatticeView &Lb, const Meanf
     P.cpw_b = cpw_b; P.cpw_g = cpw_g; P.vpt = vpt; P.nblocks = a.nunits; P.lds = lds;
     return DSRG_OK;
 }
+// measurement (bench.py's LDS model must describe the launch that runs, not re-derive the launcher's choices): planes per
+// bilateral / Gaussian workgroup, workgroups in the grid, dynamic LDS bytes of a filter launch over B images
+int filter_plan_query(const LatticeView &Lg, const LatticeView &Lb, const MeanfieldBufs &buf, int B, int C, bool gauss_local,
+                      int out[4]) {
+    FilterPlan P;
+    int rc = plan_filter(Lg, Lb, buf, B, C, gauss_local, P);
+    if (rc) return rc;
+    out[0] = (P.a.opts & kOptSeq) ? 1 : P.cpw_b;
+    out[1] = (P.a.opts & kOptSeq) ? 1 : P.cpw_g;
+    out[2] = P.nblocks;
+    out[3] = (int)P.lds;
+    return DSRG_OK;
+}
+
 static int run_filter(const FilterPlan &P, hipStream_t stream, Profiler *prof) {
     if (P.a.opts & kOptSeq) return dispatch_vpt<1, 1, true>(P.a, P.nblocks, P.lds, P.vpt, stream, prof);
     if (P.cpw_b == 2) return dispatch_vpt<2, 4>(P.a, P.nblocks, P.lds, P.vpt, stream, prof);

@@ -71,6 +71,13 @@ class Context(object):
         check(_lib.lib().dsrg_ctx_lattice_extras(self._h, B, ctypes.byref(xg), xb, _stream()))
         return xg.value, [xb[i] for i in range(B)]
 
+    def filter_plan(self, B):
+        """(planes per bilateral workgroup, planes per Gaussian workgroup, workgroups, LDS bytes) of a filter launch over B
+        images as the launcher plans it now (bench.py's LDS model)"""
+        v = [ctypes.c_int32(0) for _ in range(4)]
+        check(_lib.lib().dsrg_ctx_filter_plan(self._h, int(B), *[ctypes.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
     def lattice_dump(self, kind, b=0):
         """One lattice in the reference's own form (tests): kind 0 = Gaussian, 1 = bilateral lattice of image b.
         -> dict(M, keys (M,d) int16, vid (N,d+1) int32, bary (N,d+1) f32, n1 / n2 (d+1,M) int32 with -1 = none)."""

@@ -126,7 +126,10 @@ int dsrg_crf_refine_batch(dsrg_ctx_t ctx, int B, float *probs_dev, const float *
  * trainer can run it on a side stream underneath the backbone forward.  After this call (and a
  * stream dependency set up by the caller) dsrg_supervision_step may be given images_dev = NULL.
  * The call overwrites the context's lattices: the caller also orders it BEHIND the last call that
- * reads them (the previous step's mean field), e.g. side stream waits on the main stream first. */
+ * reads them (the previous step's mean field), e.g. side stream waits on the main stream first.
+ * One host synchronisation of `stream` happens on the FIRST call per (shape, kernel widths): the spatial lattice is built
+ * once and its "pixel-local" flag is read back so that later filter launches leave its workgroups out of the grid; inside
+ * a stream capture the read-back is postponed to the first later call outside one. */
 int dsrg_crf_prepare_batch(dsrg_ctx_t ctx, int B, const float *images_dev, int img_h, int img_w,
                            const dsrg_crf_params *params, void *stream);
 
@@ -145,6 +148,11 @@ int dsrg_ctx_lattice_sizes(dsrg_ctx_t ctx, int B, int32_t *m_gauss_host, int32_t
 /* measurement: per lattice, the number of splat entries beyond the first entry of their vertex (the part of the splat that
  * goes through LDS products; bench.py's LDS traffic model).  Host arrays as for dsrg_ctx_lattice_sizes; synchronises. */
 int dsrg_ctx_lattice_extras(dsrg_ctx_t ctx, int B, int32_t *x_gauss_host, int32_t *x_bilateral_host, void *stream);
+/* measurement: the geometry of one mean-field filter launch over B images as the launcher plans it NOW (label planes per
+ * bilateral / per Gaussian workgroup, workgroups in the grid, dynamic LDS bytes) — bench.py's LDS model reads it instead of
+ * re-deriving the launcher's rules.  Host pointers, any may be NULL. */
+int dsrg_ctx_filter_plan(dsrg_ctx_t ctx, int B, int32_t *planes_bilateral, int32_t *planes_gaussian, int32_t *workgroups,
+                         int32_t *lds_bytes);
 
 /* introspection for the parity tests: one lattice as the reference holds it.  kind 0 = the Gaussian lattice (b = 0),
  * kind 1 = the bilateral lattice of image b of the last refine / prepare / meanfield / supervision call.

@@ -135,3 +135,45 @@ def test_caffe_sgd_matches_hand_computation():
         v_q = 0.9 * v_q + 2 * lr * gq; w_q = w_q - v_q
         opt.step()
         assert np.allclose(p.detach().numpy(), w_p, atol=1e-6) and np.allclose(q.detach().numpy(), w_q, atol=1e-6)
+
+
+def _save_worker(rank, world, port, out_dir, bad):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = DSRGTrainer(torch.device("cpu"), world_size=world, seed=0, amp_dtype=None, channels_last=False,
+                     loss_fn=torch_loss, net=TinyNet(), bucket_cap_mb=0.001)
+    images, labels, cues = make_data(4)
+    sh = slice(rank * 2, rank * 2 + 2)
+    tr.step(images[sh], labels[sh], cues[sh])
+    res = {}
+    if bad:
+        # rank 0 cannot write (the "directory" is a file): EVERY rank must raise instead of hanging in a barrier
+        blocker = os.path.join(out_dir, "blocker")
+        if rank == 0:
+            open(blocker, "w").close()
+        dist.barrier()
+        try:
+            tr.save(os.path.join(blocker, "sub", "model"))
+            res["raised"] = False
+        except RuntimeError as e:
+            res["raised"] = "not written" in str(e)
+    else:
+        _, state = tr.save(os.path.join(out_dir, "snap", "model"))      # collective: both ranks
+        res["exists"] = os.path.exists(state)                            # ... and the file is there when ANY rank returns
+        tr2 = DSRGTrainer(torch.device("cpu"), world_size=world, seed=5, amp_dtype=None, channels_last=False,
+                          loss_fn=torch_loss, net=TinyNet(), bucket_cap_mb=0.001)
+        res["iter"] = tr2.load(state)
+        res["same"] = all(torch.equal(a, b) for a, b in zip(tr.net.state_dict().values(), tr2.net.state_dict().values()))
+    torch.save(res, os.path.join(out_dir, "save%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad", [False, True])
+def test_two_rank_snapshot_is_collective_and_fails_on_every_rank(tmp_path, bad):
+    mp.spawn(_save_worker, args=(2, _free_port(), str(tmp_path), bad), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), "save%d.pt" % r))
+        if bad:
+            assert res["raised"] is True
+        else:
+            assert res["exists"] and res["iter"] == 1 and res["same"]

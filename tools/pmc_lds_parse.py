@@ -10,8 +10,12 @@ x 256 CUs), conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (MI355X_MI
 cycles, IDX_ACTIVE = all LDS-array cycles).  Durations come from the same CSV (Start/End timestamps)."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsrg_amd.provenance import all_sources_sha256  # noqa: E402
 
 CUS = 256
 XCDS = 8
@@ -28,7 +32,7 @@ def main(path, out, commit=""):
         if (k, did) not in seen and r.get("Start_Timestamp"):
             seen.add((k, did))
             dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    res = {"commit": commit, "source": path, "note": "means per launch; SQ counters are summed over all SEs/CUs; durations under "
+    res = {"commit": commit, "sources_sha256": all_sources_sha256(), "source": path, "note": "means per launch; SQ counters are summed over all SEs/CUs; durations under "
            "counter collection are longer than un-profiled ones (serialised dispatches, lower clock)", "kernels": {}}
     for k, cs in acc.items():
         if "dsrg::" not in k:

@@ -6,8 +6,12 @@ Usage: python tools/pmc_parse.py FETCH_CSV WRITE_CSV OUT_JSON [commit]   (the co
 stamped into the file: re-collect when a kernel changes)"""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsrg_amd.provenance import all_sources_sha256  # noqa: E402
 
 CALIB_KERNEL = "softmax_fwd_kernel"
 CALIB_BYTES = 2048 * 21 * 41 * 41 * 4
@@ -23,7 +27,7 @@ def per_kernel(path, counter):
 
 
 def main(fetch_csv, write_csv, out, commit=""):
-    res = {"commit": commit, "units": "bytes per launch; raw counters are KiB (FETCH_SIZE/WRITE_SIZE), corrected by the "
+    res = {"commit": commit, "sources_sha256": all_sources_sha256(), "units": "bytes per launch; raw counters are KiB (FETCH_SIZE/WRITE_SIZE), corrected by the "
                     "calibration factor of a %d-byte softmax_fwd_kernel launch" % CALIB_BYTES}
     factors = {}
     tables = {}
