@@ -85,7 +85,10 @@ SIGNATURES = {
     "dsrg_heads_forward_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dsrg_conv3x3_direct_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_conv_igemm_supported": (_i, [_i, _i, _i]),
-    "dsrg_conv_igemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_ulonglong, _vp]),
+    "dsrg_conv_igemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _sz,
+                                  _vp]),
+    "dsrg_conv_igemm_workspace": (_sz, []),
+    "dsrg_conv_igemm_workspace_status": (_i, [_vp, _vp, _vp]),
     "dsrg_pack_conv_weight_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "dsrg_conv_igemm_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "dsrg_conv_igemm_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),

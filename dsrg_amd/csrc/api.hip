@@ -493,10 +493,16 @@ extern "C" int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, co
 extern "C" int dsrg_conv_igemm_supported(int cin, int cout, int ksize) { return conv_igemm_supported(cin, cout, ksize) ? 1 : 0; }
 extern "C" int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, const float *const *bias_dev,
                                     void *const *y_dev, const int *dilation, int ngroups, int B, int H, int W, int cin, int cout,
-                                    int ksize, int relu, float dropout_p, unsigned long long dropout_seed, void *stream) {
+                                    int ksize, int relu, float dropout_p, unsigned long long dropout_seed, void *workspace_dev,
+                                    size_t workspace_bytes, void *stream) {
     if (!x_dev || !w_dev || !y_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "conv_igemm: bad arguments");
     return launch_conv_igemm(x_dev, w_dev, bias_dev, y_dev, dilation, ngroups, B, H, W, cin, cout, ksize, relu, dropout_p,
-                             dropout_seed, static_cast<hipStream_t>(stream));
+                             dropout_seed, workspace_dev, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+extern "C" size_t dsrg_conv_igemm_workspace(void) { return conv_igemm_workspace(); }
+extern "C" int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, int *status_host) {
+    if (!workspace_dev || !status_host) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return conv_igemm_workspace_status(workspace_dev, static_cast<hipStream_t>(stream), status_host);
 }
 extern "C" int dsrg_pack_conv_weight_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, int ksize, void *stream) {
     return launch_pack_conv_weight(w_dev, fwd_dev, dgrad_dev, cout, cin, ksize, static_cast<hipStream_t>(stream));

@@ -184,7 +184,9 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
 bool conv_igemm_supported(int cin, int cout, int k);
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
                       int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
-                      hipStream_t stream);
+                      void *workspace, size_t workspace_bytes, hipStream_t stream);
+size_t conv_igemm_workspace();
+int conv_igemm_workspace_status(const void *workspace, hipStream_t stream, int *status);
 size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k);
 int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *const *gw, const int *dil, int ngroups, void *workspace,
                             size_t workspace_bytes, int B, int H, int W, int cin, int cout, int k, int out_bf16, hipStream_t stream);

@@ -293,6 +293,247 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel_64x2(IgemmArgs a) { 
 __global__ __launch_bounds__(512, 2) void conv_igemm_kernel_32x4(IgemmArgs a) { conv_igemm_body<32, 4>(a); }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same convolution with the K-steps of ALL tiles dealt out evenly ("stream-K"): the 41x41 layers have 212 tiles of 72
+// K-steps for 256 CUs — one round with a sixth of the chip idle — and the data gradient of conv4_1 106.  Here the grid is one
+// workgroup per CU and workgroup u takes the global K-steps [u T / U, (u + 1) T / U) of the T = tiles x steps of the launch:
+// up to one tile it finishes for an earlier workgroup (its first segment), whole tiles, and up to one tile it starts (its last
+// segment).  A tile cut this way is completed by the workgroup that holds its FIRST step — that segment is the last thing the
+// workgroup does, so the other parts (the first segments of the following workgroups, written to a workspace with
+// write-through stores and published by a flag: cdna_hip_programming.md Guideline 16, recipe R1) are there long before it
+// looks; it adds them in workgroup order (deterministic) and runs the ordinary epilogue.  Dependencies point to higher
+// workgroup ids only and nobody waits before having done all its own work, so the launch cannot deadlock however the
+// dispatcher places the workgroups; every wait is bounded all the same (error word, the tile is then left unwritten).
+struct IgemmSkArgs {
+    IgemmArgs base;
+    float *ws;              // [units][32][512] float4: a workgroup's accumulators of its first segment
+    uint32_t *flags;        // [units + 1]: published marker per workgroup (zeroed before every launch) + an error word
+    int units, tiles_total;
+};
+typedef __attribute__((address_space(1))) uint32_t gu32;
+using f32x4v = decltype(__builtin_amdgcn_raw_buffer_load_b128(rsrc_t(), 0, 0, 0));
+
+__global__ __launch_bounds__(512, 2) void conv_igemm_sk_kernel(IgemmSkArgs k) {
+    using C = ICfg<64, 2>;
+    const IgemmArgs &a = k.base;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ig_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kgrp = lane >> 5;
+    const int wn = wv >> 2, wm = wv & 3;
+    int unit;
+    {
+        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = id & 7, kk = id >> 3;
+        unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;       // neighbours in the step order share an XCD
+    }
+    const int taps = a.taps, Cin = a.Cin, W = a.W, H = a.H;
+    const int ktot = taps * Cin;
+    const int nsteps = (Cin >> 6) * taps;
+    const long long total_steps = (long long)k.tiles_total * nsteps;
+    auto unit_start = [&](int u) { return (long long)u * total_steps / k.units; };
+    const long long g1 = unit_start(unit + 1);
+    const int sw = C::swz(l31);
+    const uint32_t rowoff = (uint32_t)l31 * C::ROW;
+    uint32_t choff[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ks++) choff[ks] = rowoff + (uint32_t)(((ks * 2 + kgrp) ^ sw) << 4);
+    const rsrc_t rws = make_rsrc(k.ws, (size_t)k.units * 32 * 512 * 16);
+    const float floor_ = a.relu ? 0.0f : -__builtin_inff();
+
+    for (long long g = unit_start(unit); g < g1;) {
+        const int tile = (int)(g / nsteps);
+        const int sb = (int)(g - (long long)tile * nsteps);
+        const int se = (int)min((long long)nsteps, sb + (g1 - g));
+        int t = tile;
+        const int grp = t / a.tiles_per_group;
+        t -= grp * a.tiles_per_group;
+        const int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
+        const int m0 = tm * kBM, n0 = tn * kBN;
+        const IgemmGroup G = a.g[grp];
+        const rsrc_t rx = make_rsrc(G.x, (size_t)a.M * Cin * 2);
+        const rsrc_t rw = make_rsrc(G.w, (size_t)a.Cout * ktot * 2);
+        const bool active = n0 + wn * 128 < a.Cout;
+
+        uint32_t pbase[C::IPW], pvalid[C::IPW], wbase[C::IPW];
+#pragma unroll
+        for (int i = 0; i < C::IPW; i++) {
+            const int r = wv * 32 + i * C::RPI + lane / C::CPR;
+            const int c = (lane % C::CPR) ^ C::swz(r);
+            const int m = m0 + r;
+            const bool in = m < a.M;
+            const int mm = in ? m : 0;
+            const int hw = H * W;
+            const int b = mm / hw, rem = mm - b * hw, y = rem / W, x = rem - y * W;
+            uint32_t valid = 0;
+            if (in) {
+                if (taps == 9) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; tap++) {
+                        const int yy = y + (tap / 3 - 1) * G.dil, xx = x + (tap % 3 - 1) * G.dil;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) valid |= 1u << tap;
+                    }
+                } else {
+                    valid = 1u;
+                }
+            }
+            pbase[i] = (uint32_t)mm * (uint32_t)(Cin * 2) + (uint32_t)c * 16u;
+            pvalid[i] = valid;
+            wbase[i] = (uint32_t)(n0 + r) * (uint32_t)(ktot * 2) + (uint32_t)c * 16u;
+        }
+        auto issue = [&](int stage, int s) {
+            const int cc = s / taps, tap = s - cc * taps;
+            int dy = 0, dx = 0;
+            if (taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+            const int toff = (dy * G.dil * W + dx * G.dil) * Cin * 2 + cc * 128;
+            unsigned char *P = ig_lds + stage * C::STAGE + wv * (32 * C::ROW);
+            unsigned char *Wt = P + kBM * C::ROW;
+#pragma unroll
+            for (int i = 0; i < C::IPW; i++) {
+                const uint32_t vo = ((pvalid[i] >> tap) & 1u) ? pbase[i] + (uint32_t)toff : kOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(P + i * (C::RPI * C::ROW)), 16, vo, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < C::IPW; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Wt + i * (C::RPI * C::ROW)), 16, wbase[i], (uint32_t)s * C::ROW, 0, 0);
+        };
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+        issue(0, sb);
+        for (int s = sb; s < se; s++) {
+            const int stage = (s - sb) & 1;
+            wait_vm_barrier<0>();
+            const bool more = s + 1 < se, late = wv >= 4 && active;
+            if (more && !late) issue(stage ^ 1, s + 1);
+            if (active) {
+                const unsigned char *P = ig_lds + stage * C::STAGE + wm * (64 * C::ROW);
+                const unsigned char *Wt = ig_lds + stage * C::STAGE + kBM * C::ROW + wn * (128 * C::ROW);
+                // (fragments read slice by slice, placed by the compiler: the register budget of this kernel — accumulators, the
+                // segment loop's state and an epilogue inside the loop — has no room for a second fragment set)
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ks++) {
+                    bf16x8 af[4], bfr[2];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * C::ROW) + choff[ks]);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) bfr[j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[ks]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    if (ks == 0 && more && late) issue(stage ^ 1, s + 1);
+                }
+            }
+        }
+        __syncthreads();                                    // every wave is done reading the last stage
+
+        if (sb != 0) {
+            // ---- my first segment continues a tile an earlier workgroup starts: publish the accumulators (write-through), flag
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            f32x4v v = {__float_as_uint(acc[i][j][q * 4 + 0]), __float_as_uint(acc[i][j][q * 4 + 1]),
+                                        __float_as_uint(acc[i][j][q * 4 + 2]), __float_as_uint(acc[i][j][q * 4 + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rws, (uint32_t)(((i * 2 + j) * 4 + q) * 512 + tid) * 16u,
+                                                                   (uint32_t)unit * (32u * 512u * 16u), 16);      // aux 16 = sc1
+                        }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // every storing wave drains
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(k.flags + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            bool ok = true;
+            if (se != nsteps) {
+                // ---- I hold the tile's first steps: the rest are the first segments of the following workgroups
+                const long long tile_end = (long long)(tile + 1) * nsteps;
+                for (int v = unit + 1; v < k.units && unit_start(v) < tile_end; v++) {
+                    volatile int &sk_ok = *reinterpret_cast<volatile int *>(ig_lds);     // the stages are idle here (one LDS object only)
+                    if (tid == 0) {
+                        unsigned spins = 0;
+                        int good = 1;
+                        while (__hip_atomic_load(k.flags + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 24)) { good = 0; break; }           // ~ seconds: give up, report
+                        }
+                        if (good) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        else __hip_atomic_store(k.flags + k.units, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sk_ok = good;
+                    }
+                    __syncthreads();
+                    ok = ok && sk_ok != 0;
+                    if (ok && active) {
+#pragma unroll 1
+                        for (int i = 0; i < 4; i++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++)
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    const f32x4v p = __builtin_amdgcn_raw_buffer_load_b128(
+                                        rws, (uint32_t)(((i * 2 + j) * 4 + q) * 512 + tid) * 16u, (uint32_t)v * (32u * 512u * 16u), 0);
+                                    acc[i][j][q * 4 + 0] += __uint_as_float(p[0]); acc[i][j][q * 4 + 1] += __uint_as_float(p[1]);
+                                    acc[i][j][q * 4 + 2] += __uint_as_float(p[2]); acc[i][j][q * 4 + 3] += __uint_as_float(p[3]);
+                                }
+                    }
+                    __syncthreads();                          // sk_ok is rewritten for the next part
+                }
+            }
+            if (ok && active) {
+                // ---- epilogue of the complete tile (as conv_igemm_body)
+                unsigned char *O = ig_lds + wv * kOutWave;
+                const int nw = n0 + wn * 128;
+                const rsrc_t rb = make_rsrc(G.bias, G.bias ? (size_t)a.Cout * 4 : 0);
+                const uint32_t seed_g = a.seed_lo + (uint32_t)grp * 0x9E3779B9u;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int nl = i * 32 + q * 8 + kgrp * 4;
+                        float bq[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) bq[e] = ld_f32(rb, (uint32_t)(nw + nl + e) * 4u);
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            float v0 = acc[i][j][q * 4 + 0] + bq[0], v1 = acc[i][j][q * 4 + 1] + bq[1];
+                            float v2 = acc[i][j][q * 4 + 2] + bq[2], v3 = acc[i][j][q * 4 + 3] + bq[3];
+                            v0 = fmaxf(v0, floor_); v1 = fmaxf(v1, floor_); v2 = fmaxf(v2, floor_); v3 = fmaxf(v3, floor_);
+                            if (a.drop_thresh) {
+                                const uint32_t m = (uint32_t)(m0 + wm * 64 + j * 32 + l31);
+                                const uint32_t h = dropout_bytes((m * (uint32_t)a.Cout + (uint32_t)(nw + nl)) >> 2, seed_g, a.seed_hi);
+                                v0 = (h & 0xffu) >= a.drop_thresh ? v0 * a.drop_scale : 0.0f;
+                                v1 = ((h >> 8) & 0xffu) >= a.drop_thresh ? v1 * a.drop_scale : 0.0f;
+                                v2 = ((h >> 16) & 0xffu) >= a.drop_thresh ? v2 * a.drop_scale : 0.0f;
+                                v3 = (h >> 24) >= a.drop_thresh ? v3 * a.drop_scale : 0.0f;
+                            }
+                            *reinterpret_cast<uint2 *>(O + (j * 32 + l31) * kOutRow + nl * 2) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+                        }
+                    }
+                }
+#pragma unroll 4
+                for (int it = 0; it < 16; it++) {
+                    const int p = it * 4 + (lane >> 4), ch = lane & 15;
+                    const int m = m0 + wm * 64 + p;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(O + p * kOutRow + ch * 16);
+                    if (m < a.M) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
+                }
+            }
+        }
+        g += se - sb;
+        __syncthreads();                                    // the epilogue's LDS rows are the next segment's stages
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same convolutions, again without an im2col matrix:
 //
 //   gw[n][tap][c] = sum over pixels m of  g[m][n] * x[pixel(m) + tap offset][c]
@@ -542,9 +783,20 @@ static int igemm_variant() {
     return v;
 }
 
+static int igemm_cus() {
+    static const int n = [] {
+        int dev = 0, c = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 8) c = 256;
+        return c;
+    }();
+    return n;
+}
+// device scratch of the stream-K form: one accumulator tile (256 KB) and one flag per workgroup (= per CU), an error word
+size_t conv_igemm_workspace() { return (size_t)igemm_cus() * (32 * 512 * 16) + ((size_t)igemm_cus() + 1 + 63) / 64 * 256; }
+
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
                       int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
-                      hipStream_t stream) {
+                      void *workspace, size_t workspace_bytes, hipStream_t stream) {
     if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm: 1..4 groups");
     if (!conv_igemm_supported(cin, cout, k))
         return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: cin %% 64 == 0, cout %% 128 == 0, k in (1, 3) required (got %d, %d, %d)",
@@ -571,10 +823,29 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     if (a.drop_thresh > 255) a.drop_thresh = 255;
     a.drop_scale = 256.0f / (float)(256 - (int)a.drop_thresh);
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    static LdsGrant grant[2];
+    static LdsGrant grant[3];
     const int variant = igemm_variant() == 2 ? 1 : 0;       // 1, 3: two stages of 64; 2: ring of four stages of 32
     a.stagger = igemm_variant() == 3;
     const dim3 grid(a.tiles_per_group * ngroups), block(512);
+    // stream-K whenever whole tiles would leave more than 3 % of the chip's rounds idle and the caller lent the scratch
+    const int units = igemm_cus(), tiles_total = a.tiles_per_group * ngroups, nsteps = (cin / 64) * k * k;
+    const int rounds = (tiles_total + units - 1) / units;
+    if (workspace && workspace_bytes >= conv_igemm_workspace() && igemm_variant() == 3 && tiles_total * 100 < rounds * units * 97 &&
+        (long long)tiles_total * nsteps >= (long long)units * 8) {
+        IgemmSkArgs sk;
+        sk.base = a;
+        sk.base.stagger = 1;
+        sk.ws = static_cast<float *>(workspace);
+        sk.flags = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(workspace) + (size_t)units * (32 * 512 * 16));
+        sk.units = units;
+        sk.tiles_total = tiles_total;
+        constexpr size_t lds = ICfg<64, 2>::LDS;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_sk_kernel), lds, grant[2])) return rc;
+        DSRG_HIP_CHECK(hipMemsetAsync(sk.flags, 0, sizeof(uint32_t) * ((size_t)units + 1), stream));      // every launch (a graph replays it)
+        hipLaunchKernelGGL(conv_igemm_sk_kernel, dim3(units), block, lds, stream, sk);
+        DSRG_LAUNCH_CHECK();
+        return DSRG_OK;
+    }
     if (variant == 0) {
         constexpr size_t lds = ICfg<64, 2>::LDS;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel_64x2), lds, grant[0])) return rc;
@@ -671,6 +942,16 @@ int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, in
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cout / 64, cin / 64, k * k), dim3(256), 0, stream, w, static_cast<uint16_t *>(fwd),
                        static_cast<uint16_t *>(dgrad), cout, cin, k * k);
     DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// tests: the error word of the last stream-K launch that used this workspace (1 = a workgroup gave up waiting); synchronises
+int conv_igemm_workspace_status(const void *workspace, hipStream_t stream, int *status) {
+    uint32_t v = 0;
+    const unsigned char *p = static_cast<const unsigned char *>(workspace) + (size_t)igemm_cus() * (32 * 512 * 16) + sizeof(uint32_t) * (size_t)igemm_cus();
+    DSRG_HIP_CHECK(hipMemcpyAsync(&v, p, sizeof(v), hipMemcpyDeviceToHost, stream));
+    DSRG_HIP_CHECK(hipStreamSynchronize(stream));
+    *status = (int)v;
     return DSRG_OK;
 }
 

@@ -479,11 +479,12 @@ def pack_conv_weight_pair(weight, want_fwd=True, want_dgrad=True):
     return fwd, dg
 
 
-def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0):
+def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0, stream_k=True):
     """1 .. 4 convolutions of one geometry in one launch (the four ASPP branches): xs[g] (B,cin,H,W) bf16 channels_last,
     packed[g] = pack_conv_weight(w_g), biases[g] (cout) f32 or None -> list of (B,cout,H,W) bf16 channels_last; fp32
     accumulation, bias, ReLU and (dropout_p > 0, multiples of 1/256) the Dropout behind it fused — the mask is a function of
-    (seed, branch, position) — no im2col matrix"""
+    (seed, branch, position) — no im2col matrix.  stream_k: lend the launch a per-stream scratch so that it may deal its K-steps
+    out evenly over the CUs when whole tiles would leave part of the chip idle (same results up to fp32 summation order)"""
     n = len(xs)
     B, cin, H, W = xs[0].shape
     cout = packed[0].shape[0]
@@ -498,12 +499,34 @@ def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0
     bs = [None if b is None else _f32c(b, "bias") for b in (biases or [None] * n)]
     ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xs[0].device, memory_format=cl) for _ in range(n)]
     vp = ctypes.c_void_p * n
+    ws = _igemm_sk_workspace(xs[0].device) if stream_k else None
     check(_lib.lib().dsrg_conv_igemm_bf16(vp(*[x.data_ptr() for x in xs]), vp(*[p.data_ptr() for p in packed]),
                                           vp(*[None if b is None else b.data_ptr() for b in bs]),
                                           vp(*[y.data_ptr() for y in ys]), (ctypes.c_int * n)(*[int(d) for d in dilations]),
                                           n, B, H, W, cin, cout, ksize, int(bool(relu)), float(dropout_p),
-                                          int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()))
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
     return ys
+
+
+_igemm_sk_ws = {}
+
+
+def _igemm_sk_workspace(device):
+    """the stream-K scratch of (device, current stream): one accumulator tile per CU + flags, allocated once"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _igemm_sk_ws.get(key)
+    if ws is None:
+        ws = _igemm_sk_ws[key] = torch.empty(_lib.lib().dsrg_conv_igemm_workspace(), dtype=torch.uint8, device=device)
+    return ws
+
+
+def conv_igemm_stream_k_status(device=None):
+    """tests: 0, or 1 if a workgroup of the last stream-K launch on the current stream gave up waiting for a partial tile"""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    ws = _igemm_sk_workspace(device)
+    st = ctypes.c_int(0)
+    check(_lib.lib().dsrg_conv_igemm_workspace_status(_ptr(ws), _stream(), ctypes.byref(st)))
+    return st.value
 
 
 def dropout_seed():

@@ -273,11 +273,19 @@ int dsrg_conv3x3_wgrad_bf16(const void *x_dev, const void *g_dev, void *gw_dev, 
  * ReLU (train-s.prototxt: drop6_k, drop7_k) in the same epilogue — y = relu(..) * keep / (1 - p), keep a pure function of
  * (dropout_seed, group, element position) from a counter-based generator, p realised in steps of 1/256; the backward pass
  * reads both masks off the sign of y.  dsrg_conv_igemm_supported: 1 if the channel counts / kernel size are served, else 0
- * (the call then returns DSRG_ERR_UNSUPPORTED). */
+ * (the call then returns DSRG_ERR_UNSUPPORTED).
+ * workspace_dev (may be NULL): dsrg_conv_igemm_workspace() bytes of device scratch owned by the caller and used by ONE stream
+ * at a time.  With it, a launch whose tiles do not fill whole rounds of the chip deals its K-steps out evenly instead
+ * ("stream-K": one workgroup per CU, partial tiles handed over through the scratch, summed in a fixed order — results are
+ * deterministic, equal to the whole-tile launch up to the fp32 summation order of a cut tile).
+ * dsrg_conv_igemm_workspace_status (tests): 0, or 1 if a workgroup of the last launch on that scratch gave up waiting. */
 int dsrg_conv_igemm_supported(int cin, int cout, int ksize);
 int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, const float *const *bias_dev, void *const *y_dev,
                          const int *dilation, int ngroups, int B, int H, int W, int cin, int cout, int ksize, int relu,
-                         float dropout_p, unsigned long long dropout_seed, void *stream);
+                         float dropout_p, unsigned long long dropout_seed, void *workspace_dev, size_t workspace_bytes,
+                         void *stream);
+size_t dsrg_conv_igemm_workspace(void);
+int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, int *status_host);
 /* The two packed forms dsrg_conv_igemm_bf16 reads, from the float32 master kernel in ONE pass (cast included): w_dev
  * (cout, ksize*ksize, cin) f32 = the memory of a channels_last (cout, cin, ksize, ksize) parameter; fwd_dev (may be NULL):
  * (cout, cin / 64, taps, 64) bf16 for the forward; dgrad_dev (may be NULL): (cin, cout / 64, taps, 64) bf16 for the data

@@ -216,3 +216,30 @@ def test_igemm_fused_dropout(ops):
             assert torch.equal(two[0], a1) and not torch.equal(two[1], a1)
             both = ((two[0] != 0) & (two[1] != 0) & pos).sum().item() / pos.sum().item()
             assert abs(both - (1 - p) ** 2) < 0.01                                   # independent
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,dils", [
+    (16, 41, 41, 512, 512, 3, [2]),                  # 212 tiles of 72 steps on 256 CUs: every workgroup 59.6 steps
+    (16, 41, 41, 512, 256, 3, [1]),                  # 106 tiles: tiles cut in three
+    (4, 41, 41, 512, 1024, 3, [6, 12, 18, 24]),      # four branches, 7 x 4 x 4 tiles
+    (3, 81, 81, 256, 128, 3, [1]),                   # half-width n-tiles (waves 4-7 idle) through the stream-K form
+    (16, 41, 41, 1024, 1024, 1, [1]),                # 1x1: 16 steps per tile
+])
+def test_igemm_stream_k_equals_whole_tiles(ops, B, H, W, cin, cout, k, dils):
+    """the stream-K form (K-steps of all tiles dealt out evenly, cut tiles completed through the scratch) against the one-tile-
+    per-workgroup launch: equal up to the fp32 summation order of a cut tile, bit-reproducible, same Dropout mask, no
+    workgroup gave up waiting"""
+    n = len(dils)
+    xs, ws, bs = [], [], []
+    for i in range(n):
+        x, w, b = _case(B, H, W, cin, cout, k, 60 + i)
+        xs.append(x); ws.append(ops.pack_conv_weight(w)); bs.append(b)
+    for p in (0.0, 0.5):
+        whole = ops.conv_igemm(xs, ws, bs, dils, k, True, p, 77, stream_k=False)
+        cut = ops.conv_igemm(xs, ws, bs, dils, k, True, p, 77, stream_k=True)
+        assert ops.conv_igemm_stream_k_status() == 0
+        again = ops.conv_igemm(xs, ws, bs, dils, k, True, p, 77, stream_k=True)
+        for a, b_, c in zip(whole, cut, again):
+            assert torch.equal(b_, c)
+            assert torch.equal(a == 0, b_ == 0) or ((a == 0) != (b_ == 0)).float().mean() < 1e-4     # a sum on the edge of the ReLU
+            assert (a.float() - b_.float()).abs().max() <= 0.01 * a.float().abs().max() + 1e-3

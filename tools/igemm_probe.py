@@ -55,7 +55,7 @@ def main():
         ("conv3_2 256->256 81x81", 81, 81, 256, 256, 3, [1]),
         ("conv3_1 128->256 81x81", 81, 81, 128, 256, 3, [1]),
     ]
-    print("%-28s %9s %9s %9s %9s | %8s %8s | %s" % ("layer", "ig 64x2", "ig stagger", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
+    print("%-28s %9s %9s %9s %9s | %8s %8s | %s" % ("layer", "stream-K", "whole tiles", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
     for name, H, W, cin, cout, k, dils in layers:
         n = len(dils)
         torch.manual_seed(1)
@@ -65,8 +65,10 @@ def main():
         packed = [ops.pack_conv_weight(w) for w in ws]
         bsb = [b.bfloat16() for b in bs]
 
+        sk = [True]
+
         def run_ig():
-            return ops.conv_igemm(xs, packed, bs, dils, k, True)
+            return ops.conv_igemm(xs, packed, bs, dils, k, True, stream_k=sk[0])
 
         def run_old():
             return [_im2col_gemm(xs[g], ws[g], bsb[g], dils[g], True) for g in range(n)]
@@ -89,13 +91,13 @@ def main():
         torch.cuda.synchronize()
         t = {"ig1": [], "ig0": [], "old": [], "mm": []}
         for _ in range(args.rounds):
-            ops.set_igemm_variant(1)
+            sk[0] = True
             t["ig1"].append(timed(run_ig, args.iters))
-            ops.set_igemm_variant(3)
+            sk[0] = False
             t["ig0"].append(timed(run_ig, args.iters))
             t["old"].append(timed(run_old, args.iters))
             t["mm"].append(timed(run_mm, args.iters))
-        ops.set_igemm_variant(1)
+        ops.set_igemm_variant(-1)
         med = {k_: float(np.median(v)) for k_, v in t.items()}
         flops = 2.0 * B * H * W * cin * k * k * cout * n
         print("%-28s %9.1f %9.1f %9.1f %9.1f | %8.0f %8.0f | %.2e" % (
