@@ -309,7 +309,8 @@ struct IgemmSkArgs {
     uint32_t *flags;        // [units + 1]: published marker per workgroup (zeroed before every launch) + an error word
     int units, tiles_total;
 };
-typedef __attribute__((address_space(1))) uint32_t gu32;
+constexpr int kSkParts = 4;        // most shares a cut tile can have besides its owner's: the launcher keeps a workgroup's
+                                   // run of steps >= a third of a tile
 using f32x4v = decltype(__builtin_amdgcn_raw_buffer_load_b128(rsrc_t(), 0, 0, 0));
 
 __global__ __launch_bounds__(512, 2) void conv_igemm_sk_kernel(IgemmSkArgs k) {
@@ -454,70 +455,75 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_sk_kernel(IgemmSkArgs k) {
             if (tid == 0) __hip_atomic_store(k.flags + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             bool ok = true;
+            int nparts = 0;
             if (se != nsteps) {
-                // ---- I hold the tile's first steps: the rest are the first segments of the following workgroups
+                // ---- I hold the tile's first steps: the rest are the first segments of the following workgroups.  Wait for
+                // their flags (one lane, relaxed polls, bounded), ONE acquire, barrier; the epilogue below then adds their
+                // accumulators group by group, in workgroup order.
                 const long long tile_end = (long long)(tile + 1) * nsteps;
-                for (int v = unit + 1; v < k.units && unit_start(v) < tile_end; v++) {
-                    volatile int &sk_ok = *reinterpret_cast<volatile int *>(ig_lds);     // the stages are idle here (one LDS object only)
-                    if (tid == 0) {
+                while (unit + 1 + nparts < k.units && unit_start(unit + 1 + nparts) < tile_end) nparts++;
+                volatile int &sk_ok = *reinterpret_cast<volatile int *>(ig_lds);     // the stages are idle here (one LDS object only)
+                if (tid == 0) {
+                    int good = nparts <= kSkParts ? 1 : 0;          // (the launcher's rule makes more impossible; never drop a share silently)
+                    for (int p = 0; p < nparts && good; p++) {
                         unsigned spins = 0;
-                        int good = 1;
-                        while (__hip_atomic_load(k.flags + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+                        while (__hip_atomic_load(k.flags + unit + 1 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
                             __builtin_amdgcn_s_sleep(8);
                             if (++spins > (1u << 24)) { good = 0; break; }           // ~ seconds: give up, report
                         }
-                        if (good) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        else __hip_atomic_store(k.flags + k.units, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sk_ok = good;
                     }
-                    __syncthreads();
-                    ok = ok && sk_ok != 0;
-                    if (ok && active) {
-#pragma unroll 1
-                        for (int i = 0; i < 4; i++)
-#pragma unroll
-                            for (int j = 0; j < 2; j++)
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    const f32x4v p = __builtin_amdgcn_raw_buffer_load_b128(
-                                        rws, (uint32_t)(((i * 2 + j) * 4 + q) * 512 + tid) * 16u, (uint32_t)v * (32u * 512u * 16u), 0);
-                                    acc[i][j][q * 4 + 0] += __uint_as_float(p[0]); acc[i][j][q * 4 + 1] += __uint_as_float(p[1]);
-                                    acc[i][j][q * 4 + 2] += __uint_as_float(p[2]); acc[i][j][q * 4 + 3] += __uint_as_float(p[3]);
-                                }
-                    }
-                    __syncthreads();                          // sk_ok is rewritten for the next part
+                    if (good) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    else __hip_atomic_store(k.flags + k.units, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sk_ok = good;
                 }
+                __syncthreads();
+                ok = sk_ok != 0;
+                __syncthreads();                              // the flag word is an epilogue row again
             }
             if (ok && active) {
-                // ---- epilogue of the complete tile (as conv_igemm_body)
+                // ---- epilogue of the complete tile (as conv_igemm_body), the other workgroups' shares of a cut tile added group
+                // by group in workgroup order: the up to kSkParts 16-byte loads of group gi + 1 are in flight while group gi is
+                // finished (a share beyond nparts gets an out-of-range offset = zeros, so the code has no branch per share)
                 unsigned char *O = ig_lds + wv * kOutWave;
                 const int nw = n0 + wn * 128;
                 const rsrc_t rb = make_rsrc(G.bias, G.bias ? (size_t)a.Cout * 4 : 0);
                 const uint32_t seed_g = a.seed_lo + (uint32_t)grp * 0x9E3779B9u;
+                f32x4v shares[2][kSkParts];
+                float bq[2][4];
+                auto fetch = [&](int gi, f32x4v (&dst)[kSkParts], float (&bias4)[4]) {
+                    const int i = gi >> 3, q = (gi >> 1) & 3, j = gi & 1;
+                    const uint32_t off = (uint32_t)(((i * 2 + j) * 4 + q) * 512 + tid) * 16u;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                    for (int p = 0; p < kSkParts; p++)
+                        dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rws, p < nparts ? off : kOob, (uint32_t)(unit + 1 + p) * (32u * 512u * 16u), 0);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int nl = i * 32 + q * 8 + kgrp * 4;
-                        float bq[4];
+                    for (int e = 0; e < 4; e++) bias4[e] = ld_f32(rb, (uint32_t)(nw + i * 32 + q * 8 + kgrp * 4 + e) * 4u);
+                };
+                fetch(0, shares[0], bq[0]);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) bq[e] = ld_f32(rb, (uint32_t)(nw + nl + e) * 4u);
+                for (int gi = 0; gi < 32; gi++) {
+                    const int i = gi >> 3, q = (gi >> 1) & 3, j = gi & 1;
+                    if (gi + 1 < 32) fetch(gi + 1, shares[(gi + 1) & 1], bq[(gi + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int nl = i * 32 + q * 8 + kgrp * 4;
+                    float s0 = acc[i][j][q * 4 + 0], s1 = acc[i][j][q * 4 + 1], s2 = acc[i][j][q * 4 + 2], s3 = acc[i][j][q * 4 + 3];
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            float v0 = acc[i][j][q * 4 + 0] + bq[0], v1 = acc[i][j][q * 4 + 1] + bq[1];
-                            float v2 = acc[i][j][q * 4 + 2] + bq[2], v3 = acc[i][j][q * 4 + 3] + bq[3];
-                            v0 = fmaxf(v0, floor_); v1 = fmaxf(v1, floor_); v2 = fmaxf(v2, floor_); v3 = fmaxf(v3, floor_);
-                            if (a.drop_thresh) {
-                                const uint32_t m = (uint32_t)(m0 + wm * 64 + j * 32 + l31);
-                                const uint32_t h = dropout_bytes((m * (uint32_t)a.Cout + (uint32_t)(nw + nl)) >> 2, seed_g, a.seed_hi);
-                                v0 = (h & 0xffu) >= a.drop_thresh ? v0 * a.drop_scale : 0.0f;
-                                v1 = ((h >> 8) & 0xffu) >= a.drop_thresh ? v1 * a.drop_scale : 0.0f;
-                                v2 = ((h >> 16) & 0xffu) >= a.drop_thresh ? v2 * a.drop_scale : 0.0f;
-                                v3 = (h >> 24) >= a.drop_thresh ? v3 * a.drop_scale : 0.0f;
-                            }
-                            *reinterpret_cast<uint2 *>(O + (j * 32 + l31) * kOutRow + nl * 2) = make_uint2(pack2(v0, v1), pack2(v2, v3));
-                        }
+                    for (int p = 0; p < kSkParts; p++) {
+                        const f32x4v pv = shares[gi & 1][p];
+                        s0 += __uint_as_float(pv[0]); s1 += __uint_as_float(pv[1]); s2 += __uint_as_float(pv[2]); s3 += __uint_as_float(pv[3]);
                     }
+                    float v0 = s0 + bq[gi & 1][0], v1 = s1 + bq[gi & 1][1], v2 = s2 + bq[gi & 1][2], v3 = s3 + bq[gi & 1][3];
+                    v0 = fmaxf(v0, floor_); v1 = fmaxf(v1, floor_); v2 = fmaxf(v2, floor_); v3 = fmaxf(v3, floor_);
+                    if (a.drop_thresh) {
+                        const uint32_t m = (uint32_t)(m0 + wm * 64 + j * 32 + l31);
+                        const uint32_t h = dropout_bytes((m * (uint32_t)a.Cout + (uint32_t)(nw + nl)) >> 2, seed_g, a.seed_hi);
+                        v0 = (h & 0xffu) >= a.drop_thresh ? v0 * a.drop_scale : 0.0f;
+                        v1 = ((h >> 8) & 0xffu) >= a.drop_thresh ? v1 * a.drop_scale : 0.0f;
+                        v2 = ((h >> 16) & 0xffu) >= a.drop_thresh ? v2 * a.drop_scale : 0.0f;
+                        v3 = (h >> 24) >= a.drop_thresh ? v3 * a.drop_scale : 0.0f;
+                    }
+                    *reinterpret_cast<uint2 *>(O + (j * 32 + l31) * kOutRow + nl * 2) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll 4
                 for (int it = 0; it < 16; it++) {
@@ -831,7 +837,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     const int units = igemm_cus(), tiles_total = a.tiles_per_group * ngroups, nsteps = (cin / 64) * k * k;
     const int rounds = (tiles_total + units - 1) / units;
     if (workspace && workspace_bytes >= conv_igemm_workspace() && igemm_variant() == 3 && tiles_total * 100 < rounds * units * 97 &&
-        (long long)tiles_total * nsteps >= (long long)units * 8) {
+        (long long)tiles_total * nsteps >= (long long)units * 8 && tiles_total * 3 >= units) {
         IgemmSkArgs sk;
         sk.base = a;
         sk.base.stagger = 1;

@@ -222,7 +222,7 @@ def test_igemm_fused_dropout(ops):
     (16, 41, 41, 512, 512, 3, [2]),                  # 212 tiles of 72 steps on 256 CUs: every workgroup 59.6 steps
     (16, 41, 41, 512, 256, 3, [1]),                  # 106 tiles: tiles cut in three
     (4, 41, 41, 512, 1024, 3, [6, 12, 18, 24]),      # four branches, 7 x 4 x 4 tiles
-    (3, 81, 81, 256, 128, 3, [1]),                   # half-width n-tiles (waves 4-7 idle) through the stream-K form
+    (4, 81, 81, 256, 128, 3, [1]),                   # half-width n-tiles (waves 4-7 idle) through the stream-K form
     (16, 41, 41, 1024, 1024, 1, [1]),                # 1x1: 16 steps per tile
 ])
 def test_igemm_stream_k_equals_whole_tiles(ops, B, H, W, cin, cout, k, dils):
