@@ -355,31 +355,34 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_sk_kernel(IgemmSkArgs k) {
         const rsrc_t rw = make_rsrc(G.w, (size_t)a.Cout * ktot * 2);
         const bool active = n0 + wn * 128 < a.Cout;
 
-        uint32_t pbase[C::IPW], pvalid[C::IPW], wbase[C::IPW];
+        // DMA geometry, kept in few registers (this kernel's budget is tight): instruction i of a wave moves rows wv*32 + i*8 +
+        // lane/8; row and source chunk of i follow from those of i = 0 — the pixel / weight row advances by 8 rows per i, and
+        // the swizzle term ((r >> 1) & 7) flips bit 2 of the chunk for odd i, i.e. XORs the byte offset with 64
+        uint32_t pbase0, wbase0, pvalid01 = 0, pvalid23 = 0;
+        {
+            const int r0 = wv * 32 + lane / C::CPR;
+            const int c0 = (lane % C::CPR) ^ C::swz(r0);
+            pbase0 = (uint32_t)(m0 + r0) * (uint32_t)(Cin * 2) + (uint32_t)c0 * 16u;       // rows past M are never valid: any offset does
+            wbase0 = (uint32_t)(n0 + r0) * (uint32_t)(ktot * 2) + (uint32_t)c0 * 16u;     // rows past Cout lie beyond the descriptor
 #pragma unroll
-        for (int i = 0; i < C::IPW; i++) {
-            const int r = wv * 32 + i * C::RPI + lane / C::CPR;
-            const int c = (lane % C::CPR) ^ C::swz(r);
-            const int m = m0 + r;
-            const bool in = m < a.M;
-            const int mm = in ? m : 0;
-            const int hw = H * W;
-            const int b = mm / hw, rem = mm - b * hw, y = rem / W, x = rem - y * W;
-            uint32_t valid = 0;
-            if (in) {
-                if (taps == 9) {
+            for (int i = 0; i < C::IPW; i++) {
+                const int m = m0 + r0 + i * C::RPI;
+                uint32_t valid = 0;
+                if (m < a.M) {
+                    const int hw = H * W;
+                    const int bimg = m / hw, rem = m - bimg * hw, y = rem / W, x = rem - y * W;
+                    if (taps == 9) {
 #pragma unroll
-                    for (int tap = 0; tap < 9; tap++) {
-                        const int yy = y + (tap / 3 - 1) * G.dil, xx = x + (tap % 3 - 1) * G.dil;
-                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) valid |= 1u << tap;
+                        for (int tap = 0; tap < 9; tap++) {
+                            const int yy = y + (tap / 3 - 1) * G.dil, xx = x + (tap % 3 - 1) * G.dil;
+                            if (yy >= 0 && yy < H && xx >= 0 && xx < W) valid |= 1u << tap;
+                        }
+                    } else {
+                        valid = 1u;
                     }
-                } else {
-                    valid = 1u;
                 }
+                if (i < 2) pvalid01 |= valid << (16 * i); else pvalid23 |= valid << (16 * (i - 2));
             }
-            pbase[i] = (uint32_t)mm * (uint32_t)(Cin * 2) + (uint32_t)c * 16u;
-            pvalid[i] = valid;
-            wbase[i] = (uint32_t)(n0 + r) * (uint32_t)(ktot * 2) + (uint32_t)c * 16u;
         }
         auto issue = [&](int stage, int s) {
             const int cc = s / taps, tap = s - cc * taps;
@@ -390,12 +393,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_sk_kernel(IgemmSkArgs k) {
             unsigned char *Wt = P + kBM * C::ROW;
 #pragma unroll
             for (int i = 0; i < C::IPW; i++) {
-                const uint32_t vo = ((pvalid[i] >> tap) & 1u) ? pbase[i] + (uint32_t)toff : kOob;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(P + i * (C::RPI * C::ROW)), 16, vo, 0, 0, 0);
+                const uint32_t bits = (i < 2 ? pvalid01 : pvalid23) >> (16 * (i & 1) + tap);
+                const uint32_t off = ((pbase0 + (uint32_t)(i * C::RPI * Cin * 2)) ^ ((i & 1) ? 64u : 0u)) + (uint32_t)toff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(P + i * (C::RPI * C::ROW)), 16, (bits & 1u) ? off : kOob, 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < C::IPW; i++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Wt + i * (C::RPI * C::ROW)), 16, wbase[i], (uint32_t)s * C::ROW, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Wt + i * (C::RPI * C::ROW)), 16, (i & 1) ? wbase0 ^ 64u : wbase0,
+                                                         (uint32_t)s * C::ROW + (uint32_t)(i * C::RPI * ktot * 2), 0, 0);
         };
 
         f32x16 acc[4][2];
@@ -415,20 +420,27 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_sk_kernel(IgemmSkArgs k) {
             if (active) {
                 const unsigned char *P = ig_lds + stage * C::STAGE + wm * (64 * C::ROW);
                 const unsigned char *Wt = ig_lds + stage * C::STAGE + kBM * C::ROW + wn * (128 * C::ROW);
-                // (fragments read slice by slice, placed by the compiler: the register budget of this kernel — accumulators, the
-                // segment loop's state and an epilogue inside the loop — has no room for a second fragment set)
+                // fragments of k-slice ks + 1 are read before the MFMAs of slice ks (order pinned by sched_barrier)
+                bf16x8 af[2][4], bfr[2][2];
+#pragma unroll
+                for (int i = 0; i < 4; i++) af[0][i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * C::ROW) + choff[0]);
+#pragma unroll
+                for (int j = 0; j < 2; j++) bfr[0][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[0]);
 #pragma unroll
                 for (int ks = 0; ks < C::KS; ks++) {
-                    bf16x8 af[4], bfr[2];
+                    if (ks + 1 < C::KS) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * C::ROW) + choff[ks]);
+                        for (int i = 0; i < 4; i++) af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * C::ROW) + choff[(ks + 1) % C::KS]);
 #pragma unroll
-                    for (int j = 0; j < 2; j++) bfr[j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[ks]);
+                        for (int j = 0; j < 2; j++) bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[(ks + 1) % C::KS]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 2; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (ks == 0 && more && late) issue(stage ^ 1, s + 1);
                 }
             }
