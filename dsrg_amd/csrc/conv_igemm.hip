@@ -843,12 +843,16 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     static LdsGrant grant[3];
     const int variant = igemm_variant() == 2 ? 1 : 0;       // 1, 3: two stages of 64; 2: ring of four stages of 32
-    a.stagger = igemm_variant() == 3;
+    a.stagger = igemm_variant() >= 3;
     const dim3 grid(a.tiles_per_group * ngroups), block(512);
-    // stream-K whenever whole tiles would leave more than 3 % of the chip's rounds idle and the caller lent the scratch
+    // stream-K only where it was measured to win (profiles/r04_igemm_stream_k.txt): a single round that fills at most 60 % of
+    // the chip (conv4_1's data gradient: 106 tiles, 115 -> 88 us).  A cut tile costs its workgroups ~25 us (256 KB of
+    // accumulators written through, read back, one acquire), which eats the sixth of the chip that 212 tiles leave idle (131 ->
+    // 136 us), and launches of several rounds lose less to their last round than the round count suggests (workgroups of
+    // different rounds overlap: fc6 x 4, 6.6 rounds, 810 us whole against 902 us dealt out).
     const int units = igemm_cus(), tiles_total = a.tiles_per_group * ngroups, nsteps = (cin / 64) * k * k;
-    const int rounds = (tiles_total + units - 1) / units;
-    if (workspace && workspace_bytes >= conv_igemm_workspace() && igemm_variant() == 3 && tiles_total * 100 < rounds * units * 97 &&
+    const bool sk_wins = tiles_total * 100 <= units * 60, sk_forced = igemm_variant() == 4;      // 4: tests / tools, wherever legal
+    if (workspace && workspace_bytes >= conv_igemm_workspace() && ((igemm_variant() == 3 && sk_wins) || sk_forced) &&
         (long long)tiles_total * nsteps >= (long long)units * 8 && tiles_total * 3 >= units) {
         IgemmSkArgs sk;
         sk.base = a;
@@ -925,7 +929,7 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     a.ksplit = wgrad_ksplit(M, ngroups * a.tiles_n * a.tiles_c, 256);
     a.kchunk = (int)(((M + a.ksplit - 1) / a.ksplit + 63) / 64 * 64);
     a.tiles_per_group = a.tiles_n * a.tiles_c * a.ksplit;
-    a.stagger = igemm_variant() == 3;
+    a.stagger = igemm_variant() >= 3;
     const size_t per_group = (size_t)a.ksplit * cout * k * k * cin;
     for (int q = 0; q < ngroups; q++) {
         a.g[q].x = static_cast<const uint16_t *>(x[q]);

@@ -236,9 +236,13 @@ def test_igemm_stream_k_equals_whole_tiles(ops, B, H, W, cin, cout, k, dils):
         xs.append(x); ws.append(ops.pack_conv_weight(w)); bs.append(b)
     for p in (0.0, 0.5):
         whole = ops.conv_igemm(xs, ws, bs, dils, k, True, p, 77, stream_k=False)
-        cut = ops.conv_igemm(xs, ws, bs, dils, k, True, p, 77, stream_k=True)
-        assert ops.conv_igemm_stream_k_status() == 0
-        again = ops.conv_igemm(xs, ws, bs, dils, k, True, p, 77, stream_k=True)
+        ops.set_igemm_variant(4)                     # stream-K wherever legal (by default only where it was measured to win)
+        try:
+            cut = ops.conv_igemm(xs, ws, bs, dils, k, True, p, 77, stream_k=True)
+            assert ops.conv_igemm_stream_k_status() == 0
+            again = ops.conv_igemm(xs, ws, bs, dils, k, True, p, 77, stream_k=True)
+        finally:
+            ops.set_igemm_variant(-1)
         for a, b_, c in zip(whole, cut, again):
             assert torch.equal(b_, c)
             assert torch.equal(a == 0, b_ == 0) or ((a == 0) != (b_ == 0)).float().mean() < 1e-4     # a sum on the edge of the ReLU

@@ -92,7 +92,9 @@ def main():
         t = {"ig1": [], "ig0": [], "old": [], "mm": []}
         for _ in range(args.rounds):
             sk[0] = True
+            ops.set_igemm_variant(4)                 # stream-K wherever legal
             t["ig1"].append(timed(run_ig, args.iters))
+            ops.set_igemm_variant(-1)
             sk[0] = False
             t["ig0"].append(timed(run_ig, args.iters))
             t["old"].append(timed(run_old, args.iters))
