@@ -247,9 +247,15 @@ def main():
 
     # ---- layer glue (reference Python around the oracle CRF) -------------------
     glue = {}
-    for tag, (B, C, H, W, size) in {"voc": (1, 21, 41, 41, 321), "tiny": (2, 5, 11, 11, 81)}.items():
-        batch = S.make_batch(11 if tag == "voc" else 12, B, C, H, W, size=size)
+    # "grow": two VOC-shaped images whose logits are sharpened towards the image's present classes (+6 / -6), so that the
+    # marginals clear the 0.85 / 0.99 thresholds over whole regions and DSRGLayer.forward really grows (100 -> ~1800 seed
+    # pixels) through the reference's own Python — "voc" grows 9 pixels, "tiny" 37
+    for tag, (B, C, H, W, size) in {"voc": (1, 21, 41, 41, 321), "tiny": (2, 5, 11, 11, 81), "grow": (2, 21, 41, 41, 321)}.items():
+        batch = S.make_batch({"voc": 11, "tiny": 12, "grow": 13}[tag], B, C, H, W, size=size)
         from oracle import oracle as O
+        if tag == "grow":
+            present = batch["labels"].reshape(B, C)[:, :, None, None]
+            batch["logits"] = (batch["logits"] + 6.0 * (present * 2 - 1)).astype(np.float32)
         probs = O.softmax_forward(batch["logits"])
         labels, cues, images = batch["labels"], batch["cues"], batch["images"]
         if tag == "tiny":   # labels/cues generator assumes 21 classes; redo for C=5
