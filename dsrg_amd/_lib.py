@@ -49,6 +49,8 @@ SIGNATURES = {
     "dsrg_crf_add_pairwise_energy": (_i, [_vp] + [_f] * 9 + [_vp]),
     "dsrg_crf_inference": (_i, [_vp, _i, _vp]),
     "dsrg_crf_map": (_i, [_vp, _i, _vp]),
+    "dsrg_crf_set_stream": (_i, [_vp, _vp, _i]),
+    "dsrg_crf_synchronize": (_i, [_vp]),
     "dsrg_crf_npixels": (_i, [_vp]),
     "dsrg_crf_nlabels": (_i, [_vp]),
     "dsrg_crf_lattice_size": (_i, [_vp, _i]),

@@ -93,6 +93,15 @@ class DenseCRF(object):
     def lattice_size(self, k):
         return _lib.lib().dsrg_crf_lattice_size(self._h, int(k))
 
+    def set_stream(self, stream, asynchronous=False):
+        """run this object's copies and kernels on `stream` (a torch.cuda.Stream, a raw hipStream_t or None = the null
+        stream); asynchronous: the calls enqueue and return (device tensors only), results are final after synchronize()"""
+        raw = getattr(stream, "cuda_stream", stream) or 0
+        check(_lib.lib().dsrg_crf_set_stream(self._h, ctypes.c_void_p(raw), int(bool(asynchronous))))
+
+    def synchronize(self):
+        check(_lib.lib().dsrg_crf_synchronize(self._h))
+
     def profile_start(self, max_launches=4096):
         """bracket every launch of this object's dominant kernel with HIP events (bench.py)"""
         check(_lib.lib().dsrg_crf_profile_start(self._h, int(max_launches)))
@@ -141,3 +150,47 @@ def CRF_device(image, unary, maxiter=10, scale_factor=1.0, color_factor=13, want
     if want == "map":
         return crf.map(maxiter, out=torch.empty((H, W), dtype=torch.int32, device=unary.device))
     return crf.inference(maxiter, out=torch.empty((H, W, labels), dtype=torch.float32, device=unary.device))
+
+
+def CRF_device_many(pairs, maxiter=10, scale_factor=1.0, color_factor=13, want="map", in_flight=4):
+    """`CRF_device` over many images with `in_flight` of them overlapping on the GPU — the test-time loop of
+    training/tools/test-ms.py:84-111 / generate_train_gt.py:78-106 (10 582 images, one CRF each).  The full-resolution CRF is
+    ~170 short launches per image; run one image at a time they leave most of the chip idle between dependent launches, so
+    every image gets its own DenseCRF object on its own stream (dsrg_crf_set_stream, asynchronous calls) and the host moves
+    on to the next image while the previous ones compute.  pairs: iterable of (image (H,W,3) uint8, unary (H,W,M) float32)
+    CUDA tensors; yields the results in order: (H,W) int32 arg-max labels (want="map") or (H,W,M) float32 marginals."""
+    import torch
+    pairs = iter(pairs)
+    slots = []                                             # (object, stream, output, inputs kept alive)
+    pool = {}                                              # (H, W, M) -> idle [(object, stream)]
+
+    def finish(slot):
+        crf, stream, out, keep = slot
+        crf.synchronize()
+        pool.setdefault(keep[2], []).append((crf, stream))
+        return out
+
+    for image, unary in pairs:
+        if len(slots) >= in_flight:
+            yield finish(slots.pop(0))
+        H, W, M = unary.shape
+        idle = pool.get((H, W, M))
+        if idle:
+            crf, stream = idle.pop()
+        else:
+            crf, stream = DenseCRF(W, H, M), torch.cuda.Stream(device=unary.device)
+            crf.set_stream(stream, asynchronous=True)
+        stream.wait_stream(torch.cuda.current_stream(unary.device))      # the inputs were produced on the caller's stream
+        with torch.cuda.stream(stream):
+            neg = (-unary.to(torch.float32)).contiguous()
+            im = image.reshape(-1).to(torch.uint8).contiguous()
+            sxy_b, sxy_g = _BILATERAL_XY / scale_factor, _GAUSS_XY / scale_factor
+            crf.set_unary_energy(neg)
+            crf.add_pairwise_energy(_BILATERAL_W, sxy_b, sxy_b, color_factor, color_factor, color_factor, _GAUSS_W, sxy_g, sxy_g, im)
+            if want == "map":
+                out = crf.map(maxiter, out=torch.empty((H, W), dtype=torch.int32, device=unary.device))
+            else:
+                out = crf.inference(maxiter, out=torch.empty((H, W, M), dtype=torch.float32, device=unary.device))
+        slots.append((crf, stream, out, (neg, im, (H, W, M))))
+    while slots:
+        yield finish(slots.pop(0))

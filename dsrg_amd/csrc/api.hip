@@ -611,6 +611,7 @@ int large_crf_read_q(LargeCrf *c, float *out_host);
 int large_crf_read_map(LargeCrf *c, int32_t *labels_host);
 int large_crf_lattice_size(LargeCrf *c, int k);
 Profiler *large_crf_profiler(LargeCrf *c);
+void large_crf_set_stream(LargeCrf *c, hipStream_t s, bool async);
 }  // namespace dsrg
 
 // ---------------------------------------------------------------------------------
@@ -628,6 +629,8 @@ struct dsrg_crf_s {
     int32_t *lab;                // device N
     bool have_unary, have_pairwise;
     dsrg_crf_params prm;
+    hipStream_t stream;          // dsrg_crf_set_stream: where this object's copies and kernels run (default: the null stream)
+    bool async;                  // ... and whether its entry points return without waiting for them
 };
 
 // krahenbuhl2013.CRF() creates and destroys one object per call (CRF.py:25): destroyed objects are
@@ -646,6 +649,8 @@ extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) {
             if (c && c->W == W && c->H == H && c->M == nlabels) {
                 g_crf_cache[i] = nullptr;
                 c->have_unary = c->have_pairwise = false;
+                c->stream = nullptr; c->async = false;
+                if (c->large) large_crf_set_stream(c->large, nullptr, false);
                 *out = c;
                 return DSRG_OK;
             }
@@ -706,10 +711,10 @@ extern "C" int dsrg_crf_set_unary_energy(dsrg_crf_t h, const float *unary_host) 
     if (!h || !unary_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
     if (h->large) { int rc = large_crf_set_unary(h->large, unary_host); if (!rc) h->have_unary = true; return rc; }
     const int N = h->W * h->H;
-    DSRG_HIP_CHECK(hipMemcpy(h->stage, unary_host, sizeof(float) * (size_t)N * h->M, hipMemcpyDefault));
-    int rc = launch_lf_to_planes(N, h->M, h->stage, h->neg_unary, 1, nullptr);   // inference uses -unary (densecrf.cpp:120,122)
+    DSRG_HIP_CHECK(hipMemcpyAsync(h->stage, unary_host, sizeof(float) * (size_t)N * h->M, hipMemcpyDefault, h->stream));
+    int rc = launch_lf_to_planes(N, h->M, h->stage, h->neg_unary, 1, h->stream);   // inference uses -unary (densecrf.cpp:120,122)
     if (rc) return rc;
-    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (!h->async) DSRG_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->have_unary = true;
     return DSRG_OK;
 }
@@ -723,7 +728,10 @@ extern "C" int dsrg_crf_add_pairwise_energy(dsrg_crf_t h, float w1, float ta1, f
     int rc = check_params(&p);
     if (rc) return rc;
     if (h->large) { rc = large_crf_set_image(h->large, im_host); if (rc) return rc; }
-    else DSRG_HIP_CHECK(hipMemcpy(h->im, im_host, (size_t)h->W * h->H * 3, hipMemcpyDefault));
+    else {
+        DSRG_HIP_CHECK(hipMemcpyAsync(h->im, im_host, (size_t)h->W * h->H * 3, hipMemcpyDefault, h->stream));
+        if (!h->async) DSRG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
     h->prm = p;
     h->have_pairwise = true;
     return DSRG_OK;
@@ -740,10 +748,10 @@ static int crf_infer(dsrg_crf_t h, int n_iters) {
         return large_crf_infer(h->large, &p, n_iters);
     }
     if (!h->have_unary) {    // DenseCRF::inference starts from a zero unary when none was set (densecrf.cpp:117-119)
-        DSRG_HIP_CHECK(hipMemset(h->neg_unary, 0, sizeof(float) * (size_t)N * h->M));
+        DSRG_HIP_CHECK(hipMemsetAsync(h->neg_unary, 0, sizeof(float) * (size_t)N * h->M, h->stream));
         h->have_unary = true;
     }
-    return dsrg_crf_meanfield_batch(h->ctx, 1, h->neg_unary, h->im, &p, h->q, nullptr);
+    return dsrg_crf_meanfield_batch(h->ctx, 1, h->neg_unary, h->im, &p, h->q, h->stream);
 }
 extern "C" int dsrg_crf_inference(dsrg_crf_t h, int n_iters, float *out_host) {
     if (!h || !out_host) return set_error(DSRG_ERR_INVALID, "NULL argument");
@@ -751,12 +759,11 @@ extern "C" int dsrg_crf_inference(dsrg_crf_t h, int n_iters, float *out_host) {
     if (rc) return rc;
     if (h->large) return large_crf_read_q(h->large, out_host);
     const int N = h->W * h->H;
-    rc = launch_planes_to_lf(N, h->M, h->q, h->stage, nullptr);
+    rc = launch_planes_to_lf(N, h->M, h->q, h->stage, h->stream);
     if (rc) return rc;
-    DSRG_HIP_CHECK(hipMemcpy(out_host, h->stage, sizeof(float) * (size_t)N * h->M, hipMemcpyDefault));
-    // a device-to-device hipMemcpy may return before the copy has landed and other (non-blocking) streams do not wait
-    // for the null stream: this synchronous API returns only when `out` is final
-    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));
+    DSRG_HIP_CHECK(hipMemcpyAsync(out_host, h->stage, sizeof(float) * (size_t)N * h->M, hipMemcpyDefault, h->stream));
+    // this API returns only when `out` is final — unless the caller asked for asynchronous calls (dsrg_crf_set_stream)
+    if (!h->async) DSRG_HIP_CHECK(hipStreamSynchronize(h->stream));
     return DSRG_OK;
 }
 extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
@@ -765,10 +772,26 @@ extern "C" int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host) {
     if (rc) return rc;
     if (h->large) return large_crf_read_map(h->large, labels_host);
     const int N = h->W * h->H;
-    rc = launch_argmax_planes(N, h->M, h->q, h->lab, nullptr);
+    rc = launch_argmax_planes(N, h->M, h->q, h->lab, h->stream);
     if (rc) return rc;
-    DSRG_HIP_CHECK(hipMemcpy(labels_host, h->lab, sizeof(int32_t) * (size_t)N, hipMemcpyDefault));
-    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));      // see dsrg_crf_inference
+    DSRG_HIP_CHECK(hipMemcpyAsync(labels_host, h->lab, sizeof(int32_t) * (size_t)N, hipMemcpyDefault, h->stream));
+    if (!h->async) DSRG_HIP_CHECK(hipStreamSynchronize(h->stream));      // see dsrg_crf_inference
+    return DSRG_OK;
+}
+// Where an object's work runs: `stream` (NULL = the null stream), and with async != 0 its entry points enqueue and return —
+// pointers passed in must then be device (or pinned) memory that stays valid, and results are final after
+// dsrg_crf_synchronize.  Several objects on several streams overlap their (launch-bound) kernels: the test-time loop over
+// 10 582 images (training/tools/test-ms.py:84-111) keeps a few images in flight this way.
+extern "C" int dsrg_crf_set_stream(dsrg_crf_t h, void *stream, int async) {
+    if (!h) return set_error(DSRG_ERR_INVALID, "NULL handle");
+    h->stream = static_cast<hipStream_t>(stream);
+    h->async = async != 0;
+    if (h->large) large_crf_set_stream(h->large, h->stream, h->async);
+    return DSRG_OK;
+}
+extern "C" int dsrg_crf_synchronize(dsrg_crf_t h) {
+    if (!h) return set_error(DSRG_ERR_INVALID, "NULL handle");
+    DSRG_HIP_CHECK(hipStreamSynchronize(h->stream));
     return DSRG_OK;
 }
 // measurement hook of the object API: brackets the dominant kernel of this handle's path with HIP events on its stream —

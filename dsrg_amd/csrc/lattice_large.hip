@@ -9,8 +9,7 @@
 //
 // Build-time sorting/scanning uses hipCUB (DeviceRadixSort / DeviceScan): plumbing, once per image.
 #include <math.h>
-#include <hipcub/hipcub.hpp>
-#include <rocprim/rocprim.hpp>
+#include <cstring>
 #include "common.h"
 #include "embed.h"
 
@@ -30,7 +29,7 @@ struct LargeLattice {
     uint32_t *seg_start;     // [M+1] first segment of vertex v (exclusive scan of max(1, ceil(len / kSplatSeg)))   (aliases `first`)
     uint32_t *seg_cnt;       // [M+1] scan input                                                                (aliases `scanned`)
     uint32_t *seg_v;         // [T]   vertex of segment s                                                      (aliases `slot_e`)
-    uint32_t *multi_v;       // [..]  vertices with more than one segment, any order                           (aliases `ent_vid`)
+    uint32_t *multi_v;       // [..]  vertices with more than one segment, any order                           (aliases `key_e`)
     int T_host, nmulti_host;
     int seg_len;             // entries per splat segment
 };
@@ -541,11 +540,171 @@ __global__ void lg_argmax_rows_kernel(int N, int C, int CP, const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// The two device-wide primitives of the build, written for its sizes (the full-resolution lattices have 0.1 - 1.5 M entries):
+//
+// Exclusive sum of n uint32: blocks of 8192 elements (1024 threads x 8); kernel 1 leaves every block's total, kernel 2 lets
+// every block add up the totals in front of it (at most a few hundred: one load per thread + a block reduction) and scan its
+// own elements (serial over a thread's eight, wave shuffles, wave totals through LDS).
+constexpr int kScanT = 1024, kScanV = 8, kScanBlock = kScanT * kScanV;
+
+__device__ __forceinline__ uint32_t lg_block_reduce(uint32_t v, uint32_t *red /* [16] */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kScanT / 64; w++) t += red[w];
+    __syncthreads();
+    return t;
+}
+__global__ __launch_bounds__(kScanT) void lg_scan_totals_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ totals, int n) {
+    __shared__ uint32_t red[16];
+    const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanV;
+    uint32_t s = 0;
+#pragma unroll
+    for (int u = 0; u < kScanV; u++) s += base + u < n ? in[base + u] : 0u;
+    s = lg_block_reduce(s, red);
+    if (threadIdx.x == 0) totals[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(kScanT) void lg_scan_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                         const uint32_t *__restrict__ totals, int n) {
+    __shared__ uint32_t red[16], wave_sum[16];
+    uint32_t before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kScanT) before += totals[b];
+    before = lg_block_reduce(before, red);
+    const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanV;
+    uint32_t v[kScanV], s = 0;
+#pragma unroll
+    for (int u = 0; u < kScanV; u++) { v[u] = base + u < n ? in[base + u] : 0u; s += v[u]; }
+    uint32_t incl = s;                                       // inclusive scan of the threads' sums inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t off = before + incl - s;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += wave_sum[w];
+#pragma unroll
+    for (int u = 0; u < kScanV; u++) {
+        if (base + u < n) out[base + u] = off;
+        off += v[u];
+    }
+}
+static int lg_scan_blocks(int n) { return (n + kScanBlock - 1) / kScanBlock; }
+// tmp: lg_scan_blocks(n) uint32
+static int lg_exclusive_sum(const uint32_t *in, uint32_t *out, int n, uint32_t *tmp, hipStream_t s) {
+    const int nb = lg_scan_blocks(n);
+    hipLaunchKernelGGL(lg_scan_totals_kernel, dim3(nb), dim3(kScanT), 0, s, in, tmp, n);
+    hipLaunchKernelGGL(lg_scan_kernel, dim3(nb), dim3(kScanT), 0, s, in, out, tmp, n);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
+// Stable sort of (key, value) pairs by the low `bits` bits of the key (the vertex ids: 14 - 18 significant bits), least
+// significant digit first, 8 bits per pass.  Per pass: digit histograms of blocks of 2048 pairs -> exclusive sum over
+// (digit-major, block-minor) -> scatter.  Stability inside a block: its 32 chunks of 64 pairs are ranked chunk by chunk
+// (a lane's rank among the lanes of its chunk with the same digit from eight ballots; the chunks' digit counts scanned in
+// chunk order by one thread per digit).
+constexpr int kSortT = 256, kSortChunks = 32, kSortBlock = 64 * kSortChunks;
+__device__ __forceinline__ unsigned long long lg_same_digit_lanes(uint32_t d, bool valid) {
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const unsigned long long has = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? has : ~has;
+    }
+    return m;
+}
+__global__ __launch_bounds__(kSortT) void lg_sort_hist_kernel(const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist, int n, int shift,
+                                                              int nblk) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortBlock;
+    for (int i = threadIdx.x; i < kSortBlock; i += kSortT)
+        if (base + i < n) atomicAdd(&h[(keys[base + i] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(kSortT) void lg_sort_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                                 uint32_t *__restrict__ kout, uint32_t *__restrict__ vout,
+                                                                 const uint32_t *__restrict__ offs, int n, int shift, int nblk) {
+    __shared__ uint16_t cnt[kSortChunks][256];              // pairs of chunk c with digit d, then their first rank in the block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < kSortChunks * 256; i += kSortT) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortBlock;
+    uint32_t key[kSortChunks / 4], val[kSortChunks / 4], rank[kSortChunks / 4];
+#pragma unroll
+    for (int q = 0; q < kSortChunks / 4; q++) {            // wave w takes chunks w, w + 4, ...
+        const int c = wave + 4 * q, i = base + c * 64 + lane;
+        const bool valid = i < n;
+        key[q] = valid ? kin[i] : 0u;
+        val[q] = valid ? vin[i] : 0u;
+        const uint32_t d = (key[q] >> shift) & 255u;
+        const unsigned long long same = lg_same_digit_lanes(d, valid);
+        rank[q] = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (valid && rank[q] == 0) cnt[c][d] = (uint16_t)__popcll(same);
+    }
+    __syncthreads();
+    {   // one thread per digit: exclusive scan of its counts over the chunks (block-relative; the lanes below add where the
+        // block's pairs of the digit start globally)
+        uint32_t rel = 0;
+        for (int c = 0; c < kSortChunks; c++) {
+            const uint32_t t = cnt[c][threadIdx.x];
+            cnt[c][threadIdx.x] = (uint16_t)rel;
+            rel += t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kSortChunks / 4; q++) {
+        const int c = wave + 4 * q, i = base + c * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (key[q] >> shift) & 255u;
+            const uint32_t pos = offs[(size_t)d * nblk + blockIdx.x] + cnt[c][d] + rank[q];
+            kout[pos] = key[q];
+            vout[pos] = val[q];
+        }
+    }
+}
+static int lg_sort_blocks(int n) { return (n + kSortBlock - 1) / kSortBlock; }
+static size_t lg_sort_tmp_words(int n) {                   // histogram + its scan + the scan's block totals
+    const size_t h = (size_t)256 * lg_sort_blocks(n);
+    return 2 * h + (size_t)lg_scan_blocks((int)h) + 64;
+}
+// sorts by key bits [0, bits); the result is in (kout, vout); (kin, vin) are used as the other ping-pong buffer
+static int lg_sort_pairs(uint32_t *tmp, uint32_t *kin, uint32_t *kout, uint32_t *vin, uint32_t *vout, int n, int bits, hipStream_t s) {
+    const int nblk = lg_sort_blocks(n), passes = (bits + 7) / 8;
+    uint32_t *hist = tmp, *offs = tmp + (size_t)256 * nblk, *tot = offs + (size_t)256 * nblk;
+    uint32_t *ka = kin, *va = vin, *kb = kout, *vb = vout;
+    // an even number of passes ends in (kin, vin): start from the other pair then, so that the result lands in (kout, vout)
+    for (int p = 0; p < passes; p++) {
+        hipLaunchKernelGGL(lg_sort_hist_kernel, dim3(nblk), dim3(kSortT), 0, s, ka, hist, n, 8 * p, nblk);
+        if (int rc = lg_exclusive_sum(hist, offs, 256 * nblk, tot, s)) return rc;
+        hipLaunchKernelGGL(lg_sort_scatter_kernel, dim3(nblk), dim3(kSortT), 0, s, ka, va, kb, vb, offs, n, 8 * p, nblk);
+        uint32_t *t = ka; ka = kb; kb = t;
+        t = va; va = vb; vb = t;
+    }
+    DSRG_LAUNCH_CHECK();
+    if (ka != kout) {                                       // even number of passes: the result sits in the input pair
+        DSRG_HIP_CHECK(hipMemcpyAsync(kout, ka, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        DSRG_HIP_CHECK(hipMemcpyAsync(vout, va, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    }
+    return DSRG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 struct LargeCrf {
     int W, H, C, CP, N;
     LargeLattice Lg, Lb;
     void *arena;
-    void *cub_tmp; size_t cub_bytes;
+    uint32_t *prim_tmp; size_t prim_words;     // scratch of the scan / sort primitives above
+    hipStream_t stream;                        // every launch and copy of this object (dsrg_crf_set_stream; default: the null stream)
+    bool async;                                // the entry points do not wait for the stream (the caller does: dsrg_crf_synchronize)
     float *neg_unary, *q;                  // [N][CP]
     float *qn_b, *qn_g;                    // [N][CP] q * norm of the bilateral / Gaussian kernel: the splat inputs
     float *val_a, *val_b;                  // ping-pong [(Mb+1) + (Mg+1)][CP], grown on demand: bilateral rows first
@@ -599,16 +758,6 @@ static size_t large_lattice_carve(LargeLattice &L, unsigned char *p, int d, int 
     return off;
 }
 
-// Stable sort of the (vertex id, entry index) pairs = the splat's per-vertex gather lists.  rocPRIM's default dispatch takes
-// its MERGE sort for up to 2^20 four-byte keys (device_radix_sort.hpp: `size <= merge_sort_limit && sizeof(key) > 2`) — 29
-// launches of 5.7 us per lattice at 321x321; the keys here have 14-16 significant bits, i.e. two Onesweep passes, so the
-// limit is set to 0 (hipCUB's wrapper cannot pass a config).
-static hipError_t lg_sort_pairs(void *tmp, size_t &bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
-                                int n, int begin_bit, int end_bit, hipStream_t s) {
-    using config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
-    return rocprim::radix_sort_pairs<config>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, s);
-}
-
 int large_crf_create(int W, int H, int C, LargeCrf **out) {
     if ((long long)W * H * 6 >= (1ll << 31) / 4) return set_error(DSRG_ERR_UNSUPPORTED, "map too large");
     LargeCrf *c = new (std::nothrow) LargeCrf();
@@ -619,20 +768,16 @@ int large_crf_create(int W, int H, int C, LargeCrf **out) {
     LargeLattice tmp;
     const size_t sg = large_lattice_carve(tmp, nullptr, 2, N), sb = large_lattice_carve(tmp, nullptr, 5, N);
     const int Emax = N * 6, Mcap5 = ((N + 3) / 4 * 4) * 6;
-    size_t cb1 = 0, cb2 = 0;
-    (void)lg_sort_pairs(nullptr, cb1, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                       (uint32_t *)nullptr, Emax, 0, 32, (hipStream_t)0);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cb2, (uint32_t *)nullptr, (uint32_t *)nullptr, Mcap5 + 1, (hipStream_t)0);
-    c->cub_bytes = cb1 > cb2 ? cb1 : cb2;
+    c->prim_words = lg_sort_tmp_words(Emax) + (size_t)lg_scan_blocks(Mcap5 + 2) + 64;
     const size_t rows = sizeof(float) * (size_t)N * c->CP;
-    const size_t total = sg + sb + al(c->cub_bytes) + 4 * al(rows) + 2 * al(sizeof(float) * (size_t)(Mcap5 + 1)) +
+    const size_t total = sg + sb + al(sizeof(uint32_t) * c->prim_words) + 4 * al(rows) + 2 * al(sizeof(float) * (size_t)(Mcap5 + 1)) +
                          al((size_t)N * 3) + al(sizeof(int32_t) * (size_t)N) + al(sizeof(float) * (size_t)N * C);
     hipError_t e = hipMalloc(&c->arena, total);
     if (e != hipSuccess) { delete c; return set_error(DSRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); }
     unsigned char *p = (unsigned char *)c->arena;
     p += large_lattice_carve(c->Lg, p, 2, N);
     p += large_lattice_carve(c->Lb, p, 5, N);
-    c->cub_tmp = p; p += al(c->cub_bytes);
+    c->prim_tmp = (uint32_t *)p; p += al(sizeof(uint32_t) * c->prim_words);
     c->neg_unary = (float *)p; p += al(rows);
     c->q = (float *)p; p += al(rows);
     c->qn_b = (float *)p; p += al(rows);
@@ -666,32 +811,32 @@ static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipSt
     hipLaunchKernelGGL(lg_embed_kernel<D>, dim3(blocks_for(L.Npad, T)), dim3(T), 0, s, L, F, c->im);
     hipLaunchKernelGGL(lg_insert_kernel<D>, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
     hipLaunchKernelGGL(lg_first_kernel, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
-    size_t bytes = c->cub_bytes;
-    DSRG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, bytes, L.first, L.scanned, L.Epad, s));
+    if (int rc = lg_exclusive_sum(L.first, L.scanned, L.Epad, c->prim_tmp, s)) return rc;
     hipLaunchKernelGGL(lg_assign_kernel<D>, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
     hipLaunchKernelGGL(lg_vid_kernel, dim3(blocks_for(L.E, T)), dim3(T), 0, s, L, D1);
     DSRG_LAUNCH_CHECK();
     // CSR row starts and the splat segments, on worst-case grids (M is still on the device): the arrays they alias (first,
     // scanned, slot_e, key_e) are dead from here on
-    bytes = c->cub_bytes;
-    DSRG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, bytes, L.cnt, L.row_start, L.Mcap + 1, s));
+    if (int rc = lg_exclusive_sum(L.cnt, L.row_start, L.Mcap + 1, c->prim_tmp, s)) return rc;
     DSRG_HIP_CHECK(hipMemsetAsync(L.M + 1, 0, sizeof(int) * 2, s));
     hipLaunchKernelGGL(lg_seg_count_kernel, dim3(blocks_for((size_t)L.Mcap + 1, T)), dim3(T), 0, s, L);
-    bytes = c->cub_bytes;
-    DSRG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, bytes, L.seg_cnt, L.seg_start, L.Mcap + 1, s));
+    if (int rc = lg_exclusive_sum(L.seg_cnt, L.seg_start, L.Mcap + 1, c->prim_tmp, s)) return rc;
     hipLaunchKernelGGL(lg_seg_fill_kernel, dim3(blocks_for((size_t)L.Mcap + 1, T)), dim3(T), 0, s, L);
     DSRG_LAUNCH_CHECK();
     int mtn[3] = {0, 0, 0};
     DSRG_HIP_CHECK(hipMemcpyAsync(mtn, L.M, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
     DSRG_HIP_CHECK(hipStreamSynchronize(s));                      // M and the segment count size the remaining launches
     L.M_host = mtn[0]; L.T_host = mtn[1]; L.nmulti_host = mtn[2];
+    // the aliasing above holds segments in slot_e (Epad words) and multi-segment vertices in key_e (Epad * KW words)
+    if (L.M_host < 0 || L.M_host > L.Mcap || L.T_host < 0 || L.T_host > L.Epad || L.nmulti_host < 0 ||
+        (long long)L.nmulti_host > (long long)L.Epad * KeyWords<D>::value)
+        return set_error(DSRG_ERR_HIP, "lattice build out of range: M %d (cap %d), segments %d (cap %d), multi-segment vertices %d",
+                         L.M_host, L.Mcap, L.T_host, L.Epad, L.nmulti_host);
     const int M = L.M_host;
     hipLaunchKernelGGL(lg_neigh_kernel<D>, dim3(blocks_for(M, T)), dim3(T), 0, s, L);
     int bits = 1;
     while ((1ll << bits) < (long long)M + 1) bits++;
-    bytes = c->cub_bytes;
-    DSRG_HIP_CHECK(lg_sort_pairs(c->cub_tmp, bytes, L.ent_vid, L.srt_vid, L.ent_idx, L.srt_idx,
-                                                      L.E, 0, bits, s));
+    if (int rc = lg_sort_pairs(c->prim_tmp, L.ent_vid, L.srt_vid, L.ent_idx, L.srt_idx, L.E, bits, s)) return rc;
     hipLaunchKernelGGL(lg_csr_kernel, dim3(blocks_for(L.E, T)), dim3(T), 0, s, L, D1);
     // norm = 1/sqrt(K 1 + 1e-20)
     hipLaunchKernelGGL(lg_splat1_kernel, dim3(blocks_for(M, T)), dim3(T), 0, s, L, c->val1_a);
@@ -708,26 +853,27 @@ static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipSt
 // `unary` / `im` / outputs may be host or device pointers (hipMemcpyDefault resolves the kind): the test-time pipeline
 // keeps its scores on the GPU, the Cython-style callers pass numpy memory.
 int large_crf_set_unary(LargeCrf *c, const float *unary) {
-    DSRG_HIP_CHECK(hipMemcpy(c->stage, unary, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault));
-    hipLaunchKernelGGL(lg_pad_rows_kernel, dim3(blocks_for((size_t)c->N * c->CP, 256)), dim3(256), 0, 0, c->N, c->C,
+    DSRG_HIP_CHECK(hipMemcpyAsync(c->stage, unary, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault, c->stream));
+    hipLaunchKernelGGL(lg_pad_rows_kernel, dim3(blocks_for((size_t)c->N * c->CP, 256)), dim3(256), 0, c->stream, c->N, c->C,
                        c->CP, c->stage, c->neg_unary, 1);
     DSRG_LAUNCH_CHECK();
-    DSRG_HIP_CHECK(hipStreamSynchronize(0));
+    if (!c->async) DSRG_HIP_CHECK(hipStreamSynchronize(c->stream));         // the caller may reuse its (host) buffer
     return DSRG_OK;
 }
 int large_crf_zero_unary(LargeCrf *c) {
-    DSRG_HIP_CHECK(hipMemset(c->neg_unary, 0, sizeof(float) * (size_t)c->N * c->CP));
+    DSRG_HIP_CHECK(hipMemsetAsync(c->neg_unary, 0, sizeof(float) * (size_t)c->N * c->CP, c->stream));
     return DSRG_OK;
 }
 int large_crf_set_image(LargeCrf *c, const unsigned char *im) {
-    DSRG_HIP_CHECK(hipMemcpy(c->im, im, (size_t)c->N * 3, hipMemcpyDefault));
+    DSRG_HIP_CHECK(hipMemcpyAsync(c->im, im, (size_t)c->N * 3, hipMemcpyDefault, c->stream));
+    if (!c->async) DSRG_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->lattices_valid = false;
     return DSRG_OK;
 }
 
 // DenseCRF::inference on the large path; q ends up in c->q ([N][CP])
 int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
-    hipStream_t s = 0;
+    hipStream_t s = c->stream;
     LatticeFeat Fg, Fb;
     lattice_feat_init(Fg, 2, c->W, c->H, prm->theta_gamma_x, prm->theta_gamma_y, 1.f, 1.f, 1.f);
     lattice_feat_init(Fb, 5, c->W, c->H, prm->theta_alpha_x, prm->theta_alpha_y, prm->theta_beta_r, prm->theta_beta_g,
@@ -801,20 +947,21 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
 }
 
 int large_crf_read_q(LargeCrf *c, float *out_host) {
-    hipLaunchKernelGGL(lg_unpad_rows_kernel, dim3(blocks_for((size_t)c->N * c->C, 256)), dim3(256), 0, 0, c->N, c->C,
+    hipLaunchKernelGGL(lg_unpad_rows_kernel, dim3(blocks_for((size_t)c->N * c->C, 256)), dim3(256), 0, c->stream, c->N, c->C,
                        c->CP, c->q, c->stage);
     DSRG_LAUNCH_CHECK();
-    DSRG_HIP_CHECK(hipMemcpy(out_host, c->stage, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault));
-    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));      // device-to-device copies may return early (see dsrg_crf_inference)
+    DSRG_HIP_CHECK(hipMemcpyAsync(out_host, c->stage, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault, c->stream));
+    if (!c->async) DSRG_HIP_CHECK(hipStreamSynchronize(c->stream));    // the result is the caller's when the call returns
     return DSRG_OK;
 }
 int large_crf_read_map(LargeCrf *c, int32_t *labels_host) {
-    hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, 0, c->N, c->C, c->CP, c->q, c->lab);
+    hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, c->stream, c->N, c->C, c->CP, c->q, c->lab);
     DSRG_LAUNCH_CHECK();
-    DSRG_HIP_CHECK(hipMemcpy(labels_host, c->lab, sizeof(int32_t) * (size_t)c->N, hipMemcpyDefault));
-    DSRG_HIP_CHECK(hipStreamSynchronize(nullptr));
+    DSRG_HIP_CHECK(hipMemcpyAsync(labels_host, c->lab, sizeof(int32_t) * (size_t)c->N, hipMemcpyDefault, c->stream));
+    if (!c->async) DSRG_HIP_CHECK(hipStreamSynchronize(c->stream));
     return DSRG_OK;
 }
+void large_crf_set_stream(LargeCrf *c, hipStream_t s, bool async) { c->stream = s; c->async = async; }
 int large_crf_lattice_size(LargeCrf *c, int k) { return k == 0 ? c->Lg.M_host : c->Lb.M_host; }
 Profiler *large_crf_profiler(LargeCrf *c) { return &c->prof; }
 

@@ -72,6 +72,12 @@ int dsrg_crf_add_pairwise_energy(dsrg_crf_t h, float w1, float theta_alpha_1, fl
 int dsrg_crf_inference(dsrg_crf_t h, int n_iters, float *out_host);
 /* DenseCRFWrapper::map(int, int*)                               densecrf_wrapper.cpp:39-43 */
 int dsrg_crf_map(dsrg_crf_t h, int n_iters, int32_t *labels_host);
+/* Where an object's copies and kernels run (default: the null stream, every call synchronous as the reference's).  With
+ * async != 0 the entry points enqueue and return: buffers passed in must be device (or pinned host) memory that stays valid,
+ * results are final after dsrg_crf_synchronize.  Objects on different streams overlap their launches — how a test-time loop
+ * (training/tools/test-ms.py:84-111) keeps several images in flight (dsrg_amd.crf.CRF_device_many). */
+int dsrg_crf_set_stream(dsrg_crf_t crf, void *stream, int async);
+int dsrg_crf_synchronize(dsrg_crf_t crf);
 /* DenseCRFWrapper::npixels / nlabels                            densecrf_wrapper.cpp:14-15 */
 int dsrg_crf_npixels(dsrg_crf_t h);
 int dsrg_crf_nlabels(dsrg_crf_t h);

@@ -1012,3 +1012,27 @@ def test_four_host_threads_four_contexts(ops):
     for k in range(4):
         for a, b in zip(alone[k], together[k]):
             assert torch.equal(a, b), k
+
+
+def test_crf_objects_on_their_own_streams(ops, O):
+    """dsrg_crf_set_stream: several images in flight (one DenseCRF object and stream each, asynchronous calls) give exactly the
+    one-at-a-time results, in order — mixed sizes, both paths (LDS-resident and global-memory), maps and marginals"""
+    from dsrg_amd.crf import CRF_device, CRF_device_many
+    pairs = []
+    for k, (H, W, C) in enumerate([(97, 131, 21), (41, 41, 21), (97, 131, 21), (120, 90, 5), (97, 131, 21), (120, 90, 5), (97, 131, 21)]):
+        rng = np.random.default_rng(500 + k)
+        img = S.make_images(rng, 1, size=max(H, W))[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]
+        im = torch.from_numpy(np.ascontiguousarray(np.transpose(img, (1, 2, 0))).astype(np.uint8)).cuda()
+        logits = S.make_logits(rng, 1, C, H, W, gain=12.0, sigma=6.0)[0]
+        e = np.exp(logits - logits.max(0, keepdims=True))
+        un = torch.from_numpy(np.log(np.maximum(e / e.sum(0, keepdims=True), 1e-5)).transpose(1, 2, 0).astype(np.float32).copy()).cuda()
+        pairs.append((im, un))
+    for want in ("map", "marginals"):
+        one = [CRF_device(im, un, scale_factor=1.0, want=want) for im, un in pairs]
+        many = list(CRF_device_many(pairs, scale_factor=1.0, want=want, in_flight=3))
+        assert len(many) == len(one)
+        for a, b in zip(one, many):
+            assert torch.equal(a, b)
+    q = many[0].cpu().numpy()
+    want_q = O.CRF(pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy(), scale_factor=1.0)
+    assert np.abs(q - want_q).max() < CRF_TOL
