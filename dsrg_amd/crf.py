@@ -155,42 +155,45 @@ def CRF_device(image, unary, maxiter=10, scale_factor=1.0, color_factor=13, want
 def CRF_device_many(pairs, maxiter=10, scale_factor=1.0, color_factor=13, want="map", in_flight=4):
     """`CRF_device` over many images with `in_flight` of them overlapping on the GPU — the test-time loop of
     training/tools/test-ms.py:84-111 / generate_train_gt.py:78-106 (10 582 images, one CRF each).  The full-resolution CRF is
-    ~170 short launches per image; run one image at a time they leave most of the chip idle between dependent launches, so
-    every image gets its own DenseCRF object on its own stream (dsrg_crf_set_stream, asynchronous calls) and the host moves
-    on to the next image while the previous ones compute.  pairs: iterable of (image (H,W,3) uint8, unary (H,W,M) float32)
-    CUDA tensors; yields the results in order: (H,W) int32 arg-max labels (want="map") or (H,W,M) float32 marginals."""
+    ~170 short dependent launches per image (and one host read-back of the lattice sizes): one image at a time leaves most of
+    the chip idle and the host waiting.  Here `in_flight` host threads each own a DenseCRF object per image size and a stream
+    (dsrg_crf_set_stream); the library calls release the GIL, so the threads' launch sequences interleave on the host and
+    their kernels overlap on the device.  pairs: iterable of (image (H,W,3) uint8, unary (H,W,M) float32) CUDA tensors;
+    yields the results in order: (H,W) int32 arg-max labels (want="map") or (H,W,M) float32 marginals."""
+    import threading
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
     import torch
-    pairs = iter(pairs)
-    slots = []                                             # (object, stream, output, inputs kept alive)
-    pool = {}                                              # (H, W, M) -> idle [(object, stream)]
+    local = threading.local()
+    device = torch.cuda.current_device()
+    caller = torch.cuda.current_stream(device)
+    sxy_b, sxy_g = _BILATERAL_XY / scale_factor, _GAUSS_XY / scale_factor
 
-    def finish(slot):
-        crf, stream, out, keep = slot
-        crf.synchronize()
-        pool.setdefault(keep[2], []).append((crf, stream))
-        return out
-
-    for image, unary in pairs:
-        if len(slots) >= in_flight:
-            yield finish(slots.pop(0))
+    def work(image, unary, ready):
+        torch.cuda.set_device(device)
+        if not hasattr(local, "stream"):
+            local.stream, local.objs = torch.cuda.Stream(device=device), {}
         H, W, M = unary.shape
-        idle = pool.get((H, W, M))
-        if idle:
-            crf, stream = idle.pop()
-        else:
-            crf, stream = DenseCRF(W, H, M), torch.cuda.Stream(device=unary.device)
-            crf.set_stream(stream, asynchronous=True)
-        stream.wait_stream(torch.cuda.current_stream(unary.device))      # the inputs were produced on the caller's stream
-        with torch.cuda.stream(stream):
-            neg = (-unary.to(torch.float32)).contiguous()
-            im = image.reshape(-1).to(torch.uint8).contiguous()
-            sxy_b, sxy_g = _BILATERAL_XY / scale_factor, _GAUSS_XY / scale_factor
-            crf.set_unary_energy(neg)
-            crf.add_pairwise_energy(_BILATERAL_W, sxy_b, sxy_b, color_factor, color_factor, color_factor, _GAUSS_W, sxy_g, sxy_g, im)
+        crf = local.objs.get((H, W, M))
+        if crf is None:
+            crf = local.objs[(H, W, M)] = DenseCRF(W, H, M)
+            crf.set_stream(local.stream)
+        local.stream.wait_event(ready)                      # the inputs were produced on the caller's stream
+        with torch.cuda.stream(local.stream):
+            crf.set_unary_energy((-unary.to(torch.float32)).contiguous())
+            crf.add_pairwise_energy(_BILATERAL_W, sxy_b, sxy_b, color_factor, color_factor, color_factor, _GAUSS_W, sxy_g, sxy_g,
+                                    image.reshape(-1).to(torch.uint8).contiguous())
             if want == "map":
-                out = crf.map(maxiter, out=torch.empty((H, W), dtype=torch.int32, device=unary.device))
-            else:
-                out = crf.inference(maxiter, out=torch.empty((H, W, M), dtype=torch.float32, device=unary.device))
-        slots.append((crf, stream, out, (neg, im, (H, W, M))))
-    while slots:
-        yield finish(slots.pop(0))
+                return crf.map(maxiter, out=torch.empty((H, W), dtype=torch.int32, device=unary.device))
+            return crf.inference(maxiter, out=torch.empty((H, W, M), dtype=torch.float32, device=unary.device))
+
+    pending = deque()
+    with ThreadPoolExecutor(max_workers=max(1, int(in_flight))) as ex:
+        for image, unary in pairs:
+            ready = torch.cuda.Event()
+            ready.record(caller)
+            pending.append(ex.submit(work, image, unary, ready))
+            if len(pending) > 2 * in_flight:
+                yield pending.popleft().result()            # (every call of the object API returns with its stream drained)
+        while pending:
+            yield pending.popleft().result()
