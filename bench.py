@@ -106,11 +106,12 @@ def cpu_baseline(batch_np, target_s=12.0):
                       "reference runs exactly this part on the CPU (its convolutions run in Caffe on a GPU)" % (n_done, dt)}
 
 
-def cpu_baseline_all_cores(seconds=6.0, max_workers=32, timeout_s=90.0):
-    """the same port, image-parallel over the host cores as the reference's multiprocessing.Pool does it: independent
-    `oracle/baseline_worker.py` processes (they never touch the GPU), every wait bounded by a timeout"""
+def cpu_baseline_all_cores(seconds=6.0, max_workers=None, timeout_s=150.0):
+    """the same port, image-parallel over the host's logical CPUs as the reference's multiprocessing.Pool() does it (one worker
+    per CPU, BASELINE.md §3: nproc): independent `oracle/baseline_worker.py` processes (they never touch the GPU), every wait
+    bounded by a timeout; `cores` in the record is the number of workers that finished"""
     import subprocess
-    workers = max(1, min(os.cpu_count() or 1, max_workers))
+    workers = max(1, min(os.cpu_count() or 1, max_workers or (os.cpu_count() or 1)))
     t0 = time.perf_counter()
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "baseline_worker.py"), str(5000 + w), str(seconds)],
