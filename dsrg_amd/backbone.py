@@ -292,14 +292,22 @@ class _IgemmConvFn(torch.autograd.Function):
         return (None,) * 6 + tuple(gx if nx else None for gx, nx in zip(gxs, need_x)) + tuple(gws) + tuple(gbs)
 
 
-def _igemm_route(conv, x):
+_IGEMM_MIN_TILES = int(_os.environ.get("DSRG_IGEMM_MIN_TILES", "64"))
+
+
+def _igemm_route(conv, x, groups=1):
     """does this GemmConv2d call take the implicit-GEMM kernels: a 3x3 'same' convolution with bias on bf16 activations
-    (autocast), 64 | input channels, 256 | output channels"""
+    (autocast), 64 | input channels, 256 | output channels — and enough 256 x 256 output tiles to occupy the chip: one image
+    at 41x41 is 14 tiles of 72 K-steps for 256 CUs, where the library GEMM's small-M kernels win (batch-1 inference 740 against
+    970 images/s); `groups` problems share the launch (the four fc6_k)"""
     if not (_IGEMM and x.is_cuda and conv.gemm and conv.kernel_size == (3, 3) and conv.bias is not None and conv.groups == 1):
         return False
     if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
         return False
     if conv.out_channels < 256:                 # conv1_x / conv2_x: the direct kernels (weights in registers) serve the narrow layers
+        return False
+    pixels = x.shape[0] * x.shape[2] * x.shape[3]
+    if groups * ((pixels + 255) // 256) * ((conv.out_channels + 255) // 256) < _IGEMM_MIN_TILES:
         return False
     from .ops import conv_igemm_supported
     return conv_igemm_supported(conv.in_channels, conv.out_channels, 3)
@@ -483,7 +491,7 @@ class VGG16ASPP(nn.Module):
         f = self.features(x)
         hs = []
         fc6 = [br[0] for br in self.branches]
-        if len(fc6) <= 4 and all(_igemm_route(m, f) and m.stride == (1, 1) and m.padding == m.dilation for m in fc6):
+        if len(fc6) <= 4 and all(_igemm_route(m, f, len(fc6)) and m.stride == (1, 1) and m.padding == m.dilation for m in fc6):
             # the four fc6_k (same input, own dilation) in one launch each way: 1696 tiles fill the chip where 424 leave a sixth idle
             p = fc6[0].fuse_dropout if self.training else 0.0
             n = len(fc6)

@@ -19,7 +19,12 @@
  *     the reference sources line by line (citations below), following the SSE
  *     code path that an x86 build takes; it is checked against analytic
  *     known-answer properties (rows sum to 1, label-permutation equivariance,
- *     identity kernel at sub-pixel sigma, brute-force Gaussian agreement).
+ *     identity kernel at sub-pixel sigma, brute-force Gaussian agreement) and
+ *     against the reference's SECOND formulation of the lattice — the scalar
+ *     Permutohedral::init of permutohedral.cpp:323-474, restated below as
+ *     orc_lattice_init_scalar and used by nothing but that cross-check
+ *     (tests/test_oracle_golden.py): same vertex keys, same per-pixel weights,
+ *     marginals within 5e-6.  Still unpinned: both are restatements.
  *   - Softmax / BalancedSeedLoss / ConstrainLoss: PARITY UNPINNED (Theano is
  *     absent); closed forms derived from the Theano expressions and verified
  *     against torch autograd in fp64 (tests/test_oracle_layers.py).
