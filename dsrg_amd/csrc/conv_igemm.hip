@@ -45,6 +45,11 @@ constexpr uint32_t kOob = 0x80000000u;                     // beyond any descrip
 // BK = reduction elements per K-step, NST = LDS stages.  (64, 2): one step in flight behind the one being multiplied;
 // (32, 4): a ring with three steps in flight (counted vmcnt: the DMA of steps s + 1, s + 2 stays in flight across the barrier of
 // step s) — same 128 KB of LDS, deeper prefetch, twice the barriers.
+__device__ __forceinline__ void wait_vm_lgkm_barrier() {
+    // as wait_vm_barrier<0>, and this wave's LDS reads have returned too (the barrier then also says "done reading")
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int BK, int NST> struct ICfg {
     static constexpr int ROW = BK * 2;                     // bytes per LDS row
     static constexpr int CPR = ROW / 16;                   // 16-byte chunks per row (8 / 4)
@@ -104,7 +109,12 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 
 // (the body is a device function template behind two plain kernels: hipcc 7.2's HOST pass drops the stub of a kernel TEMPLATE
 // whose body calls a lambda that uses the template's constants — no diagnostic, an undefined symbol at load time)
-template <int BK, int NST>
+// EARLY (two stages only): the step's barrier sits in front of its LAST MFMA cluster instead of behind it, and the first
+// fragments of the next step are read (from the other stage, complete and visible once the barrier is passed) before that
+// cluster — so the LDS round trip of a step's first fragments runs under MFMAs instead of holding both waves of a SIMD right
+// behind the barrier.  All fragment reads of the current stage have been issued by then (the last slice is prefetched during
+// the one before) and are waited for in front of the barrier, so the stage is free for the DMA of step s + 2 as before.
+template <int BK, int NST, bool EARLY = false>
 __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
     using C = ICfg<BK, NST>;
     extern __shared__ __attribute__((aligned(16))) unsigned char ig_lds[];
@@ -196,13 +206,62 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
 
     // an output-channel count of 128 (mod 256) leaves the upper half of the last n-tile empty: its waves (4-7) only move data
     const bool active = n0 + wn * 128 < a.Cout;
+    constexpr int LPS = 2 * C::IPW;                         // DMA instructions per wave and step
+    if (EARLY) {
+        static_assert(!EARLY || NST == 2, "the early-barrier schedule is written for two stages");
+        bf16x8 af[2][4], bfr[2][2];
+        const bool late = a.stagger && wv >= 4 && active;
+        issue(0, 0);
+        if (nsteps > 1) { issue(1, 1); wait_vm_barrier<LPS>(); } else { wait_vm_barrier<0>(); }
+        if (active) {
+            const unsigned char *P = ig_lds + wm * (64 * C::ROW), *Wt = ig_lds + kBM * C::ROW + wn * (128 * C::ROW);
+#pragma unroll
+            for (int i = 0; i < 4; i++) af[0][i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * C::ROW) + choff[0]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) bfr[0][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[0]);
+        }
+        for (int s = 0; s < nsteps; s++) {
+            const int stage = s & 1;
+            const bool next = s + 1 < nsteps, more = s + 2 < nsteps;
+            if (!active) {                                  // a wave without output columns: it only moves data
+                if (next) { wait_vm_lgkm_barrier(); if (more) issue(stage, s + 2); }
+                continue;
+            }
+            const unsigned char *P = ig_lds + stage * C::STAGE + wm * (64 * C::ROW);
+            const unsigned char *Wt = ig_lds + stage * C::STAGE + kBM * C::ROW + wn * (128 * C::ROW);
+            const unsigned char *Pn = ig_lds + (stage ^ 1) * C::STAGE + wm * (64 * C::ROW);
+            const unsigned char *Wn = ig_lds + (stage ^ 1) * C::STAGE + kBM * C::ROW + wn * (128 * C::ROW);
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ks++) {
+                if (ks + 1 < C::KS) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(Wt + i * (32 * C::ROW) + choff[ks + 1 < C::KS ? ks + 1 : 0]);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[ks + 1 < C::KS ? ks + 1 : 0]);
+                } else if (next) {
+                    wait_vm_lgkm_barrier();                 // step s + 1 has landed for everybody; nobody reads this stage any more
+                    if (more && !late) issue(stage, s + 2);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) af[C::KS & 1][i] = *reinterpret_cast<const bf16x8 *>(Wn + i * (32 * C::ROW) + choff[0]);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) bfr[C::KS & 1][j] = *reinterpret_cast<const bf16x8 *>(Pn + j * (32 * C::ROW) + choff[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == C::KS - 1 && more && late) issue(stage, s + 2);
+            }
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < C::AHEAD; p++)
         if (p < nsteps) issue(p, p);
-    constexpr int LPS = 2 * C::IPW;                         // DMA instructions per wave and step
     int stage = 0;
-    for (int s = 0; s < nsteps; s++) {
-        // the steps behind s that are already on their way: min(AHEAD - 1, nsteps - 1 - s)
+    for (int s = 0; s < nsteps; s++) {        // the steps behind s that are already on their way: min(AHEAD - 1, nsteps - 1 - s)
         if (C::AHEAD >= 3 && s + 2 < nsteps) wait_vm_barrier<2 * LPS>();
         else if (C::AHEAD >= 2 && s + 1 < nsteps) wait_vm_barrier<LPS>();
         else wait_vm_barrier<0>();
@@ -237,6 +296,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         }
         }
         stage = stage + 1 == NST ? 0 : stage + 1;
+    }
     }
     __syncthreads();                                        // every wave is done reading the last stage
     if (!active) return;
@@ -290,6 +350,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
 
 
 __global__ __launch_bounds__(512, 2) void conv_igemm_kernel_64x2(IgemmArgs a) { conv_igemm_body<64, 2>(a); }
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_64x2e(IgemmArgs a) { conv_igemm_body<64, 2, true>(a); }
 __global__ __launch_bounds__(512, 2) void conv_igemm_kernel_32x4(IgemmArgs a) { conv_igemm_body<32, 4>(a); }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -868,7 +929,12 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
         DSRG_LAUNCH_CHECK();
         return DSRG_OK;
     }
-    if (variant == 0) {
+    if (igemm_variant() == 5) {                              // early barrier (see conv_igemm_body)
+        static LdsGrant grant_e;
+        constexpr size_t lds = ICfg<64, 2>::LDS;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel_64x2e), lds, grant_e)) return rc;
+        hipLaunchKernelGGL(conv_igemm_kernel_64x2e, grid, block, lds, stream, a);
+    } else if (variant == 0) {
         constexpr size_t lds = ICfg<64, 2>::LDS;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel_64x2), lds, grant[0])) return rc;
         hipLaunchKernelGGL(conv_igemm_kernel_64x2, grid, block, lds, stream, a);

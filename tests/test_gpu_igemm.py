@@ -46,7 +46,7 @@ def test_igemm_conv_matches_torch(ops, B, H, W, cin, cout, k, dil, relu, bias):
     want = F.conv2d(x.float(), w.float(), b if bias else None, padding=dil * (k // 2), dilation=dil)
     want = torch.relu(want) if relu else want
     packed = ops.pack_conv_weight(w)
-    for variant in (1, 2):
+    for variant in (1, 2, 5):
         ops.set_igemm_variant(variant)
         (got,) = ops.conv_igemm([x], [packed], [b if bias else None], [dil], k, relu)
         assert got.shape == want.shape and got.dtype == torch.bfloat16 and got.is_contiguous(memory_format=CL)

@@ -55,7 +55,7 @@ def main():
         ("conv3_2 256->256 81x81", 81, 81, 256, 256, 3, [1]),
         ("conv3_1 128->256 81x81", 81, 81, 128, 256, 3, [1]),
     ]
-    print("%-28s %9s %9s %9s %9s | %8s %8s | %s" % ("layer", "stream-K", "whole tiles", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
+    print("%-28s %9s %9s %9s %9s | %8s %8s | %s" % ("layer", "variant", "default", "im2col+mm", "mm only", "TF/s ig", "TF/s old", "max err"))
     for name, H, W, cin, cout, k, dils in layers:
         n = len(dils)
         torch.manual_seed(1)
@@ -91,8 +91,9 @@ def main():
         torch.cuda.synchronize()
         t = {"ig1": [], "ig0": [], "old": [], "mm": []}
         for _ in range(args.rounds):
-            sk[0] = True
-            ops.set_igemm_variant(4)                 # stream-K wherever legal
+            sk[0] = False
+            ops.set_igemm_variant(int(os.environ.get("PROBE_VARIANT", "4")))     # 4: stream-K wherever legal (needs the scratch)
+            sk[0] = os.environ.get("PROBE_VARIANT", "4") == "4"
             t["ig1"].append(timed(run_ig, args.iters))
             ops.set_igemm_variant(-1)
             sk[0] = False
