@@ -90,6 +90,8 @@ SIGNATURES = {
     "dsrg_conv_igemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _sz,
                                   _vp]),
     "dsrg_conv_igemm_workspace": (_sz, []),
+    "dsrg_conv_igemm_dgrad_workspace": (_sz, [_i] * 5),
+    "dsrg_conv_igemm_dgrad_bf16": (_i, [_vp] * 6 + [_i] * 7 + [_f, _vp, _sz, _vp]),
     "dsrg_conv_igemm_workspace_status": (_i, [_vp, _vp, _vp]),
     "dsrg_pack_conv_weight_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "dsrg_conv_igemm_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),

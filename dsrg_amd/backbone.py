@@ -196,9 +196,24 @@ class _ConvFn(torch.autograd.Function):
         return (gx if gemm_dgrad else gx2), (gw if gemm_wgrad else gw2), (gb if fused else gb2), None, None, None, None, None
 
 
+class _GradLink:
+    """side channel between two adjacent nodes of a conv chain: when the upper node's data gradient was taken with the lower
+    node's ReLU (+ Dropout) backward and bias gradient folded into its store (ops.conv_igemm_dgrad), it leaves the bias gradient
+    here and the lower node's backward takes the incoming gradient as already masked.  Only wired where the model declares the
+    lower node's output to have this one consumer (GemmConv2d(chain_input=True); VGG16ASPP's fc6 -> fc7)."""
+    __slots__ = ("scale", "gb")
+
+    def __init__(self):
+        self.scale, self.gb = 1.0, None
+
+
+_FUSE_CHAIN = _os.environ.get("DSRG_FUSE_CHAIN", "1") != "0"
+
+
 class _IgemmConvFn(torch.autograd.Function):
     """n convolutions of one geometry (n = 1, or the four ASPP branches) + bias (+ ReLU (+ Dropout) (+ the stride-2 max pool)):
-    apply(k, dils, relu, drop_p, pool, n, x_1..x_n, w_1..w_n, b_1..b_n).  k = 3 (conv3_x .. fc6_k): forward, data and weight
+    apply(k, dils, relu, drop_p, pool, n, links_in, links_out, x_1..x_n, w_1..w_n, b_1..b_n) (links: lists of _GradLink or None —
+    links_in[i] says x_i is the sole-consumer output of a ReLU node whose backward this node's data gradient absorbs).  k = 3 (conv3_x .. fc6_k): forward, data and weight
     gradient by the implicit-GEMM kernels; k = 1 (fc7_k): forward and data gradient are plain hipBLASLt GEMMs over the NHWC
     matrices (nothing to gather), the weight gradients of all branches one implicit-GEMM launch.
     x: bf16 channels_last; w, b: the float32 master parameters — the kernel is cast to bf16 by the same copy that packs it
@@ -207,7 +222,7 @@ class _IgemmConvFn(torch.autograd.Function):
     (the same kernel on the flipped, transposed kernels), weight gradients in one launch."""
 
     @staticmethod
-    def forward(ctx, k, dils, relu, drop_p, pool, n, *t):
+    def forward(ctx, k, dils, relu, drop_p, pool, n, links_in, links_out, *t):
         from .ops import conv_igemm, conv_igemm_supported, pack_conv_weight_pair, dropout_seed
         xs, ws, bs = t[:n], t[n:2 * n], t[2 * n:3 * n]
         xs = [x if x.dtype == torch.bfloat16 else x.bfloat16() for x in xs]
@@ -221,16 +236,20 @@ class _IgemmConvFn(torch.autograd.Function):
         elif drop_p > 0.0:
             scale = 1.0 / (1.0 - drop_p)
         seed = dropout_seed() if fused_drop else 0
+        if links_in is not None and not all(lk is not None for lk in links_in):
+            links_in = None
         if k == 3:
             # both packed forms of every kernel from the float32 master in one pass each; the data-gradient form waits for backward
-            need_d = any(ctx.needs_input_grad[6:6 + n]) and conv_igemm_supported(ws[0].shape[0], ws[0].shape[1], 3)
+            need_d = any(ctx.needs_input_grad[8:8 + n]) and conv_igemm_supported(ws[0].shape[0], ws[0].shape[1], 3)
             packs = [pack_conv_weight_pair(w, True, need_d) for w in ws]
             packs_d = [p[1] for p in packs]
             outs = conv_igemm(xs, [p[0] for p in packs], fb, dils, 3, relu, drop_p if fused_drop else 0.0, seed)
         elif fused_drop:
             # fc7_k with Dropout behind it: one 1x1 implicit-GEMM launch for all branches with the mask in its epilogue beats four
             # hipBLASLt GEMMs + four dropout passes
-            outs = conv_igemm(xs, [pack_conv_weight_pair(w, True, False)[0] for w in ws], fb, dils, 1, relu, drop_p, seed)
+            packs = [pack_conv_weight_pair(w, True, links_in is not None and _FUSE_CHAIN) for w in ws]
+            packs_d = [p[1] for p in packs]
+            outs = conv_igemm(xs, [p[0] for p in packs], fb, dils, 1, relu, drop_p, seed)
         else:
             outs = [_im2col_gemm(x, w.to(torch.bfloat16), b.to(torch.bfloat16), 1, relu) for x, w, b in zip(xs, ws, bs)]
         if drop_p > 0.0 and not fused_drop:
@@ -242,19 +261,30 @@ class _IgemmConvFn(torch.autograd.Function):
         ctx.save_for_backward(code, *xs, *ws, *(outs if relu else ()))
         ctx.packs_d = packs_d                  # not an input or output of the node: kept outside save_for_backward
         ctx.dils, ctx.relu, ctx.scale, ctx.pool, ctx.n, ctx.k = dils, relu, scale, pool, n, k
+        ctx.links_in = links_in
+        ctx.links_out = links_out if (relu and pool is None) else None
+        if ctx.links_out is not None:
+            for lk in ctx.links_out:
+                lk.scale, lk.gb = scale, None
         return tuple(outs) if pool is None else (pooled,)
 
     @staticmethod
     def backward(ctx, *gs):
-        from .ops import (conv_igemm, conv_igemm_supported, conv_igemm_wgrad, conv_igemm_wgrad_supported, pack_conv_weight,
-                          relu_bwd_bias, bias_grad, maxpool3x3_bwd_relu)
+        from .ops import (conv_igemm, conv_igemm_dgrad, conv_igemm_supported, conv_igemm_wgrad, conv_igemm_wgrad_supported,
+                          pack_conv_weight, relu_bwd_bias, bias_grad, maxpool3x3_bwd_relu)
         n = ctx.n
         code, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         xs, ws, ys = saved[:n], saved[n:2 * n], saved[2 * n:]
         cout, cin = ws[0].shape[0], ws[0].shape[1]
         gms, gbs = [], []
+        cl = torch.channels_last
         for i, g in enumerate(gs):
-            if ctx.pool is not None:
+            lk = ctx.links_out[i] if ctx.links_out is not None else None
+            if lk is not None and lk.gb is not None:
+                # the consumer's data gradient came masked by this node's ReLU (+ Dropout) with the bias gradient beside it
+                gm, gb = g, lk.gb
+                lk.gb = None
+            elif ctx.pool is not None:
                 gm, gb = maxpool3x3_bwd_relu(g, code, ys[i], ctx.pool[0])
             elif ctx.relu:
                 gm, gb = relu_bwd_bias(g, ys[i], ctx.scale)
@@ -262,17 +292,27 @@ class _IgemmConvFn(torch.autograd.Function):
                 gm = g.contiguous(memory_format=torch.channels_last)
                 gb = bias_grad(gm)
             gms.append(gm); gbs.append(gb)
-        need_x = [ctx.needs_input_grad[6 + i] for i in range(n)]
+        need_x = [ctx.needs_input_grad[8 + i] for i in range(n)]
         gxs = [None] * n
+        # inputs that are another node's ReLU outputs with no other consumer: that node's backward rides in this data gradient
+        absorb = _FUSE_CHAIN and ctx.links_in is not None and all(need_x) and conv_igemm_supported(cout, cin, ctx.k) and \
+            cin >= 256 and all(x.is_contiguous(memory_format=cl) for x in xs)
+        if absorb:
+            packs_d = [p if p is not None else pack_conv_weight(w, for_dgrad=True) for p, w in zip(ctx.packs_d, ws)]
+            gxs, gb_below = conv_igemm_dgrad(gms, packs_d, list(xs), ctx.dils, ctx.k, ctx.links_in[0].scale)
+            for lk, gb_ in zip(ctx.links_in, gb_below):
+                lk.gb = gb_
         if ctx.k == 1:
             for i in range(n):
+                if absorb:
+                    break
                 if need_x[i]:
                     g2d = gms[i].permute(0, 2, 3, 1).reshape(-1, cout)
                     B_, _, H_, W_ = xs[i].shape
                     gxs[i] = torch.mm(g2d, ws[i].to(torch.bfloat16).reshape(cout, cin)).view(B_, H_, W_, cin).permute(0, 3, 1, 2)
             gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 1)
-            return (None,) * 6 + tuple(gxs) + tuple(gws) + tuple(gbs)
-        if any(need_x):
+            return (None,) * 8 + tuple(gxs) + tuple(gws) + tuple(gbs)
+        if any(need_x) and not absorb:
             if conv_igemm_supported(cout, cin, 3):
                 packs_d = [p if p is not None else pack_conv_weight(w, for_dgrad=True) for p, w in zip(ctx.packs_d, ws)]
                 gxs = conv_igemm(gms, packs_d, None, ctx.dils, 3, False)
@@ -289,7 +329,7 @@ class _IgemmConvFn(torch.autograd.Function):
                 d = ctx.dils[i]
                 gws.append(torch.ops.aten.convolution_backward(gms[i], xs[i], ws[i].to(torch.bfloat16), None, [1, 1], [d, d], [d, d],
                                                                False, [0, 0], 1, [False, True, False])[1].float())
-        return (None,) * 6 + tuple(gx if nx else None for gx, nx in zip(gxs, need_x)) + tuple(gws) + tuple(gbs)
+        return (None,) * 8 + tuple(gx if nx else None for gx, nx in zip(gxs, need_x)) + tuple(gws) + tuple(gbs)
 
 
 _IGEMM_MIN_TILES = int(_os.environ.get("DSRG_IGEMM_MIN_TILES", "64"))
@@ -318,8 +358,11 @@ class GemmConv2d(nn.Conv2d):
     with the following ReLU (`fuse_relu`) and Dropout (`fuse_dropout` = p, needs fuse_relu) fused; on the CPU it is the
     plain convolution (+ ReLU (+ Dropout))."""
 
-    def __init__(self, *args, fuse_relu=False, gemm=True, fuse_dropout=0.0, fuse_pool=None, **kw):
+    def __init__(self, *args, fuse_relu=False, gemm=True, fuse_dropout=0.0, fuse_pool=None, chain_input=False, **kw):
         super().__init__(*args, **kw)
+        # chain_input: the caller's promise that this layer's input is the fused-ReLU output of the GemmConv2d in front of it and
+        # feeds nothing else — the data gradient may then carry that layer's ReLU backward and bias gradient (_GradLink)
+        self.chain_input = bool(chain_input)
         if fuse_dropout and not fuse_relu:
             raise ValueError("fuse_dropout needs fuse_relu (the fused backward reads both masks from the output sign)")
         if fuse_pool is not None and (not fuse_relu or fuse_dropout or fuse_pool[0] != 2):
@@ -336,8 +379,13 @@ class GemmConv2d(nn.Conv2d):
             cout = self.out_channels
             if _igemm_route(self, x):
                 in_node = pool is not None and _FUSE_POOL
-                (out,) = _IgemmConvFn.apply(3, [self.dilation[0]], self.fuse_relu, p, pool if in_node else None, 1, x, self.weight,
+                lin = getattr(x, "_dsrg_grad_link", None) if self.chain_input else None
+                lout = _GradLink() if (self.fuse_relu and pool is None and torch.is_grad_enabled()) else None
+                (out,) = _IgemmConvFn.apply(3, [self.dilation[0]], self.fuse_relu, p, pool if in_node else None, 1,
+                                            [lin] if lin is not None else None, [lout] if lout is not None else None, x, self.weight,
                                             self.bias)
+                if lout is not None:
+                    out._dsrg_grad_link = lout
                 return out if pool is None or in_node else _pool3x3(out, pool[0], pool[1])
             in_node = pool is not None and _FUSE_POOL and cout % 8 == 0 and 256 % (cout // 8) == 0 and self.bias is not None and (
                 x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16))
@@ -429,9 +477,10 @@ def _pool3x3(x, stride, ceil_mode):
     return F.max_pool2d(x, 3, stride, 1, ceil_mode=ceil_mode)
 
 
-def _conv_relu(cin, cout, dilation=1, gemm=False, pool=None):
-    """conv + ReLU (+ the stride-2 max pool behind them, `pool` = (2, ceil_mode)): Sequential slots as in the prototxt"""
-    conv = GemmConv2d(cin, cout, 3, padding=dilation, dilation=dilation, fuse_relu=True, gemm=gemm, fuse_pool=pool)
+def _conv_relu(cin, cout, dilation=1, gemm=False, pool=None, chain=False):
+    """conv + ReLU (+ the stride-2 max pool behind them, `pool` = (2, ceil_mode)): Sequential slots as in the prototxt;
+    chain: the input is the conv + ReLU in front and nothing else reads it (GemmConv2d.chain_input)"""
+    conv = GemmConv2d(cin, cout, 3, padding=dilation, dilation=dilation, fuse_relu=True, gemm=gemm, fuse_pool=pool, chain_input=chain)
     return [conv, FusedReLU()] + ([FusedPool()] if pool is not None else [])
 
 
@@ -465,10 +514,11 @@ class VGG16ASPP(nn.Module):
         p2 = (2, True)                                                  # pool1-3: 3x3 / stride 2 / pad 1, ceil mode (Caffe), inside the conv node
         L += _conv_relu(3, 64) + _conv_relu(64, 64, pool=p2)
         L += _conv_relu(64, 128, 1, gemm_convs) + _conv_relu(128, 128, 1, gemm_convs, pool=p2)
-        L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs, pool=p2)
+        L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs, chain=True) + \
+            _conv_relu(256, 256, 1, gemm_convs, pool=p2, chain=True)
         g = gemm_convs                                                  # the 41x41 stages
-        L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g) + _conv_relu(512, 512, 1, g) + [MaxPool3x3(1)]
-        L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g) + [MaxPool3x3(1)]
+        L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g, chain=True) + _conv_relu(512, 512, 1, g, chain=True) + [MaxPool3x3(1)]
+        L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g, chain=True) + _conv_relu(512, 512, 2, g, chain=True) + [MaxPool3x3(1)]
         L += [AvgPool3x3()]                                   # pool5a AVE (count_include_pad, as Caffe)
         self.features = nn.Sequential(*L)
         self.branches = nn.ModuleList()
@@ -495,14 +545,17 @@ class VGG16ASPP(nn.Module):
             # the four fc6_k (same input, own dilation) in one launch each way: 1696 tiles fill the chip where 424 leave a sixth idle
             p = fc6[0].fuse_dropout if self.training else 0.0
             n = len(fc6)
-            hs = list(_IgemmConvFn.apply(3, [m.dilation[0] for m in fc6], True, p, None, n, *([f] * n), *[m.weight for m in fc6],
-                                         *[m.bias for m in fc6]))
+            links = [_GradLink() for _ in range(n)] if torch.is_grad_enabled() else None
+            hs = list(_IgemmConvFn.apply(3, [m.dilation[0] for m in fc6], True, p, None, n, None, links, *([f] * n),
+                                         *[m.weight for m in fc6], *[m.bias for m in fc6]))
             fc7 = [br[3] for br in self.branches]
             if all(isinstance(m, GemmConv2d) and m.kernel_size == (1, 1) and m.fuse_relu and m.bias is not None and m.gemm
                    and m.in_channels % 256 == 0 and m.out_channels % 256 == 0 for m in fc7):
                 # fc7_k: own input each, one launch for the four weight gradients
                 p7 = fc7[0].fuse_dropout if self.training else 0.0
-                hs = list(_IgemmConvFn.apply(1, [1] * n, True, p7, None, n, *hs, *[m.weight for m in fc7], *[m.bias for m in fc7]))
+                # (fc6_k's output feeds fc7_k only: its ReLU / Dropout backward and bias gradient ride in fc7_k's data gradient)
+                hs = list(_IgemmConvFn.apply(1, [1] * n, True, p7, None, n, links, None, *hs, *[m.weight for m in fc7],
+                                             *[m.bias for m in fc7]))
             else:
                 for i, br in enumerate(self.branches):
                     for m in list(br)[1:-1]:

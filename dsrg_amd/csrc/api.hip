@@ -500,6 +500,18 @@ extern "C" int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const 
     return launch_conv_igemm(x_dev, w_dev, bias_dev, y_dev, dilation, ngroups, B, H, W, cin, cout, ksize, relu, dropout_p,
                              dropout_seed, workspace_dev, workspace_bytes, static_cast<hipStream_t>(stream));
 }
+extern "C" size_t dsrg_conv_igemm_dgrad_workspace(int ngroups, int B, int H, int W, int cout) {
+    return conv_igemm_colsum_workspace(ngroups, B, H, W, cout);
+}
+extern "C" int dsrg_conv_igemm_dgrad_bf16(const void *const *g_dev, const void *const *w_dev, const void *const *mask_dev,
+                                          void *const *gx_dev, float *const *bias_grad_dev, const int *dilation, int ngroups, int B,
+                                          int H, int W, int cin, int cout, int ksize, float mask_scale, void *workspace_dev,
+                                          size_t workspace_bytes, void *stream) {
+    if (!g_dev || !w_dev || !gx_dev || !mask_dev || B < 1 || H < 1 || W < 1)
+        return set_error(DSRG_ERR_INVALID, "conv_igemm_dgrad: bad arguments");
+    return launch_conv_igemm(g_dev, w_dev, nullptr, gx_dev, dilation, ngroups, B, H, W, cin, cout, ksize, 0, 0.0f, 0ull, nullptr, 0,
+                             static_cast<hipStream_t>(stream), mask_dev, mask_scale, bias_grad_dev, workspace_dev, workspace_bytes);
+}
 extern "C" size_t dsrg_conv_igemm_workspace(void) { return conv_igemm_workspace(); }
 extern "C" int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, int *status_host) {
     if (!workspace_dev || !status_host) return set_error(DSRG_ERR_INVALID, "bad argument");

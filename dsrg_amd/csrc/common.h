@@ -184,7 +184,9 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
 bool conv_igemm_supported(int cin, int cout, int k);
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
                       int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
-                      void *workspace, size_t workspace_bytes, hipStream_t stream);
+                      void *workspace, size_t workspace_bytes, hipStream_t stream, const void *const *mask = nullptr,
+                      float out_scale = 1.0f, float *const *colsum = nullptr, void *colsum_ws = nullptr, size_t colsum_ws_bytes = 0);
+size_t conv_igemm_colsum_workspace(int ngroups, int B, int H, int W, int cout);
 size_t conv_igemm_workspace();
 int conv_igemm_workspace_status(const void *workspace, hipStream_t stream, int *status);
 size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k);

@@ -70,6 +70,10 @@ struct IgemmGroup {
     const uint16_t *w;      // (Cout, Cin / 64, taps, 64) bf16
     const float *bias;      // (Cout) or nullptr
     uint16_t *y;            // (B, H, W, Cout) bf16
+    const uint16_t *mask;   // (B, H, W, Cout) bf16 or nullptr: outputs are kept where mask > 0 (times out_scale), else zeroed —
+                            // the ReLU (+ Dropout) backward of the layer below, when this launch is a data gradient
+    float *colsum;          // (tiles_m, Cout) fp32 or nullptr: per 256-row tile, the column sums of what was stored —
+                            // the partial bias gradient of the layer below (summed in fixed order by igemm_colsum_kernel)
     int dil, pad_;
 };
 struct IgemmArgs {
@@ -80,6 +84,7 @@ struct IgemmArgs {
     uint32_t drop_thresh;   // Dropout behind the ReLU, fused: keep an element iff its random byte >= drop_thresh (p = thresh / 256;
     float drop_scale;       // 0 = no dropout), kept elements times drop_scale = 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
+    float out_scale;        // every output times this (1 unless a mask carries a Dropout scale)
 };
 
 // the random bytes of the four consecutive channels starting at element 4 * e4 of a launch's output: a counter-based
@@ -325,7 +330,8 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
             for (int j = 0; j < 2; j++) {
                 float v0 = acc[i][j][q * 4 + 0] + b4.x, v1 = acc[i][j][q * 4 + 1] + b4.y;
                 float v2 = acc[i][j][q * 4 + 2] + b4.z, v3 = acc[i][j][q * 4 + 3] + b4.w;
-                v0 = fmaxf(v0, floor_); v1 = fmaxf(v1, floor_); v2 = fmaxf(v2, floor_); v3 = fmaxf(v3, floor_);
+                v0 = fmaxf(v0, floor_) * a.out_scale; v1 = fmaxf(v1, floor_) * a.out_scale;
+                v2 = fmaxf(v2, floor_) * a.out_scale; v3 = fmaxf(v3, floor_) * a.out_scale;
                 if (a.drop_thresh) {                                             // uniform
                     const uint32_t m = (uint32_t)(m0 + wm * 64 + j * 32 + l31);
                     const uint32_t h = dropout_bytes((m * (uint32_t)a.Cout + (uint32_t)(nw + nl)) >> 2, seed_g, a.seed_hi);
@@ -339,12 +345,72 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         }
     }
     // the wave reads back its own rows only: LDS operations of one wave complete in order
+    if (!G.mask && !G.colsum) {
 #pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const int p = it * 4 + (lane >> 4), ch = lane & 15;
+            const int m = m0 + wm * 64 + p;
+            const uint4 v = *reinterpret_cast<const uint4 *>(O + p * kOutRow + ch * 16);
+            if (m < a.M) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
+        }
+        return;
+    }
+    // data gradient with the backward of the ReLU (+ Dropout) below it and that layer's bias gradient: keep a value where the
+    // layer's OUTPUT was positive (bf16 halves compared as signed 16-bit integers: +0 and negatives drop), sum what is stored.
+    // The accumulators are dead by now: all sixteen mask rows of the lane are fetched in one batch (one latency, not sixteen).
+    uint4 mk[16];
+    if (G.mask) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int m = m0 + wm * 64 + it * 4 + (lane >> 4);
+            mk[it] = m < a.M ? *reinterpret_cast<const uint4 *>(G.mask + (size_t)m * a.Cout + nw + (lane & 15) * 8)
+                             : make_uint4(0, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 16; it++) mk[it] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    }
+    float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
     for (int it = 0; it < 16; it++) {
         const int p = it * 4 + (lane >> 4), ch = lane & 15;
         const int m = m0 + wm * 64 + p;
         const uint4 v = *reinterpret_cast<const uint4 *>(O + p * kOutRow + ch * 16);
-        if (m < a.M) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
+        uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t y4[4] = {mk[it].x, mk[it].y, mk[it].z, mk[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t lo = (int16_t)(y4[e] & 0xffffu) > 0 ? 0x0000ffffu : 0u;
+            const uint32_t hi = (int32_t)y4[e] >= 0x10000 ? 0xffff0000u : 0u;       // upper half positive and non-zero
+            w4[e] &= lo | hi;                                                        // (rows past the end: mask 0 -> adds 0)
+            cs[2 * e] += __uint_as_float(w4[e] << 16);
+            cs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+        }
+        if (m < a.M) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+    if (G.colsum) {                                          // uniform for the workgroup
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            cs[e] += __shfl_xor(cs[e], 16);
+            cs[e] += __shfl_xor(cs[e], 32);
+        }
+        // the four 64-row slabs of the tile are summed here (fixed order) so that the scratch holds one row per tile.  A wave's
+        // own staging region is free again (its reads above have returned: their values were used)
+        float *slab = reinterpret_cast<float *>(O);
+        if (lane < 16) {
+            *reinterpret_cast<float4 *>(slab + lane * 8) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            *reinterpret_cast<float4 *>(slab + lane * 8 + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+        }
+        __syncthreads();                                     // (waves of a 128-wide n-tile's idle half have left: not counted)
+        if (wm == 0) {
+            const float *s0 = reinterpret_cast<const float *>(ig_lds + (wn * 4 + 0) * kOutWave);
+            const float *s1 = reinterpret_cast<const float *>(ig_lds + (wn * 4 + 1) * kOutWave);
+            const float *s2 = reinterpret_cast<const float *>(ig_lds + (wn * 4 + 2) * kOutWave);
+            const float *s3 = reinterpret_cast<const float *>(ig_lds + (wn * 4 + 3) * kOutWave);
+            float *dst = G.colsum + (size_t)tm * a.Cout + nw;
+            dst[lane] = (s0[lane] + s1[lane]) + (s2[lane] + s3[lane]);
+            dst[lane + 64] = (s0[lane + 64] + s1[lane + 64]) + (s2[lane + 64] + s3[lane + 64]);
+        }
     }
 }
 
@@ -873,10 +939,46 @@ static int igemm_cus() {
 // device scratch of the stream-K form: one accumulator tile (256 KB) and one flag per workgroup (= per CU), an error word
 size_t conv_igemm_workspace() { return (size_t)igemm_cus() * (32 * 512 * 16) + ((size_t)igemm_cus() + 1 + 63) / 64 * 256; }
 
+// bias gradient from the per-tile column sums of a masked data gradient: fixed order (sixteen interleaved row streams, then
+// a tree), one workgroup per 64 channels of a group
+struct ColsumArgs {
+    const float *part[4];
+    float *out[4];
+    int rows, cout;
+};
+__global__ __launch_bounds__(1024) void igemm_colsum_kernel(ColsumArgs a) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, q = threadIdx.x >> 6;
+    const float *p = a.part[blockIdx.y];
+    float s0 = 0.0f, s1 = 0.0f;
+    int r = q;
+    for (; r + 16 < a.rows; r += 32) {
+        s0 += p[(size_t)r * a.cout + c];
+        s1 += p[(size_t)(r + 16) * a.cout + c];
+    }
+    if (r < a.rows) s0 += p[(size_t)r * a.cout + c];
+    red[q][cl] = s0 + s1;
+    __syncthreads();
+    if (q == 0) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) t[k] = (red[4 * k][cl] + red[4 * k + 1][cl]) + (red[4 * k + 2][cl] + red[4 * k + 3][cl]);
+        a.out[blockIdx.y][c] = (t[0] + t[1]) + (t[2] + t[3]);
+    }
+}
+
+size_t conv_igemm_colsum_workspace(int ngroups, int B, int H, int W, int cout) {
+    const long long M = (long long)B * H * W;
+    return (size_t)ngroups * (size_t)((M + kBM - 1) / kBM) * (size_t)cout * sizeof(float);
+}
+
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
                       int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
-                      void *workspace, size_t workspace_bytes, hipStream_t stream) {
+                      void *workspace, size_t workspace_bytes, hipStream_t stream, const void *const *mask, float out_scale,
+                      float *const *colsum, void *colsum_ws, size_t colsum_ws_bytes) {
     if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm: 1..4 groups");
+    if (colsum && (!colsum_ws || colsum_ws_bytes < conv_igemm_colsum_workspace(ngroups, B, H, W, cout)))
+        return set_error(DSRG_ERR_INVALID, "conv_igemm: column-sum scratch missing or too small");
     if (!conv_igemm_supported(cin, cout, k))
         return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: cin %% 64 == 0, cout %% 128 == 0, k in (1, 3) required (got %d, %d, %d)",
                          cin, cout, k);
@@ -891,8 +993,13 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
         a.g[g].bias = bias ? bias[g] : nullptr;
         a.g[g].y = static_cast<uint16_t *>(y[g]);
         a.g[g].dil = dil ? dil[g] : 1;
-        if (!a.g[g].x || !a.g[g].w || !a.g[g].y) return set_error(DSRG_ERR_INVALID, "conv_igemm: null pointer");
+        a.g[g].mask = mask ? static_cast<const uint16_t *>(mask[g]) : nullptr;
+        a.g[g].colsum = colsum ? static_cast<float *>(colsum_ws) + (size_t)g * ((M + kBM - 1) / kBM) * cout : nullptr;
+        if (!a.g[g].x || !a.g[g].w || !a.g[g].y || (mask && !mask[g]) || (colsum && !colsum[g]))
+            return set_error(DSRG_ERR_INVALID, "conv_igemm: null pointer");
     }
+    a.out_scale = out_scale;
+    const bool fused_bwd = mask || colsum;
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.relu = relu; a.M = (int)M;
     a.tiles_m = (int)((M + kBM - 1) / kBM);
     a.tiles_n = (cout + kBN - 1) / kBN;
@@ -913,7 +1020,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     // different rounds overlap: fc6 x 4, 6.6 rounds, 810 us whole against 902 us dealt out).
     const int units = igemm_cus(), tiles_total = a.tiles_per_group * ngroups, nsteps = (cin / 64) * k * k;
     const bool sk_wins = tiles_total * 100 <= units * 60, sk_forced = igemm_variant() == 4;      // 4: tests / tools, wherever legal
-    if (workspace && workspace_bytes >= conv_igemm_workspace() && ((igemm_variant() == 3 && sk_wins) || sk_forced) &&
+    if (!fused_bwd && workspace && workspace_bytes >= conv_igemm_workspace() && ((igemm_variant() == 3 && sk_wins) || sk_forced) &&
         (long long)tiles_total * nsteps >= (long long)units * 8 && tiles_total * 3 >= units) {
         IgemmSkArgs sk;
         sk.base = a;
@@ -944,6 +1051,14 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
         hipLaunchKernelGGL(conv_igemm_kernel_32x4, grid, block, lds, stream, a);
     }
     DSRG_LAUNCH_CHECK();
+    if (colsum) {
+        ColsumArgs c;
+        memset(&c, 0, sizeof(c));
+        for (int g = 0; g < ngroups; g++) { c.part[g] = a.g[g].colsum; c.out[g] = colsum[g]; }
+        c.rows = a.tiles_m; c.cout = cout;
+        hipLaunchKernelGGL(igemm_colsum_kernel, dim3(cout / 64, ngroups), dim3(1024), 0, stream, c);
+        DSRG_LAUNCH_CHECK();
+    }
     return DSRG_OK;
 }
 

@@ -508,6 +508,38 @@ def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0
     return ys
 
 
+def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias_grad=True):
+    """the data gradient of 1 .. 4 convolutions whose inputs were ReLU (+ Dropout) outputs, with that layer's backward folded
+    in: gs[g] (B,cout_fwd,H,W) bf16 channels_last, packed_t[g] the flipped + transposed packing, masks[g] (B,cin_fwd,H,W) bf16
+    the outputs of the layer below -> (list of (B,cin_fwd,H,W) bf16 = conv_T(g) * mask_scale where mask > 0, list of (cin_fwd)
+    f32 bias gradients of the layer below or None)"""
+    n = len(gs)
+    B, cin, H, W = gs[0].shape
+    cout = packed_t[0].shape[0]
+    cl = torch.channels_last
+    if not (1 <= n <= 4 and len(packed_t) == n and len(dilations) == n and len(masks) == n):
+        raise ValueError("conv_igemm_dgrad: 1..4 groups")
+    for g, p, m in zip(gs, packed_t, masks):
+        if not (g.is_cuda and g.dtype == torch.bfloat16 and tuple(g.shape) == (B, cin, H, W) and p.dtype == torch.bfloat16
+                and tuple(p.shape) == (cout, cin // 64, ksize * ksize, 64) and p.is_contiguous() and m.dtype == torch.bfloat16
+                and tuple(m.shape) == (B, cout, H, W) and m.is_contiguous(memory_format=cl)):
+            raise ValueError("conv_igemm_dgrad needs bf16 channels_last gradients / masks of one shape and packed kernels")
+    gs = [g if g.is_contiguous(memory_format=cl) else g.contiguous(memory_format=cl) for g in gs]
+    outs = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=gs[0].device, memory_format=cl) for _ in range(n)]
+    vp = ctypes.c_void_p * n
+    L = _lib.lib()
+    gb = ws = None
+    if bias_grad:
+        gb = [torch.empty(cout, dtype=torch.float32, device=gs[0].device) for _ in range(n)]
+        ws = torch.empty(L.dsrg_conv_igemm_dgrad_workspace(n, B, H, W, cout), dtype=torch.uint8, device=gs[0].device)
+    check(L.dsrg_conv_igemm_dgrad_bf16(vp(*[g.data_ptr() for g in gs]), vp(*[p.data_ptr() for p in packed_t]),
+                                       vp(*[m.data_ptr() for m in masks]), vp(*[o.data_ptr() for o in outs]),
+                                       vp(*[b.data_ptr() for b in gb]) if gb else None,
+                                       (ctypes.c_int * n)(*[int(d) for d in dilations]), n, B, H, W, cin, cout, ksize,
+                                       float(mask_scale), _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
+    return outs, gb
+
+
 _igemm_sk_ws = {}
 
 

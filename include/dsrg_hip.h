@@ -291,6 +291,17 @@ int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, con
                          float dropout_p, unsigned long long dropout_seed, void *workspace_dev, size_t workspace_bytes,
                          void *stream);
 size_t dsrg_conv_igemm_workspace(void);
+/* The same launch as the data gradient of a convolution whose INPUT was the output y_below of a ReLU (optionally followed by
+ * Dropout) layer: gx = conv(g, w_dgrad) * mask_scale where mask = y_below > 0, else 0 — the ReLU / Dropout backward folded
+ * into the store — and bias_grad[g][c] = sum over pixels of gx (the bias gradient of the layer below; fp32, fixed summation
+ * order).  g: (B, H, W, cin) gradient of this layer's output; w: the flipped + transposed packing of dsrg_pack_conv_weight_f32
+ * (cout = the layer's INPUT channels); mask, gx: (B, H, W, cout) bf16; bias_grad_dev: NULL or ngroups pointers to cout floats;
+ * workspace_dev: dsrg_conv_igemm_dgrad_workspace(...) bytes when bias_grad_dev is given.  Replaces the separate
+ * relu-backward + bias-sum pass over the gradient (mirror: torch.autograd of Conv -> ReLU -> Dropout in one step). */
+size_t dsrg_conv_igemm_dgrad_workspace(int ngroups, int B, int H, int W, int cout);
+int dsrg_conv_igemm_dgrad_bf16(const void *const *g_dev, const void *const *w_dev, const void *const *mask_dev, void *const *gx_dev,
+                               float *const *bias_grad_dev, const int *dilation, int ngroups, int B, int H, int W, int cin,
+                               int cout, int ksize, float mask_scale, void *workspace_dev, size_t workspace_bytes, void *stream);
 int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, int *status_host);
 /* The two packed forms dsrg_conv_igemm_bf16 reads, from the float32 master kernel in ONE pass (cast included): w_dev
  * (cout, ksize*ksize, cin) f32 = the memory of a channels_last (cout, cin, ksize, ksize) parameter; fwd_dev (may be NULL):

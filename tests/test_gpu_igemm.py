@@ -247,3 +247,105 @@ def test_igemm_stream_k_equals_whole_tiles(ops, B, H, W, cin, cout, k, dils):
             assert torch.equal(b_, c)
             assert torch.equal(a == 0, b_ == 0) or ((a == 0) != (b_ == 0)).float().mean() < 1e-4     # a sum on the edge of the ReLU
             assert (a.float() - b_.float()).abs().max() <= 0.01 * a.float().abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("B,H,W,cf,cb,k,dils,scale", [
+    (2, 41, 41, 512, 512, 3, [1], 1.0),            # conv4_2 -> conv4_1's ReLU
+    (1, 33, 29, 256, 256, 3, [2], 1.0),            # ragged pixel tail, dilation
+    (2, 41, 41, 1024, 1024, 1, [1, 1, 1, 1], 2.0),  # fc7_k -> fc6_k's ReLU + Dropout (scale 2), four branches
+    (1, 20, 23, 512, 256, 3, [1, 3], 2.0),
+])
+def test_igemm_dgrad_absorbs_relu_backward_and_bias_gradient(ops, B, H, W, cf, cb, k, dils, scale):
+    """dsrg_conv_igemm_dgrad_bf16 == the plain data gradient followed by the ReLU / Dropout backward of the layer below
+    (values kept where that layer's output is positive, times the Dropout scale) and that layer's bias gradient (column sums
+    of what was stored).  cf: channels of the incoming gradient (the layer's outputs), cb: channels of the layer below."""
+    n = len(dils)
+    torch.manual_seed(77)
+    gs = [torch.randn(B, cf, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(n)]
+    ws = [(torch.randn(cf, cb, k, k, device="cuda") * (2.0 / (cf * k * k)) ** 0.5) for _ in range(n)]
+    # outputs of the layer below: ReLU output with zeros, a few negative zeros / negatives must count as "off" too
+    ys = []
+    for _ in range(n):
+        y = torch.relu(torch.randn(B, cb, H, W, device="cuda")).bfloat16().contiguous(memory_format=CL)
+        y.permute(0, 2, 3, 1).view(-1)[::97] = -0.0
+        ys.append(y)
+    packs = [ops.pack_conv_weight(w, for_dgrad=True) for w in ws]
+    plain = ops.conv_igemm(gs, packs, None, dils, k, False, stream_k=False)
+    got, gb = ops.conv_igemm_dgrad(gs, packs, ys, dils, k, scale)
+    for g in range(n):
+        want = torch.where(ys[g] > 0, (plain[g].float() * scale).bfloat16(), torch.zeros_like(plain[g]))
+        assert got[g].is_contiguous(memory_format=CL)
+        if scale in (1.0, 2.0):                                          # a power of two: the same roundings
+            assert torch.equal(got[g], want)
+        else:
+            _close(got[g], want.float(), "masked data gradient")
+        ref_b = want.float().sum((0, 2, 3))
+        assert gb[g].dtype == torch.float32 and gb[g].shape == (cb,)
+        assert float((gb[g] - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max()) + 1e-4
+    only, none = ops.conv_igemm_dgrad(gs, packs, ys, dils, k, scale, bias_grad=False)
+    assert none is None and all(torch.equal(a, b) for a, b in zip(only, got))
+
+
+def _grads(net, x, gout, amp=True, seed=11):
+    net.zero_grad(set_to_none=True)
+    torch.manual_seed(seed)                                              # the fused Dropout's seeds come from torch's CPU generator
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = net(x)
+    gout = torch.randn_like(y) if gout is None else gout
+    y.backward(gout)
+    return y.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}, gout
+
+
+def test_conv_chain_fusion_is_bit_identical_for_3x3_chains():
+    """conv -> ReLU -> conv -> ReLU -> conv (GemmConv2d(chain_input=True)): the upper layer's data gradient with the lower
+    layer's ReLU backward and bias gradient folded in (backbone._GradLink) against the separate relu_bwd_bias passes: masked
+    gradients are the same bits, so weight gradients are equal and bias gradients agree to the fp32 summation order"""
+    from dsrg_amd import backbone
+    torch.manual_seed(5)
+    G = backbone.GemmConv2d
+    net = torch.nn.Sequential(G(256, 256, 3, padding=1, fuse_relu=True), G(256, 512, 3, padding=2, dilation=2, fuse_relu=True, chain_input=True),
+                              G(512, 256, 3, padding=1, fuse_relu=True, chain_input=True)).cuda().to(memory_format=CL)
+    x = torch.randn(4, 256, 41, 41, device="cuda").contiguous(memory_format=CL).requires_grad_(True)
+    res, gout = {}, None
+    try:
+        for tag, on in (("fused", True), ("separate", False)):
+            backbone._FUSE_CHAIN = on
+            x.grad = None
+            y, gr, gout = _grads(net, x, gout)
+            res[tag] = (y, gr, x.grad.clone())
+    finally:
+        backbone._FUSE_CHAIN = True
+    assert torch.equal(res["fused"][0], res["separate"][0]) and torch.equal(res["fused"][2], res["separate"][2])
+    for n, ref in res["separate"][1].items():
+        a = res["fused"][1][n]
+        if n.endswith("bias"):
+            assert float((a - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-6, n
+        else:
+            assert torch.equal(a, ref), n
+
+
+def test_backbone_chain_fusion_matches_the_separate_backward_passes():
+    """VGG16-ASPP with Dropout on, same seeds: chains fused (conv3_x .. conv5_x, fc6_k -> fc7_k through the 1x1 implicit-GEMM
+    data gradient instead of hipBLASLt's) against the separate passes.  fc7 / fc8 gradients do not see the difference; below
+    them only the fp32 summation order of fc7's data gradient differs (bf16 roundings flip here and there)"""
+    from dsrg_amd import backbone
+    torch.manual_seed(5)
+    net = backbone.VGG16ASPP(dropout=0.5).cuda().to(memory_format=CL).train()
+    x = torch.randn(4, 3, 161, 161, device="cuda").contiguous(memory_format=CL)
+    res, gout = {}, None
+    try:
+        for tag, on in (("fused", True), ("separate", False)):
+            backbone._FUSE_CHAIN = on
+            y, gr, gout = _grads(net, x, gout)
+            res[tag] = (y, gr)
+    finally:
+        backbone._FUSE_CHAIN = True
+    assert torch.equal(res["fused"][0], res["separate"][0])
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-20))      # noqa: E731
+    for n, ref in res["separate"][1].items():
+        a = res["fused"][1][n]
+        top = n.startswith("branches") and (".3." in n or ".6." in n)          # fc7_k, fc8_k
+        if top and not n.endswith("bias"):
+            assert torch.equal(a, ref), n
+        else:
+            assert rel(a, ref) < (1e-3 if top else 0.03), (n, rel(a, ref))

@@ -107,6 +107,38 @@ def main():
             name, med["ig1"], med["ig0"], med["old"], med["mm"], flops / min(med["ig1"], med["ig0"]) / 1e6,
             flops / med["old"] / 1e6, err), flush=True)
     wgrad_probe(B, args.rounds, args.iters)
+    absorb_probe(B, args.rounds, args.iters)
+
+
+def absorb_probe(B, rounds, iters):
+    """the data gradient with the ReLU (+ Dropout) backward and bias gradient of the layer below in its store against the plain
+    data gradient followed by ops.relu_bwd_bias"""
+    layers = [("conv4_3 -> conv4_2 out", 41, 41, 512, 512, 3, [1]), ("conv3_3 -> conv3_2 out", 81, 81, 256, 256, 3, [1]),
+              ("fc7 x4 -> fc6 out", 41, 41, 1024, 1024, 1, [1] * 4)]
+    print("%-28s %9s %9s %9s" % ("fused backward", "fused", "separate", "dgrad only"))
+    for name, H, W, cf, cb, k, dils in layers:
+        n = len(dils)
+        torch.manual_seed(3)
+        gs = [torch.randn(B, cf, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(n)]
+        ys = [torch.relu(torch.randn(B, cb, H, W, device="cuda")).bfloat16().contiguous(memory_format=CL) for _ in range(n)]
+        packs = [ops.pack_conv_weight((torch.randn(cf, cb, k, k, device="cuda") * 0.02), for_dgrad=True) for _ in range(n)]
+
+        def fused():
+            return ops.conv_igemm_dgrad(gs, packs, ys, dils, k, 2.0)
+
+        def plain():
+            return ops.conv_igemm(gs, packs, None, dils, k, False, stream_k=False)
+
+        def separate():
+            return [ops.relu_bwd_bias(g, y, 2.0) for g, y in zip(plain(), ys)]
+        for fn in (fused, separate, plain):
+            for _ in range(3):
+                fn()
+        torch.cuda.synchronize()
+        t = {"f": [], "s": [], "p": []}
+        for _ in range(rounds):
+            t["f"].append(timed(fused, iters)); t["s"].append(timed(separate, iters)); t["p"].append(timed(plain, iters))
+        print("%-28s %9.1f %9.1f %9.1f" % (name, np.median(t["f"]), np.median(t["s"]), np.median(t["p"])), flush=True)
 
 
 def wgrad_probe(B, rounds, iters):
