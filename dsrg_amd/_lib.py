@@ -100,6 +100,8 @@ SIGNATURES = {
     "dsrg_conv3x3_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "dsrg_heads_backward_chunks": (_i, [_i]),
     "dsrg_heads_backward_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dsrg_heads_backward_relu_workspace": (_sz, [_i] * 3),
+    "dsrg_heads_backward_relu_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _f, _vp, _vp, _sz] + [_i] * 4 + [_vp]),
     "dsrg_maxpool3x3_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_maxpool3x3_bwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_maxpool3x3_bwd_relu_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -490,9 +490,13 @@ class _HeadsFn(torch.autograd.Function):
     continues into the bf16 trunk is accumulated in fp32 and rounded once; weight and bias gradients are fp32."""
 
     @staticmethod
-    def forward(ctx, weight, bias, *xs):
+    def forward(ctx, links, weight, bias, *xs):
         from .ops import heads_forward
-        xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+        cl = torch.channels_last
+        # links: the x_k are ReLU (+ Dropout) outputs of nodes that feed these classifiers only (their backward rides along)
+        ctx.links = links if (links is not None and all(lk is not None for lk in links) and
+                              all(x.is_contiguous(memory_format=cl) for x in xs)) else None
+        xs = [x.contiguous(memory_format=cl) for x in xs]
         weight = weight.contiguous()
         ctx.save_for_backward(weight, *xs)
         return heads_forward(xs, weight, bias.contiguous())
@@ -502,9 +506,14 @@ class _HeadsFn(torch.autograd.Function):
         from .ops import heads_backward
         weight, *xs = ctx.saved_tensors
         n, O, K = weight.shape
-        gxs, gw = heads_backward(xs, weight, g, need_gx=any(ctx.needs_input_grad[2:]))
+        if _FUSE_CHAIN and ctx.links is not None and all(ctx.needs_input_grad[3:]):
+            gxs, gw, gb_below = heads_backward(xs, weight, g, True, ctx.links[0].scale)
+            for i, lk in enumerate(ctx.links):
+                lk.gb = gb_below[i]
+        else:
+            gxs, gw = heads_backward(xs, weight, g, need_gx=any(ctx.needs_input_grad[3:]))
         gb1 = g.sum((0, 2, 3))                                            # fp32, the same for every branch
-        return (gw, gb1.unsqueeze(0).expand(n, O).contiguous()) + (tuple(gxs) if gxs is not None else (None,) * n)
+        return (None, gw, gb1.unsqueeze(0).expand(n, O).contiguous()) + (tuple(gxs) if gxs is not None else (None,) * n)
 
 
 class VGG16ASPP(nn.Module):
@@ -554,8 +563,11 @@ class VGG16ASPP(nn.Module):
                 # fc7_k: own input each, one launch for the four weight gradients
                 p7 = fc7[0].fuse_dropout if self.training else 0.0
                 # (fc6_k's output feeds fc7_k only: its ReLU / Dropout backward and bias gradient ride in fc7_k's data gradient)
-                hs = list(_IgemmConvFn.apply(1, [1] * n, True, p7, None, n, links, None, *hs, *[m.weight for m in fc7],
+                links7 = [_GradLink() for _ in range(n)] if torch.is_grad_enabled() else None
+                hs = list(_IgemmConvFn.apply(1, [1] * n, True, p7, None, n, links, links7, *hs, *[m.weight for m in fc7],
                                              *[m.bias for m in fc7]))
+                for h, lk in zip(hs, links7 or []):
+                    h._dsrg_grad_link = lk
             else:
                 for i, br in enumerate(self.branches):
                     for m in list(br)[1:-1]:
@@ -571,7 +583,9 @@ class VGG16ASPP(nn.Module):
                 and heads[0].in_channels % 256 == 0:
             w = torch.stack([m.weight.reshape(m.out_channels, m.in_channels) for m in heads])
             b = torch.stack([m.bias for m in heads])
-            return _HeadsFn.apply(w.float(), b.float(), *hs)
+            # (on the grouped route the fc7_k outputs feed these classifiers and nothing else)
+            links = [getattr(h, "_dsrg_grad_link", None) for h in hs]
+            return _HeadsFn.apply(links, w.float(), b.float(), *hs)
         out = None
         with torch.autocast(device_type=hs[0].device.type, enabled=False):
             for m, h in zip(heads, hs):

@@ -550,6 +550,18 @@ extern "C" int dsrg_heads_backward_bf16(const void *const *x_dev, int n_branches
     return launch_heads_bwd(x_dev, n_branches, w_dev, g_dev, gx_dev, gx_branch_stride_bytes, gw_dev, partial_dev, B, HW, K, O,
                             static_cast<hipStream_t>(stream));
 }
+extern "C" size_t dsrg_heads_backward_relu_workspace(int n_branches, int M, int K) { return heads_bwd_relu_workspace(n_branches, M, K); }
+extern "C" int dsrg_heads_backward_relu_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *g_dev,
+                                             void *gx_dev, size_t gx_branch_stride_bytes, float *gw_dev, float *partial_dev,
+                                             float relu_scale, float *bias_grad_dev, void *workspace_dev, size_t workspace_bytes,
+                                             int B, int HW, int K, int O, void *stream) {
+    if (!x_dev || !w_dev || !g_dev || !gx_dev || (gw_dev && !partial_dev) || B < 1 || HW < 1 || !(relu_scale > 0.0f) || !bias_grad_dev)
+        return set_error(DSRG_ERR_INVALID, "bad argument");
+    for (int k = 0; k < n_branches && k < 4; k++)
+        if (!x_dev[k]) return set_error(DSRG_ERR_INVALID, "NULL branch input");
+    return launch_heads_bwd(x_dev, n_branches, w_dev, g_dev, gx_dev, gx_branch_stride_bytes, gw_dev, partial_dev, B, HW, K, O,
+                            static_cast<hipStream_t>(stream), relu_scale, bias_grad_dev, workspace_dev, workspace_bytes);
+}
 extern "C" int dsrg_maxpool3x3_fwd_bf16(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C,
                                         int stride, void *stream) {
     if (!in || !out || !code) return set_error(DSRG_ERR_INVALID, "NULL argument");

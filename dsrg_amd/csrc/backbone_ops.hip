@@ -591,46 +591,98 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadArgs a) {
     }
 }
 
-// data gradient: gx_k[m][c] = sum_o g[m][o] W_k[o][c] -> bf16 (M, K) row-major.  One workgroup = 16 rows of one branch,
-// thread = 8 channels x 8 rows; g tile through LDS (broadcast reads), W rows straight from L2.
+// data gradient: gx_k[m][c] = sum_o g[m][o] W_k[o][c] -> bf16 (M, K) row-major.  One workgroup = 16 T rows of one branch (T
+// tiles of 16 in turn), thread = 8 channels x 8 rows; g tile through LDS (broadcast reads), W rows straight from L2.
+// MASK: the backward of the ReLU (+ Dropout) that produced x_k rides in the store — values kept where x_k > 0 (times
+// `scale`), and the column sums of what was stored (that layer's bias gradient) go out as one partial row per workgroup.
+struct HeadMask {
+    const uint16_t *y[4];
+    float *part;            // (nbr, gridDim.x, K)
+    float scale;
+    int tiles;              // 16-row tiles per workgroup
+};
+template <bool MASK>
 __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float *__restrict__ g, const float *__restrict__ w,
-                                                           uint4 *__restrict__ gx, int M, int K, int O, int HW, size_t branch_stride) {
+                                                           uint4 *__restrict__ gx, int M, int K, int O, int HW, size_t branch_stride,
+                                                           HeadMask hm) {
     __shared__ __attribute__((aligned(16))) float gs[32][16];        // [o][row]
-    const int k = blockIdx.y, m0 = blockIdx.x * 16, t = threadIdx.x;
-    for (int e = t; e < 32 * 16; e += 256) {
-        const int o = e >> 4, r = e & 15, m = m0 + r;
-        float v = 0.0f;
-        if (o < O && m < M) { const int b = m / HW, hw = m - b * HW; v = g[((size_t)b * O + o) * HW + hw]; }
-        gs[o][r] = v;
-    }
-    __syncthreads();
-    const int K8 = K / 8;
-    for (int cg = t & 127; cg < K8; cg += 128) {
-        const int rh = t >> 7;                                       // rows 8 rh .. 8 rh + 7
-        float acc[8][8];
+    __shared__ __attribute__((aligned(16))) float cs_l[MASK ? 128 : 1][8];
+    const int k = blockIdx.y, t = threadIdx.x;
+    const int K8 = K / 8, T = MASK ? hm.tiles : 1;
+    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(gx) + (size_t)k * branch_stride);
+    for (int cg0 = 0; cg0 < K8; cg0 += 128) {                        // workgroup-uniform trip counts (barriers inside)
+        const int cg = cg0 + (t & 127), rh = t >> 7;                 // rows 8 rh .. 8 rh + 7 of a tile
+        const bool live = cg < K8;
+        float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ti = 0; ti < T; ti++) {
+            const int m0 = (blockIdx.x * T + ti) * 16;
+            if (m0 >= M) break;
+            if (MASK || cg0 > 0) __syncthreads();                    // the previous tile's readers are done with gs
+            for (int e = t; e < 32 * 16; e += 256) {
+                const int o = e >> 4, r = e & 15, m = m0 + r;
+                float v = 0.0f;
+                if (o < O && m < M) { const int b = m / HW, hw = m - b * HW; v = g[((size_t)b * O + o) * HW + hw]; }
+                gs[o][r] = v;
+            }
+            __syncthreads();
+            if (!live) continue;
+            uint4 yk[8];
+            if (MASK) {
 #pragma unroll
-        for (int r = 0; r < 8; r++)
-#pragma unroll
-            for (int c = 0; c < 8; c++) acc[r][c] = 0.0f;
-        const float *wk = w + (size_t)k * O * K + (size_t)cg * 8;
-#pragma unroll 7
-        for (int o = 0; o < O; o++) {
-            const float4 w0 = *reinterpret_cast<const float4 *>(wk + (size_t)o * K), w1 = *reinterpret_cast<const float4 *>(wk + (size_t)o * K + 4);
-            const float4 g0 = *reinterpret_cast<const float4 *>(&gs[o][rh * 8]), g1 = *reinterpret_cast<const float4 *>(&gs[o][rh * 8 + 4]);
-            const float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            const float gf[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                for (int r = 0; r < 8; r++) {
+                    const int m = m0 + rh * 8 + r;
+                    yk[r] = m < M ? *reinterpret_cast<const uint4 *>(hm.y[k] + (size_t)m * K + (size_t)cg * 8) : make_uint4(0, 0, 0, 0);
+                }
+            }
+            float acc[8][8];
 #pragma unroll
             for (int r = 0; r < 8; r++)
 #pragma unroll
-                for (int c = 0; c < 8; c++) acc[r][c] = __builtin_fmaf(gf[r], wf[c], acc[r][c]);
-        }
-        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(gx) + (size_t)k * branch_stride);
+                for (int c = 0; c < 8; c++) acc[r][c] = 0.0f;
+            const float *wk = w + (size_t)k * O * K + (size_t)cg * 8;
+#pragma unroll 7
+            for (int o = 0; o < O; o++) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(wk + (size_t)o * K), w1 = *reinterpret_cast<const float4 *>(wk + (size_t)o * K + 4);
+                const float4 g0 = *reinterpret_cast<const float4 *>(&gs[o][rh * 8]), g1 = *reinterpret_cast<const float4 *>(&gs[o][rh * 8 + 4]);
+                const float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                const float gf[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int m = m0 + rh * 8 + r;
-            if (m < M)
-                dst[(size_t)m * K8 + cg] = make_uint4(pack_bf16(acc[r][0], acc[r][1]), pack_bf16(acc[r][2], acc[r][3]),
-                                                      pack_bf16(acc[r][4], acc[r][5]), pack_bf16(acc[r][6], acc[r][7]));
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) acc[r][c] = __builtin_fmaf(gf[r], wf[c], acc[r][c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int m = m0 + rh * 8 + r;
+                uint32_t o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (MASK) {
+                        const uint32_t y = e == 0 ? yk[r].x : e == 1 ? yk[r].y : e == 2 ? yk[r].z : yk[r].w;
+                        const uint32_t keep = ((int16_t)(y & 0xffffu) > 0 ? 0x0000ffffu : 0u) | ((int32_t)y >= 0x10000 ? 0xffff0000u : 0u);
+                        o4[e] = pack_bf16(acc[r][2 * e] * hm.scale, acc[r][2 * e + 1] * hm.scale) & keep;
+                        cs[2 * e] += __uint_as_float(o4[e] << 16);                 // (rows past the end: mask 0)
+                        cs[2 * e + 1] += __uint_as_float(o4[e] & 0xffff0000u);
+                    } else {
+                        o4[e] = pack_bf16(acc[r][2 * e], acc[r][2 * e + 1]);
+                    }
+                }
+                if (m < M) dst[(size_t)m * K8 + cg] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            }
+        }
+        if (MASK) {                                                  // the two row halves of the tiles, then one partial row
+            __syncthreads();
+            if (rh == 1 && live) {
+                *reinterpret_cast<float4 *>(&cs_l[t & 127][0]) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                *reinterpret_cast<float4 *>(&cs_l[t & 127][4]) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+            }
+            __syncthreads();
+            if (rh == 0 && live) {
+                float *p = hm.part + ((size_t)k * gridDim.x + blockIdx.x) * K + (size_t)cg * 8;
+                const float4 a0 = *reinterpret_cast<const float4 *>(&cs_l[t][0]), a1 = *reinterpret_cast<const float4 *>(&cs_l[t][4]);
+                *reinterpret_cast<float4 *>(p) = make_float4(cs[0] + a0.x, cs[1] + a0.y, cs[2] + a0.z, cs[3] + a0.w);
+                *reinterpret_cast<float4 *>(p + 4) = make_float4(cs[4] + a1.x, cs[5] + a1.y, cs[6] + a1.z, cs[7] + a1.w);
+            }
         }
     }
 }
@@ -918,14 +970,37 @@ int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float 
 // loads hide behind the other's MFMAs; capped so that the partial sums stay small (chunks x n x O x K floats)
 int heads_bwd_chunks(int M) { int c = (M + 255) / 256; return c < 1 ? 1 : (c > 128 ? 128 : c); }
 
+constexpr int kHeadMaskTiles = 8;      // 128 rows per workgroup of the masked data gradient: one partial bias row each
+size_t heads_bwd_relu_workspace(int nbr, int M, int K) {
+    return (size_t)nbr * ((M + 16 * kHeadMaskTiles - 1) / (16 * kHeadMaskTiles)) * (size_t)K * sizeof(float);
+}
+
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
-                     float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream) {
+                     float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream, float relu_scale, float *bias_grad,
+                     void *colsum_ws, size_t colsum_ws_bytes) {
     int rc = heads_check(nbr, K, O);
     if (rc) return rc;
     const int M = B * HW;
-    if (gx) {
-        hipLaunchKernelGGL(heads_bwd_dx_kernel, dim3((M + 15) / 16, nbr), dim3(256), 0, stream, g, w, static_cast<uint4 *>(gx), M, K, O,
-                           HW, gx_branch_stride);
+    if (gx && relu_scale > 0.0f) {
+        HeadMask hm;
+        for (int k = 0; k < 4; k++) hm.y[k] = static_cast<const uint16_t *>(x[k < nbr ? k : 0]);
+        hm.tiles = kHeadMaskTiles; hm.scale = relu_scale;
+        const int nblk = (M + 16 * kHeadMaskTiles - 1) / (16 * kHeadMaskTiles);
+        if (!bias_grad || !colsum_ws || colsum_ws_bytes < heads_bwd_relu_workspace(nbr, M, K))
+            return set_error(DSRG_ERR_INVALID, "heads backward: bias gradient / scratch of the absorbed ReLU missing or too small");
+        hm.part = static_cast<float *>(colsum_ws);
+        hipLaunchKernelGGL(heads_bwd_dx_kernel<true>, dim3(nblk, nbr), dim3(256), 0, stream, g, w, static_cast<uint4 *>(gx), M, K, O, HW,
+                           gx_branch_stride, hm);
+        DSRG_LAUNCH_CHECK();
+        const float *parts[4];
+        float *outs[4];
+        for (int k = 0; k < nbr; k++) { parts[k] = hm.part + (size_t)k * nblk * K; outs[k] = bias_grad + (size_t)k * K; }
+        if (int rc2 = launch_igemm_colsum(parts, outs, nbr, nblk, K, stream)) return rc2;
+    } else if (gx) {
+        HeadMask hm;
+        memset(&hm, 0, sizeof(hm));
+        hipLaunchKernelGGL(heads_bwd_dx_kernel<false>, dim3((M + 15) / 16, nbr), dim3(256), 0, stream, g, w, static_cast<uint4 *>(gx), M,
+                           K, O, HW, gx_branch_stride, hm);
         DSRG_LAUNCH_CHECK();
     }
     if (gw) {

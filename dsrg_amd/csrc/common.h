@@ -195,7 +195,10 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
 int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream);
 int heads_bwd_chunks(int M);
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
-                     float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream);
+                     float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream, float relu_scale = 0.0f,
+                     float *bias_grad = nullptr, void *colsum_ws = nullptr, size_t colsum_ws_bytes = 0);
+size_t heads_bwd_relu_workspace(int nbr, int M, int K);
+int launch_igemm_colsum(const float *const *parts, float *const *outs, int ngroups, int rows, int cout, hipStream_t stream);
 int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y, void *gin, float *bias_grad, float *part,
                                 int part_blocks, int B, int H, int W, int OH, int OW, int C, hipStream_t stream);
 int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,

@@ -967,6 +967,17 @@ __global__ __launch_bounds__(1024) void igemm_colsum_kernel(ColsumArgs a) {
     }
 }
 
+int launch_igemm_colsum(const float *const *parts, float *const *outs, int ngroups, int rows, int cout, hipStream_t stream) {
+    if (ngroups < 1 || ngroups > 4 || cout % 64 || rows < 1) return set_error(DSRG_ERR_INVALID, "column sums: 1..4 groups, 64 | channels");
+    ColsumArgs c;
+    memset(&c, 0, sizeof(c));
+    for (int g = 0; g < ngroups; g++) { c.part[g] = parts[g]; c.out[g] = outs[g]; }
+    c.rows = rows; c.cout = cout;
+    hipLaunchKernelGGL(igemm_colsum_kernel, dim3(cout / 64, ngroups), dim3(1024), 0, stream, c);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
 size_t conv_igemm_colsum_workspace(int ngroups, int B, int H, int W, int cout) {
     const long long M = (long long)B * H * W;
     return (size_t)ngroups * (size_t)((M + kBM - 1) / kBM) * (size_t)cout * sizeof(float);
@@ -1052,12 +1063,9 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     }
     DSRG_LAUNCH_CHECK();
     if (colsum) {
-        ColsumArgs c;
-        memset(&c, 0, sizeof(c));
-        for (int g = 0; g < ngroups; g++) { c.part[g] = a.g[g].colsum; c.out[g] = colsum[g]; }
-        c.rows = a.tiles_m; c.cout = cout;
-        hipLaunchKernelGGL(igemm_colsum_kernel, dim3(cout / 64, ngroups), dim3(1024), 0, stream, c);
-        DSRG_LAUNCH_CHECK();
+        const float *parts[4];
+        for (int g = 0; g < ngroups; g++) parts[g] = a.g[g].colsum;
+        if (int rc = launch_igemm_colsum(parts, colsum, ngroups, a.tiles_m, cout, stream)) return rc;
     }
     return DSRG_OK;
 }

@@ -624,9 +624,10 @@ def heads_forward(xs, weight, bias):
     return out
 
 
-def heads_backward(xs, weight, g, need_gx=True):
+def heads_backward(xs, weight, g, need_gx=True, relu_scale=0.0):
     """backward of heads_forward from the float32 score gradient g (B,O,H,W): -> (list of gx_k (B,K,H,W) bf16 channels_last or
-    None, gw (n,O,K) float32)"""
+    None, gw (n,O,K) float32).  relu_scale > 0: the x_k are ReLU (+ Dropout, scale relu_scale) outputs nobody else reads — the
+    gx_k come out masked by x_k > 0 and scaled, and a third result (n,K) float32 is the bias gradient of the layer below"""
     B, K, H, W = xs[0].shape
     n, O = weight.shape[0], weight.shape[1]
     cl = torch.channels_last
@@ -640,6 +641,12 @@ def heads_backward(xs, weight, g, need_gx=True):
     gw = torch.empty((n, O, K), dtype=torch.float32, device=g.device)
     part = torch.empty(L.dsrg_heads_backward_chunks(M) * n * O * K, dtype=torch.float32, device=g.device)
     ptrs = (ctypes.c_void_p * 4)(*([x.data_ptr() for x in xs] + [None] * (4 - n)))
+    if relu_scale > 0.0 and need_gx:
+        gb = torch.empty((n, K), dtype=torch.float32, device=g.device)
+        ws = torch.empty(L.dsrg_heads_backward_relu_workspace(n, M, K), dtype=torch.uint8, device=g.device)
+        check(L.dsrg_heads_backward_relu_bf16(ptrs, n, _ptr(weight), _ptr(g), _ptr(gx), M * K * 2, _ptr(gw), _ptr(part),
+                                              float(relu_scale), _ptr(gb), _ptr(ws), ws.numel(), B, H * W, K, O, _stream()))
+        return [gx[k].permute(0, 3, 1, 2) for k in range(n)], gw, gb
     check(L.dsrg_heads_backward_bf16(ptrs, n, _ptr(weight), _ptr(g), _ptr(gx), M * K * 2, _ptr(gw), _ptr(part), B, H * W, K, O,
                                      _stream()))
     return ([gx[k].permute(0, 3, 1, 2) for k in range(n)] if need_gx else None), gw

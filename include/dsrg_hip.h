@@ -334,6 +334,15 @@ int dsrg_heads_backward_chunks(int M);
 int dsrg_heads_backward_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *g_dev,
                              void *gx_dev, size_t gx_branch_stride_bytes, float *gw_dev, float *partial_dev, int B,
                              int HW, int K, int O, void *stream);
+/* The same with the backward of the ReLU (+ Dropout) layers that produced the x_k folded into the data gradient's store:
+ * gx_k[m][c] = relu_scale * sum_o g[m][o] w[k][o][c] where x_k[m][c] > 0, else 0, and bias_grad_dev (n_branches, K) f32 =
+ * sum over m of gx_k (the bias gradient of the layer below; fixed summation order).  workspace_dev:
+ * dsrg_heads_backward_relu_workspace(n_branches, B*HW, K) bytes.  gw as above (from the unmasked x_k, g). */
+size_t dsrg_heads_backward_relu_workspace(int n_branches, int M, int K);
+int dsrg_heads_backward_relu_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *g_dev,
+                                  void *gx_dev, size_t gx_branch_stride_bytes, float *gw_dev, float *partial_dev,
+                                  float relu_scale, float *bias_grad_dev, void *workspace_dev, size_t workspace_bytes, int B,
+                                  int HW, int K, int O, void *stream);
 /* 3x3 max pooling, pad 1, stride 1 or 2, NHWC bf16 (the Pooling layers of train-s.prototxt:69-80 etc.; OH/OW chosen by
  * the caller, ceil mode included).  code_dev: B*OH*OW*C bytes, the window position (3*dy+dx) of the first maximum. */
 int dsrg_maxpool3x3_fwd_bf16(const void *in_dev, void *out_dev, void *code_dev, int B, int H, int W, int OH, int OW, int C,

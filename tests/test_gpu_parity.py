@@ -757,7 +757,7 @@ def test_fp32_heads_kernel_matches_fp32_convolutions(ops):
         assert torch.equal(got, ops.heads_forward(xs, w.detach(), b.detach()))              # deterministic
         xa = [x.clone().requires_grad_(True) for x in xs]
         wa, ba = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
-        ya = _HeadsFn.apply(wa, ba, *xa)
+        ya = _HeadsFn.apply(None, wa, ba, *xa)
         g = torch.randn_like(ya)
         ya.backward(g)
         xr = [x.float().requires_grad_(True) for x in xs]
@@ -767,6 +767,27 @@ def test_fp32_heads_kernel_matches_fp32_convolutions(ops):
         assert (ba.grad - b.grad).norm() <= 1e-4 * b.grad.norm()
         for u, v in zip(xa, xr):
             assert u.grad.dtype == torch.bfloat16 and (u.grad.float() - v.grad).norm() <= 0.005 * v.grad.norm()   # one bf16 rounding
+
+
+def test_heads_backward_absorbs_the_relu_backward_of_its_inputs(ops):
+    """dsrg_heads_backward_relu_bf16: data gradients masked by x_k > 0 and scaled == the plain ones pushed through
+    ops.relu_bwd_bias' arithmetic (same bits for a power-of-two scale); the bias gradient of the layer below == column sums of
+    what was stored; the weight gradient is untouched"""
+    torch.manual_seed(9)
+    for B, K, H, W, O, n, scale in [(2, 1024, 41, 41, 21, 4, 2.0), (1, 256, 5, 7, 32, 2, 1.0), (3, 512, 9, 15, 3, 1, 2.0)]:
+        xs = [torch.relu(torch.randn(B, K, H, W, device="cuda")).bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(n)]
+        for x in xs:
+            x.permute(0, 2, 3, 1).view(-1)[::53] = -0.0
+        w = torch.randn(n, O, K, device="cuda") * 0.05
+        g = torch.randn(B, O, H, W, device="cuda")
+        plain, gw0 = ops.heads_backward(xs, w, g)
+        got, gw1, gb = ops.heads_backward(xs, w, g, True, scale)
+        assert torch.equal(gw0, gw1) and gb.shape == (n, K) and gb.dtype == torch.float32
+        for k in range(n):
+            want = torch.where(xs[k] > 0, (plain[k].float() * scale).bfloat16(), torch.zeros_like(plain[k]))
+            assert torch.equal(got[k], want)
+            ref_b = want.float().sum((0, 2, 3))
+            assert float((gb[k] - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max()) + 1e-4
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 128), (128, 64), (3, 64)])
