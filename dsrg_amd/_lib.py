@@ -86,6 +86,8 @@ SIGNATURES = {
     "dsrg_bias_grad_bf16": (_i, [_vp, _vp, _vp, _i, ctypes.c_long, _i, _vp]),
     "dsrg_heads_forward_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dsrg_conv3x3_direct_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dsrg_conv3x3_direct_dgrad_workspace": (_sz, [_i]),
+    "dsrg_conv3x3_direct_dgrad_bf16": (_i, [_vp] * 6 + [_sz] + [_i] * 5 + [_vp]),
     "dsrg_conv_igemm_supported": (_i, [_i, _i, _i]),
     "dsrg_conv_igemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _sz,
                                   _vp]),

@@ -72,7 +72,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
-    def forward(ctx, x, weight, bias, dilation, relu, gemm, drop_p, pool=None):
+    def forward(ctx, x, weight, bias, dilation, relu, gemm, drop_p, pool=None, link_in=None, link_out=None):
         k = weight.shape[2]
         cols = None
         # 64 / 128 channels on both sides (conv1_2 at full resolution, conv2_1 / conv2_2 at half): the direct MFMA kernel
@@ -107,6 +107,12 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, out if relu else None, cols, code)
         ctx.dilation, ctx.k, ctx.relu, ctx.scale, ctx.gemm = dilation, k, relu, 1.0 / (1.0 - drop_p), gemm
         ctx.direct, ctx.pool = direct, pool
+        # _GradLink (see below): link_in — x is the ReLU output of the node in front and feeds nothing else; link_out — ours
+        ctx.link_in = link_in if (direct and link_in is not None and link_in.scale == 1.0 and x.shape[1] in (64, 128) and
+                                  x.is_contiguous(memory_format=torch.channels_last)) else None
+        ctx.link_out = link_out if (relu and pool is None and drop_p == 0.0) else None
+        if ctx.link_out is not None:
+            ctx.link_out.scale, ctx.link_out.gb = 1.0, None
         return out if pool is None else pooled
 
     @staticmethod
@@ -116,7 +122,11 @@ class _ConvFn(torch.autograd.Function):
         pad = ctx.dilation * (ctx.k // 2)
         cout = weight.shape[0]
         fused = g.dtype == torch.bfloat16 and ((cout % 8 == 0 and cout <= 2048) or (not ctx.relu and cout <= 256))
-        if ctx.pool is not None:                                        # forward guaranteed bf16, ReLU, no dropout, cout | 2048
+        if ctx.link_out is not None and ctx.link_out.gb is not None:
+            # the consumer's data gradient came masked by this node's ReLU, with the bias gradient beside it
+            gb, ctx.link_out.gb = ctx.link_out.gb, None
+            fused = True
+        elif ctx.pool is not None:                                      # forward guaranteed bf16, ReLU, no dropout, cout | 2048
             from .ops import maxpool3x3_bwd_relu
             g, gb = maxpool3x3_bwd_relu(g, code, y, ctx.pool[0])
             fused = True
@@ -148,8 +158,11 @@ class _ConvFn(torch.autograd.Function):
             gemm_dgrad = True
         elif ctx.direct and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and x.shape[1] in (64, 128):
             # the data gradient is the same convolution with the kernel flipped and its channel axes swapped
-            from .ops import conv3x3_direct
-            gx = conv3x3_direct(g, weight.flip(2, 3).transpose(0, 1), None, False)
+            from .ops import conv3x3_direct, conv3x3_direct_dgrad
+            if _FUSE_CHAIN and ctx.link_in is not None:
+                gx, ctx.link_in.gb = conv3x3_direct_dgrad(g, weight.flip(2, 3).transpose(0, 1), x)
+            else:
+                gx = conv3x3_direct(g, weight.flip(2, 3).transpose(0, 1), None, False)
             gemm_dgrad = True
         elif gemm_dgrad and cout > x.shape[1] and x.shape[1] % 8 == 0 and g.dtype == torch.bfloat16:
             # more output than input channels (fc6: 1024 vs 512): g @ W^T first, then gather the nine taps (col2im) —
@@ -193,7 +206,7 @@ class _ConvFn(torch.autograd.Function):
             gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
                 g, x, weight, None if fused else [weight.shape[0]], [1, 1], [pad, pad],
                 [ctx.dilation, ctx.dilation], False, [0, 0], 1, mask)
-        return (gx if gemm_dgrad else gx2), (gw if gemm_wgrad else gw2), (gb if fused else gb2), None, None, None, None, None
+        return (gx if gemm_dgrad else gx2), (gw if gemm_wgrad else gw2), (gb if fused else gb2), None, None, None, None, None, None, None
 
 
 class _GradLink:
@@ -389,7 +402,12 @@ class GemmConv2d(nn.Conv2d):
                 return out if pool is None or in_node else _pool3x3(out, pool[0], pool[1])
             in_node = pool is not None and _FUSE_POOL and cout % 8 == 0 and 256 % (cout // 8) == 0 and self.bias is not None and (
                 x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16))
-            out = _ConvFn.apply(x, self.weight, self.bias, self.dilation[0], self.fuse_relu, self.gemm, p, pool if in_node else None)
+            lin = getattr(x, "_dsrg_grad_link", None) if self.chain_input else None
+            lout = _GradLink() if (self.fuse_relu and pool is None and p == 0.0 and torch.is_grad_enabled()) else None
+            out = _ConvFn.apply(x, self.weight, self.bias, self.dilation[0], self.fuse_relu, self.gemm, p, pool if in_node else None,
+                                lin, lout)
+            if lout is not None:
+                out._dsrg_grad_link = lout
             return out if pool is None or in_node else _pool3x3(out, pool[0], pool[1])
         out = super().forward(x)
         out = F.relu(out) if self.fuse_relu else out
@@ -521,8 +539,8 @@ class VGG16ASPP(nn.Module):
         super().__init__()
         L = []
         p2 = (2, True)                                                  # pool1-3: 3x3 / stride 2 / pad 1, ceil mode (Caffe), inside the conv node
-        L += _conv_relu(3, 64) + _conv_relu(64, 64, pool=p2)
-        L += _conv_relu(64, 128, 1, gemm_convs) + _conv_relu(128, 128, 1, gemm_convs, pool=p2)
+        L += _conv_relu(3, 64) + _conv_relu(64, 64, pool=p2, chain=True)
+        L += _conv_relu(64, 128, 1, gemm_convs) + _conv_relu(128, 128, 1, gemm_convs, pool=p2, chain=True)
         L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs, chain=True) + \
             _conv_relu(256, 256, 1, gemm_convs, pool=p2, chain=True)
         g = gemm_convs                                                  # the 41x41 stages

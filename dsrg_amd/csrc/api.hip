@@ -491,6 +491,14 @@ extern "C" int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, co
     if (!x_dev || !w_dev || !y_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "bad argument");
     return launch_conv3x3_direct(x_dev, w_dev, bias_dev, y_dev, B, H, W, cin, cout, relu, static_cast<hipStream_t>(stream));
 }
+extern "C" size_t dsrg_conv3x3_direct_dgrad_workspace(int cout) { return conv3x3_direct_colsum_workspace(cout); }
+extern "C" int dsrg_conv3x3_direct_dgrad_bf16(const void *g_dev, const void *w_dev, const void *mask_dev, void *gx_dev,
+                                              float *bias_grad_dev, void *workspace_dev, size_t workspace_bytes, int B, int H, int W,
+                                              int cin, int cout, void *stream) {
+    if (!g_dev || !w_dev || !mask_dev || !gx_dev || !bias_grad_dev) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_conv3x3_direct(g_dev, w_dev, nullptr, gx_dev, B, H, W, cin, cout, 0, static_cast<hipStream_t>(stream), mask_dev,
+                                 bias_grad_dev, workspace_dev, workspace_bytes);
+}
 extern "C" int dsrg_conv_igemm_supported(int cin, int cout, int ksize) { return conv_igemm_supported(cin, cout, ksize) ? 1 : 0; }
 extern "C" int dsrg_conv_igemm_bf16(const void *const *x_dev, const void *const *w_dev, const float *const *bias_dev,
                                     void *const *y_dev, const int *dilation, int ngroups, int B, int H, int W, int cin, int cout,

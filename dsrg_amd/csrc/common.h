@@ -180,7 +180,9 @@ size_t conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout);
 int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspace, size_t workspace_bytes, int B, int H, int W,
                          int cin, int cout, hipStream_t stream);
 int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void *y, int B, int H, int W, int cin, int cout,
-                          int relu, hipStream_t stream);
+                          int relu, hipStream_t stream, const void *mask = nullptr, float *colsum = nullptr,
+                          void *colsum_ws = nullptr, size_t colsum_ws_bytes = 0);
+size_t conv3x3_direct_colsum_workspace(int cout);
 bool conv_igemm_supported(int cin, int cout, int k);
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
                       int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,

@@ -31,6 +31,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void lds_void;
 constexpr int kTH = 8, kTW = 16;             // output tile (pixels): 4 M-tiles of (2 rows x 16 columns)
 constexpr int kHH = kTH + 2, kHW = kTW + 2;  // halo tile
 
@@ -65,6 +66,10 @@ struct ConvArgs {
     const float *bias;      // (COUT) or nullptr
     uint16_t *y;            // (B, H, W, COUT) bf16
     int B, H, W, relu, tiles_x, tiles_y, ntiles;
+    const uint16_t *mask;   // (B, H, W, COUT) bf16 or nullptr: outputs kept where mask > 0, else zeroed — the ReLU backward of the
+                            // layer below when this launch is a data gradient (conv3x3_direct_kernel only)
+    float *colsum;          // (workgroups, COUT) f32 or nullptr: every workgroup's column sums of what it stored (that layer's
+                            // partial bias gradient)
 };
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
@@ -73,7 +78,7 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // v_cvt_pk_bf
     return *reinterpret_cast<uint32_t *>(&b);
 }
 
-template <int CIN, int COUT, int TPW_>
+template <int CIN, int COUT, int TPW_, bool BWD = false>      // BWD: the masked data-gradient form (a.mask / a.colsum)
 __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direct_kernel(ConvArgs a) {
     using C = Cfg<CIN, COUT, TPW_>;
     extern __shared__ __attribute__((aligned(16))) unsigned char conv_lds[];
@@ -143,10 +148,33 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
         park(conv_lds, c);
     }
     __syncthreads();
+    // masked launch: the column sums of this thread's channel group (tid % OVP) over all its tiles live in LDS behind the two
+    // tile buffers (own slot per thread: no barrier) — the kernel has no registers to spare
+    float *csl = reinterpret_cast<float *>(conv_lds + 2 * C::BUF) + tid * 8;
+    if (BWD) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) csl[e] = 0.0f;
+    }
+    // ... and the tile's mask rows are brought into LDS by DMA while the tile is computed (vector v = tid + 256 u of the store
+    // phase at byte 16 v: a wave's 64 lanes land back to back, pixels outside the image read zeros through the descriptor's range)
+    unsigned char *mtile = conv_lds + 2 * C::BUF + 256 * 8 * sizeof(float);
+    const rsrc_t rmask = make_rsrc(a.mask, BWD ? (size_t)a.B * a.H * a.W * COUT * 2 : 0);
     for (; t < a.ntiles; t += gridDim.x) {
         const int tn = t + gridDim.x;
         const bool more = tn < a.ntiles;
         unsigned char *in = conv_lds + cur * C::BUF, *other = conv_lds + (cur ^ 1) * C::BUF;
+        if (BWD) {
+            int b, y0, x0;
+            tile_origin(t, b, y0, x0);
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+            for (int u = 0; u < C::OVT; u++) {
+                const int v = tid + u * 256, px = v / C::OVP, cg = v % C::OVP;
+                const int yy = y0 + (px >> 4), xx = x0 + (px & 15);
+                const uint32_t off = (yy < a.H && xx < a.W) ? (uint32_t)((b * a.H + yy) * a.W + xx) * (uint32_t)(COUT * 2) + (uint32_t)(cg * 16) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rmask, (lds_void *)(mtile + (u * 256 + wv * 64) * 16), 16, off, 0, 0, 0);
+            }
+        }
         f32x16 acc[C::MT][C::TPW];
 #pragma unroll
         for (int mt = 0; mt < C::MT; mt++) {
@@ -210,33 +238,75 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
                 }
             }
         }
+        if (BWD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's mask rows have landed (it reads back its own)
         __syncthreads();
         {
             int b, y0, x0;
             tile_origin(t, b, y0, x0);
+            float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < C::OVT; u++) {                   // 128 pixels x OVP vectors of 16 bytes
                 const int v = tid + u * 256, px = v / C::OVP, cg = v % C::OVP;
                 const int yy = y0 + (px >> 4), xx = x0 + (px & 15);
+                uint4 val = *reinterpret_cast<const uint4 *>(ot + px * C::OUT_STRIDE + cg * 16);
+                if (BWD) {
+                    uint32_t w4[4] = {val.x, val.y, val.z, val.w};
+                    const uint4 mkv = *reinterpret_cast<const uint4 *>(mtile + v * 16);
+                    const uint32_t y4[4] = {mkv.x, mkv.y, mkv.z, mkv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        w4[e] &= ((int16_t)(y4[e] & 0xffffu) > 0 ? 0x0000ffffu : 0u) | ((int32_t)y4[e] >= 0x10000 ? 0xffff0000u : 0u);
+                        cs[2 * e] += __uint_as_float(w4[e] << 16);          // (pixels outside the image: mask 0)
+                        cs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+                    }
+                    val = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
                 if (yy < a.H && xx < a.W)
-                    *reinterpret_cast<uint4 *>(a.y + (((size_t)b * a.H + yy) * a.W + xx) * COUT + cg * 8) =
-                        *reinterpret_cast<const uint4 *>(ot + px * C::OUT_STRIDE + cg * 16);
+                    *reinterpret_cast<uint4 *>(a.y + (((size_t)b * a.H + yy) * a.W + xx) * COUT + cg * 8) = val;
+            }
+            if (BWD) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) csl[e] += cs[e];
             }
         }
         __syncthreads();                                         // this buffer is free for the tile after next
         cur ^= 1;
     }
+    if (BWD) {                                                   // one partial bias row per workgroup, fixed order
+        const float *red = reinterpret_cast<const float *>(conv_lds + 2 * C::BUF);        // [256 threads][8]
+        __syncthreads();
+        if (tid < COUT) {
+            const int cg = tid >> 3, e = tid & 7;
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 4
+            for (int i = 0; i < 256 / C::OVP; i += 2) {
+                s0 += red[(cg + C::OVP * i) * 8 + e];
+                s1 += red[(cg + C::OVP * (i + 1)) * 8 + e];
+            }
+            a.colsum[(size_t)blockIdx.x * COUT + tid] = s0 + s1;
+        }
+    }
 }
 
 template <int CIN, int COUT, int TPW_>
+int variant_grid(const ConvArgs &a, int n_cus) {
+    const int slots = n_cus * Cfg<CIN, COUT, TPW_>::WGS;
+    return a.ntiles < slots ? a.ntiles : slots;
+}
+template <int CIN, int COUT, int TPW_>
 int launch_variant(const ConvArgs &a, int n_cus, hipStream_t stream) {
     using C = Cfg<CIN, COUT, TPW_>;
-    static LdsGrant grant;
-    const size_t lds = 2 * (size_t)C::BUF;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_direct_kernel<CIN, COUT, TPW_>), lds, grant)) return rc;
-    const int slots = n_cus * C::WGS;                            // persistent: one or two workgroups per CU
-    const int grid = a.ntiles < slots ? a.ntiles : slots;
-    hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT, TPW_>), dim3(grid), dim3(256), lds, stream, a);
+    static LdsGrant grant, grant_b;
+    const int grid = variant_grid<CIN, COUT, TPW_>(a, n_cus);    // persistent: one or two workgroups per CU
+    if (a.mask) {                                                // masked data gradient: + 8 KB of column sums
+        const size_t lds = 2 * (size_t)C::BUF + 256 * 8 * sizeof(float) + (size_t)kTH * kTW * COUT * 2;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_direct_kernel<CIN, COUT, TPW_, true>), lds, grant_b)) return rc;
+        hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT, TPW_, true>), dim3(grid), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = 2 * (size_t)C::BUF;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_direct_kernel<CIN, COUT, TPW_>), lds, grant)) return rc;
+        hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT, TPW_>), dim3(grid), dim3(256), lds, stream, a);
+    }
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
@@ -765,11 +835,20 @@ bool conv3x3_direct_supported(int cin, int cout) {
     return ((cin == 64 || cin == 128) && (cout == 64 || cout == 128)) || (cin == 3 && cout == 64);
 }
 
+size_t conv3x3_direct_colsum_workspace(int cout) { return (size_t)2 * device_cus() * (size_t)cout * sizeof(float); }
+
 int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void *y, int B, int H, int W, int cin, int cout,
-                          int relu, hipStream_t stream) {
+                          int relu, hipStream_t stream, const void *mask, float *colsum, void *colsum_ws, size_t colsum_ws_bytes) {
     if (!conv3x3_direct_supported(cin, cout))
         return set_error(DSRG_ERR_INVALID, "conv3x3_direct: %d -> %d channels is not one of 64/128 -> 64/128 or 3 -> 64", cin, cout);
+    if ((mask || colsum) && (cin == 3 || !mask || !colsum))
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv3x3_direct: the masked form takes 64 / 128 channels, mask and bias gradient together");
+    if (mask && (long long)B * H * W * cout * 2 >= 0x7fffffffLL)
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv3x3_direct: mask too large for a 32-bit buffer offset");
+    if (colsum && (!colsum_ws || colsum_ws_bytes < conv3x3_direct_colsum_workspace(cout)))
+        return set_error(DSRG_ERR_INVALID, "conv3x3_direct: column-sum scratch missing or too small");
     ConvArgs a;
+    a.mask = static_cast<const uint16_t *>(mask); a.colsum = colsum ? static_cast<float *>(colsum_ws) : nullptr;
     a.x = static_cast<const uint16_t *>(x); a.w = static_cast<const uint16_t *>(w); a.bias = bias;
     a.y = static_cast<uint16_t *>(y); a.B = B; a.H = H; a.W = W; a.relu = relu ? 1 : 0;
     a.tiles_x = (W + kTW - 1) / kTW; a.tiles_y = (H + kTH - 1) / kTH;
@@ -785,9 +864,18 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
     // 64 -> 64: one output tile per wave (144 weight VGPRs) and two workgroups per CU by default — the halo loads of a
     // workgroup are its only memory parallelism (24 KB in flight), a second one doubles it; DSRG_CONV_OCC=1: two tiles per wave
     static const bool occ2 = [] { const char *e = getenv("DSRG_CONV_OCC"); return !(e && !strcmp(e, "1")); }();
-    if (cin == 64 && cout == 64 && occ2) return launch_variant<64, 64, 1>(a, n_cus, stream);
-    if (cin == 64) return cout == 64 ? launch_variant<64, 64, 2>(a, n_cus, stream) : launch_variant<64, 128, 2>(a, n_cus, stream);
-    return cout == 64 ? launch_variant<128, 64, 1>(a, n_cus, stream) : launch_variant<128, 128, 1>(a, n_cus, stream);
+    int rc, grid;
+    // (the masked form of the two-workgroup variant spills a few loop-invariant addresses — 281 against 267 us for conv1_2's data
+    // gradient + the separate pass; two tiles per wave does not)
+    if (cin == 64 && cout == 64 && occ2 && !mask) { rc = launch_variant<64, 64, 1>(a, n_cus, stream); grid = variant_grid<64, 64, 1>(a, n_cus); }
+    else if (cin == 64 && cout == 64) { rc = launch_variant<64, 64, 2>(a, n_cus, stream); grid = variant_grid<64, 64, 2>(a, n_cus); }
+    else if (cin == 64) { rc = launch_variant<64, 128, 2>(a, n_cus, stream); grid = variant_grid<64, 128, 2>(a, n_cus); }
+    else if (cout == 64) { rc = launch_variant<128, 64, 1>(a, n_cus, stream); grid = variant_grid<128, 64, 1>(a, n_cus); }
+    else { rc = launch_variant<128, 128, 1>(a, n_cus, stream); grid = variant_grid<128, 128, 1>(a, n_cus); }
+    if (rc || !colsum) return rc;
+    const float *parts[1] = {a.colsum};
+    float *outs[1] = {colsum};
+    return launch_igemm_colsum(parts, outs, 1, grid, cout, stream);
 }
 
 }  // namespace dsrg

@@ -412,6 +412,28 @@ def conv3x3_direct(x, weight, bias=None, relu=False):
     return y
 
 
+def conv3x3_direct_dgrad(g, weight_t, mask):
+    """conv3x3_direct(g, weight_t) — weight_t the flipped, channel-swapped kernel, 64 / 128 channels either side — with the ReLU
+    backward of the layer below in the store: mask (B,cout,H,W) bf16 channels_last, that layer's output -> (gx bf16 masked by
+    mask > 0, the layer's bias gradient (cout) f32)"""
+    B, C, H, W = g.shape
+    cl = torch.channels_last
+    cout = weight_t.shape[0]
+    if not (g.is_cuda and g.dtype == torch.bfloat16 and weight_t.dtype == torch.bfloat16 and tuple(weight_t.shape) == (cout, C, 3, 3)
+            and C in DIRECT_CONV_CHANNELS and cout in DIRECT_CONV_CHANNELS and mask.dtype == torch.bfloat16
+            and tuple(mask.shape) == (B, cout, H, W) and mask.is_contiguous(memory_format=cl)):
+        raise ValueError("conv3x3_direct_dgrad needs bf16 CUDA tensors, 64 / 128 channels, a channels_last mask of the output's shape")
+    g = g if g.is_contiguous(memory_format=cl) else g.contiguous(memory_format=cl)
+    w = weight_t if weight_t.is_contiguous(memory_format=cl) else weight_t.contiguous(memory_format=cl)
+    L = _lib.lib()
+    gx = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=g.device, memory_format=cl)
+    gb = torch.empty(cout, dtype=torch.float32, device=g.device)
+    ws = torch.empty(L.dsrg_conv3x3_direct_dgrad_workspace(cout), dtype=torch.uint8, device=g.device)
+    check(L.dsrg_conv3x3_direct_dgrad_bf16(_ptr(g), _ptr(w), _ptr(mask), _ptr(gx), _ptr(gb), _ptr(ws), ws.numel(), B, H, W, C, cout,
+                                           _stream()))
+    return gx, gb
+
+
 WGRAD_CONV_SHAPES = ((3, 64), (64, 64), (64, 128), (128, 128))      # (cin, cout)
 _wgrad_ws = {}
 

@@ -260,6 +260,12 @@ int dsrg_avgpool3x3_s1_bf16(const void *in_dev, void *out_dev, int B, int H, int
  * channel axes swapped the same call is the data gradient of that convolution.  Other channel counts: DSRG_ERR_INVALID. */
 int dsrg_conv3x3_direct_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int B, int H, int W,
                              int cin, int cout, int relu, void *stream);
+/* The data-gradient form with the ReLU backward of the layer below in its store (cin, cout in {64, 128}): gx = conv(g, w) where
+ * mask_dev (B,H,W,cout) bf16 — that layer's output — is positive, else 0; bias_grad_dev (cout f32) = sum over pixels of gx
+ * (fixed summation order).  workspace_dev: dsrg_conv3x3_direct_dgrad_workspace(cout) bytes. */
+size_t dsrg_conv3x3_direct_dgrad_workspace(int cout);
+int dsrg_conv3x3_direct_dgrad_bf16(const void *g_dev, const void *w_dev, const void *mask_dev, void *gx_dev, float *bias_grad_dev,
+                                   void *workspace_dev, size_t workspace_bytes, int B, int H, int W, int cin, int cout, void *stream);
 /* Weight gradient of the same convolution for (cin, cout) in {(3, 64), (64, 64), (64, 128), (128, 128)}:
  *   gw[o][dy+1][dx+1][c] = sum_{b,y,x} g[b,y,x,o] * x[b,y+dy,x+dx,c]      (zero padding)
  * x_dev (B,H,W,cin) and g_dev (B,H,W,cout) NHWC bf16; gw_dev (cout, 3, 3, cin) bf16 = the memory of a channels_last

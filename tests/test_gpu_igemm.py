@@ -296,16 +296,18 @@ def _grads(net, x, gout, amp=True, seed=11):
     return y.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}, gout
 
 
-def test_conv_chain_fusion_is_bit_identical_for_3x3_chains():
+@pytest.mark.parametrize("widths,size", [((256, 256, 512, 256), 41), ((64, 64, 64), 97), ((64, 128, 128), 50), ((128, 128, 64, 64), 33)])
+def test_conv_chain_fusion_is_bit_identical_for_3x3_chains(widths, size):
     """conv -> ReLU -> conv -> ReLU -> conv (GemmConv2d(chain_input=True)): the upper layer's data gradient with the lower
     layer's ReLU backward and bias gradient folded in (backbone._GradLink) against the separate relu_bwd_bias passes: masked
     gradients are the same bits, so weight gradients are equal and bias gradients agree to the fp32 summation order"""
     from dsrg_amd import backbone
     torch.manual_seed(5)
     G = backbone.GemmConv2d
-    net = torch.nn.Sequential(G(256, 256, 3, padding=1, fuse_relu=True), G(256, 512, 3, padding=2, dilation=2, fuse_relu=True, chain_input=True),
-                              G(512, 256, 3, padding=1, fuse_relu=True, chain_input=True)).cuda().to(memory_format=CL)
-    x = torch.randn(4, 256, 41, 41, device="cuda").contiguous(memory_format=CL).requires_grad_(True)
+    wide = widths[0] >= 256                                              # implicit-GEMM route (dilation on the middle layer) / direct kernels
+    net = torch.nn.Sequential(*[G(a, b, 3, padding=2 if (wide and i == 1) else 1, dilation=2 if (wide and i == 1) else 1, fuse_relu=True,
+                                  chain_input=i > 0) for i, (a, b) in enumerate(zip(widths[:-1], widths[1:]))]).cuda().to(memory_format=CL)
+    x = torch.randn(4, widths[0], size, size, device="cuda").contiguous(memory_format=CL).requires_grad_(True)
     res, gout = {}, None
     try:
         for tag, on in (("fused", True), ("separate", False)):

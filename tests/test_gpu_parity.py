@@ -769,6 +769,27 @@ def test_fp32_heads_kernel_matches_fp32_convolutions(ops):
             assert u.grad.dtype == torch.bfloat16 and (u.grad.float() - v.grad).norm() <= 0.005 * v.grad.norm()   # one bf16 rounding
 
 
+@pytest.mark.parametrize("cf,cb", [(64, 64), (128, 128), (128, 64), (64, 128)])
+def test_direct_conv_data_gradient_absorbs_the_relu_backward(ops, cf, cb):
+    """dsrg_conv3x3_direct_dgrad_bf16 == the plain direct convolution masked by (output of the layer below > 0) afterwards, and the
+    bias gradient == the column sums of what was stored; ragged tiles, more tiles than workgroups"""
+    torch.manual_seed(21)
+    cl = torch.channels_last
+    for B, H, W in [(2, 33, 29), (1, 8, 16), (3, 161, 161)]:
+        g = torch.randn(B, cf, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        wt = (torch.randn(cb, cf, 3, 3, device="cuda") * 0.05).bfloat16()
+        y = torch.relu(torch.randn(B, cb, H, W, device="cuda")).bfloat16().contiguous(memory_format=cl)
+        y.permute(0, 2, 3, 1).view(-1)[::41] = -0.0
+        plain = ops.conv3x3_direct(g, wt, None, False)
+        got, gb = ops.conv3x3_direct_dgrad(g, wt, y)
+        want = torch.where(y > 0, plain, torch.zeros_like(plain))
+        assert torch.equal(got, want) and got.is_contiguous(memory_format=cl)
+        ref_b = want.float().sum((0, 2, 3))
+        assert gb.dtype == torch.float32 and float((gb - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max()) + 1e-4
+        got2, gb2 = ops.conv3x3_direct_dgrad(g, wt, y)
+        assert torch.equal(got, got2) and torch.equal(gb, gb2)                        # deterministic
+
+
 def test_heads_backward_absorbs_the_relu_backward_of_its_inputs(ops):
     """dsrg_heads_backward_relu_bf16: data gradients masked by x_k > 0 and scaled == the plain ones pushed through
     ops.relu_bwd_bias' arithmetic (same bits for a power-of-two scale); the bias gradient of the layer below == column sums of
