@@ -626,14 +626,6 @@ __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float *__restri
             }
             __syncthreads();
             if (!live) continue;
-            uint4 yk[8];
-            if (MASK) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int m = m0 + rh * 8 + r;
-                    yk[r] = m < M ? *reinterpret_cast<const uint4 *>(hm.y[k] + (size_t)m * K + (size_t)cg * 8) : make_uint4(0, 0, 0, 0);
-                }
-            }
             float acc[8][8];
 #pragma unroll
             for (int r = 0; r < 8; r++)
@@ -651,14 +643,24 @@ __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float *__restri
 #pragma unroll
                     for (int c = 0; c < 8; c++) acc[r][c] = __builtin_fmaf(gf[r], wf[c], acc[r][c]);
             }
+            // (mask rows fetched four at a time behind the fma loop: holding all eight through it costs the kernel half its waves)
+            uint4 yk[4];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int m = m0 + rh * 8 + r;
+                if (MASK && (r & 3) == 0) {
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; r2++) {
+                        const int m2 = m + r2;
+                        yk[r2] = m2 < M ? *reinterpret_cast<const uint4 *>(hm.y[k] + (size_t)m2 * K + (size_t)cg * 8) : make_uint4(0, 0, 0, 0);
+                    }
+                }
                 uint32_t o4[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     if (MASK) {
-                        const uint32_t y = e == 0 ? yk[r].x : e == 1 ? yk[r].y : e == 2 ? yk[r].z : yk[r].w;
+                        const uint4 yr = yk[r & 3];
+                        const uint32_t y = e == 0 ? yr.x : e == 1 ? yr.y : e == 2 ? yr.z : yr.w;
                         const uint32_t keep = ((int16_t)(y & 0xffffu) > 0 ? 0x0000ffffu : 0u) | ((int32_t)y >= 0x10000 ? 0xffff0000u : 0u);
                         o4[e] = pack_bf16(acc[r][2 * e] * hm.scale, acc[r][2 * e + 1] * hm.scale) & keep;
                         cs[2 * e] += __uint_as_float(o4[e] << 16);                 // (rows past the end: mask 0)
@@ -970,8 +972,14 @@ int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float 
 // loads hide behind the other's MFMAs; capped so that the partial sums stay small (chunks x n x O x K floats)
 int heads_bwd_chunks(int M) { int c = (M + 255) / 256; return c < 1 ? 1 : (c > 128 ? 128 : c); }
 
-constexpr int kHeadMaskTiles = 8;      // 128 rows per workgroup of the masked data gradient: one partial bias row each
+// 16-row tiles per workgroup of the masked data gradient (one partial bias row each): fewer rows per workgroup = more of them
+// in flight, more partial rows to write and sum (DSRG_HEAD_TILES overrides, tools only)
+static int head_mask_tiles() {
+    static const int t = [] { const char *e = getenv("DSRG_HEAD_TILES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 8; }();
+    return t;
+}
 size_t heads_bwd_relu_workspace(int nbr, int M, int K) {
+    const int kHeadMaskTiles = head_mask_tiles();
     return (size_t)nbr * ((M + 16 * kHeadMaskTiles - 1) / (16 * kHeadMaskTiles)) * (size_t)K * sizeof(float);
 }
 
@@ -984,6 +992,7 @@ int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float 
     if (gx && relu_scale > 0.0f) {
         HeadMask hm;
         for (int k = 0; k < 4; k++) hm.y[k] = static_cast<const uint16_t *>(x[k < nbr ? k : 0]);
+        const int kHeadMaskTiles = head_mask_tiles();
         hm.tiles = kHeadMaskTiles; hm.scale = relu_scale;
         const int nblk = (M + 16 * kHeadMaskTiles - 1) / (16 * kHeadMaskTiles);
         if (!bias_grad || !colsum_ws || colsum_ws_bytes < heads_bwd_relu_workspace(nbr, M, K))
