@@ -26,6 +26,7 @@ python tools/rocpd_stats.py /tmp/prof_t/train_results.db 70 20 avgpool3x3_s1 2 >
 python tools/rocpd_stats.py /tmp/prof_s/sup_results.db 40 20 sup_grad_kernel > $OUT/sup_kernel_stats.txt 2>&1
 python tools/rocpd_stats.py /tmp/prof_f/fr_results.db 40 > $OUT/fullres_kernel_stats.txt 2>&1
 timeout 500 python tools/igemm_probe.py --rounds 3 --iters 10 2>&1 | grep -v amdgpu > $OUT/igemm_probe.txt
+{ timeout 200 python tools/direct_dgrad_probe.py; timeout 200 python tools/heads_bwd_probe.py; } 2>&1 | grep -v amdgpu > $OUT/fused_backward_probe.txt
 { timeout 400 python tools/parity_sweep.py 30; timeout 400 python tools/parity_sweep_crf.py 60; timeout 600 python tools/parity_sweep_shapes.py 40; } 2>&1 | grep -v amdgpu > $OUT/parity_sweeps.txt
 python tools/filter_trace.py 16 2>&1 | grep -v amdgpu > $OUT/filter_trace.txt
 timeout 200 python tools/pylayers_route_cost.py 16 2>&1 | tail -1 > $OUT/pylayers_route.txt
