@@ -122,9 +122,10 @@ class _ConvFn(torch.autograd.Function):
         pad = ctx.dilation * (ctx.k // 2)
         cout = weight.shape[0]
         fused = g.dtype == torch.bfloat16 and ((cout % 8 == 0 and cout <= 2048) or (not ctx.relu and cout <= 256))
-        if ctx.link_out is not None and ctx.link_out.gb is not None:
+        gb_left = ctx.link_out.take(g) if ctx.link_out is not None else None
+        if gb_left is not None:
             # the consumer's data gradient came masked by this node's ReLU, with the bias gradient beside it
-            gb, ctx.link_out.gb = ctx.link_out.gb, None
+            gb = gb_left
             fused = True
         elif ctx.pool is not None:                                      # forward guaranteed bf16, ReLU, no dropout, cout | 2048
             from .ops import maxpool3x3_bwd_relu
@@ -160,7 +161,8 @@ class _ConvFn(torch.autograd.Function):
             # the data gradient is the same convolution with the kernel flipped and its channel axes swapped
             from .ops import conv3x3_direct, conv3x3_direct_dgrad
             if _FUSE_CHAIN and ctx.link_in is not None:
-                gx, ctx.link_in.gb = conv3x3_direct_dgrad(g, weight.flip(2, 3).transpose(0, 1), x)
+                gx, gb_below = conv3x3_direct_dgrad(g, weight.flip(2, 3).transpose(0, 1), x)
+                ctx.link_in.leave(gx, gb_below)
             else:
                 gx = conv3x3_direct(g, weight.flip(2, 3).transpose(0, 1), None, False)
             gemm_dgrad = True
@@ -214,10 +216,28 @@ class _GradLink:
     node's ReLU (+ Dropout) backward and bias gradient folded into its store (ops.conv_igemm_dgrad), it leaves the bias gradient
     here and the lower node's backward takes the incoming gradient as already masked.  Only wired where the model declares the
     lower node's output to have this one consumer (GemmConv2d(chain_input=True); VGG16ASPP's fc6 -> fc7)."""
-    __slots__ = ("scale", "gb")
+    __slots__ = ("scale", "gb", "ptr", "version")
 
     def __init__(self):
-        self.scale, self.gb = 1.0, None
+        self.scale, self.gb, self.ptr, self.version = 1.0, None, 0, -1
+
+    def leave(self, gx, gb):
+        """upper node: gx is the masked (and scaled) data gradient it returns for the lower node's output, gb that node's bias gradient"""
+        self.gb, self.ptr, self.version = gb, gx.data_ptr(), gx._version
+
+    def take(self, g):
+        """lower node: the bias gradient if g is exactly the tensor the upper node left (autograd hands a lone gradient through
+        untouched; had the output a second consumer after all, the sum would be another tensor or a later version of this one),
+        else None — the caller then runs its own ReLU backward, which is still right on a masked gradient unless a Dropout
+        scale was applied with it"""
+        gb, self.gb = self.gb, None
+        if gb is None:
+            return None
+        if g.data_ptr() == self.ptr and g._version == self.version:
+            return gb
+        if self.scale != 1.0:
+            raise RuntimeError("chain_input: the output of a conv + ReLU + Dropout node declared to have one consumer has several")
+        return None
 
 
 _FUSE_CHAIN = _os.environ.get("DSRG_FUSE_CHAIN", "1") != "0"
@@ -293,10 +313,10 @@ class _IgemmConvFn(torch.autograd.Function):
         cl = torch.channels_last
         for i, g in enumerate(gs):
             lk = ctx.links_out[i] if ctx.links_out is not None else None
-            if lk is not None and lk.gb is not None:
+            gb_left = lk.take(g) if lk is not None else None
+            if gb_left is not None:
                 # the consumer's data gradient came masked by this node's ReLU (+ Dropout) with the bias gradient beside it
-                gm, gb = g, lk.gb
-                lk.gb = None
+                gm, gb = g, gb_left
             elif ctx.pool is not None:
                 gm, gb = maxpool3x3_bwd_relu(g, code, ys[i], ctx.pool[0])
             elif ctx.relu:
@@ -313,8 +333,8 @@ class _IgemmConvFn(torch.autograd.Function):
         if absorb:
             packs_d = [p if p is not None else pack_conv_weight(w, for_dgrad=True) for p, w in zip(ctx.packs_d, ws)]
             gxs, gb_below = conv_igemm_dgrad(gms, packs_d, list(xs), ctx.dils, ctx.k, ctx.links_in[0].scale)
-            for lk, gb_ in zip(ctx.links_in, gb_below):
-                lk.gb = gb_
+            for lk, gx_, gb_ in zip(ctx.links_in, gxs, gb_below):
+                lk.leave(gx_, gb_)
         if ctx.k == 1:
             for i in range(n):
                 if absorb:
@@ -446,7 +466,8 @@ class _MaxPool3x3Fn(torch.autograd.Function):
         from .ops import maxpool3x3_bwd, maxpool3x3_bwd_relu
         code, x = ctx.saved_tensors
         if _FUSE_CHAIN and ctx.link_in is not None and g.dtype == torch.bfloat16:
-            gin, ctx.link_in.gb = maxpool3x3_bwd_relu(g, code, x, ctx.stride)
+            gin, gb_below = maxpool3x3_bwd_relu(g, code, x, ctx.stride)
+            ctx.link_in.leave(gin, gb_below)
             return gin, None, None, None
         return maxpool3x3_bwd(g, code, ctx.in_shape, ctx.stride), None, None, None
 
@@ -536,7 +557,7 @@ class _HeadsFn(torch.autograd.Function):
         if _FUSE_CHAIN and ctx.links is not None and all(ctx.needs_input_grad[3:]):
             gxs, gw, gb_below = heads_backward(xs, weight, g, True, ctx.links[0].scale)
             for i, lk in enumerate(ctx.links):
-                lk.gb = gb_below[i]
+                lk.leave(gxs[i], gb_below[i])
         else:
             gxs, gw = heads_backward(xs, weight, g, need_gx=any(ctx.needs_input_grad[3:]))
         gb1 = g.sum((0, 2, 3))                                            # fp32, the same for every branch

@@ -351,3 +351,30 @@ def test_backbone_chain_fusion_matches_the_separate_backward_passes():
             assert torch.equal(a, ref), n
         else:
             assert rel(a, ref) < (1e-3 if top else 0.03), (n, rel(a, ref))
+
+
+@pytest.mark.parametrize("width", [64, 256])
+def test_chain_link_declines_when_the_output_has_a_second_consumer(width):
+    """GemmConv2d(chain_input=True) is a promise that the input feeds nothing else.  If it does after all, autograd hands the lower
+    node the SUM of the gradients — not the tensor the upper node left — and the node runs its own ReLU backward on it (right on an
+    already masked part, right on the rest): same gradients as with the separate passes"""
+    from dsrg_amd import backbone
+    torch.manual_seed(8)
+    G = backbone.GemmConv2d
+    a = G(width, width, 3, padding=1, fuse_relu=True).cuda().to(memory_format=CL)
+    b = G(width, width, 3, padding=1, fuse_relu=True, chain_input=True).cuda().to(memory_format=CL)
+    x = torch.randn(2, width, 41, 41, device="cuda").contiguous(memory_format=CL)
+    res = {}
+    try:
+        for tag, on in (("fused", True), ("separate", False)):
+            backbone._FUSE_CHAIN = on
+            a.zero_grad(set_to_none=True); b.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y1 = a(x)
+                y2 = b(y1)
+            (y2.float().sum() + 0.5 * y1.float().square().sum()).backward()
+            res[tag] = [p.grad.clone() for p in list(a.parameters()) + list(b.parameters())]
+    finally:
+        backbone._FUSE_CHAIN = True
+    for u, v in zip(res["fused"], res["separate"]):
+        assert float((u - v).norm()) <= 2e-3 * float(v.norm()) + 1e-6
