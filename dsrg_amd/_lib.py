@@ -100,6 +100,8 @@ SIGNATURES = {
     "dsrg_conv_igemm_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_conv3x3_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dsrg_conv3x3_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    "dsrg_conv3x3_wgrad_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    "dsrg_pack_conv_weight_direct_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "dsrg_heads_backward_chunks": (_i, [_i]),
     "dsrg_heads_backward_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dsrg_heads_backward_relu_workspace": (_sz, [_i] * 3),

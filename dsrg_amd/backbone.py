@@ -19,6 +19,7 @@ _WGRAD_MIN_COUT = int(_os.environ.get("DSRG_WGRAD_MIN_COUT", "512"))
 # conv1_2 / conv2_1 / conv2_2 by the direct MFMA kernel: "1" all of them, "64" only conv1_2, "0" none (MIOpen / im2col + GEMM)
 _DIRECT_CONV = _os.environ.get("DSRG_DIRECT_CONV", "1")
 _DIRECT_C3 = _os.environ.get("DSRG_DIRECT_C3", "1") == "1"          # conv1_1 (3 -> 64) forward with bias + ReLU in one pass (0: MIOpen + 2 passes)
+_DIRECT_FN = _os.environ.get("DSRG_DIRECT_FN", "1") == "1"         # conv1_1 … conv2_2 take the float32 master parameters (_DirectConvFn; 0: through autocast's casts)
 _FUSE_POOL = _os.environ.get("DSRG_FUSE_POOL", "1") == "1"           # pool1-3 inside the conv node: pool backward + ReLU mask + bias gradient in one pass
 _GEMM_1X1_BWD = _os.environ.get("DSRG_GEMM_1X1_BWD", "1") == "1"   # 1x1 layers (fc7): both gradients as hipBLASLt GEMMs (0: MIOpen/CK)
 _DIRECT_WGRAD = _os.environ.get("DSRG_DIRECT_WGRAD", "1") == "1"   # their weight gradients by the direct kernel too (0: MIOpen)
@@ -365,6 +366,79 @@ class _IgemmConvFn(torch.autograd.Function):
         return (None,) * 8 + tuple(gx if nx else None for gx, nx in zip(gxs, need_x)) + tuple(gws) + tuple(gbs)
 
 
+class _DirectConvFn(torch.autograd.Function):
+    """conv1_1 … conv2_2 (3 / 64 / 128 channels at 321x321 and 161x161) + bias + ReLU (+ the stride-2 max pool) on the direct
+    kernels with the float32 MASTER parameters as inputs, as _IgemmConvFn takes them: one pass makes both bf16 kernels (forward;
+    flipped + transposed for the data gradient), the bias is read as it is, weight and bias gradients come back in float32 —
+    autocast's casts (kernel and bias down, both gradients up), the flip and its copy are gone: five small launches per layer.
+    apply(x, weight, bias, relu, pool, link_in, link_out); links as in _IgemmConvFn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, pool, link_in, link_out):
+        from .ops import conv3x3_direct, pack_direct_weight_pair, maxpool3x3_fwd
+        x = x if x.dtype == torch.bfloat16 else x.bfloat16()
+        cl = torch.channels_last
+        x = x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl)
+        if weight.shape[1] == 3:
+            w16, wd = weight.detach().to(torch.bfloat16), None                            # the image needs no gradient
+        else:
+            w16, wd = pack_direct_weight_pair(weight, ctx.needs_input_grad[0])
+        out = conv3x3_direct(x, w16, bias.detach(), relu)
+        code, pooled = None, None
+        if pool is not None:
+            pooled, code = maxpool3x3_fwd(out, pool[0], pool[1])
+        ctx.save_for_backward(x, out if relu else None, code)
+        ctx.wd = wd                                    # not an input or output of the node: kept outside save_for_backward
+        ctx.relu, ctx.pool = relu, pool
+        ctx.link_in = link_in if (link_in is not None and link_in.scale == 1.0 and wd is not None) else None
+        ctx.link_out = link_out if (relu and pool is None) else None
+        if ctx.link_out is not None:
+            ctx.link_out.scale, ctx.link_out.gb = 1.0, None
+        return out if pool is None else pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import conv3x3_direct, conv3x3_direct_dgrad, conv3x3_wgrad, relu_bwd_bias, bias_grad, maxpool3x3_bwd_relu
+        x, y, code = ctx.saved_tensors
+        gb = ctx.link_out.take(g) if ctx.link_out is not None else None
+        if gb is not None:
+            pass                                       # g came masked by this node's ReLU, its bias gradient beside it
+        elif ctx.pool is not None:
+            g, gb = maxpool3x3_bwd_relu(g, code, y, ctx.pool[0])
+        elif ctx.relu:
+            g, gb = relu_bwd_bias(g, y, 1.0)
+        else:
+            g = g.contiguous(memory_format=torch.channels_last)
+            gb = bias_grad(g)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if _FUSE_CHAIN and ctx.link_in is not None:
+                gx, gb_below = conv3x3_direct_dgrad(g, ctx.wd, x)
+                ctx.link_in.leave(gx, gb_below)
+            else:
+                gx = conv3x3_direct(g, ctx.wd, None, False)
+        gw = conv3x3_wgrad(x, g, torch.float32)
+        return gx, gw, gb, None, None, None, None
+
+
+def _direct_route(conv, x, p, pool):
+    """does this GemmConv2d call take _DirectConvFn: one of the four narrow full-resolution layers with float32 channels_last
+    master parameters under bf16 autocast, every direct kernel enabled, no Dropout, a pool only if it rides in the node"""
+    from .ops import WGRAD_CONV_SHAPES
+    cin, cout = conv.in_channels, conv.out_channels
+    if not (_DIRECT_FN and _DIRECT_CONV == "1" and _DIRECT_C3 and _DIRECT_WGRAD and conv.kernel_size == (3, 3) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is not None and (cin, cout) in WGRAD_CONV_SHAPES and p == 0.0):
+        return False
+    if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
+        return False
+    w = conv.weight
+    if not (w.dtype == torch.float32 and conv.bias.dtype == torch.float32 and w.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    if cin == 3 and x.requires_grad and torch.is_grad_enabled():      # no direct data gradient into three channels (the image needs none)
+        return False
+    return pool is None or (_FUSE_POOL and 256 % (cout // 8) == 0)
+
+
 _IGEMM_MIN_TILES = int(_os.environ.get("DSRG_IGEMM_MIN_TILES", "64"))
 
 
@@ -420,6 +494,13 @@ class GemmConv2d(nn.Conv2d):
                 if lout is not None:
                     out._dsrg_grad_link = lout
                 return out if pool is None or in_node else _pool3x3(out, pool[0], pool[1])
+            if _direct_route(self, x, p, pool):
+                lin = getattr(x, "_dsrg_grad_link", None) if self.chain_input else None
+                lout = _GradLink() if (self.fuse_relu and pool is None and torch.is_grad_enabled()) else None
+                out = _DirectConvFn.apply(x, self.weight, self.bias, self.fuse_relu, pool, lin, lout)
+                if lout is not None:
+                    out._dsrg_grad_link = lout
+                return out
             in_node = pool is not None and _FUSE_POOL and cout % 8 == 0 and 256 % (cout // 8) == 0 and self.bias is not None and (
                 x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16))
             lin = getattr(x, "_dsrg_grad_link", None) if self.chain_input else None

@@ -547,6 +547,17 @@ extern "C" int dsrg_conv3x3_wgrad_bf16(const void *x_dev, const void *g_dev, voi
     return launch_conv3x3_wgrad(x_dev, g_dev, gw_dev, static_cast<float *>(workspace_dev), workspace_bytes, B, H, W, cin, cout,
                                 static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_conv3x3_wgrad_f32(const void *x_dev, const void *g_dev, float *gw_dev, void *workspace_dev, size_t workspace_bytes,
+                                      int B, int H, int W, int cin, int cout, void *stream) {
+    if (!x_dev || !g_dev || !gw_dev || !workspace_dev) return set_error(DSRG_ERR_INVALID, "bad argument");
+    return launch_conv3x3_wgrad(x_dev, g_dev, gw_dev, static_cast<float *>(workspace_dev), workspace_bytes, B, H, W, cin, cout,
+                                static_cast<hipStream_t>(stream), 1);
+}
+extern "C" int dsrg_pack_conv_weight_direct_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, void *stream) {
+    if ((cin != 64 && cin != 128) || (cout != 64 && cout != 128))
+        return set_error(DSRG_ERR_INVALID, "pack_conv_weight_direct: 64 / 128 channels either side (got %d -> %d)", cin, cout);
+    return launch_pack_conv_weight(w_dev, fwd_dev, dgrad_dev, cout, cin, 3, static_cast<hipStream_t>(stream), 1);
+}
 extern "C" int dsrg_heads_backward_chunks(int M) { return heads_bwd_chunks(M); }
 extern "C" int dsrg_heads_backward_bf16(const void *const *x_dev, int n_branches, const float *w_dev, const float *g_dev,
                                         void *gx_dev, size_t gx_branch_stride_bytes, float *gw_dev, float *partial_dev, int B,

@@ -178,7 +178,7 @@ int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float 
 bool conv3x3_direct_supported(int cin, int cout);
 size_t conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout);
 int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspace, size_t workspace_bytes, int B, int H, int W,
-                         int cin, int cout, hipStream_t stream);
+                         int cin, int cout, hipStream_t stream, int out_f32 = 0);
 int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void *y, int B, int H, int W, int cin, int cout,
                           int relu, hipStream_t stream, const void *mask = nullptr, float *colsum = nullptr,
                           void *colsum_ws = nullptr, size_t colsum_ws_bytes = 0);
@@ -194,7 +194,7 @@ int conv_igemm_workspace_status(const void *workspace, hipStream_t stream, int *
 size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k);
 int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *const *gw, const int *dil, int ngroups, void *workspace,
                             size_t workspace_bytes, int B, int H, int W, int cin, int cout, int k, int out_bf16, hipStream_t stream);
-int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream);
+int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream, int plain = 0);
 int heads_bwd_chunks(int M);
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
                      float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream, float relu_scale = 0.0f,

@@ -617,7 +617,8 @@ __global__ __launch_bounds__(CO_TILES * 128, (CO_TILES == 2 ? 2 : 1)) void conv3
 // workgroup order.  1024 threads = 64 consecutive channels x 16 interleaved sixteenths of the workgroups (loads of many
 // partials in flight per thread: the sum is a latency chain otherwise), combined in a fixed order.
 constexpr int kRedChunks = 16;
-__global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float *part, uint16_t *gw, int nwg, int roles, int cout,
+template <bool F32_OUT>
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float *part, void *gw, int nwg, int roles, int cout,
                                                                     int cin) {
     __shared__ float red[kRedChunks][64];
     const int el = threadIdx.x & 63, ch = threadIdx.x >> 6;
@@ -633,9 +634,13 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float 
         float t = 0.0f;
 #pragma unroll
         for (int k = 0; k < kRedChunks; k++) t += red[k][el];
-        f32x2 v = {t, 0.0f};
-        bf16x2 bv = __builtin_convertvector(v, bf16x2);
-        gw[(size_t)e0 + el] = *reinterpret_cast<uint16_t *>(&bv);
+        if (F32_OUT) {
+            static_cast<float *>(gw)[(size_t)e0 + el] = t;
+        } else {
+            f32x2 v = {t, 0.0f};
+            bf16x2 bv = __builtin_convertvector(v, bf16x2);
+            static_cast<uint16_t *>(gw)[(size_t)e0 + el] = *reinterpret_cast<uint16_t *>(&bv);
+        }
     }
 }
 
@@ -739,7 +744,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(WgradArgs a) {   
 
 // gw[o][tap][c] (bf16, (64, 3, 3, 3) channels_last) = sum over the workgroups of part[wg][o][tap * 4 + c], in a fixed order;
 // as above: 64 consecutive entries of the 64 x 64 partial x 16 interleaved sixteenths of the workgroups per block
-__global__ __launch_bounds__(1024) void conv3x3_c3_wgrad_reduce_kernel(const float *part, uint16_t *gw, int nwg) {
+template <bool F32_OUT>
+__global__ __launch_bounds__(1024) void conv3x3_c3_wgrad_reduce_kernel(const float *part, void *gw, int nwg) {
     __shared__ float red[kRedChunks][64];
     const int el = threadIdx.x & 63, ch = threadIdx.x >> 6;
     const int o = blockIdx.x;                                    // one row of the partial: n = tap * 4 + c
@@ -753,9 +759,13 @@ __global__ __launch_bounds__(1024) void conv3x3_c3_wgrad_reduce_kernel(const flo
         float t = 0.0f;
 #pragma unroll
         for (int k = 0; k < kRedChunks; k++) t += red[k][el];
-        f32x2 v = {t, 0.0f};
-        bf16x2 bv = __builtin_convertvector(v, bf16x2);
-        gw[(o * 9 + tap) * 3 + c] = *reinterpret_cast<uint16_t *>(&bv);
+        if (F32_OUT) {
+            static_cast<float *>(gw)[(o * 9 + tap) * 3 + c] = t;
+        } else {
+            f32x2 v = {t, 0.0f};
+            bf16x2 bv = __builtin_convertvector(v, bf16x2);
+            static_cast<uint16_t *>(gw)[(o * 9 + tap) * 3 + c] = *reinterpret_cast<uint16_t *>(&bv);
+        }
     }
 }
 
@@ -800,7 +810,7 @@ size_t conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
 }
 
 int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspace, size_t workspace_bytes, int B, int H, int W,
-                         int cin, int cout, hipStream_t stream) {
+                         int cin, int cout, hipStream_t stream, int out_f32) {
     if (!wgrad_supported(cin, cout))
         return set_error(DSRG_ERR_INVALID, "conv3x3_wgrad: %d -> %d channels is not one of 3 -> 64, 64 -> 64, 64 -> 128, 128 -> 128", cin, cout);
     WgradArgs a;
@@ -820,13 +830,18 @@ int launch_conv3x3_wgrad(const void *x, const void *g, void *gw, float *workspac
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_c3_wgrad_kernel), lds, grant)) return rc;
         hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel, dim3(grid), dim3(256), lds, stream, a);
         DSRG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv3x3_c3_wgrad_reduce_kernel, dim3(64), dim3(1024), 0, stream, workspace, static_cast<uint16_t *>(gw), grid);
+        if (out_f32) hipLaunchKernelGGL(conv3x3_c3_wgrad_reduce_kernel<true>, dim3(64), dim3(1024), 0, stream, workspace, gw, grid);
+        else hipLaunchKernelGGL(conv3x3_c3_wgrad_reduce_kernel<false>, dim3(64), dim3(1024), 0, stream, workspace, gw, grid);
         DSRG_LAUNCH_CHECK();
         return DSRG_OK;
     }
     if (int rc = cout == 64 ? launch_wgrad_variant<2>(a, grid, stream) : launch_wgrad_variant<4>(a, grid, stream)) return rc;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cout * 9 * cin / 64), dim3(1024), 0, stream, workspace,
-                       static_cast<uint16_t *>(gw), grid, a.roles, cout, cin);
+    if (out_f32)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel<true>, dim3(cout * 9 * cin / 64), dim3(1024), 0, stream, workspace, gw, grid, a.roles,
+                           cout, cin);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel<false>, dim3(cout * 9 * cin / 64), dim3(1024), 0, stream, workspace, gw, grid, a.roles,
+                           cout, cin);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

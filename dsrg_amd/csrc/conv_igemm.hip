@@ -891,16 +891,20 @@ __global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(const floa
 // parameter): the forward form fwd[o][c / 64][tap][64] and the data-gradient form dg[c][o / 64][T - tap][64] (the kernel
 // flipped, T = k*k - 1, and its channel axes swapped), both bf16.  One block per (64 outputs, 64 inputs, tap): the forward
 // form is the tile as it is read; the data-gradient form is its transpose, taken through LDS.
-__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float *w, uint16_t *fwd, uint16_t *dg, int cout, int cin, int taps) {
+// plain = 1: the layouts of the direct kernels (conv_direct.hip) instead — fwd[o][tap][c] (the parameter's own order, cast) and
+// dg[c][T - tap][o] (a channels_last (cin, cout, k, k) tensor: the kernel flipped, channel axes swapped).
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float *w, uint16_t *fwd, uint16_t *dg, int cout, int cin, int taps,
+                                                               int plain) {
     __shared__ uint16_t tile[64][64 + 4];
     const int ob = blockIdx.x, cb = blockIdx.y, tap = blockIdx.z, t = threadIdx.x;
     const int r = t >> 4, q = t & 15;                        // 16 rows x 16 float4 per pass
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int o = r + 16 * i;
-        const float4 v = *reinterpret_cast<const float4 *>(w + ((size_t)(ob * 64 + o) * taps + tap) * cin + cb * 64 + q * 4);
+        const size_t src = ((size_t)(ob * 64 + o) * taps + tap) * cin + cb * 64 + q * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(w + src);
         const uint2 pk = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
-        if (fwd) *reinterpret_cast<uint2 *>(fwd + (((size_t)(ob * 64 + o) * (cin >> 6) + cb) * taps + tap) * 64 + q * 4) = pk;
+        if (fwd) *reinterpret_cast<uint2 *>(fwd + (plain ? src : (((size_t)(ob * 64 + o) * (cin >> 6) + cb) * taps + tap) * 64 + q * 4)) = pk;
         *reinterpret_cast<uint2 *>(&tile[o][q * 4]) = pk;
     }
     if (!dg) return;
@@ -910,7 +914,9 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float *w, u
         const int c = r + 16 * i;                            // row of the transposed tile; q*4 .. q*4+3 = its outputs
         const uint32_t lo = (uint32_t)tile[q * 4 + 0][c] | ((uint32_t)tile[q * 4 + 1][c] << 16);
         const uint32_t hi = (uint32_t)tile[q * 4 + 2][c] | ((uint32_t)tile[q * 4 + 3][c] << 16);
-        *reinterpret_cast<uint2 *>(dg + (((size_t)(cb * 64 + c) * (cout >> 6) + ob) * taps + (taps - 1 - tap)) * 64 + q * 4) = make_uint2(lo, hi);
+        const size_t dst = plain ? ((size_t)(cb * 64 + c) * taps + (taps - 1 - tap)) * cout + ob * 64 + q * 4
+                                 : (((size_t)(cb * 64 + c) * (cout >> 6) + ob) * taps + (taps - 1 - tap)) * 64 + q * 4;
+        *reinterpret_cast<uint2 *>(dg + dst) = make_uint2(lo, hi);
     }
 }
 
@@ -1150,12 +1156,12 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
 }
 
 
-int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream) {
+int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream, int plain) {
     if (!w || cout < 64 || cout % 64 || cin < 64 || cin % 64 || (k != 1 && k != 3))
         return set_error(DSRG_ERR_INVALID, "pack_conv_weight: 64 | cout, 64 | cin, k in (1, 3) required (got %d, %d, %d)", cout, cin, k);
     if (!fwd && !dgrad) return DSRG_OK;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cout / 64, cin / 64, k * k), dim3(256), 0, stream, w, static_cast<uint16_t *>(fwd),
-                       static_cast<uint16_t *>(dgrad), cout, cin, k * k);
+                       static_cast<uint16_t *>(dgrad), cout, cin, k * k, plain);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

@@ -438,9 +438,24 @@ WGRAD_CONV_SHAPES = ((3, 64), (64, 64), (64, 128), (128, 128))      # (cin, cout
 _wgrad_ws = {}
 
 
-def conv3x3_wgrad(x, g):
+def pack_direct_weight_pair(weight, want_dgrad=True):
+    """the bf16 kernels of conv3x3_direct from a float32 channels_last (cout, cin, 3, 3) parameter with 64 / 128 channels either
+    side, one pass: (weight cast, weight flipped with its channel axes swapped — the data gradient's kernel — or None)"""
+    cout, cin = weight.shape[0], weight.shape[1]
+    cl = torch.channels_last
+    if not (weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous(memory_format=cl) and tuple(weight.shape[2:]) == (3, 3)
+            and cin in DIRECT_CONV_CHANNELS and cout in DIRECT_CONV_CHANNELS):
+        raise ValueError("pack_direct_weight_pair needs a float32 channels_last (cout,cin,3,3) CUDA parameter with 64 / 128 channels")
+    fwd = torch.empty((cout, cin, 3, 3), dtype=torch.bfloat16, device=weight.device, memory_format=cl)
+    dg = torch.empty((cin, cout, 3, 3), dtype=torch.bfloat16, device=weight.device, memory_format=cl) if want_dgrad else None
+    check(_lib.lib().dsrg_pack_conv_weight_direct_f32(_ptr(weight.detach()), _ptr(fwd), _ptr(dg), cout, cin, _stream()))
+    return fwd, dg
+
+
+def conv3x3_wgrad(x, g, out_dtype=torch.bfloat16):
     """weight gradient of the 3x3 / stride 1 / pad 1 convolution y = conv(x, w): x (B,cin,H,W) and g = dL/dy (B,cout,H,W) bf16
-    channels_last, (cin, cout) in WGRAD_CONV_SHAPES -> (cout,cin,3,3) bf16 channels_last; fp32 accumulation, deterministic"""
+    channels_last, (cin, cout) in WGRAD_CONV_SHAPES -> (cout,cin,3,3) bf16 (or float32: out_dtype) channels_last; fp32
+    accumulation, deterministic"""
     B, cin, H, W = x.shape
     cout = g.shape[1]
     cl = torch.channels_last
@@ -454,8 +469,11 @@ def conv3x3_wgrad(x, g):
     ws = _wgrad_ws.get(key)                                          # per-stream scratch, reused across layers and steps
     if ws is None or ws.numel() < need:
         ws = _wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
-    gw = torch.empty((cout, cin, 3, 3), dtype=torch.bfloat16, device=x.device, memory_format=cl)
-    check(_lib.lib().dsrg_conv3x3_wgrad_bf16(_ptr(x), _ptr(g), _ptr(gw), _ptr(ws), ws.numel(), B, H, W, cin, cout, _stream()))
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("conv3x3_wgrad: bf16 or float32 output")
+    gw = torch.empty((cout, cin, 3, 3), dtype=out_dtype, device=x.device, memory_format=cl)
+    fn = _lib.lib().dsrg_conv3x3_wgrad_f32 if out_dtype == torch.float32 else _lib.lib().dsrg_conv3x3_wgrad_bf16
+    check(fn(_ptr(x), _ptr(g), _ptr(gw), _ptr(ws), ws.numel(), B, H, W, cin, cout, _stream()))
     return gw
 
 

@@ -274,6 +274,13 @@ int dsrg_conv3x3_direct_dgrad_bf16(const void *g_dev, const void *w_dev, const v
 size_t dsrg_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout);
 int dsrg_conv3x3_wgrad_bf16(const void *x_dev, const void *g_dev, void *gw_dev, void *workspace_dev, size_t workspace_bytes,
                             int B, int H, int W, int cin, int cout, void *stream);
+/* The same with the gradient in float32 (the master parameters' dtype: no rounding, no cast pass). */
+int dsrg_conv3x3_wgrad_f32(const void *x_dev, const void *g_dev, float *gw_dev, void *workspace_dev, size_t workspace_bytes, int B,
+                           int H, int W, int cin, int cout, void *stream);
+/* Both bf16 kernels dsrg_conv3x3_direct_bf16 reads, from the float32 master (cout, 3, 3, cin) in one pass (cin, cout in {64, 128}):
+ * fwd_dev (cout, 3, 3, cin) — the parameter cast — and dgrad_dev (cin, 3, 3, cout) — flipped, channel axes swapped: the kernel of
+ * the data gradient.  Either may be NULL. */
+int dsrg_pack_conv_weight_direct_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, void *stream);
 /* Implicit-GEMM convolution for the wide layers (conv3_x, conv4_x, conv5_x, fc6_k, fc7_k of train-s.prototxt:161-736): 3x3
  * with any dilation ('same' zero padding) or 1x1, stride 1, cin % 64 == 0, cout % 256 == 0, NHWC bf16 in and out, fp32
  * accumulation, optional bias (cout f32) and ReLU in the epilogue; no im2col matrix is formed:
