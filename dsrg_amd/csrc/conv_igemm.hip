@@ -1091,6 +1091,8 @@ static int wgrad_col_tiles(int cin, int k) { return cin == 128 ? (k * k + 1) / 2
 static int wgrad_ksplit(long long M, int tiles, int cus) {
     long long best_cost = -1;
     int best = 1;
+    static const int forced = [] { const char *e = getenv("DSRG_WGRAD_KSPLIT"); return e ? atoi(e) : 0; }();     // tools only
+    if (forced >= 1 && forced <= 128 && (long long)(forced - 1) * (((M + forced - 1) / forced + 63) / 64 * 64) < M) return forced;
     for (int ks = 1; ks <= 128; ks++) {
         const long long chunk = ((M + ks - 1) / ks + 63) / 64 * 64;
         if ((long long)(ks - 1) * chunk >= M) continue;                 // an empty last split
