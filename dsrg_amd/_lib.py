@@ -109,7 +109,6 @@ SIGNATURES = {
     "dsrg_maxpool3x3_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_maxpool3x3_bwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_maxpool3x3_bwd_relu_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "dsrg_maxpool3x3_s1_bwd_relu_bf16": (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
     "dsrg_supervision_step": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _d, _d, ctypes.POINTER(CrfParams),
                                    _vp, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -531,26 +531,18 @@ class FusedDropout(nn.Identity):
 
 class _MaxPool3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stride, ceil_mode, link_in=None):
+    def forward(ctx, x, stride, ceil_mode):
         from .ops import maxpool3x3_fwd
         out, code = maxpool3x3_fwd(x, stride, ceil_mode)
-        # link_in (_GradLink): x is the ReLU output of the conv in front, read by this pool only — the pool's backward then
-        # carries that ReLU's backward and the conv's bias gradient (x is saved by that node anyway)
-        C = x.shape[1]
-        ctx.link_in = link_in if (link_in is not None and link_in.scale == 1.0 and stride in (1, 2) and 256 % (C // 8) == 0) else None
-        ctx.save_for_backward(code, x if ctx.link_in is not None else None)
+        ctx.save_for_backward(code)
         ctx.in_shape, ctx.stride = x.shape, stride
         return out
 
     @staticmethod
     def backward(ctx, g):
-        from .ops import maxpool3x3_bwd, maxpool3x3_bwd_relu
-        code, x = ctx.saved_tensors
-        if _FUSE_CHAIN and ctx.link_in is not None and g.dtype == torch.bfloat16:
-            gin, gb_below = maxpool3x3_bwd_relu(g, code, x, ctx.stride)
-            ctx.link_in.leave(gin, gb_below)
-            return gin, None, None, None
-        return maxpool3x3_bwd(g, code, ctx.in_shape, ctx.stride), None, None, None
+        from .ops import maxpool3x3_bwd
+        (code,) = ctx.saved_tensors
+        return maxpool3x3_bwd(g, code, ctx.in_shape, ctx.stride), None, None
 
 
 class _AvgPool3x3Fn(torch.autograd.Function):
@@ -587,15 +579,13 @@ class MaxPool3x3(nn.MaxPool2d):
     """3x3 / pad 1 max pooling (stride 1 or 2): one HIP pass each way over bf16 channels_last activations with
     1-byte window codes instead of torch's int64 indices; anything else takes nn.MaxPool2d's path."""
 
-    def __init__(self, stride, ceil_mode=False, chain_input=False):
+    def __init__(self, stride, ceil_mode=False):
         super().__init__(3, stride, 1, ceil_mode=ceil_mode)
-        self.chain_input = bool(chain_input)          # the input is the fused-ReLU output of the conv in front, read by nothing else
 
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and \
                 x.is_contiguous(memory_format=torch.channels_last):
-            lin = getattr(x, "_dsrg_grad_link", None) if self.chain_input else None
-            return _MaxPool3x3Fn.apply(x, self.stride, self.ceil_mode, lin)
+            return _MaxPool3x3Fn.apply(x, self.stride, self.ceil_mode)
         return super().forward(x)
 
 
@@ -655,8 +645,8 @@ class VGG16ASPP(nn.Module):
         L += _conv_relu(128, 256, 1, gemm_convs) + _conv_relu(256, 256, 1, gemm_convs, chain=True) + \
             _conv_relu(256, 256, 1, gemm_convs, pool=p2, chain=True)
         g = gemm_convs                                                  # the 41x41 stages
-        L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g, chain=True) + _conv_relu(512, 512, 1, g, chain=True) + [MaxPool3x3(1, chain_input=True)]
-        L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g, chain=True) + _conv_relu(512, 512, 2, g, chain=True) + [MaxPool3x3(1, chain_input=True)]
+        L += _conv_relu(256, 512, 1, g) + _conv_relu(512, 512, 1, g, chain=True) + _conv_relu(512, 512, 1, g, chain=True) + [MaxPool3x3(1)]
+        L += _conv_relu(512, 512, 2, g) + _conv_relu(512, 512, 2, g, chain=True) + _conv_relu(512, 512, 2, g, chain=True) + [MaxPool3x3(1)]
         L += [AvgPool3x3()]                                   # pool5a AVE (count_include_pad, as Caffe)
         self.features = nn.Sequential(*L)
         self.branches = nn.ModuleList()

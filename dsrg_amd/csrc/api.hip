@@ -600,13 +600,6 @@ extern "C" int dsrg_maxpool3x3_bwd_relu_bf16(const void *gout, const void *code,
                                       static_cast<hipStream_t>(stream));
 }
 
-extern "C" int dsrg_maxpool3x3_s1_bwd_relu_bf16(const void *gout, const void *code, const void *relu_out, void *gin, float *bias_grad,
-                                                float *partials, int partial_blocks, int B, int H, int W, int C, void *stream) {
-    if (!gout || !code || !relu_out || !gin || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
-    return launch_maxpool3x3_bwd_relu(gout, code, relu_out, gin, bias_grad, partials, partial_blocks, B, H, W, H, W, C,
-                                      static_cast<hipStream_t>(stream), 1);
-}
-
 extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, const float *images, int img_h,
                                      int img_w, const float *labels, const float *cues, double th1, double th2,
                                      const dsrg_crf_params *prm, float *losses, float *grad_logits,

@@ -370,72 +370,6 @@ __global__ __launch_bounds__(kRbThreads) void maxpool3x3_s2_bwd_relu_kernel(cons
     }
 }
 
-// The stride-1 pools (pool4, pool5: train-s.prototxt:263-274, :331-342) the same way — gather form, every input pixel visits its
-// <= 9 windows — with the ReLU backward of conv4_3 / conv5_3 and their bias gradients in the store.
-__global__ __launch_bounds__(kRbThreads) void maxpool3x3_s1_bwd_relu_kernel(const uint4 *__restrict__ gout, const uint2 *__restrict__ code,
-                                                                             const uint4 *__restrict__ y, uint4 *__restrict__ gin,
-                                                                             float *__restrict__ part, int B, int H, int W, int C8,
-                                                                             size_t items_per_block) {
-    __shared__ float red[kRbThreads][9];
-    const size_t total = (size_t)B * H * W * C8;
-    const size_t beg = (size_t)blockIdx.x * items_per_block, end = beg + items_per_block < total ? beg + items_per_block : total;
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (size_t idx = beg + threadIdx.x; idx < end; idx += kRbThreads) {
-        const int c = (int)(idx % C8);
-        size_t r = idx / C8;
-        const int x = (int)(r % W);
-        r /= W;
-        const int yy = (int)(r % H);
-        const int b = (int)(r / H);
-        const uint4 yv = y[idx];
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int oy = yy + 1 - dy;                                       // window row whose tap dy is this pixel
-            if (oy < 0 || oy >= H) continue;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ox = x + 1 - dx;
-                if (ox < 0 || ox >= W) continue;
-                const size_t o = (((size_t)b * H + oy) * W + ox) * C8 + c;
-                const uint2 cd = code[o];
-                const uint4 gv = gout[o];
-                const uint32_t want = 3 * dy + dx;
-                const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t cw = k < 2 ? cd.x : cd.y;
-                    const uint32_t c0 = (cw >> (16 * (k & 1))) & 0xffu, c1 = (cw >> (16 * (k & 1) + 8)) & 0xffu;
-                    if (c0 == want) acc[2 * k] += bf16_lo(gw[k]);
-                    if (c1 == want) acc[2 * k + 1] += bf16_hi(gw[k]);
-                }
-            }
-        }
-        const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
-        uint32_t ow[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool plo = (yw[k] & 0x8000u) == 0 && (yw[k] & 0x7fffu) != 0;              // as relu_bwd_bias_kernel
-            const bool phi = (yw[k] & 0x80000000u) == 0 && (yw[k] & 0x7fff0000u) != 0;
-            const uint32_t m = (plo ? 0xffffu : 0u) | (phi ? 0xffff0000u : 0u);
-            ow[k] = pack_bf16(acc[2 * k], acc[2 * k + 1]) & m;
-            bsum[2 * k] += bf16_lo(ow[k]);
-            bsum[2 * k + 1] += bf16_hi(ow[k]);
-        }
-        gin[idx] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = bsum[k];
-    __syncthreads();
-    const int lanes = kRbThreads / C8;                                       // threads that share a channel group: t % C8 equal
-    for (int ch = threadIdx.x; ch < C8 * 8; ch += kRbThreads) {
-        const int g8 = ch >> 3, k = ch & 7;
-        float s2 = 0.f;
-        for (int l = 0; l < lanes; ++l) s2 += red[l * C8 + g8][k];
-        part[(size_t)blockIdx.x * (C8 * 8) + ch] = s2;
-    }
-}
-
 // ---- 3x3 / stride 1 / pad 1 average pooling over padded windows (Caffe AVE pooling = count_include_pad), NHWC bf16 --------
 // out = (sum of the in-image taps) / 9.  The stencil is symmetric, so the backward pass is the same kernel on the gradient.
 __global__ void avgpool3x3_s1_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, int B, int H, int W, int C8) {
@@ -532,25 +466,12 @@ int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, i
 }
 
 int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y, void *gin, float *bias_grad, float *part,
-                                int part_blocks, int B, int H, int W, int OH, int OW, int C, hipStream_t stream, int stride) {
-    int rc = pool_check(B, H, W, OH, OW, C, stride);
+                                int part_blocks, int B, int H, int W, int OH, int OW, int C, hipStream_t stream) {
+    int rc = pool_check(B, H, W, OH, OW, C, 2);
     if (rc) return rc;
     const int C8 = C / 8;
     if (kRbThreads % C8 != 0) return set_error(DSRG_ERR_UNSUPPORTED, "maxpool3x3_bwd_relu: channels / 8 must divide %d", kRbThreads);
     if (part_blocks < 1) return set_error(DSRG_ERR_INVALID, "maxpool3x3_bwd_relu: no partial-sum blocks");
-    if (stride == 1) {
-        if (OH != H || OW != W) return set_error(DSRG_ERR_INVALID, "maxpool3x3_bwd_relu: a stride-1 pool keeps the map size");
-        const size_t total1 = (size_t)B * H * W * C8;
-        size_t ipb1 = (total1 + part_blocks - 1) / part_blocks;
-        ipb1 = (ipb1 + kRbThreads - 1) / kRbThreads * kRbThreads;
-        const int nblk1 = (int)((total1 + ipb1 - 1) / ipb1);
-        hipLaunchKernelGGL(maxpool3x3_s1_bwd_relu_kernel, dim3(nblk1), dim3(kRbThreads), 0, stream, (const uint4 *)gout, (const uint2 *)code,
-                           (const uint4 *)y, (uint4 *)gin, part, B, H, W, C8, ipb1);
-        DSRG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk1, C);
-        DSRG_LAUNCH_CHECK();
-        return DSRG_OK;
-    }
     const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * C8;
     size_t ipb = (total + part_blocks - 1) / part_blocks;
     ipb = (ipb + kRbThreads - 1) / kRbThreads * kRbThreads;                  // whole rounds: a thread keeps its channel group

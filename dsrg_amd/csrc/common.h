@@ -202,7 +202,7 @@ int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float 
 size_t heads_bwd_relu_workspace(int nbr, int M, int K);
 int launch_igemm_colsum(const float *const *parts, float *const *outs, int ngroups, int rows, int cout, hipStream_t stream);
 int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y, void *gin, float *bias_grad, float *part,
-                                int part_blocks, int B, int H, int W, int OH, int OW, int C, hipStream_t stream, int stride = 2);
+                                int part_blocks, int B, int H, int W, int OH, int OW, int C, hipStream_t stream);
 int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,
                           hipStream_t stream);
 int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, int H, int W, int OH, int OW, int C,

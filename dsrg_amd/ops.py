@@ -721,15 +721,15 @@ def maxpool3x3_bwd(gout, code, in_shape, stride):
 
 
 def maxpool3x3_bwd_relu(gout, code, relu_out, stride=2):
-    """3x3 / pad 1 max-pool (stride 2, or 1) backward + the ReLU backward and bias gradient of the convolution in front of the pool:
+    """3x3 / stride 2 / pad 1 max-pool backward + the ReLU backward and bias gradient of the convolution in front of the pool:
     relu_out (B,C,H,W) bf16 channels_last = the pool's input -> (masked input gradient (B,C,H,W) bf16 channels_last,
     bias gradient (C) f32); the same values as maxpool3x3_bwd followed by relu_bwd_bias"""
     B, C, H, W = relu_out.shape
     OH, OW = gout.shape[2], gout.shape[3]
     cl = torch.channels_last
-    if stride not in (1, 2) or not (relu_out.is_cuda and relu_out.dtype == torch.bfloat16 and gout.dtype == torch.bfloat16
-                                    and relu_out.is_contiguous(memory_format=cl) and C % 8 == 0 and 256 % (C // 8) == 0):
-        raise ValueError("maxpool3x3_bwd_relu: stride 1 or 2, bf16 channels_last, channels / 8 a divisor of 256")
+    if stride != 2 or not (relu_out.is_cuda and relu_out.dtype == torch.bfloat16 and gout.dtype == torch.bfloat16
+                           and relu_out.is_contiguous(memory_format=cl) and C % 8 == 0 and 256 % (C // 8) == 0):
+        raise ValueError("maxpool3x3_bwd_relu: stride 2, bf16 channels_last, channels / 8 a divisor of 256")
     gout = gout.contiguous(memory_format=cl)
     gin = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=gout.device, memory_format=cl)
     gb = torch.empty(C, dtype=torch.float32, device=gout.device)
@@ -737,12 +737,6 @@ def maxpool3x3_bwd_relu(gout, code, relu_out, stride=2):
     part = _partials.get(key)
     if part is None:
         part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=gout.device)
-    if stride == 1:
-        if (OH, OW) != (H, W):
-            raise ValueError("maxpool3x3_bwd_relu: a stride-1 pool keeps the map size")
-        check(_lib.lib().dsrg_maxpool3x3_s1_bwd_relu_bf16(_ptr(gout), _ptr(code), _ptr(relu_out), _ptr(gin), _ptr(gb), _ptr(part),
-                                                          _PARTIAL_BLOCKS, B, H, W, C, _stream()))
-        return gin, gb
     check(_lib.lib().dsrg_maxpool3x3_bwd_relu_bf16(_ptr(gout), _ptr(code), _ptr(relu_out), _ptr(gin), _ptr(gb), _ptr(part),
                                                    _PARTIAL_BLOCKS, B, H, W, OH, OW, C, _stream()))
     return gin, gb

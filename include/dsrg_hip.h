@@ -370,10 +370,6 @@ int dsrg_maxpool3x3_bwd_bf16(const void *gout_dev, const void *code_dev, void *g
 int dsrg_maxpool3x3_bwd_relu_bf16(const void *gout_dev, const void *code_dev, const void *relu_out_dev, void *gin_dev,
                                   float *bias_grad_dev, float *partials_dev, int partial_blocks, int B, int H, int W, int OH,
                                   int OW, int C, void *stream);
-/* The same for the stride-1 pools (pool4, pool5 of train-s.prototxt:263-274, :331-342 behind conv4_3 / conv5_3; OH = H, OW = W). */
-int dsrg_maxpool3x3_s1_bwd_relu_bf16(const void *gout_dev, const void *code_dev, const void *relu_out_dev, void *gin_dev,
-                                     float *bias_grad_dev, float *partials_dev, int partial_blocks, int B, int H, int W, int C,
-                                     void *stream);
 
 /* The five Python layers of train-s.prototxt:746-810 as ONE stream-ordered
  * sequence (Softmax -> CRF -> DSRG -> BalancedSeedLoss + ConstrainLoss, then
