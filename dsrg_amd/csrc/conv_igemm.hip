@@ -85,7 +85,6 @@ struct IgemmArgs {
     float drop_scale;       // 0 = no dropout), kept elements times drop_scale = 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
     float out_scale;        // every output times this (1 unless a mask carries a Dropout scale)
-    int prio;               // raise the wave's issue priority around its MFMA clusters
 };
 
 // the random bytes of the four consecutive channels starting at element 4 * e4 of a launch's output: a counter-based
@@ -292,13 +291,11 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
                 for (int j = 0; j < 2; j++) bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(P + j * (32 * C::ROW) + choff[(ks + 1) % C::KS]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (a.prio) __builtin_amdgcn_s_setprio(2);      // (variant 6) the wave inside its MFMA cluster goes first on its SIMD
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
-            if (a.prio) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0 && more && late) issue(nstage, s + C::AHEAD);
         }
@@ -1032,7 +1029,6 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     static LdsGrant grant[3];
     const int variant = igemm_variant() == 2 ? 1 : 0;       // 1, 3: two stages of 64; 2: ring of four stages of 32
     a.stagger = igemm_variant() >= 3;
-    a.prio = igemm_variant() == 6;
     const dim3 grid(a.tiles_per_group * ngroups), block(512);
     // stream-K only where it was measured to win (profiles/r04_igemm_stream_k.txt): a single round that fills at most 60 % of
     // the chip (conv4_1's data gradient: 106 tiles, 115 -> 88 us).  A cut tile costs its workgroups ~25 us (256 KB of
