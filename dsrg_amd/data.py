@@ -5,13 +5,16 @@
   BatchLoader        <-> layer.py:77-116
   SimpleTransformer  <-> layer.py:119-251
 
-Pure data marshalling, done on the host like the reference.  Differences forced by the image:
-OpenCV is absent, so files are read with PIL (converted to OpenCV's BGR order) and borders are
-padded with numpy; `param_str` is parsed with ast.literal_eval, never eval (layer.py:30 uses eval).
+Pure data marshalling, done on the host like the reference; class, method and parameter names are the ones the prototxt's
+`module: 'pylayers.layer'` and its `param_str` bind to.  The form is this repo's own: pad-then-crop is ONE placement of the
+source window on a crop-sized canvas (`_Window`), never a padded copy of the whole image; the mirror is a boolean; the list
+reader is a generator.  What has to match the reference exactly is kept and said where: which random draws are made, from
+which generator, in which order and over which ranges (a training run seeded like the reference's sees the same crops).
+Differences forced by the image: OpenCV is absent, so files are read with PIL (converted to OpenCV's BGR order); `param_str` is
+parsed with ast.literal_eval, never eval (layer.py:30 uses eval).
 """
 import ast
 import random
-from random import shuffle
 
 import numpy as np
 
@@ -21,29 +24,44 @@ try:
 except ImportError:
     _Base = object
 
+# layer.py:238-251: the keys a param_str may leave out
+_DEFAULTS = (('crop_size', (505, 505)), ('mean', [128, 128, 128]), ('scale', 1.0), ('mirror', False), ('phase', 'Train'),
+             ('ignore_label', 255))
 
-def _pad_bottom_right(a, pad_h, pad_w, value):
-    """cv2.copyMakeBorder(a, 0, pad_h, 0, pad_w, BORDER_CONSTANT, value)"""
-    if a.ndim == 3:
-        out = np.empty((a.shape[0] + pad_h, a.shape[1] + pad_w, a.shape[2]), dtype=a.dtype)
-        out[...] = np.asarray(value, dtype=a.dtype)
-    else:
-        out = np.full((a.shape[0] + pad_h, a.shape[1] + pad_w), value[0] if isinstance(value, tuple) else value, dtype=a.dtype)
-    out[:a.shape[0], :a.shape[1]] = a
-    return out
+
+class _Window(object):
+    """Where a (crop_h, crop_w) crop sits on an image that is first extended to at least the crop size at its bottom / right
+    edges (layer.py:156-166,200-225: copyMakeBorder + slicing).  `top`, `left` are the crop's offsets on the EXTENDED image;
+    only the part of the crop that lies on the real image is ever copied."""
+
+    def __init__(self, shape, crop, top=None, left=None):
+        self.crop = crop
+        self.ext = (max(shape[0], crop[0]), max(shape[1], crop[1]))         # size after the border extension
+        # centred unless the caller drew the offsets ((ext - crop) // 2: the reference's py2 integer division)
+        self.top = (self.ext[0] - crop[0]) // 2 if top is None else top
+        self.left = (self.ext[1] - crop[1]) // 2 if left is None else left
+        self.rows = max(0, min(shape[0] - self.top, crop[0]))                # rows / columns of the crop that hold image data
+        self.cols = max(0, min(shape[1] - self.left, crop[1]))
+
+    def slack(self):
+        """largest admissible (top, left): the ranges the training phase draws its offsets from"""
+        return self.ext[0] - self.crop[0], self.ext[1] - self.crop[1]
+
+    def cut(self, a, fill):
+        """the crop of `a` (H,W[,C]) as float32, border = fill"""
+        out = np.full(tuple(self.crop) + a.shape[2:], fill, dtype=np.float32)
+        out[:self.rows, :self.cols] = a[self.top:self.top + self.rows, self.left:self.left + self.cols]
+        return out
 
 
 class SimpleTransformer:
     """layer.py:119-251"""
 
     def __init__(self, params):
-        SimpleTransformer.check_params(params)
-        self.mean = params['mean']
-        self.is_mirror = params['mirror']
+        self.check_params(params)
         self.crop_h, self.crop_w = params['crop_size']
-        self.scale = params['scale']
-        self.phase = params['phase']
-        self.ignore_label = params['ignore_label']
+        self.mean, self.scale = params['mean'], params['scale']
+        self.is_mirror, self.phase, self.ignore_label = params['mirror'], params['phase'], params['ignore_label']
 
     def set_mean(self, mean):
         self.mean = mean
@@ -51,61 +69,38 @@ class SimpleTransformer:
     def set_scale(self, scale):
         self.scale = scale
 
-    def _center_crop(self, img_pad):
-        img_h, img_w = img_pad.shape[:2]
-        h_off = (img_h - self.crop_h) // 2
-        w_off = (img_w - self.crop_w) // 2
-        return np.asarray(img_pad[h_off:h_off + self.crop_h, w_off:w_off + self.crop_w], np.float32)
-
-    def _pad_image(self, image):
-        img_h, img_w = image.shape[:2]
-        pad_h = max(self.crop_h - img_h, 0)
-        pad_w = max(self.crop_w - img_w, 0)
-        return (_pad_bottom_right(image, pad_h, pad_w, (0.0, 0.0, 0.0)) if (pad_h > 0 or pad_w > 0) else image), pad_h, pad_w
+    def _centred(self, image):
+        """mean-subtracted HWC image -> centre crop (zero border where the image is smaller), CHW"""
+        return _Window(image.shape, (self.crop_h, self.crop_w)).cut(image, 0.0).transpose(2, 0, 1)
 
     def pre_test_image(self, image):
-        """layer.py:150-169: RGB -> BGR, mean, pad, centre crop, CHW"""
-        image = np.asarray(image, np.float32)
-        image = image[:, :, [2, 1, 0]]
-        image = image - np.asarray(self.mean, np.float32)
-        img_pad, _, _ = self._pad_image(image)
-        return self._center_crop(img_pad).transpose((2, 0, 1))
+        """layer.py:150-169: an RGB image (PIL order) -> BGR, mean, centre crop, CHW; no scaling on this path"""
+        bgr = np.asarray(image, np.float32)[:, :, ::-1]
+        return self._centred(bgr - np.asarray(self.mean, np.float32))
 
     def preprocess(self, image, label=None):
-        """layer.py:171-236: image is BGR (cv2.imread order); returns CHW float32 (and the label crop)"""
-        image = np.asarray(image, np.float32).copy()
-        image -= np.asarray(self.mean, np.float32)
-        image *= self.scale
+        """layer.py:171-236: image is BGR (cv2.imread order) -> CHW float32 crop (and the label crop, float32).
+        Random draws, as the reference makes them: `random.randint` for the row offset, then for the column offset, both over
+        the slack of the EXTENDED image and only in phase 'Train'; then, only with `mirror`, ONE `np.random.choice(2)` whose
+        value 0 means "mirror" (the reference's stride 2*0-1 = -1)."""
+        x = (np.asarray(image, np.float32) - np.asarray(self.mean, np.float32)) * np.float32(self.scale)
         if label is None:
-            img_pad, _, _ = self._pad_image(image)
-            return self._center_crop(img_pad).transpose((2, 0, 1))
-        img_pad, pad_h, pad_w = self._pad_image(image)
-        label_pad = _pad_bottom_right(np.asarray(label), pad_h, pad_w, (self.ignore_label,)) \
-            if (pad_h > 0 or pad_w > 0) else np.asarray(label)
-        img_h, img_w = label_pad.shape
+            return self._centred(x)
+        label = np.asarray(label)
+        crop = (self.crop_h, self.crop_w)
+        win = _Window(label.shape, crop)
         if self.phase == 'Train':
-            h_off = random.randint(0, img_h - self.crop_h)
-            w_off = random.randint(0, img_w - self.crop_w)
-        else:
-            h_off = (img_h - self.crop_h) // 2
-            w_off = (img_w - self.crop_w) // 2
-        image = np.asarray(img_pad[h_off:h_off + self.crop_h, w_off:w_off + self.crop_w], np.float32)
-        label = np.asarray(label_pad[h_off:h_off + self.crop_h, w_off:w_off + self.crop_w], np.float32)
-        image = image.transpose((2, 0, 1))
-        if self.is_mirror:
-            flip = np.random.choice(2) * 2 - 1
-            image = image[:, :, ::flip]
-            label = label[:, ::flip]
-        return image, label
+            max_top, max_left = win.slack()
+            top = random.randint(0, max_top)
+            win = _Window(label.shape, crop, top, random.randint(0, max_left))
+        img, lab = win.cut(x, 0.0).transpose(2, 0, 1), win.cut(label, self.ignore_label)
+        mirrored = bool(self.is_mirror) and int(np.random.choice(2)) == 0
+        return (img[:, :, ::-1], lab[:, ::-1]) if mirrored else (img, lab)
 
     @classmethod
     def check_params(cls, params):
-        params.setdefault('crop_size', (505, 505))
-        params.setdefault('mean', [128, 128, 128])
-        params.setdefault('scale', 1.0)
-        params.setdefault('mirror', False)
-        params.setdefault('phase', 'Train')
-        params.setdefault('ignore_label', 255)
+        for key, value in _DEFAULTS:
+            params.setdefault(key, value)
 
 
 def _imread_bgr(path):
@@ -119,48 +114,48 @@ def _imread_gray(path):
 
 
 class BatchLoader(object):
-    """layer.py:77-116: `source` lists "image_path label_path" pairs relative to root_folder"""
+    """layer.py:77-116: `source` lists "image_path label_path" pairs relative to root_folder.  The list is walked in file order
+    for the first epoch and reshuffled (`random.shuffle`, the generator the crop offsets also come from) before every later one."""
 
     def __init__(self, params):
-        self.batch_size = params['batch_size']
-        self.root_folder = params['root_folder']
-        self.source = params['source']
-        self.indexlist = [line.strip().split() for line in open(self.source) if line.strip()]
-        self._cur = 0
+        self.batch_size, self.root_folder, self.source = params['batch_size'], params['root_folder'], params['source']
+        with open(self.source) as f:
+            self.indexlist = [ln.split() for ln in f if ln.strip()]
+        if not self.indexlist:
+            raise ValueError("%s lists no image / label pair" % self.source)
         self.transformer = SimpleTransformer(params)
+        self._epochs = self._walk()
+
+    def _walk(self):
+        while True:
+            for image_path, label_path in list(self.indexlist):
+                yield self.root_folder + image_path, self.root_folder + label_path
+            random.shuffle(self.indexlist)
 
     def load_next_image(self):
-        if self._cur == len(self.indexlist):
-            self._cur = 0
-            shuffle(self.indexlist)
-        image_file_path, label_file_path = self.indexlist[self._cur]
-        image = _imread_bgr(self.root_folder + image_file_path)
-        label = _imread_gray(self.root_folder + label_file_path)
-        self._cur += 1
-        return self.transformer.preprocess(image, label)
+        image_path, label_path = next(self._epochs)
+        return self.transformer.preprocess(_imread_bgr(image_path), _imread_gray(label_path))
 
 
 class ImageSegDataLayer(_Base):
-    """layer.py:17-74: tops = [data (B,3,h,w), label (B,1,h,w)]"""
+    """layer.py:17-74: tops = [data (B,3,h,w), label (B,1,h,w)], filled image by image on the host"""
+
+    top_names = ['data', 'label']
 
     def setup(self, bottom, top):
-        self.top_names = ['data', 'label']
         params = ast.literal_eval(self.param_str)
-        SimpleTransformer.check_params(params)
-        self.batch_size = params['batch_size']
-        self.input_shape = params['crop_size']
-        self.batch_loader = BatchLoader(params)
-        top[0].reshape(self.batch_size, 3, self.input_shape[0], self.input_shape[1])
-        top[1].reshape(self.batch_size, 1, self.input_shape[0], self.input_shape[1])
+        self.batch_loader = BatchLoader(params)                 # (its transformer fills in the defaults: crop_size is set below)
+        self.batch_size, self.input_shape = params['batch_size'], tuple(params['crop_size'])
+        for blob, channels in zip(top, (3, 1)):
+            blob.reshape(self.batch_size, channels, *self.input_shape)
 
     def forward(self, bottom, top):
-        for itt in range(self.batch_size):
-            im, label = self.batch_loader.load_next_image()
-            top[0].data[itt, ...] = im
-            top[1].data[itt, ...] = label
+        data, label = top[0].data, top[1].data
+        for n in range(self.batch_size):
+            data[n], label[n, 0] = self.batch_loader.load_next_image()
 
     def reshape(self, bottom, top):
-        pass
+        pass                                                    # fixed crop size: shaped once in setup
 
     def backward(self, top, propagate_down, bottom):
-        pass
+        pass                                                    # a data layer has nothing to propagate

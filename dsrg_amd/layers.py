@@ -249,12 +249,8 @@ class DSRGLayer(_Base):
     def setup(self, bottom, top):
         if len(bottom) != 4:
             raise Exception("The layer needs four inputs!")
-        layer_params = yaml.safe_load(self.param_str)
-        self._th1 = layer_params['th1']
-        self._th2 = layer_params['th2']
-        if 'iters' not in layer_params:
-            layer_params['iters'] = -1
-        self._max_iters = layer_params['iters']
+        cfg = dict({'iters': -1}, **(yaml.safe_load(self.param_str) or {}))
+        self._th1, self._th2, self._max_iters = cfg['th1'], cfg['th2'], cfg['iters']      # th1 / th2 are required (KeyError)
         self._iter_index = 0
         # the reference forks a multiprocessing.Pool here; the batch runs as one kernel launch instead
 

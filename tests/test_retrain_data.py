@@ -68,6 +68,62 @@ def test_simple_transformer_pad_crop_mirror():
     assert np.array_equal(x[0], img[2:18, 17:33, 2].astype(np.float32) - 1.0)
 
 
+def test_transformer_equals_pad_then_slice_on_random_shapes():
+    """the crop window placed on a crop-sized canvas == the reference's sequence (extend the image at the bottom / right to the
+    crop size, slice at the drawn offsets, mirror with stride -1 when np.random.choice(2) draws 0: layer.py:200-236), draws
+    replayed from the same seeds"""
+    rng = np.random.default_rng(5)
+    for case in range(40):
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        ch, cw = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        phase = 'Train' if case % 3 else 'Test'
+        mirror = bool(case % 2)
+        t = SimpleTransformer({'mean': (10.0, 20.0, 30.0), 'scale': 0.5, 'mirror': mirror, 'crop_size': (ch, cw), 'phase': phase,
+                               'ignore_label': 254})
+        img = rng.integers(0, 256, size=(H, W, 3)).astype(np.uint8)
+        lab = rng.integers(0, 21, size=(H, W)).astype(np.uint8)
+        random.seed(case); np.random.seed(case)
+        im, lb = t.preprocess(img, lab)
+        st_py, st_np = random.getstate(), np.random.get_state()[2]
+        random.seed(case); np.random.seed(case)
+        ph, pw = max(ch - H, 0), max(cw - W, 0)
+        x = np.pad((img.astype(np.float32) - np.array([10.0, 20.0, 30.0], np.float32)) * np.float32(0.5), ((0, ph), (0, pw), (0, 0)))
+        y = np.pad(lab, ((0, ph), (0, pw)), constant_values=254)
+        if phase == 'Train':
+            ho = random.randint(0, y.shape[0] - ch); wo = random.randint(0, y.shape[1] - cw)
+        else:
+            ho, wo = (y.shape[0] - ch) // 2, (y.shape[1] - cw) // 2
+        x, y = x[ho:ho + ch, wo:wo + cw].transpose(2, 0, 1), y[ho:ho + ch, wo:wo + cw].astype(np.float32)
+        if mirror:
+            st = np.random.choice(2) * 2 - 1
+            x, y = x[:, :, ::st], y[:, ::st]
+        assert im.dtype == np.float32 and lb.dtype == np.float32
+        assert np.array_equal(im, x) and np.array_equal(lb, y), case
+        assert random.getstate() == st_py and np.random.get_state()[2] == st_np      # same draws, no further ones
+        # the label-less call: centre crop on the zero-extended image
+        x0 = np.pad((img.astype(np.float32) - np.array([10.0, 20.0, 30.0], np.float32)) * np.float32(0.5), ((0, ph), (0, pw), (0, 0)))
+        ho, wo = (x0.shape[0] - ch) // 2, (x0.shape[1] - cw) // 2
+        assert np.array_equal(t.preprocess(img), x0[ho:ho + ch, wo:wo + cw].transpose(2, 0, 1))
+
+
+def test_batch_loader_walks_in_file_order_then_reshuffles(tmp_path):
+    from PIL import Image
+    root = str(tmp_path) + "/"
+    for k in range(4):
+        Image.fromarray(np.full((8, 8, 3), 10 * k, np.uint8)).save(root + "i%d.png" % k)
+        Image.fromarray(np.full((8, 8), k, np.uint8)).save(root + "l%d.png" % k)
+    src = root + "list.txt"
+    open(src, "w").write("".join("i%d.png l%d.png\n" % (k, k) for k in range(4)) + "\n")
+    random.seed(11)
+    ld = BatchLoader({'batch_size': 2, 'root_folder': root, 'source': src, 'mean': (0.0, 0.0, 0.0), 'crop_size': (8, 8), 'phase': 'Test'})
+    seen = [int(ld.load_next_image()[1][0, 0]) for _ in range(12)]
+    assert seen[:4] == [0, 1, 2, 3]                                       # first epoch: file order (layer.py:99-103)
+    random.seed(11)
+    order = [0, 1, 2, 3]
+    random.shuffle(order); assert seen[4:8] == order                      # reshuffled at the epoch boundary by random.shuffle ...
+    random.shuffle(order); assert seen[8:12] == order                     # ... in place, epoch after epoch
+
+
 def test_image_seg_data_layer_protocol(tmp_path):
     from PIL import Image
     rng = np.random.default_rng(1)
