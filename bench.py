@@ -645,6 +645,12 @@ def main():
         rank_ms = [float(t.item()) / args.steps * 1e3 for t in ts]
         dt = max(float(t.item()) for t in ts)                     # the job's time is its slowest rank's
 
+    # replicas in lock step?  every rank all-gathers a 64-bit checksum pair of its parameters and momentum buffers (a
+    # data-parallel number is only a number if the ranks still hold the same weights); outside the timed region
+    weights_equal, weight_words = None, None
+    if trainer is not None:
+        weights_equal, weight_words = trainer.weights_equal_across_ranks()
+
     # the dominant hot-path kernel inside the train step: a separate, untimed pass with every filter launch bracketed by HIP
     # events on its launch stream (the brackets cost ~5 us each: they must not sit in the timed region)
     filt_ms, filt_n, ev_overhead = 0.0, 0, 0.0
@@ -698,6 +704,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "baseline_config": "configs[2] (batch 16 on 1 GPU); configs[3] at 8 GPUs"},
             "rccl_ranks": dist.get_world_size() if dist is not None else 0,     # 0: no process group (plain single-GPU run)
+            "weights_equal_across_ranks": weights_equal,                         # checksums all-gathered after the timed steps
+            "weights_checksum_rank0": ("%016x" % (weight_words[0][0] & (2 ** 64 - 1))) if weight_words else None,
             "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms)},
             "losses": [float(x) for x in losses.detach().cpu()],
             "supervision_ms_per_step": sup_ms,
@@ -772,6 +780,10 @@ def main():
             out["modes"] = modes
         print(json.dumps(out))
     finish()
+    if weights_equal is False:
+        # every rank leaves with the same status: a scaling number from replicas that drifted apart is not a measurement
+        raise SystemExit("bench.py: the ranks' weights differ after %d steps (checksums %s)" % (
+            args.warmup + args.steps, ["%016x" % (w[0] & (2 ** 64 - 1)) for w in weight_words]))
 
 
 if __name__ == "__main__":

@@ -78,6 +78,22 @@ class CaffeSGD(object):
         # B = V / lr is rescaled at the next step through buf_lr)
 
 
+@torch.no_grad()
+def params_checksum(tensors):
+    """-> int64[2] on the tensors' device: (sum of the 32-bit patterns, sum of pattern x (1 + index mod 65521)), both mod 2^64"""
+    dev = tensors[0].device
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    for k, t in enumerate(tensors):
+        t = t.detach().contiguous().view(-1)
+        if t.element_size() != 4:
+            t = t.float()
+        bits = t.view(torch.int32).to(torch.int64)
+        idx = torch.arange(bits.numel(), device=dev, dtype=torch.int64)
+        acc[0] += bits.sum() + (k + 1)
+        acc[1] += (bits * (1 + (idx + 7919 * k) % 65521)).sum()
+    return acc
+
+
 class DSRGTrainer(object):
     def __init__(self, device, world_size=1, seed=0, amp_dtype=torch.bfloat16, channels_last=True,
                  loss_fn=None, net=None, ddp=None, weights=None, snapshot=None, bucket_cap_mb=32):
@@ -132,6 +148,24 @@ class DSRGTrainer(object):
         out = losses.detach().clone()
         dist.all_reduce(out, op=dist.ReduceOp.SUM)
         return out / dist.get_world_size()
+
+    def weights_checksum(self):
+        """two 64-bit words over the BIT PATTERNS of every parameter and momentum buffer, in parameter order: the plain sum and a
+        position-weighted sum (so equal values in another order do not pass), exact integer arithmetic on the device"""
+        return params_checksum(list(self.net.parameters()) + [b for g in self.opt.groups for b in g["bufs"]])
+
+    def weights_equal_across_ranks(self):
+        """data-parallel replicas must hold bit-identical weights after every step (same initial weights, same
+        all-reduced gradients, same update).  All-gathers weights_checksum() (16 bytes per rank) -> (equal?, [[sum, weighted
+        sum] per rank]); collective — every rank calls it; a single process returns (True, [its own])."""
+        import torch.distributed as dist
+        mine = self.weights_checksum()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return True, [[int(v) for v in mine.cpu()]]
+        parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        words = [[int(v) for v in p.cpu()] for p in parts]
+        return all(w == words[0] for w in words), words
 
     def step(self, images, labels, cues):
         """images (B,3,321,321) f32 mean-subtracted, labels (B,1,1,21), cues (B,21,41,41) -> losses[2] (this rank's shard;

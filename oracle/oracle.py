@@ -23,7 +23,10 @@ c_ubyte_p = ctypes.POINTER(ctypes.c_ubyte)
 
 
 def build():
-    """Compile liboracle.so with gcc (idempotent)."""
+    """Compile liboracle.so with gcc (idempotent).  DSRG_ORACLE_LIB names another build of the same source to load instead
+    (tests/test_oracle_sanitized.py: the -fsanitize=address,undefined build)."""
+    if os.environ.get("DSRG_ORACLE_LIB"):
+        return os.environ["DSRG_ORACLE_LIB"]
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "dsrg_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

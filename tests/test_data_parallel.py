@@ -82,8 +82,14 @@ def _worker(rank, world, port, out_dir):
         l = tr.step(images[sh], labels[sh], cues[sh])
         shard_losses.append(l.clone())
         reduced.append(tr.reduce_losses(l))                  # the 8-byte logging all-reduce
+    equal, words = tr.weights_equal_across_ranks()          # what bench.py --gpus N prints and exits on
+    if rank == 1:
+        with torch.no_grad():
+            tr.net.features[0].bias[0] += 1e-7               # one parameter of one replica drifts by an ulp-sized amount
+    equal_after_drift, words_drift = tr.weights_equal_across_ranks()
     torch.save({"w": [p.detach().clone() for p in tr.net.parameters()], "events": events, "shard": shard_losses,
-                "reduced": reduced}, os.path.join(out_dir, "w%d.pt" % rank))
+                "reduced": reduced, "equal": equal, "words": words, "equal_after_drift": equal_after_drift,
+                "words_drift": words_drift}, os.path.join(out_dir, "w%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -93,8 +99,17 @@ def test_two_rank_gloo_equals_single_process_global_batch(tmp_path):
     r0 = torch.load(os.path.join(str(tmp_path), "w0.pt"))
     r1 = torch.load(os.path.join(str(tmp_path), "w1.pt"))
     w0, w1 = r0["w"], r1["w"]
-    for a, b in zip(w0, w1):
+    for k, (a, b) in enumerate(zip(w0, w1)):
+        if k == 1:                                           # features.0.bias: rank 1 injected a drift into its first element below
+            assert torch.equal(a[1:], b[1:]) and a[0] != b[0] and abs(float(a[0] - b[0])) < 1e-6
+            b[0] = a[0]
         assert torch.equal(a, b)                             # replicas stay in lock step
+    # the self-check of the multi-GPU bench line: equal on both ranks while the replicas agree, unequal — on BOTH ranks — as soon
+    # as one bit of one replica differs
+    for r in (r0, r1):
+        assert r["equal"] is True and r["words"][0] == r["words"][1] and len(r["words"]) == 2
+        assert r["equal_after_drift"] is False and r["words_drift"][0] != r["words_drift"][1]
+    assert r0["words"] == r1["words"] and r0["words_drift"] == r1["words_drift"]
     torch.manual_seed(0)
     tr = DSRGTrainer(torch.device("cpu"), world_size=1, seed=0, amp_dtype=None, channels_last=False,
                      loss_fn=torch_loss, net=TinyNet())

@@ -339,7 +339,13 @@ def test_pylayers_protocol_vs_reference_glue(golden_glue, tag):
     assert np.abs(np.exp(top.data) - g[tag + "_refined"]).max() < CRF_TOL
     top.diff[...] = g[tag + "_top_diff"]
     crf.backward([top], [True, False], [b_probs, b_im])
-    assert np.abs(b_probs.diff - g[tag + "_crf_bottom_diff"]).max() < 1e-3 * np.abs(g[tag + "_top_diff"]).max()
+    # backward = (1 - result) * top.diff (pylayers.py:90-92): held to 1e-6 on the layer's own marginals (as
+    # test_crf_refine_batch_vs_oracle holds dsrg_crf_layer_backward), and against the reference's output as far as the two sets
+    # of marginals agree — the only other source of a difference
+    dmax = np.abs(g[tag + "_top_diff"]).max()
+    gap = np.abs(crf.result - g[tag + "_refined"]).max()
+    assert np.abs(b_probs.diff - (1.0 - crf.result) * g[tag + "_top_diff"]).max() <= 1e-6 * dmax
+    assert np.abs(b_probs.diff - g[tag + "_crf_bottom_diff"]).max() <= (gap + 1e-6) * dmax
 
     dsrg = pylayers.DSRGLayer()
     dsrg.param_str = "{'th1': 0.99, 'th2': 0.85}"

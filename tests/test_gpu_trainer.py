@@ -282,6 +282,25 @@ def test_config4_ddp_rccl_two_ranks(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 4
+    assert line["weights_equal_across_ranks"] is True        # the ranks all-gathered their checksums after the timed steps
+
+
+def test_bench_line_under_the_launcher_checks_the_replicas(tmp_path):
+    """the driver's N>1 launch line at the one world size a one-GPU box has: `python -m torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1` goes through the RCCL process group, DDP and the checksum all-gather that N=8 goes through, and the line
+    says so (rccl_ranks, weights_equal_across_ranks); a plain run reports no process group and a trivially equal replica set"""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTORCH_TUNABLEOP_ENABLED="0")
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-fp32",
+            "--no-cpu-baseline", "--no-modes", "--no-profile"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port)] + tail, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["weights_equal_across_ranks"] is True and len(line["weights_checksum_rank0"]) == 16
+    assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 2 and np.isfinite(line["losses"]).all()
 
 
 def test_bench_gpus_beyond_the_visible_ones_fails_in_one_line():

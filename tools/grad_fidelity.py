@@ -12,6 +12,8 @@ is compared is the backbone's backward chain alone.  Legs, each against the floa
   f32+act     float32 arithmetic, every activation rounded to bf16 where the bf16 route stores one
   f32+grad    float32 arithmetic, every activation gradient rounded to bf16 where the bf16 route stores one
   f32+both    both roundings (the bf16 route's storage precision with float32 products)
+  act,amax2   f32+act, but pool1-3 (stride 2) pick each window's maximum on the unrounded convolution output
+  act,amax12  ... and pool4 / pool5 (stride 1) too
 
 per parameter: cosine to the float32 gradient and relative L2 distance.   usage: grad_fidelity.py [B] [--loss-own]"""
 import os, sys
@@ -48,22 +50,25 @@ class _Round(torch.autograd.Function):
         return (g.bfloat16().float() if ctx.bwd else g), None, None
 
 
-def plain_forward(net, x, rnd=(False, False)):
-    """the prototxt's layer sequence on torch ops; rnd = (round activations, round activation gradients) at every stored blob"""
+def plain_forward(net, x, rnd=(False, False), argmax32=()):
+    """the prototxt's layer sequence on torch ops; rnd = (round activations, round activation gradients) at every stored blob;
+    argmax32: strides of the max pools that pick their window maximum on the UNROUNDED convolution output (the value stored is
+    the same — rounding is monotone — but ties between bf16-equal neighbours are decided as float32 decides them)"""
     r = lambda t: _Round.apply(t, rnd[0], rnd[1]) if (rnd[0] or rnd[1]) else t          # noqa: E731
 
-    def conv(m, h, training):
+    def conv(m, h, training, raw_out=False):
         h = F.conv2d(h, m.weight, m.bias, 1, m.padding, m.dilation)
         if getattr(m, "fuse_relu", False):
             h = F.relu(h)
-        h = r(h)
         if getattr(m, "fuse_pool", None) is not None:
-            h = r(F.max_pool2d(h, 3, 2, 1, ceil_mode=True))
-        return h
+            h = h if 2 in argmax32 else r(h)
+            return r(F.max_pool2d(h, 3, 2, 1, ceil_mode=True))
+        return h if raw_out else r(h)
     h = r(x)
-    for m in net.features:
+    feats = [m for m in net.features if isinstance(m, (backbone.GemmConv2d, backbone.MaxPool3x3, backbone.AvgPool3x3))]
+    for i, m in enumerate(feats):
         if isinstance(m, backbone.GemmConv2d):
-            h = conv(m, h, net.training)
+            h = conv(m, h, net.training, raw_out=1 in argmax32 and isinstance(feats[i + 1], backbone.MaxPool3x3))
         elif isinstance(m, backbone.MaxPool3x3):
             h = r(F.max_pool2d(h, 3, 1, 1))
         elif isinstance(m, backbone.AvgPool3x3):
@@ -103,7 +108,8 @@ def main():
                 y = plain_forward(net, x)
         else:
             y = plain_forward(net, x, {"f32+act": (True, False), "f32+grad": (False, True), "f32+both": (True, True),
-                                       "f32plain": (False, False)}[tag])
+                                       "f32plain": (False, False), "act,amax2": (True, False), "act,amax12": (True, False)}[tag],
+                              argmax32={"act,amax2": (2,), "act,amax12": (1, 2)}.get(tag, ()))
         y = y.float().contiguous()
         if gout is None or own:
             yl = y.detach().requires_grad_(True)
@@ -118,7 +124,7 @@ def main():
 
     y32, gout, ref = run("fp32", None)
     print("# scores: rms %.3f  max %.3f; batch %d" % (float(y32.pow(2).mean().sqrt()), float(y32.abs().max()), B))
-    legs = ["bf16", "stock", "f32plain", "f32+act", "f32+grad", "f32+both"]
+    legs = ["bf16", "stock", "f32plain", "f32+act", "f32+grad", "f32+both", "act,amax2", "act,amax12"]
     res = {}
     for tag in legs:
         y, _, gr = run(tag, gout)

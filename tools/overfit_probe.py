@@ -46,8 +46,8 @@ def main():
     b = S.make_batch(7, B)
     batch = tuple(torch.from_numpy(b[k]).to(dev) for k in ("images", "labels", "cues"))
     for p in drops:
-        h16 = trajectory(dev, torch.bfloat16, p, steps, B, init, lr)
-        h32 = trajectory(dev, None, p, steps, B, init, lr)
+        h16 = trajectory(dev, torch.bfloat16, p, steps, batch, init, lr)
+        h32 = trajectory(dev, None, p, steps, batch, init, lr)
         assert np.isfinite(h16).all() and np.isfinite(h32).all(), "non-finite loss"
         t16, t32 = h16.sum(1), h32.sum(1)
         gap = np.abs(t16 - t32) / np.maximum(np.abs(t32), 1e-12)
