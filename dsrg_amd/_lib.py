@@ -107,6 +107,7 @@ SIGNATURES = {
     "dsrg_heads_backward_relu_workspace": (_sz, [_i] * 3),
     "dsrg_heads_backward_relu_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _f, _vp, _vp, _sz] + [_i] * 4 + [_vp]),
     "dsrg_maxpool3x3_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dsrg_maxpool3x3_relu_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_maxpool3x3_bwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_maxpool3x3_bwd_relu_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_supervision_step": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _d, _d, ctypes.POINTER(CrfParams),

@@ -104,8 +104,11 @@ class _ConvFn(torch.autograd.Function):
             # this ReLU and sums the bias gradient in the same pass (ops.maxpool3x3_bwd_relu) instead of handing an unmasked
             # gradient to a separate relu_bwd_bias pass — three fewer passes over the largest activations of the net
             from .ops import maxpool3x3_fwd
-            pooled, code = maxpool3x3_fwd(out, pool[0], pool[1])
-        ctx.save_for_backward(x, weight, out if relu else None, cols, code)
+            # (relu_input: the window codes carry this ReLU's mask, so the backward never reads the full-resolution output again
+            # and the node does not keep it)
+            pooled, code = maxpool3x3_fwd(out, pool[0], pool[1], relu_input=True)
+        ctx.save_for_backward(x, weight, out if (relu and pool is None) else None, cols, code)
+        ctx.out_shape = tuple(out.shape)
         ctx.dilation, ctx.k, ctx.relu, ctx.scale, ctx.gemm = dilation, k, relu, 1.0 / (1.0 - drop_p), gemm
         ctx.direct, ctx.pool = direct, pool
         # _GradLink (see below): link_in — x is the ReLU output of the node in front and feeds nothing else; link_out — ours
@@ -130,7 +133,7 @@ class _ConvFn(torch.autograd.Function):
             fused = True
         elif ctx.pool is not None:                                      # forward guaranteed bf16, ReLU, no dropout, cout | 2048
             from .ops import maxpool3x3_bwd_relu
-            g, gb = maxpool3x3_bwd_relu(g, code, y, ctx.pool[0])
+            g, gb = maxpool3x3_bwd_relu(g, code, ctx.out_shape, ctx.pool[0])
             fused = True
         elif fused and ctx.relu:
             from .ops import relu_bwd_bias
@@ -291,8 +294,9 @@ class _IgemmConvFn(torch.autograd.Function):
         code, pooled = None, None
         if pool is not None:                                                             # n == 1 (conv3_3)
             from .ops import maxpool3x3_fwd
-            pooled, code = maxpool3x3_fwd(outs[0], pool[0], pool[1])
-        ctx.save_for_backward(code, *xs, *ws, *(outs if relu else ()))
+            pooled, code = maxpool3x3_fwd(outs[0], pool[0], pool[1], relu_input=True)    # the codes carry the ReLU mask
+        ctx.save_for_backward(code, *xs, *ws, *(outs if (relu and pool is None) else ()))
+        ctx.out_shape = tuple(outs[0].shape)
         ctx.packs_d = packs_d                  # not an input or output of the node: kept outside save_for_backward
         ctx.dils, ctx.relu, ctx.scale, ctx.pool, ctx.n, ctx.k = dils, relu, scale, pool, n, k
         ctx.links_in = links_in
@@ -319,7 +323,7 @@ class _IgemmConvFn(torch.autograd.Function):
                 # the consumer's data gradient came masked by this node's ReLU (+ Dropout) with the bias gradient beside it
                 gm, gb = g, gb_left
             elif ctx.pool is not None:
-                gm, gb = maxpool3x3_bwd_relu(g, code, ys[i], ctx.pool[0])
+                gm, gb = maxpool3x3_bwd_relu(g, code, ctx.out_shape, ctx.pool[0])
             elif ctx.relu:
                 gm, gb = relu_bwd_bias(g, ys[i], ctx.scale)
             else:
@@ -386,8 +390,9 @@ class _DirectConvFn(torch.autograd.Function):
         out = conv3x3_direct(x, w16, bias.detach(), relu)
         code, pooled = None, None
         if pool is not None:
-            pooled, code = maxpool3x3_fwd(out, pool[0], pool[1])
-        ctx.save_for_backward(x, out if relu else None, code)
+            pooled, code = maxpool3x3_fwd(out, pool[0], pool[1], relu_input=True)         # the codes carry the ReLU mask
+        ctx.save_for_backward(x, out if (relu and pool is None) else None, code)
+        ctx.out_shape = tuple(out.shape)
         ctx.wd = wd                                    # not an input or output of the node: kept outside save_for_backward
         ctx.relu, ctx.pool = relu, pool
         ctx.link_in = link_in if (link_in is not None and link_in.scale == 1.0 and wd is not None) else None
@@ -404,7 +409,7 @@ class _DirectConvFn(torch.autograd.Function):
         if gb is not None:
             pass                                       # g came masked by this node's ReLU, its bias gradient beside it
         elif ctx.pool is not None:
-            g, gb = maxpool3x3_bwd_relu(g, code, y, ctx.pool[0])
+            g, gb = maxpool3x3_bwd_relu(g, code, ctx.out_shape, ctx.pool[0])
         elif ctx.relu:
             g, gb = relu_bwd_bias(g, y, 1.0)
         else:
@@ -485,7 +490,7 @@ class GemmConv2d(nn.Conv2d):
             # the pool rides inside the node when its kernels apply: bf16 activations (autocast), 8 | channels, (channels / 8) | 256
             cout = self.out_channels
             if _igemm_route(self, x):
-                in_node = pool is not None and _FUSE_POOL
+                in_node = pool is not None and _FUSE_POOL and cout % 8 == 0 and 256 % (cout // 8) == 0     # the pool kernels' tiling
                 lin = getattr(x, "_dsrg_grad_link", None) if self.chain_input else None
                 lout = _GradLink() if (self.fuse_relu and pool is None and torch.is_grad_enabled()) else None
                 (out,) = _IgemmConvFn.apply(3, [self.dilation[0]], self.fuse_relu, p, pool if in_node else None, 1,

@@ -586,6 +586,11 @@ extern "C" int dsrg_maxpool3x3_fwd_bf16(const void *in, void *out, void *code, i
     if (!in || !out || !code) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_maxpool3x3_fwd(in, out, code, B, H, W, OH, OW, C, stride, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_maxpool3x3_relu_fwd_bf16(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C,
+                                             int stride, void *stream) {
+    if (!in || !out || !code) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_maxpool3x3_fwd(in, out, code, B, H, W, OH, OW, C, stride, static_cast<hipStream_t>(stream), true);
+}
 extern "C" int dsrg_maxpool3x3_bwd_bf16(const void *gout, const void *code, void *gin, int B, int H, int W, int OH, int OW,
                                         int C, int stride, void *stream) {
     if (!gout || !code || !gin) return set_error(DSRG_ERR_INVALID, "NULL argument");
@@ -595,7 +600,7 @@ extern "C" int dsrg_maxpool3x3_bwd_bf16(const void *gout, const void *code, void
 extern "C" int dsrg_maxpool3x3_bwd_relu_bf16(const void *gout, const void *code, const void *relu_out, void *gin, float *bias_grad,
                                              float *partials, int partial_blocks, int B, int H, int W, int OH, int OW, int C,
                                              void *stream) {
-    if (!gout || !code || !relu_out || !gin || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    if (!gout || !code || !gin || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_maxpool3x3_bwd_relu(gout, code, relu_out, gin, bias_grad, partials, partial_blocks, B, H, W, OH, OW, C,
                                       static_cast<hipStream_t>(stream));
 }

@@ -115,6 +115,12 @@ int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_gra
 // ---- 3x3 max pooling, NHWC bf16 ----------------------------------------------------------------------------------
 // forward: out[b,oy,ox,c] = max over the window clipped to the image; code = 3*dy+dx of the FIRST maximum in row-major
 // window order (the rule of Caffe's PoolingLayer and of torch's max_pool2d); NaN propagates as in torch.
+// RELU_IN: the input is a ReLU's output and the pool's backward is to carry that ReLU's backward too: a window whose maximum is
+// not positive gets the code kPoolDead, which matches no tap — its gradient goes nowhere, exactly what masking the pooled-back
+// gradient with (input > 0) does afterwards (a pixel receives gradient only as the argmax of a window, and its value IS that
+// window's maximum), so the backward never has to read the pool's input again (211 MB at pool1).
+constexpr uint32_t kPoolDead = 0xfeu;
+template <bool RELU_IN>
 __global__ void maxpool3x3_fwd_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, uint2 *__restrict__ code,
                                       int B, int H, int W, int OH, int OW, int C8, int stride) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,6 +156,11 @@ __global__ void maxpool3x3_fwd_kernel(const uint4 *__restrict__ in, uint4 *__res
     }
     out[idx] = make_uint4(pack_bf16(best[0], best[1]), pack_bf16(best[2], best[3]), pack_bf16(best[4], best[5]),
                           pack_bf16(best[6], best[7]));
+    if (RELU_IN) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (best[k] <= 0.0f) bc[k] = kPoolDead;                          // (+0, -0, negatives; a NaN keeps its window)
+    }
     code[idx] = make_uint2(bc[0] | (bc[1] << 8) | (bc[2] << 16) | (bc[3] << 24), bc[4] | (bc[5] << 8) | (bc[6] << 16) | (bc[7] << 24));
 }
 
@@ -274,6 +285,8 @@ __global__ void maxpool3x3_s2_bwd_kernel(const uint4 *__restrict__ gout, const u
 // part[block][c] = this block's column sums of gin — instead of writing the unmasked gradient and passing over it again with
 // relu_bwd_bias_kernel (three more passes over the largest activations of the net).  A block owns a contiguous range of
 // (2 x 2 pixel block, channel group) items, 256 per round, so a thread keeps its channel group (256 % C8 == 0).
+// HAS_Y = false: the codes come from maxpool3x3_fwd_kernel<true> and carry the mask already (y is not read: same bits).
+template <bool HAS_Y>
 __global__ __launch_bounds__(kRbThreads) void maxpool3x3_s2_bwd_relu_kernel(const uint4 *__restrict__ gout, const uint2 *__restrict__ code,
                                                                              const uint4 *__restrict__ y, uint4 *__restrict__ gin,
                                                                              float *__restrict__ part, int B, int H, int W, int OH,
@@ -317,7 +330,8 @@ __global__ __launch_bounds__(kRbThreads) void maxpool3x3_s2_bwd_relu_kernel(cons
         auto store = [&](const float (&acc)[8], int yy, int xx) {
             if (yy >= H || xx >= W) return;
             const size_t i = (((size_t)b * H + yy) * W + xx) * C8 + c;
-            const uint4 yv = y[i];
+            uint4 yv = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+            if (HAS_Y) yv = y[i];
             const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
             uint32_t ow[4];
 #pragma unroll
@@ -455,12 +469,16 @@ static int pool_check(int B, int H, int W, int OH, int OW, int C, int stride) {
 }
 
 int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,
-                          hipStream_t stream) {
+                          hipStream_t stream, bool relu_in) {
     int rc = pool_check(B, H, W, OH, OW, C, stride);
     if (rc) return rc;
     const size_t total = (size_t)B * OH * OW * (C / 8);
-    hipLaunchKernelGGL(maxpool3x3_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint4 *)in,
-                       (uint4 *)out, (uint2 *)code, B, H, W, OH, OW, C / 8, stride);
+    if (relu_in)
+        hipLaunchKernelGGL(maxpool3x3_fwd_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint4 *)in,
+                           (uint4 *)out, (uint2 *)code, B, H, W, OH, OW, C / 8, stride);
+    else
+        hipLaunchKernelGGL(maxpool3x3_fwd_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint4 *)in,
+                           (uint4 *)out, (uint2 *)code, B, H, W, OH, OW, C / 8, stride);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
@@ -476,8 +494,12 @@ int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y
     size_t ipb = (total + part_blocks - 1) / part_blocks;
     ipb = (ipb + kRbThreads - 1) / kRbThreads * kRbThreads;                  // whole rounds: a thread keeps its channel group
     const int nblk = (int)((total + ipb - 1) / ipb);
-    hipLaunchKernelGGL(maxpool3x3_s2_bwd_relu_kernel, dim3(nblk), dim3(kRbThreads), 0, stream, (const uint4 *)gout, (const uint2 *)code,
-                       (const uint4 *)y, (uint4 *)gin, part, B, H, W, OH, OW, C8, ipb);
+    if (y)
+        hipLaunchKernelGGL(maxpool3x3_s2_bwd_relu_kernel<true>, dim3(nblk), dim3(kRbThreads), 0, stream, (const uint4 *)gout,
+                           (const uint2 *)code, (const uint4 *)y, (uint4 *)gin, part, B, H, W, OH, OW, C8, ipb);
+    else
+        hipLaunchKernelGGL(maxpool3x3_s2_bwd_relu_kernel<false>, dim3(nblk), dim3(kRbThreads), 0, stream, (const uint4 *)gout,
+                           (const uint2 *)code, (const uint4 *)nullptr, (uint4 *)gin, part, B, H, W, OH, OW, C8, ipb);
     DSRG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
     DSRG_LAUNCH_CHECK();

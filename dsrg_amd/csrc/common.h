@@ -204,7 +204,7 @@ int launch_igemm_colsum(const float *const *parts, float *const *outs, int ngrou
 int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y, void *gin, float *bias_grad, float *part,
                                 int part_blocks, int B, int H, int W, int OH, int OW, int C, hipStream_t stream);
 int launch_maxpool3x3_fwd(const void *in, void *out, void *code, int B, int H, int W, int OH, int OW, int C, int stride,
-                          hipStream_t stream);
+                          hipStream_t stream, bool relu_in = false);
 int launch_maxpool3x3_bwd(const void *gout, const void *code, void *gin, int B, int H, int W, int OH, int OW, int C,
                           int stride, hipStream_t stream);
 

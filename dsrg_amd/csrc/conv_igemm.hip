@@ -85,6 +85,8 @@ struct IgemmArgs {
     float drop_scale;       // 0 = no dropout), kept elements times drop_scale = 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
     float out_scale;        // every output times this (1 unless a mask carries a Dropout scale)
+    int skip_taps;          // 1: a K-step whose tap reaches no pixel of the tile (a dilated kernel near the map's border: all of
+                            // its operand rows would be the zeros of the padding) is not loaded and not multiplied
 };
 
 // the random bytes of the four consecutive channels starting at element 4 * e4 of a launch's output: a counter-based
@@ -142,7 +144,6 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
     const IgemmGroup G = a.g[grp];
     const int taps = a.taps, Cin = a.Cin, W = a.W, H = a.H;
     const int ktot = taps * Cin;
-    const int nsteps = (Cin >> 6) * taps * C::SPC;
 
     const rsrc_t rx = make_rsrc(G.x, (size_t)a.M * Cin * 2);
     const rsrc_t rw = make_rsrc(G.w, (size_t)a.Cout * ktot * 2);
@@ -175,9 +176,43 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         wbase[i] = (uint32_t)(n0 + r) * (uint32_t)(ktot * 2) + (uint32_t)c * 16u;   // rows past Cout lie beyond the descriptor
     }
 
-    auto issue = [&](int stage, int s) {
-        const int q = s / C::SPC, h = s - q * C::SPC;
-        const int cc = q / taps, tap = q - cc * taps;
+    // ---- the taps this tile multiplies.  With a dilated kernel whole taps fall into the zero padding for every pixel of a tile
+    // (fc6_4, dilation 24 on a 41-row map: the three upper taps reach a pixel only from row 24 on — for the tiles above they
+    // are 64-deep K-steps of zeros times weights): the tile's taps are the OR of its pixels' validity bits, and the K loop runs
+    // over those only — 15 % of the four fc6_k's steps at 16 images (30 % for dilation 24).  A skipped step adds exact zeros
+    // to every accumulator, so results are bit-identical with and without (tests/test_gpu_igemm.py).  Taps stay in their
+    // order, chunk outer / tap inner as before; a tile that reaches every tap runs the very same sequence.
+    uint32_t tapmask = taps == 9 ? 0x1ffu : 1u;
+    if (a.skip_taps && taps == 9 && G.dil >= 3) {           // (workgroup-uniform; below 3 no 256-pixel tile loses a tap)
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < C::IPW; i++) v |= pvalid[i];
+#pragma unroll
+        for (int o = 32; o; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
+        volatile uint32_t *red = reinterpret_cast<volatile uint32_t *>(ig_lds);
+        if (lane == 0) red[wv] = v;
+        __syncthreads();
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v |= red[k];
+        __syncthreads();                                    // the words are stage 0's first row again
+        tapmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    }
+    unsigned long long taplist = 0;                         // nibble k = the k-th live tap
+    int nlive = 0;
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
+        if ((tapmask >> tp) & 1u) { taplist |= (unsigned long long)tp << (4 * nlive); nlive++; }
+    const int nsteps = (Cin >> 6) * nlive * C::SPC;
+
+    // issue(stage, s): the DMA of K-step s into `stage`; the steps are issued in order, so (chunk, live tap, half) advance as
+    // counters instead of being divided out of s
+    int it_cc = 0, it_tap = 0, it_h = 0;
+    auto issue = [&](int stage, int) {
+        const int tap = (int)((taplist >> (4 * it_tap)) & 15u);
+        const int cc = it_cc, h = it_h;
+        const uint32_t s_real = (uint32_t)((cc * taps + tap) * C::SPC + h);     // position of the step's weights in a packed row
+        if (++it_h == C::SPC) { it_h = 0; if (++it_tap == nlive) { it_tap = 0; it_cc++; } }
         int dy = 0, dx = 0;
         if (taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
         const int toff = (dy * G.dil * W + dx * G.dil) * Cin * 2 + cc * 128 + h * C::ROW;      // wave-uniform
@@ -190,7 +225,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         }
 #pragma unroll
         for (int i = 0; i < C::IPW; i++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Wt + i * (C::RPI * C::ROW)), 16, wbase[i], (uint32_t)s * C::ROW, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Wt + i * (C::RPI * C::ROW)), 16, wbase[i], s_real * C::ROW, 0, 0);
     };
 
     f32x16 acc[4][2];
@@ -706,6 +741,8 @@ struct IgemmWgradArgs {
     WgradGroup g[4];
     int ngroups, B, H, W, Cin, Cout, taps, M, tiles_n, tiles_c, ksplit, kchunk, tiles_per_group;
     int stagger;            // as IgemmArgs::stagger
+    int skip_rows;          // 1: a K-step (64 pixels) whose rows the tile's tap shifts out of the map entirely is not loaded and
+                            // not multiplied (its x rows would all be padding zeros)
 };
 constexpr int kWRow = 512;                                 // bytes per LDS row: 256 channels
 constexpr int kWTile = 64 * kWRow;                         // 64 pixels
@@ -775,6 +812,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     }
     const int qW = 64 / W, rW = 64 - qW * W;                // a step advances every row by 64 pixels
 
+    auto advance = [&]() {                                   // the lanes' pixels move on by one step
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            pm[i] += 64;
+            px[i] += rW;
+            py[i] += qW;
+            if (px[i] >= W) { px[i] -= W; py[i] += 1; }
+            while (py[i] >= H) py[i] -= H;
+        }
+    };
     auto issue = [&](int stage) {
         unsigned char *A = ig_lds + stage * kWStage + wv * (8 * kWRow);
         unsigned char *Bt = A + kWTile;
@@ -791,14 +838,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
             const uint32_t vo = live ? (uint32_t)(pm[i] * (Cin * 2) + ltapoff[i]) + xsrcoff[i] : kOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(Bt + i * (2 * kWRow)), 16, vo, 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {                        // the next step's pixels
-            pm[i] += 64;
-            px[i] += rW;
-            py[i] += qW;
-            if (px[i] >= W) { px[i] -= W; py[i] += 1; }
-            while (py[i] >= H) py[i] -= H;
-        }
+        advance();                                           // the next step's pixels
     };
 
     f32x16 acc[4][2];
@@ -820,11 +860,36 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     for (int j = 0; j < 2; j++) boff[j] = lane_off + (uint32_t)(kWTile + ((wm * 2 + j) ^ swz) * 64);
     lds_u8 *lds = (lds_u8 *)ig_lds;
 
-    if (nsteps > 0) issue(0);
-    for (int s = 0; s < nsteps; s++) {
+    // ---- the K-steps this tile multiplies.  A dilated tap shifts whole rows of the map into the padding: with dilation 24 on 41
+    // rows the three upper taps see x only from rows >= 24 — for the 64-pixel steps that lie in rows 0..23 of an image every
+    // x row is zero and the step adds exact zeros (22 % of the four fc6_k's steps at 16 images, 37 % for dilation 24).  Such
+    // steps are skipped: the lanes' pixel counters run on, nothing is loaded, nothing multiplied; the partial sums are
+    // bit-identical.  Decided per step from the rows its first and last pixel lie in (wave-uniform, scalar): a step inside one
+    // image is dead when no row in [y_first, y_last] lands in [0, H) after the shift; a step that crosses into the next image
+    // always holds live rows of one of the two (|shift| < H), and so does any tile without a vertical shift.
+    const int tdy = (taps == 9 && !two) ? (tap / 3 - 1) * G.dil : 0;
+    const bool may_skip = a.skip_rows && tdy != 0 && tdy > -H && tdy < H;
+    const int hw_ = H * W;
+    auto step_dead = [&](int st) -> bool {
+        const int p0 = mbeg + st * 64, p1 = min(p0 + 63, mend - 1);
+        const int b0 = p0 / hw_, b1 = p1 / hw_;
+        if (b0 != b1) return false;
+        const int y0 = (p0 - b0 * hw_) / W, y1 = (p1 - b0 * hw_) / W;
+        return y1 + tdy < 0 || y0 + tdy >= H;
+    };
+    int cur = 0;                                             // the step the lanes' counters stand at = the next one to issue
+    auto seek = [&]() {
+        if (may_skip)
+            while (cur < nsteps && step_dead(cur)) { advance(); cur++; }
+    };
+    seek();
+    bool have = cur < nsteps;
+    if (have) { issue(0); cur++; }
+    for (int s = 0; have; s++) {
         wait_vm_barrier<0>();
-        const bool more = s + 1 < nsteps, late = a.stagger && wv >= 4;
-        if (more && !late) issue((s + 1) & 1);
+        seek();
+        const bool more = cur < nsteps, late = a.stagger && wv >= 4;
+        if (more && !late) { issue((s + 1) & 1); cur++; }
         lds_u8 *st = lds + (s & 1) * kWStage;
         bf16x8 af[2][4], bfr[2][2];
 #pragma unroll
@@ -846,8 +911,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0 && more && late) issue((s + 1) & 1);
+            if (ks == 0 && more && late) { issue((s + 1) & 1); cur++; }
         }
+        have = more;
     }
     // C[row = channel of g][col = channel of x]: lane holds column l31, rows (reg & 3) + 8 (reg >> 2) + 4 kgrp
     float *pp = G.part + (size_t)split * ((size_t)Cout * taps * Cin);
@@ -1016,6 +1082,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
             return set_error(DSRG_ERR_INVALID, "conv_igemm: null pointer");
     }
     a.out_scale = out_scale;
+    a.skip_taps = igemm_variant() != 6;                      // 6: tests / tools — every tap of every tile, as before round 5
     const bool fused_bwd = mask || colsum;
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.relu = relu; a.M = (int)M;
     a.tiles_m = (int)((M + kBM - 1) / kBM);
@@ -1127,6 +1194,7 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     a.kchunk = (int)(((M + a.ksplit - 1) / a.ksplit + 63) / 64 * 64);
     a.tiles_per_group = a.tiles_n * a.tiles_c * a.ksplit;
     a.stagger = igemm_variant() >= 3;
+    a.skip_rows = igemm_variant() != 6;
     const size_t per_group = (size_t)a.ksplit * cout * k * k * cin;
     for (int q = 0; q < ngroups; q++) {
         a.g[q].x = static_cast<const uint16_t *>(x[q]);

@@ -85,6 +85,10 @@ __device__ __forceinline__ void pv_set(float4 &v, int c, float x) {
 
 template <int V> using IC = std::integral_constant<int, V>;
 
+#if DSRG_EXP & 16
+#define g_exp_qimg (exp_qimg)
+#define g_exp_C (exp_C)
+#endif
 #define DSRG_STAMP(i_) do { if (dbg && tid == 0) dbg[(i_)] = wall_clock64(); } while (0)
 
 // one lattice (dimension D, index li of set L), planes [c0, c0+nc) of image b:
@@ -94,7 +98,11 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
                                                float *__restrict__ out, int nc, int N,
                                                typename PlaneVec<CPW>::type *val,
                                                typename PlaneVec<CPW>::type *inq, unsigned long long *dbg,
-                                               int lds_elems, int opts) {
+                                               int lds_elems, int opts
+#if DSRG_EXP & 16
+                                               , const float *exp_qimg, int exp_C
+#endif
+                                               ) {
     using vec_t = typename PlaneVec<CPW>::type;
     constexpr int D1 = D + 1;
     constexpr bool DEEP = VPT <= 10;             // all index words of a thread fit the register file
@@ -132,6 +140,28 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
         for (int c = 0; c < CPW; c++)
             qv[p][c] = ld_f32(r_q, (uint32_t)tid * 4u, (uint32_t)p * (kWG * 4u) + (uint32_t)c * (uint32_t)N * 4u);
     }
+#if DSRG_EXP & 16
+    // PROTOTYPE, measurement only (round-4 review item 3: "fold mf_update_split_kernel into the head of the next filter launch"):
+    // the least a folded head can do — per pixel ONE pre-combined logit plane per label (21 loads where the update kernel has
+    // 63), the fp64-rounded exp of every label and their label-order sum (the softmax denominator every plane pair of the image
+    // needs).  The result only feeds an empty asm, the separate update kernel still runs: this build times the head's cost
+    // inside the filter workgroup's critical path, nothing else (profiles/r05_filter_ab.txt).
+    {
+        const float *qimg = g_exp_qimg;
+        const int Call = g_exp_C;
+        const rsrc_t r_all = make_rsrc(qimg, sizeof(float) * (size_t)Call * N);
+        float keep = 0.0f;
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            float mx = -INFINITY, sum = 0.0f;
+            for (int c = 0; c < Call; c++) mx = fmaxf(mx, ld_f32(r_all, (uint32_t)tid * 4u, ((uint32_t)p * kWG + (uint32_t)c * (uint32_t)N) * 4u));
+            for (int c = 0; c < Call; c++)
+                sum = sum + exp_cr(ld_f32(r_all, (uint32_t)tid * 4u, ((uint32_t)p * kWG + (uint32_t)c * (uint32_t)N) * 4u) - mx);
+            keep += sum;
+        }
+        asm volatile("" :: "v"(keep));
+    }
+#endif
     const bool norm_pass = SEQ && (opts & kOptNormPass);
     if (norm_pass) {                          // (the loads above hit valid memory — q aliases the norm vector — and are dropped)
 #pragma unroll
@@ -520,7 +550,11 @@ __global__ __launch_bounds__(kWG) void mf_filter_kernel(FilterArgs a) {
         vec_t *inq = reinterpret_cast<vec_t *>(smem + a.lds_bytes) - a.N;  // [N] at the end of the region
         const size_t o = ((size_t)b * a.C + c0) * a.N;
         filter_lattice<CPW_B, VPT_B, PPT, 5, SEQ>(a.Lb, b, a.q + o, a.msg_b + o, nc, a.N, val, inq, dbg,
-                                             a.lds_bytes / (int)sizeof(vec_t), a.opts);
+                                             a.lds_bytes / (int)sizeof(vec_t), a.opts
+#if DSRG_EXP & 16
+                                             , a.q + (size_t)b * a.C * a.N, SEQ ? 1 : a.C
+#endif
+                                             );
     } else {
         using vec_t = typename PlaneVec<CPW_G>::type;
         if ((a.opts & kOptLocalGauss) && (a.Lg.flags[0] & kLatticeLocal)) return;   // the update kernel forms this message
@@ -531,7 +565,11 @@ __global__ __launch_bounds__(kWG) void mf_filter_kernel(FilterArgs a) {
         vec_t *inq = reinterpret_cast<vec_t *>(smem + a.lds_bytes) - a.N;
         const size_t o = ((size_t)b * a.C + c0) * a.N;
         filter_lattice<CPW_G, VPT_G, PPT, 2, SEQ>(a.Lg, 0, a.q + o, a.msg_g + o, nc, a.N, val, inq, dbg ? dbg + 16 : nullptr,
-                                             a.lds_bytes / (int)sizeof(vec_t), a.opts);
+                                             a.lds_bytes / (int)sizeof(vec_t), a.opts
+#if DSRG_EXP & 16
+                                             , a.q + (size_t)b * a.C * a.N, 0
+#endif
+                                             );
     }
 }
 #undef DSRG_STAMP

@@ -701,13 +701,16 @@ def maxpool3x3_out_size(n, stride, ceil_mode):
     return o
 
 
-def maxpool3x3_fwd(x, stride, ceil_mode):
-    """x (B,C,H,W) bf16 channels_last -> (pooled (B,C,OH,OW) channels_last, window codes (B,OH,OW,C) uint8)"""
+def maxpool3x3_fwd(x, stride, ceil_mode, relu_input=False):
+    """x (B,C,H,W) bf16 channels_last -> (pooled (B,C,OH,OW) channels_last, window codes (B,OH,OW,C) uint8).
+    relu_input: x is a ReLU's output and maxpool3x3_bwd_relu will be given these codes WITHOUT x — windows whose maximum is
+    not positive get a code that names no position (the ReLU mask rides in the codes; the pooled values are the same)"""
     B, C, H, W = x.shape
     OH, OW = maxpool3x3_out_size(H, stride, ceil_mode), maxpool3x3_out_size(W, stride, ceil_mode)
     out = torch.empty((B, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     code = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device)
-    check(_lib.lib().dsrg_maxpool3x3_fwd_bf16(_ptr(x), _ptr(out), _ptr(code), B, H, W, OH, OW, C, stride, _stream()))
+    fn = _lib.lib().dsrg_maxpool3x3_relu_fwd_bf16 if relu_input else _lib.lib().dsrg_maxpool3x3_fwd_bf16
+    check(fn(_ptr(x), _ptr(out), _ptr(code), B, H, W, OH, OW, C, stride, _stream()))
     return out, code
 
 
@@ -723,21 +726,24 @@ def maxpool3x3_bwd(gout, code, in_shape, stride):
 def maxpool3x3_bwd_relu(gout, code, relu_out, stride=2):
     """3x3 / stride 2 / pad 1 max-pool backward + the ReLU backward and bias gradient of the convolution in front of the pool:
     relu_out (B,C,H,W) bf16 channels_last = the pool's input -> (masked input gradient (B,C,H,W) bf16 channels_last,
-    bias gradient (C) f32); the same values as maxpool3x3_bwd followed by relu_bwd_bias"""
-    B, C, H, W = relu_out.shape
+    bias gradient (C) f32); the same values as maxpool3x3_bwd followed by relu_bwd_bias.
+    relu_out may be the pool input's SHAPE (a torch.Size / tuple) when `code` was made by maxpool3x3_fwd(relu_input=True): the
+    codes then carry the mask and the input is not read (same bits)"""
+    have_y = torch.is_tensor(relu_out)
+    B, C, H, W = relu_out.shape if have_y else relu_out
     OH, OW = gout.shape[2], gout.shape[3]
     cl = torch.channels_last
-    if stride != 2 or not (relu_out.is_cuda and relu_out.dtype == torch.bfloat16 and gout.dtype == torch.bfloat16
-                           and relu_out.is_contiguous(memory_format=cl) and C % 8 == 0 and 256 % (C // 8) == 0):
+    if stride != 2 or not (gout.is_cuda and gout.dtype == torch.bfloat16 and C % 8 == 0 and 256 % (C // 8) == 0) or (
+            have_y and not (relu_out.is_cuda and relu_out.dtype == torch.bfloat16 and relu_out.is_contiguous(memory_format=cl))):
         raise ValueError("maxpool3x3_bwd_relu: stride 2, bf16 channels_last, channels / 8 a divisor of 256")
     gout = gout.contiguous(memory_format=cl)
     gin = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=gout.device, memory_format=cl)
     gb = torch.empty(C, dtype=torch.float32, device=gout.device)
-    key = (relu_out.device, C)                                      # shared with relu_bwd_bias (same stream-ordering rule)
+    key = (gout.device, C)                                          # shared with relu_bwd_bias (same stream-ordering rule)
     part = _partials.get(key)
     if part is None:
         part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=gout.device)
-    check(_lib.lib().dsrg_maxpool3x3_bwd_relu_bf16(_ptr(gout), _ptr(code), _ptr(relu_out), _ptr(gin), _ptr(gb), _ptr(part),
+    check(_lib.lib().dsrg_maxpool3x3_bwd_relu_bf16(_ptr(gout), _ptr(code), _ptr(relu_out) if have_y else None, _ptr(gin), _ptr(gb), _ptr(part),
                                                    _PARTIAL_BLOCKS, B, H, W, OH, OW, C, _stream()))
     return gin, gb
 

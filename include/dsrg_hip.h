@@ -360,13 +360,20 @@ int dsrg_heads_backward_relu_bf16(const void *const *x_dev, int n_branches, cons
  * the caller, ceil mode included).  code_dev: B*OH*OW*C bytes, the window position (3*dy+dx) of the first maximum. */
 int dsrg_maxpool3x3_fwd_bf16(const void *in_dev, void *out_dev, void *code_dev, int B, int H, int W, int OH, int OW, int C,
                              int stride, void *stream);
+/* The same pooling of a ReLU's OUTPUT when the pool's backward is to carry that ReLU's backward as well: windows whose maximum
+ * is not positive get the code 0xfe, which names no window position — their gradient goes nowhere, which is what masking the
+ * pooled-back gradient with (input > 0) does (a pixel receives gradient only as the argmax of a window, and its value is
+ * that window's maximum).  Pooled values are the same as dsrg_maxpool3x3_fwd_bf16's. */
+int dsrg_maxpool3x3_relu_fwd_bf16(const void *in_dev, void *out_dev, void *code_dev, int B, int H, int W, int OH, int OW, int C,
+                                  int stride, void *stream);
 int dsrg_maxpool3x3_bwd_bf16(const void *gout_dev, const void *code_dev, void *gin_dev, int B, int H, int W, int OH, int OW,
                              int C, int stride, void *stream);
 /* Stride-2 pooling backward fused with the ReLU backward and the bias gradient of the convolution in front of the pool
  * (conv + ReLU + pool, train-s.prototxt:65-226): relu_out_dev = the pool's input = that ReLU's output (B,H,W,C) bf16;
  * gin = (relu_out > 0) ? pooled-back gradient : 0 (bit-identical to dsrg_maxpool3x3_bwd_bf16 followed by
  * dsrg_relu_bwd_bias_bf16), bias_grad_dev[c] = sum of gin over (b, y, x).  partials_dev: partial_blocks * C floats;
- * (C / 8) must divide 256. */
+ * (C / 8) must divide 256.  relu_out_dev may be NULL when code_dev comes from dsrg_maxpool3x3_relu_fwd_bf16: the codes then
+ * carry the mask, the pool's input (211 MB at pool1, batch 16) is not read again, and the result is the same bit for bit. */
 int dsrg_maxpool3x3_bwd_relu_bf16(const void *gout_dev, const void *code_dev, const void *relu_out_dev, void *gin_dev,
                                   float *bias_grad_dev, float *partials_dev, int partial_blocks, int B, int H, int W, int OH,
                                   int OW, int C, void *stream);

@@ -87,6 +87,38 @@ def test_igemm_four_branches_share_a_launch(ops):
     _close(shared[2], want, "shared input")
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 41, 41), (3, 41, 41), (2, 65, 65), (2, 30, 50)])
+def test_igemm_border_taps_are_skipped_bit_identically(ops, B, H, W):
+    """A dilated tap that reaches no pixel of a 256-pixel tile (forward / data gradient) or no row of a 64-pixel step (weight
+    gradient) multiplies padding zeros only; those K-steps are not loaded and not multiplied (conv_igemm.hip).  Same bits as
+    with every step multiplied (variant 6: the launch of rounds 4), four branches, dilations 6 .. 24 — and right against torch."""
+    cin, cout = 512, 1024
+    dils = [6, 12, 18, 24]
+    xs, ws, ws32, bs = [], [], [], []
+    for i in range(4):
+        x, w, b = _case(B, H, W, cin, cout, 3, 50 + i)
+        xs.append(x); ws.append(ops.pack_conv_weight(w)); ws32.append(w); bs.append(b)
+    gs = [torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(4)]
+    try:
+        ops.set_igemm_variant(6)
+        full = ops.conv_igemm(xs, ws, bs, dils, 3, True, stream_k=False)      # (stream-K cuts the K range: another summation order)
+        full_w = ops.conv_igemm_wgrad([xs[0]] * 4, gs, dils, 3)
+        ops.set_igemm_variant(3)
+        skip = ops.conv_igemm(xs, ws, bs, dils, 3, True, stream_k=False)
+        skip_w = ops.conv_igemm_wgrad([xs[0]] * 4, gs, dils, 3)
+    finally:
+        ops.set_igemm_variant(-1)
+    for i in range(4):
+        assert torch.equal(full[i], skip[i]), dils[i]
+        assert torch.equal(full_w[i], skip_w[i]), dils[i]
+    i = 3
+    want = torch.relu(F.conv2d(xs[i].float(), ws32[i].float(), bs[i], padding=dils[i], dilation=dils[i]))
+    _close(skip[i], want, "dilation 24 forward")
+    wr = torch.zeros(cout, cin, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(xs[0].float(), wr, None, padding=dils[i], dilation=dils[i]).backward(gs[i].float())
+    assert (skip_w[i] - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max() + 1e-4
+
+
 def _unpack(p):
     o, cc, taps, _ = p.shape
     k = int(round(taps ** 0.5))

@@ -922,6 +922,18 @@ def test_pool_backward_with_fused_relu_mask_and_bias_gradient(ops):
         g, gb = ops.maxpool3x3_bwd_relu(go, code, y, 2)
         assert torch.equal(g, g_ref), (B, C, H, W)
         assert (gb - gb_ref).abs().max() <= 1e-4 * gb_ref.abs().max() + 1e-4                    # fp32 sums, other grouping
+        # the mask inside the window codes (round 5): windows without a positive value get a code that names no position, and
+        # the backward runs without the pool's input — same pooled values, same gradient and bias gradient, bit for bit.  A third
+        # of the planes are zeroed so that whole windows are dead
+        y[:, ::3] = 0
+        pooled, code = ops.maxpool3x3_fwd(y, 2, ceil)
+        pooled_m, code_m = ops.maxpool3x3_fwd(y, 2, ceil, relu_input=True)
+        assert torch.equal(pooled, pooled_m)
+        dead = code_m.permute(0, 3, 1, 2) == 0xfe
+        assert torch.equal(dead, pooled <= 0) and bool(dead.any()) and torch.equal(code_m.permute(0, 3, 1, 2)[~dead], code.permute(0, 3, 1, 2)[~dead])
+        g_y, gb_y = ops.maxpool3x3_bwd_relu(go, code, y, 2)
+        g_m, gb_m = ops.maxpool3x3_bwd_relu(go, code_m, tuple(y.shape), 2)
+        assert torch.equal(g_m, g_y) and torch.equal(gb_m, gb_y), (B, C, H, W)
     from dsrg_amd.backbone import _pool3x3
     for cin, cout in [(64, 64), (128, 128), (256, 256)]:
         a = GemmConv2d(cin, cout, 3, padding=1, fuse_relu=True, fuse_pool=(2, True)).cuda().to(memory_format=cl)

@@ -1,149 +1,19 @@
 #!/usr/bin/env python
-"""Does the bf16 train step compute the float32 step's gradients?  (round-4 review, item 2)
-
-VGG16-ASPP with an ImageNet-scale initialisation (Kaiming fan-in for every ReLU layer, so activations stay O(input) through the
-net as they do under vgg16_20M_mc.caffemodel, run.sh:5; fc8-SEC N(0, 0.01) as the prototxt), the bench's synthetic images,
-Dropout off (the bf16 leg draws its masks in the convolution epilogues, the float32 leg from torch: different masks would hide
-the arithmetic).  The score gradient is the train-s loss gradient taken ONCE at the float32 scores and fed to every leg, so what
-is compared is the backbone's backward chain alone.  Legs, each against the float32 backbone (the reference's Caffe arithmetic):
-
-  bf16        the shipped route (direct + implicit-GEMM kernels, fp32 master weights, fp32 heads)
-  stock       torch's own bf16 autocast (F.conv2d / max_pool2d through MIOpen) — what "bf16 mixed precision" means elsewhere
-  f32+act     float32 arithmetic, every activation rounded to bf16 where the bf16 route stores one
-  f32+grad    float32 arithmetic, every activation gradient rounded to bf16 where the bf16 route stores one
-  f32+both    both roundings (the bf16 route's storage precision with float32 products)
-  act,amax2   f32+act, but pool1-3 (stride 2) pick each window's maximum on the unrounded convolution output
-  act,amax12  ... and pool4 / pool5 (stride 1) too
-
+"""Does the bf16 train step compute the float32 step's gradients?  (round-4 review, item 2)  Legs and set-up: dsrg_amd/fidelity.py.
 per parameter: cosine to the float32 gradient and relative L2 distance.   usage: grad_fidelity.py [B] [--loss-own]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import torch.nn.functional as F
-from dsrg_amd import backbone, synthetic as S
-from dsrg_amd.ops import dsrg_supervision_loss
-
-CL = torch.channels_last
-
-
-def kaiming_(net, seed=5):
-    g = torch.Generator().manual_seed(seed)
-    for name, m in net.named_modules():
-        if isinstance(m, torch.nn.Conv2d):
-            fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
-            std = 0.01 if m.out_channels == 21 else (2.0 / fan_in) ** 0.5
-            with torch.no_grad():
-                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * std)
-                m.bias.zero_()
-    return net
-
-
-class _Round(torch.autograd.Function):
-    """storage rounding of the bf16 route imitated in float32: value and / or gradient through bf16"""
-    @staticmethod
-    def forward(ctx, x, fwd, bwd):
-        ctx.bwd = bwd
-        return x.bfloat16().float() if fwd else x
-
-    @staticmethod
-    def backward(ctx, g):
-        return (g.bfloat16().float() if ctx.bwd else g), None, None
-
-
-def plain_forward(net, x, rnd=(False, False), argmax32=()):
-    """the prototxt's layer sequence on torch ops; rnd = (round activations, round activation gradients) at every stored blob;
-    argmax32: strides of the max pools that pick their window maximum on the UNROUNDED convolution output (the value stored is
-    the same — rounding is monotone — but ties between bf16-equal neighbours are decided as float32 decides them)"""
-    r = lambda t: _Round.apply(t, rnd[0], rnd[1]) if (rnd[0] or rnd[1]) else t          # noqa: E731
-
-    def conv(m, h, training, raw_out=False):
-        h = F.conv2d(h, m.weight, m.bias, 1, m.padding, m.dilation)
-        if getattr(m, "fuse_relu", False):
-            h = F.relu(h)
-        if getattr(m, "fuse_pool", None) is not None:
-            h = h if 2 in argmax32 else r(h)
-            return r(F.max_pool2d(h, 3, 2, 1, ceil_mode=True))
-        return h if raw_out else r(h)
-    h = r(x)
-    feats = [m for m in net.features if isinstance(m, (backbone.GemmConv2d, backbone.MaxPool3x3, backbone.AvgPool3x3))]
-    for i, m in enumerate(feats):
-        if isinstance(m, backbone.GemmConv2d):
-            h = conv(m, h, net.training, raw_out=1 in argmax32 and isinstance(feats[i + 1], backbone.MaxPool3x3))
-        elif isinstance(m, backbone.MaxPool3x3):
-            h = r(F.max_pool2d(h, 3, 1, 1))
-        elif isinstance(m, backbone.AvgPool3x3):
-            h = r(F.avg_pool2d(h.contiguous(), 3, 1, 1))       # (torch's channels_last avg_pool backward is wrong on this build)
-    out = None
-    for br in net.branches:
-        t = h
-        for m in br:
-            if isinstance(m, backbone.GemmConv2d):
-                if m.out_channels == 21:
-                    with torch.autocast("cuda", enabled=False):
-                        s = F.conv2d(t.float(), m.weight, m.bias)
-                    out = s if out is None else out + s
-                else:
-                    t = conv(m, t, net.training)
-    return out
+from dsrg_amd.fidelity import LEGS, gradient_fidelity, kaiming_                      # noqa: F401  (kaiming_: tools/overfit_probe.py)
 
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2
-    own = "--loss-own" in sys.argv
-    dev = torch.device("cuda", 0)
-    b = S.make_batch(77, B)
-    images, labels, cues = (torch.from_numpy(b[k]).to(dev) for k in ("images", "labels", "cues"))
-    x = images.contiguous(memory_format=CL)
-    net = kaiming_(backbone.VGG16ASPP(dropout=0.0)).to(dev).to(memory_format=CL)
-
-    def run(tag, gout):
-        net.zero_grad(set_to_none=True)
-        if tag == "fp32":
-            y = net(x)
-        elif tag == "bf16":
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = net(x)
-        elif tag == "stock":
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = plain_forward(net, x)
-        else:
-            y = plain_forward(net, x, {"f32+act": (True, False), "f32+grad": (False, True), "f32+both": (True, True),
-                                       "f32plain": (False, False), "act,amax2": (True, False), "act,amax12": (True, False)}[tag],
-                              argmax32={"act,amax2": (2,), "act,amax12": (1, 2)}.get(tag, ()))
-        y = y.float().contiguous()
-        if gout is None or own:
-            yl = y.detach().requires_grad_(True)
-            total, losses = dsrg_supervision_loss(yl, images, labels, cues)
-            total.backward()
-            g = yl.grad.detach()
-            print("# %-9s losses %s  |score grad| %.4e" % (tag, [round(float(v), 5) for v in losses], float(g.norm())))
-        else:
-            g = gout
-        y.backward(g)
-        return y.detach(), g, {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
-
-    y32, gout, ref = run("fp32", None)
-    print("# scores: rms %.3f  max %.3f; batch %d" % (float(y32.pow(2).mean().sqrt()), float(y32.abs().max()), B))
-    legs = ["bf16", "stock", "f32plain", "f32+act", "f32+grad", "f32+both", "act,amax2", "act,amax12"]
-    res = {}
-    for tag in legs:
-        y, _, gr = run(tag, gout)
-        res[tag] = gr
-        print("# %-9s scores vs float32: rel %.3e" % (tag, float((y - y32).norm() / y32.norm())))
-    cos = lambda a, c: float((a * c).sum() / (a.norm() * c.norm()).clamp_min(1e-30))     # noqa: E731
-    rel = lambda a, c: float((a - c).norm() / c.norm().clamp_min(1e-30))                 # noqa: E731
-    print("%-22s %10s | " % ("parameter", "|g| fp32") + " | ".join("%-17s" % t for t in legs) + "   (cosine / relative distance to float32)")
-    worst = {t: 1.0 for t in legs}
-    for n in ref:
-        row = []
-        for t in legs:
-            c = cos(res[t][n], ref[n])
-            worst[t] = min(worst[t], c)
-            row.append("%.5f %.2e" % (c, rel(res[t][n], ref[n])))
-        print("%-22s %10.3e | " % (n, float(ref[n].norm())) + " | ".join("%-17s" % r for r in row))
-    allc = {t: cos(torch.cat([res[t][n].flatten() for n in ref]), torch.cat([ref[n].flatten() for n in ref])) for t in legs}
-    print("min cosine over parameters: " + "  ".join("%s %.5f" % (t, worst[t]) for t in legs))
-    print("cosine of the whole gradient: " + "  ".join("%s %.6f" % (t, allc[t]) for t in legs))
+    r = gradient_fidelity(B, LEGS, own_loss="--loss-own" in sys.argv, log=print)
+    print("%-22s %10s | " % ("parameter", "|g| fp32") + " | ".join("%-17s" % t for t in LEGS) + "   (cosine / relative distance to float32)")
+    for n, norm in r["ref_norm"].items():
+        print("%-22s %10.3e | " % (n, norm) + " | ".join("%-17s" % ("%.5f %.2e" % (r["cos"][t][n], r["rel"][t][n])) for t in LEGS))
+    print("min cosine over parameters: " + "  ".join("%s %.5f" % (t, min(r["cos"][t].values())) for t in LEGS))
+    print("cosine of the whole gradient: " + "  ".join("%s %.6f" % (t, r["cos_all"][t]) for t in LEGS))
 
 
 if __name__ == "__main__":
