@@ -85,6 +85,7 @@ struct IgemmArgs {
     float drop_scale;       // 0 = no dropout), kept elements times drop_scale = 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
     float out_scale;        // every output times this (1 unless a mask carries a Dropout scale)
+    int xcd_mix;            // 1: XCD-interleaved tile map (see the kernel); the grid is 8 * ngroups * ceil(tiles_m / 8) * tiles_n blocks
     int skip_taps;          // 1: a K-step whose tap reaches no pixel of the tile (a dilated kernel near the map's border: all of
                             // its operand rows would be the zeros of the padding) is not loaded and not multiplied
 };
@@ -130,16 +131,30 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
     const int l31 = lane & 31, kgrp = lane >> 5;
     const int wn = wv >> 2, wm = wv & 3;
 
-    // tile of this workgroup: consecutive ids share an XCD (blockIdx % 8) in runs, n-tile fastest
-    int t;
-    {
+    // tile of this workgroup: consecutive ids share an XCD (blockIdx % 8) in runs, n-tile fastest.
+    // xcd_mix (launches that skip taps): tiles no longer cost the same — a dilation-24 tile runs 3 to 6 of its 9 taps, a
+    // dilation-6 tile all of them — and an XCD only ever runs the blocks with its own id % 8: with runs of consecutive tiles
+    // per XCD the two XCDs that hold fc6_1's tiles set the launch's duration while those with fc6_4's idle (measured: skipping
+    // 15 % of the steps bought 0 %).  There XCD x takes the pixel tiles x, x + 8, .. of EVERY group (its blocks in the
+    // order group, pixel tile, n-tile), so that all XCDs hold the same mix; blocks beyond an XCD's share exit at once.
+    int grp, tm, tn;
+    if (a.xcd_mix) {
+        const int id = (int)blockIdx.x, xcd = id & 7, k = id >> 3;
+        const int cm = (a.tiles_m - xcd + 7) >> 3, per_group = cm * a.tiles_n;
+        if (cm <= 0 || k >= per_group * a.ngroups) return;
+        grp = k / per_group;
+        const int r = k - grp * per_group, tml = r / a.tiles_n;
+        tn = r - tml * a.tiles_n;
+        tm = xcd + 8 * tml;
+    } else {
         const int total = (int)gridDim.x, id = (int)blockIdx.x;
         const int q = total >> 3, r = total & 7, xcd = id & 7, k = id >> 3;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        grp = t / a.tiles_per_group;
+        t -= grp * a.tiles_per_group;
+        tm = t / a.tiles_n;
+        tn = t - tm * a.tiles_n;
     }
-    const int grp = t / a.tiles_per_group;
-    t -= grp * a.tiles_per_group;
-    const int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
     const int m0 = tm * kBM, n0 = tn * kBN;
     const IgemmGroup G = a.g[grp];
     const int taps = a.taps, Cin = a.Cin, W = a.W, H = a.H;
@@ -741,6 +756,7 @@ struct IgemmWgradArgs {
     WgradGroup g[4];
     int ngroups, B, H, W, Cin, Cout, taps, M, tiles_n, tiles_c, ksplit, kchunk, tiles_per_group;
     int stagger;            // as IgemmArgs::stagger
+    int xcd_mix;            // 1: XCD-interleaved map of the (group, pixel chunk, tile) workgroups (see the kernel); needs 8 | ksplit
     int skip_rows;          // 1: a K-step (64 pixels) whose rows the tile's tap shifts out of the map entirely is not loaded and
                             // not multiplied (its x rows would all be padding zeros)
 };
@@ -763,18 +779,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     const int l31 = lane & 31, kgrp = lane >> 5, i16 = lane & 15, gq = lane >> 4;
     const int wn = wv >> 2, wm = wv & 3;
 
-    int t;
-    {
+    // all tiles of one pixel chunk are neighbours in t (they read the same rows of g and x): they share an XCD's L2.
+    // xcd_mix (launches that skip rows; 8 | ksplit): workgroups no longer cost the same (a dilation-24 tile skips 37 % of its
+    // steps, a dilation-6 one 7 %) and an XCD only runs the blocks with its id % 8 — XCD x takes the pixel chunks x, x + 8, ..
+    // of EVERY group and tile (order: group, chunk, tile), which keeps a chunk's tiles on one XCD and gives all XCDs the same mix.
+    const int tiles = a.tiles_n * a.tiles_c;
+    int grp, split, t;
+    if (a.xcd_mix) {
+        const int id = (int)blockIdx.x, xcd = id & 7, k = id >> 3;
+        const int per_group = (a.ksplit >> 3) * tiles;
+        grp = k / per_group;
+        const int r = k - grp * per_group, sl = r / tiles;
+        t = r - sl * tiles;
+        split = xcd + 8 * sl;
+    } else {
         const int total = (int)gridDim.x, id = (int)blockIdx.x;
         const int q = total >> 3, r = total & 7, xcd = id & 7, k = id >> 3;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        grp = t / a.tiles_per_group;
+        t -= grp * a.tiles_per_group;
+        split = t / tiles;
+        t -= split * tiles;
     }
-    // all tiles of one pixel chunk are neighbours in t (they read the same rows of g and x): they share an XCD's L2
-    const int grp = t / a.tiles_per_group;
-    t -= grp * a.tiles_per_group;
-    const int tiles = a.tiles_n * a.tiles_c;
-    const int split = t / tiles;
-    t -= split * tiles;
     const int tn = t / a.tiles_c, tc = t - tn * a.tiles_c;
     const WgradGroup G = a.g[grp];
     const int taps = a.taps, Cin = a.Cin, Cout = a.Cout, W = a.W, H = a.H;
@@ -1096,7 +1122,11 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     static LdsGrant grant[3];
     const int variant = igemm_variant() == 2 ? 1 : 0;       // 1, 3: two stages of 64; 2: ring of four stages of 32
     a.stagger = igemm_variant() >= 3;
-    const dim3 grid(a.tiles_per_group * ngroups), block(512);
+    // tap skipping makes tiles unequal: spread every group's tiles over all XCDs (conv_igemm_body).  Only then: the layers
+    // whose tiles all run the same steps keep the map they were tuned with (neighbouring pixel tiles share rows in one L2)
+    for (int g = 0; g < ngroups; g++)
+        if (a.skip_taps && k == 3 && a.g[g].dil >= 3) a.xcd_mix = 1;
+    const dim3 grid(a.xcd_mix ? 8 * ngroups * ((a.tiles_m + 7) / 8) * a.tiles_n : a.tiles_per_group * ngroups), block(512);
     // stream-K only where it was measured to win (profiles/r04_igemm_stream_k.txt): a single round that fills at most 60 % of
     // the chip (conv4_1's data gradient: 106 tiles, 115 -> 88 us).  A cut tile costs its workgroups ~25 us (256 KB of
     // accumulators written through, read back, one acquire), which eats the sixth of the chip that 212 tiles leave idle (131 ->
@@ -1203,6 +1233,8 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
         a.g[q].dil = dil ? dil[q] : 1;
         if (!a.g[q].x || !a.g[q].g || !gw[q]) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: null pointer");
     }
+    for (int q = 0; q < ngroups; q++)
+        if (a.skip_rows && k == 3 && a.g[q].dil >= 3 && a.ksplit % 8 == 0) a.xcd_mix = 1;
     static LdsGrant grant;
     constexpr size_t lds = 2 * kWStage;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_wgrad_kernel), lds, grant)) return rc;
