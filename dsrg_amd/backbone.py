@@ -245,18 +245,9 @@ class _GradLink:
 
 
 _FUSE_CHAIN = _os.environ.get("DSRG_FUSE_CHAIN", "1") != "0"
-# the weight gradient of an implicit-GEMM layer on a second stream beside its data gradient (both only need the masked output
-# gradient): the 212-tile data-gradient launches of the 41x41 layers leave a sixth of the chip idle, the weight gradient's
-# workgroups fill it.  Joined again before the node returns, so autograd / DDP see finished tensors on the main stream.
-_WGRAD_SIDE = _os.environ.get("DSRG_WGRAD_SIDE", "0") == "1"
-_side_streams = {}
-
-
-def _side_stream(device):
-    st = _side_streams.get(device.index)
-    if st is None:
-        st = _side_streams[device.index] = torch.cuda.Stream(device=device)
-    return st
+# (measured and dropped in round 5: the weight gradient of an implicit-GEMM layer on a second stream beside its data gradient,
+# to fill the sixth of the chip a 212-tile data-gradient launch leaves idle — 1 761 -> 1 715 images/s, the two 139 KB-LDS kernels
+# only take CUs from each other; profiles/r05_wgrad_side_stream_ab.txt)
 
 
 class _IgemmConvFn(torch.autograd.Function):
@@ -347,12 +338,6 @@ class _IgemmConvFn(torch.autograd.Function):
         # inputs that are another node's ReLU outputs with no other consumer: that node's backward rides in this data gradient
         absorb = _FUSE_CHAIN and ctx.links_in is not None and all(need_x) and conv_igemm_supported(cout, cin, ctx.k) and \
             cin >= 256 and all(x.is_contiguous(memory_format=cl) for x in xs)
-        side_gws = None
-        if _WGRAD_SIDE and ctx.k == 3 and conv_igemm_wgrad_supported(cin, cout, 3) and any(need_x):
-            main, side = torch.cuda.current_stream(), _side_stream(gms[0].device)
-            side.wait_stream(main)                                                       # the masked gradients are ready
-            with torch.cuda.stream(side):
-                side_gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 3)
         if absorb:
             packs_d = [p if p is not None else pack_conv_weight(w, for_dgrad=True) for p, w in zip(ctx.packs_d, ws)]
             gxs, gb_below = conv_igemm_dgrad(gms, packs_d, list(xs), ctx.dils, ctx.k, ctx.links_in[0].scale)
@@ -377,14 +362,7 @@ class _IgemmConvFn(torch.autograd.Function):
                     d = ctx.dils[i]
                     gxs[i] = torch.ops.aten.convolution_backward(gms[i], xs[i], ws[i].to(torch.bfloat16), None, [1, 1], [d, d], [d, d],
                                                                  False, [0, 0], 1, [True, False, False])[0]
-        if side_gws is not None:
-            gws = side_gws
-            torch.cuda.current_stream().wait_stream(_side_stream(gms[0].device))      # joined: the node returns finished tensors
-            for t_ in list(gms) + list(xs):
-                t_.record_stream(_side_stream(gms[0].device))                        # (allocated on the main stream, read on the side one)
-            for t_ in gws:
-                t_.record_stream(torch.cuda.current_stream())                        # (and the other way round)
-        elif conv_igemm_wgrad_supported(cin, cout, 3):
+        if conv_igemm_wgrad_supported(cin, cout, 3):
             gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 3)                           # float32, the parameters' own layout
         else:
             gws = []
