@@ -232,6 +232,43 @@ def crf_fullres_record(device, steps, warmup, cpu=True, size=321):
         pass
     torch.cuda.synchronize()
     pipelined = npipe / (time.perf_counter() - t0)
+    # ... and batched (round 5, dsrg_crf_create_batch): eight same-sized images per call — every launch of the build and of the
+    # mean-field loop carries all of them — alone and with two such calls in flight
+    from dsrg_amd.crf import CRF_device_batch, DenseCRF as _DenseCRF
+    nb = 8
+    ims8, uns8 = torch.stack([im0] * nb), torch.stack([un0] * nb)
+    for _ in range(2):
+        CRF_device_batch(ims8, uns8, scale_factor=1.0, want="map")
+    torch.cuda.synchronize()
+    reps = max(2, steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        CRF_device_batch(ims8, uns8, scale_factor=1.0, want="map")
+    torch.cuda.synchronize()
+    batched = nb * reps / (time.perf_counter() - t0)
+    for _ in CRF_device_many([(im0, un0)] * (4 * nb), scale_factor=1.0, in_flight=2, batch=nb):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in CRF_device_many([(im0, un0)] * (8 * nb), scale_factor=1.0, in_flight=2, batch=nb):
+        pass
+    torch.cuda.synchronize()
+    batched_pipelined = 8 * nb / (time.perf_counter() - t0)
+    # the batched object's splat launch, bracketed like the single-image one: the same algorithmic bytes per image, x nb per launch
+    bcrf = _DenseCRF(head["W"], head["H"], C, nimages=nb)
+    bout = torch.empty((nb, head["H"], head["W"], C), dtype=torch.float32, device=device)
+
+    def one_batch():
+        bcrf.set_unary_energy((-uns8).contiguous())
+        bcrf.add_pairwise_energy(10, 80.0, 80.0, 13, 13, 13, 3, 3.0, 3.0, ims8)
+        bcrf.inference(10, out=bout)
+    one_batch()
+    bcrf.profile_start(3 * 10 + 8)
+    for _ in range(3):
+        one_batch()
+    torch.cuda.synchronize()
+    bsplat_ms, bsplat_n = bcrf.profile_stop()
+    batch_same = bool(torch.equal(bout[0], bout[nb - 1]))                   # eight copies of one image: eight equal results
     ev_us = event_overhead_ms(torch.cuda.default_stream()) * 1e3
     per_launch_s = max(head["splat_us_per_launch_event_bracket"] - ev_us, 1e-3) * 1e-6
     tj, traffic_src = _counter_file("pmc_traffic_fullres", "fullres")
@@ -254,6 +291,13 @@ def crf_fullres_record(device, steps, warmup, cpu=True, size=321):
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "krahenbuhl2013.CRF on device tensors, log-prob unaries, scale_factor 1, maxiter 10"},
            "images_per_s_four_in_flight": pipelined,
+           "images_per_s_batch8": batched, "ms_per_image_batch8": 1e3 / batched,
+           "images_per_s_batch8_two_in_flight": batched_pipelined,
+           "batch8_splat": {"us_per_launch": (bsplat_ms / max(bsplat_n, 1)) * 1e3 - ev_us, "launches": bsplat_n,
+                            "alg_bytes_per_launch": nb * head["alg_bytes_per_splat_launch"],
+                            "hbm_gbs": nb * head["alg_bytes_per_splat_launch"] / max((bsplat_ms / max(bsplat_n, 1)) * 1e-3 - ev_us * 1e-6, 1e-9) / 1e9,
+                            "frac_of_8TBs": nb * head["alg_bytes_per_splat_launch"] / max((bsplat_ms / max(bsplat_n, 1)) * 1e-3 - ev_us * 1e-6, 1e-9) / 1e9 / HBM_PEAK_GBS,
+                            "eight_copies_equal": batch_same},
            "sizes": [{k: v for k, v in o.items() if k not in ("q", "im", "un", "dt")} for o in out_sizes],
            "roofline": roofline}
     if cpu:

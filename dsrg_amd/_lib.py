@@ -44,6 +44,7 @@ SIGNATURES = {
     "dsrg_last_error": (ctypes.c_char_p, []),
     "dsrg_device_count": (_i, []),
     "dsrg_crf_create": (_i, [_i, _i, _i, ctypes.POINTER(_vp)]),
+    "dsrg_crf_create_batch": (_i, [_i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "dsrg_crf_destroy": (_i, [_vp]),
     "dsrg_crf_set_unary_energy": (_i, [_vp, _vp]),
     "dsrg_crf_add_pairwise_energy": (_i, [_vp] + [_f] * 9 + [_vp]),

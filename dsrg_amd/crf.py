@@ -18,12 +18,20 @@ def _is_cuda_tensor(x):
     return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
 
 
+MAX_BATCH = 8            # images per batched object (include/dsrg_hip.h: dsrg_crf_create_batch)
+
+
 class DenseCRF(object):
-    def __init__(self, W, H, nlabels):
+    def __init__(self, W, H, nlabels, nimages=None):
+        """nimages: None = the reference's one-image object; n >= 1 = a batched object (dsrg_crf_create_batch) whose unary,
+        image and result buffers hold n same-sized images back to back and whose every launch carries all of them"""
         _lib.require_gpu()
         self._h = None
         h = ctypes.c_void_p()
-        check(_lib.lib().dsrg_crf_create(int(W), int(H), int(nlabels), ctypes.byref(h)))
+        if nimages is None:
+            check(_lib.lib().dsrg_crf_create(int(W), int(H), int(nlabels), ctypes.byref(h)))
+        else:
+            check(_lib.lib().dsrg_crf_create_batch(int(W), int(H), int(nlabels), int(nimages), ctypes.byref(h)))
         self._h = h
 
     def __del__(self):
@@ -152,14 +160,43 @@ def CRF_device(image, unary, maxiter=10, scale_factor=1.0, color_factor=13, want
     return crf.inference(maxiter, out=torch.empty((H, W, labels), dtype=torch.float32, device=unary.device))
 
 
-def CRF_device_many(pairs, maxiter=10, scale_factor=1.0, color_factor=13, want="map", in_flight=4):
+def CRF_device_batch(images, unary, maxiter=10, scale_factor=1.0, color_factor=13, want="marginals", crf=None):
+    """`CRF_device` for B same-sized images in ONE set of launches (a batched object, at most MAX_BATCH images per object; more
+    are taken in chunks): images (B,H,W,3) uint8 and unary (B,H,W,M) float32 CUDA tensors -> (B,H,W,M) float32 marginals or,
+    want="map", (B,H,W) int32 labels.  Each image's result equals CRF_device's on that image bit for bit.  crf: a DenseCRF(W, H,
+    M, nimages=B) to reuse (its stream setting is kept); otherwise objects come from the library's cache on the null stream."""
+    import torch
+    B, H, W, M = unary.shape
+    assert tuple(images.shape) == (B, H, W, 3)
+    if crf is None and torch.cuda.current_stream(unary.device) != torch.cuda.default_stream(unary.device):
+        torch.cuda.current_stream(unary.device).synchronize()     # the object API works on the null stream
+    sxy_b, sxy_g = _BILATERAL_XY / scale_factor, _GAUSS_XY / scale_factor
+    out = torch.empty((B, H, W) if want == "map" else (B, H, W, M), dtype=torch.int32 if want == "map" else torch.float32,
+                      device=unary.device)
+    for b0 in range(0, B, MAX_BATCH):
+        n = min(MAX_BATCH, B - b0)
+        obj = crf if (crf is not None and B <= MAX_BATCH) else DenseCRF(W, H, M, nimages=n)
+        obj.set_unary_energy((-unary[b0:b0 + n].to(torch.float32)).contiguous())
+        obj.add_pairwise_energy(_BILATERAL_W, sxy_b, sxy_b, color_factor, color_factor, color_factor, _GAUSS_W, sxy_g, sxy_g,
+                                images[b0:b0 + n].to(torch.uint8).contiguous())
+        if want == "map":
+            obj.map(maxiter, out=out[b0:b0 + n])
+        else:
+            obj.inference(maxiter, out=out[b0:b0 + n])
+    return out
+
+
+def CRF_device_many(pairs, maxiter=10, scale_factor=1.0, color_factor=13, want="map", in_flight=4, batch=1):
     """`CRF_device` over many images with `in_flight` of them overlapping on the GPU — the test-time loop of
     training/tools/test-ms.py:84-111 / generate_train_gt.py:78-106 (10 582 images, one CRF each).  The full-resolution CRF is
     ~170 short dependent launches per image (and one host read-back of the lattice sizes): one image at a time leaves most of
     the chip idle and the host waiting.  Here `in_flight` host threads each own a DenseCRF object per image size and a stream
     (dsrg_crf_set_stream); the library calls release the GIL, so the threads' launch sequences interleave on the host and
     their kernels overlap on the device.  pairs: iterable of (image (H,W,3) uint8, unary (H,W,M) float32) CUDA tensors;
-    yields the results in order: (H,W) int32 arg-max labels (want="map") or (H,W,M) float32 marginals."""
+    yields the results in order: (H,W) int32 arg-max labels (want="map") or (H,W,M) float32 marginals.
+    batch > 1: consecutive pairs of one shape (up to `batch`, at most MAX_BATCH) additionally share ONE batched object call —
+    every launch of the build and of the mean-field loop then carries that many images (the loop is launch-bound: ~6 us
+    launches for 10 MB each at one image); results are the same bit for bit."""
     import threading
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
@@ -169,31 +206,55 @@ def CRF_device_many(pairs, maxiter=10, scale_factor=1.0, color_factor=13, want="
     caller = torch.cuda.current_stream(device)
     sxy_b, sxy_g = _BILATERAL_XY / scale_factor, _GAUSS_XY / scale_factor
 
-    def work(image, unary, ready):
+    batch = max(1, min(int(batch), MAX_BATCH))
+
+    def work(group, ready):
+        """group: list of (image, unary) of one shape -> list of results"""
         torch.cuda.set_device(device)
         if not hasattr(local, "stream"):
             local.stream, local.objs = torch.cuda.Stream(device=device), {}
-        H, W, M = unary.shape
-        crf = local.objs.get((H, W, M))
+        H, W, M = group[0][1].shape
+        n = len(group)
+        key = (H, W, M, n if batch > 1 else None)
+        crf = local.objs.get(key)
         if crf is None:
-            crf = local.objs[(H, W, M)] = DenseCRF(W, H, M)
+            crf = local.objs[key] = DenseCRF(W, H, M, nimages=n if batch > 1 else None)
             crf.set_stream(local.stream)
         local.stream.wait_event(ready)                      # the inputs were produced on the caller's stream
         with torch.cuda.stream(local.stream):
-            crf.set_unary_energy((-unary.to(torch.float32)).contiguous())
+            un = torch.stack([u for _, u in group]) if n > 1 else group[0][1]
+            im = torch.stack([i for i, _ in group]) if n > 1 else group[0][0]
+            crf.set_unary_energy((-un.to(torch.float32)).contiguous())
             crf.add_pairwise_energy(_BILATERAL_W, sxy_b, sxy_b, color_factor, color_factor, color_factor, _GAUSS_W, sxy_g, sxy_g,
-                                    image.reshape(-1).to(torch.uint8).contiguous())
+                                    im.reshape(-1).to(torch.uint8).contiguous())
             if want == "map":
-                return crf.map(maxiter, out=torch.empty((H, W), dtype=torch.int32, device=unary.device))
-            return crf.inference(maxiter, out=torch.empty((H, W, M), dtype=torch.float32, device=unary.device))
+                out = crf.map(maxiter, out=torch.empty((n, H, W), dtype=torch.int32, device=un.device))
+            else:
+                out = crf.inference(maxiter, out=torch.empty((n, H, W, M), dtype=torch.float32, device=un.device))
+        # allocated on this worker's stream, consumed on the caller's: keep the block out of this stream's pool until the
+        # caller's queued work is done with it (the call above returned with the worker's stream drained)
+        out.record_stream(caller)
+        return [out[k] for k in range(n)]
+
+    def groups():
+        run = []
+        for image, unary in pairs:
+            if run and (len(run) == batch or tuple(unary.shape) != tuple(run[0][1].shape)):
+                yield run
+                run = []
+            run.append((image, unary))
+        if run:
+            yield run
 
     pending = deque()
     with ThreadPoolExecutor(max_workers=max(1, int(in_flight))) as ex:
-        for image, unary in pairs:
+        for group in groups():
             ready = torch.cuda.Event()
             ready.record(caller)
-            pending.append(ex.submit(work, image, unary, ready))
+            pending.append(ex.submit(work, group, ready))
             if len(pending) > 2 * in_flight:
-                yield pending.popleft().result()            # (every call of the object API returns with its stream drained)
+                for r in pending.popleft().result():        # (every call of the object API returns with its stream drained)
+                    yield r
         while pending:
-            yield pending.popleft().result()
+            for r in pending.popleft().result():
+                yield r

@@ -649,7 +649,7 @@ extern "C" int dsrg_supervision_step(dsrg_ctx_t c, int B, const float *logits, c
 
 namespace dsrg {
 struct LargeCrf;
-int large_crf_create(int W, int H, int C, LargeCrf **out);
+int large_crf_create(int W, int H, int C, LargeCrf **out, int nimages);
 void large_crf_destroy(LargeCrf *c);
 int large_crf_set_unary(LargeCrf *c, const float *unary_host);
 int large_crf_zero_unary(LargeCrf *c);
@@ -668,6 +668,7 @@ void large_crf_set_stream(LargeCrf *c, hipStream_t s, bool async);
 // resolution) use the global-memory path of lattice_large.hip.
 struct dsrg_crf_s {
     int W, H, M;
+    int nimg;                    // images per call: 1, or the batch size of dsrg_crf_create_batch (global-memory path only)
     dsrg::LargeCrf *large;
     dsrg_ctx_t ctx;
     float *neg_unary;            // device (M,N) planes = -U
@@ -688,13 +689,24 @@ static constexpr int kCrfCacheSlots = 4;
 static dsrg_crf_s *g_crf_cache[kCrfCacheSlots] = {nullptr, nullptr, nullptr, nullptr};
 static std::mutex g_crf_cache_mutex;
 
-extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) {
+static int crf_create(int W, int H, int nlabels, int nimages, dsrg_crf_t *out);
+extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) { return crf_create(W, H, nlabels, 1, out); }
+// nimages same-sized images per call (training/tools/test-ms.py:84-111 and generate_train_gt.py:78-106 loop over 10 582 images
+// one at a time: here `nimages` of them share every launch of the build and of the mean-field loop).  Always the global-memory
+// path; unary / image / result buffers hold the images back to back; 1 <= nimages <= 8.
+extern "C" int dsrg_crf_create_batch(int W, int H, int nlabels, int nimages, dsrg_crf_t *out) {
+    if (nimages < 1) return set_error(DSRG_ERR_INVALID, "bad CRF batch");
+    return crf_create(W, H, nlabels, nimages == 1 ? -1 : nimages, out);          // (-1: one image, but on the batched objects' path)
+}
+static int crf_create(int W, int H, int nlabels, int nimages, dsrg_crf_t *out) {
+    const bool force_large = nimages != 1;
+    if (nimages < 0) nimages = 1;
     if (!out || W < 1 || H < 1 || nlabels < 1) return set_error(DSRG_ERR_INVALID, "bad CRF shape");
     {
         std::lock_guard<std::mutex> lock(g_crf_cache_mutex);
         for (int i = 0; i < kCrfCacheSlots; i++) {
             dsrg_crf_s *c = g_crf_cache[i];
-            if (c && c->W == W && c->H == H && c->M == nlabels) {
+            if (c && c->W == W && c->H == H && c->M == nlabels && c->nimg == nimages && (!force_large || c->large)) {
                 g_crf_cache[i] = nullptr;
                 c->have_unary = c->have_pairwise = false;
                 c->stream = nullptr; c->async = false;
@@ -707,11 +719,11 @@ extern "C" int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out) {
     dsrg_crf_s *h = new (std::nothrow) dsrg_crf_s();
     if (!h) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
     memset(h, 0, sizeof(*h));
-    h->W = W; h->H = H; h->M = nlabels;
+    h->W = W; h->H = H; h->M = nlabels; h->nimg = nimages;
     if (nlabels > kMaxLabels) { delete h; return set_error(DSRG_ERR_UNSUPPORTED, "at most %d labels", kMaxLabels); }
     if (dsrg_device_count() < 1) { delete h; return set_error(DSRG_ERR_HIP, "no HIP device visible"); }
-    if (!lattice_supported(2, W * H) || !lattice_supported(5, W * H)) {
-        int rc = large_crf_create(W, H, nlabels, &h->large);
+    if (force_large || !lattice_supported(2, W * H) || !lattice_supported(5, W * H)) {
+        int rc = large_crf_create(W, H, nlabels, &h->large, nimages);
         if (rc) { delete h; return rc; }
         *out = h;
         return DSRG_OK;
@@ -752,7 +764,7 @@ static int crf_free(dsrg_crf_t h) {
     delete h;
     return DSRG_OK;
 }
-extern "C" int dsrg_crf_npixels(dsrg_crf_t h) { return h ? h->W * h->H : 0; }
+extern "C" int dsrg_crf_npixels(dsrg_crf_t h) { return h ? h->W * h->H * h->nimg : 0; }     // of all images of a batched object
 extern "C" int dsrg_crf_nlabels(dsrg_crf_t h) { return h ? h->M : 0; }
 
 extern "C" int dsrg_crf_set_unary_energy(dsrg_crf_t h, const float *unary_host) {

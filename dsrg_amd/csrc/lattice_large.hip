@@ -19,6 +19,13 @@ constexpr uint32_t kEmptyL = 0xFFFFFFFFu;
 
 struct LargeLattice {
     int d, N, Npad, E, Epad, Mcap, cap;
+    // batch mode (nimg > 1, dsrg_crf_create_batch): the object filters nimg same-sized images at once.  Pixel index space =
+    // nimg slots of Npimg = 4 * ceil(Nimg / 4) pixels: image b's Nimg pixels, then the up to three zero-feature pixels with
+    // which the reference's SSE loop pads ITS image (permutohedral.cpp:191-199) — here ordinary pixels with barycentric weight
+    // 0.  Every key carries its image's number (embedding kernel), so images share no vertex and the build, the splat rows
+    // (an image's entries in the reference's order, its padding entries last with weight 0) and the blur neighbours come out
+    // per image exactly as in a single-image object; every kernel below just sees one lattice over N = nimg * Npimg pixels.
+    int nimg, Nimg, Npimg;
     int M_host;
     uint32_t *key_e, *table, *slot_e, *first, *scanned, *key_v, *vid, *nb1, *nb2;
     uint32_t *ent_vid, *ent_idx, *srt_vid, *srt_idx, *cnt, *row_start, *csr_pix;
@@ -34,6 +41,7 @@ struct LargeLattice {
     int seg_len;             // entries per splat segment
 };
 constexpr int kSplatSeg = 64;
+constexpr int kLargeBatchMax = 8;          // images per batched object: the image number's room in the d = 2 keys (lg_embed_kernel)
 
 
 // ---------------------------------------------------------------------------------------------
@@ -44,7 +52,33 @@ __global__ void lg_embed_kernel(LargeLattice L, LatticeFeat F, const unsigned ch
     if (i >= L.Npad) return;
     uint32_t keys[D1][KW];
     float bc[D1];
-    embed_pixel<D>(F, i, L.N, im, keys, bc);
+    if (L.nimg > 1) {
+        const int b = i / L.Npimg, il = i - b * L.Npimg;
+        const bool real = il < L.Nimg;
+        float pr = 0.0f, pg = 0.0f, pb = 0.0f;
+        if (D == 5 && real) {
+            const unsigned char *px = im + ((size_t)b * L.Nimg + il) * 3;
+            pr = (float)px[0]; pg = (float)px[1]; pb = (float)px[2];
+        }
+        embed_pixel_rgb<D>(F, il, L.Nimg, pr, pg, pb, keys, bc);
+        bool out_of_range = false;
+#pragma unroll
+        for (int r = 0; r < D1; r++) {
+            if (!real) bc[r] = 0.0f;                        // a padding pixel only creates its vertices (the reference never splats it)
+            if (D == 5) {
+                keys[r][KW - 1] |= (uint32_t)b << 16;       // 5 x 16 bits of key in three words: the last word's upper half is free
+            } else {
+                // two 16-bit fields fill the only word: the image number goes on top of the first field, 4096 per image — room for
+                // eight images of coordinates within +-2048 (a 500-pixel side at sigma = 3 reaches ~300); checked, never assumed
+                const uint32_t f0 = keys[r][0] & 0xffffu;
+                out_of_range |= f0 < 0x8000u - 2040u || f0 >= 0x8000u + 2040u;     // (a neighbour key reaches 3 further)
+                keys[r][0] += (uint32_t)b * 4096u;
+            }
+        }
+        if (out_of_range) atomicOr(reinterpret_cast<unsigned int *>(L.M + 3), 1u);
+    } else {
+        embed_pixel<D>(F, i, L.N, im, keys, bc);
+    }
 #pragma unroll
     for (int r = 0; r < D1; r++) {
 #pragma unroll
@@ -515,28 +549,40 @@ __global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, L
     }
 }
 
-__global__ void lg_pad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out, int negate) {
+// (Nimg, Npimg): batch mode — row i of the padded side is pixel i % Npimg of image i / Npimg, the caller's side holds the
+// images' Nimg pixels back to back; the slots' padding pixels read as zero rows and are never written out.  Npimg = 0: one image.
+__device__ __forceinline__ long long lg_user_row(size_t i, int Nimg, int Npimg) {
+    if (Npimg == 0) return (long long)i;
+    const size_t b = i / (size_t)Npimg, il = i - b * (size_t)Npimg;
+    return il < (size_t)Nimg ? (long long)(b * (size_t)Nimg + il) : -1;
+}
+__global__ void lg_pad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out, int negate,
+                                   int Nimg, int Npimg) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * CP) return;
     const size_t i = idx / CP;
     const int c = (int)(idx - i * CP);
-    const float v = c < C ? in[i * C + c] : 0.0f;
+    const long long u = lg_user_row(i, Nimg, Npimg);
+    const float v = (c < C && u >= 0) ? in[(size_t)u * C + c] : 0.0f;
     out[idx] = negate ? -v : v;
 }
-__global__ void lg_unpad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out) {
+__global__ void lg_unpad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out, int Nimg, int Npimg) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * C) return;
     const size_t i = idx / C;
     const int c = (int)(idx - i * C);
-    out[idx] = in[i * CP + c];
+    const long long u = lg_user_row(i, Nimg, Npimg);
+    if (u >= 0) out[(size_t)u * C + c] = in[i * CP + c];
 }
-__global__ void lg_argmax_rows_kernel(int N, int C, int CP, const float *__restrict__ q, int32_t *__restrict__ lab) {
+__global__ void lg_argmax_rows_kernel(int N, int C, int CP, const float *__restrict__ q, int32_t *__restrict__ lab, int Nimg, int Npimg) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    const long long u = lg_user_row((size_t)i, Nimg, Npimg);
+    if (u < 0) return;
     int m = 0;
     float best = q[(size_t)i * CP];
     for (int c = 1; c < C; c++) { const float v = q[(size_t)i * CP + c]; if (v > best) { best = v; m = c; } }
-    lab[i] = m;
+    lab[u] = m;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -699,7 +745,8 @@ static int lg_sort_pairs(uint32_t *tmp, uint32_t *kin, uint32_t *kout, uint32_t 
 
 // ---------------------------------------------------------------------------------------------
 struct LargeCrf {
-    int W, H, C, CP, N;
+    int W, H, C, CP, N;                        // N: pixel slots of the object (W * H, or nimg * Npimg in batch mode)
+    int nimg, Nimg, Npimg;                     // images per call (1 = the plain object), pixels per image, per slot (0 when nimg == 1)
     LargeLattice Lg, Lb;
     void *arena;
     uint32_t *prim_tmp; size_t prim_words;     // scratch of the scan / sort primitives above
@@ -755,15 +802,21 @@ static size_t large_lattice_carve(LargeLattice &L, unsigned char *p, int d, int 
     L.seg_start = L.first; L.seg_cnt = L.scanned; L.seg_v = L.slot_e; L.multi_v = L.key_e;        // dead once lg_vid_kernel has run
     L.T_host = L.nmulti_host = 0;
     L.seg_len = kSplatSeg;
+    L.nimg = 1; L.Nimg = N; L.Npimg = 0;
     return off;
 }
 
-int large_crf_create(int W, int H, int C, LargeCrf **out) {
-    if ((long long)W * H * 6 >= (1ll << 31) / 4) return set_error(DSRG_ERR_UNSUPPORTED, "map too large");
+int large_crf_create(int W, int H, int C, LargeCrf **out, int nimages) {
+    if (nimages < 1 || nimages > kLargeBatchMax)
+        return set_error(DSRG_ERR_UNSUPPORTED, "1 .. %d images per batched CRF object", kLargeBatchMax);
+    const long long slot = nimages > 1 ? ((long long)W * H + 3) / 4 * 4 : (long long)W * H;
+    if (slot * nimages * 6 >= (1ll << 31) / 4) return set_error(DSRG_ERR_UNSUPPORTED, "map too large");
     LargeCrf *c = new (std::nothrow) LargeCrf();
     if (!c) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
     memset(c, 0, sizeof(*c));
-    c->W = W; c->H = H; c->C = C; c->CP = (C + 3) & ~3; c->N = W * H;
+    c->W = W; c->H = H; c->C = C; c->CP = (C + 3) & ~3;
+    c->nimg = nimages; c->Nimg = W * H; c->Npimg = nimages > 1 ? (int)slot : 0;
+    c->N = (int)(slot * nimages);
     const int N = c->N;
     LargeLattice tmp;
     const size_t sg = large_lattice_carve(tmp, nullptr, 2, N), sb = large_lattice_carve(tmp, nullptr, 5, N);
@@ -777,6 +830,7 @@ int large_crf_create(int W, int H, int C, LargeCrf **out) {
     unsigned char *p = (unsigned char *)c->arena;
     p += large_lattice_carve(c->Lg, p, 2, N);
     p += large_lattice_carve(c->Lb, p, 5, N);
+    c->Lg.nimg = c->Lb.nimg = c->nimg; c->Lg.Nimg = c->Lb.Nimg = c->Nimg; c->Lg.Npimg = c->Lb.Npimg = c->Npimg;
     c->prim_tmp = (uint32_t *)p; p += al(sizeof(uint32_t) * c->prim_words);
     c->neg_unary = (float *)p; p += al(rows);
     c->q = (float *)p; p += al(rows);
@@ -808,6 +862,7 @@ static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipSt
     const int T = 256;
     DSRG_HIP_CHECK(hipMemsetAsync(L.table, 0xFF, sizeof(uint32_t) * (size_t)L.cap, s));
     DSRG_HIP_CHECK(hipMemsetAsync(L.cnt, 0, sizeof(uint32_t) * (size_t)(L.Mcap + 1), s));
+    DSRG_HIP_CHECK(hipMemsetAsync(L.M + 3, 0, sizeof(int), s));               // batch mode: "a key left the tagged range"
     hipLaunchKernelGGL(lg_embed_kernel<D>, dim3(blocks_for(L.Npad, T)), dim3(T), 0, s, L, F, c->im);
     hipLaunchKernelGGL(lg_insert_kernel<D>, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
     hipLaunchKernelGGL(lg_first_kernel, dim3(blocks_for(L.Epad, T)), dim3(T), 0, s, L);
@@ -823,10 +878,13 @@ static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipSt
     if (int rc = lg_exclusive_sum(L.seg_cnt, L.seg_start, L.Mcap + 1, c->prim_tmp, s)) return rc;
     hipLaunchKernelGGL(lg_seg_fill_kernel, dim3(blocks_for((size_t)L.Mcap + 1, T)), dim3(T), 0, s, L);
     DSRG_LAUNCH_CHECK();
-    int mtn[3] = {0, 0, 0};
-    DSRG_HIP_CHECK(hipMemcpyAsync(mtn, L.M, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
+    int mtn[4] = {0, 0, 0, 0};
+    DSRG_HIP_CHECK(hipMemcpyAsync(mtn, L.M, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
     DSRG_HIP_CHECK(hipStreamSynchronize(s));                      // M and the segment count size the remaining launches
     L.M_host = mtn[0]; L.T_host = mtn[1]; L.nmulti_host = mtn[2];
+    if (mtn[3] != 0)
+        return set_error(DSRG_ERR_UNSUPPORTED, "batched CRF: a lattice coordinate of the d = %d kernel lies beyond +-2048 — the image "
+                         "number does not fit its key; filter these images one at a time", D);
     // the aliasing above holds segments in slot_e (Epad words) and multi-segment vertices in key_e (Epad * KW words)
     if (L.M_host < 0 || L.M_host > L.Mcap || L.T_host < 0 || L.T_host > L.Epad || L.nmulti_host < 0 ||
         (long long)L.nmulti_host > (long long)L.Epad * KeyWords<D>::value)
@@ -853,9 +911,9 @@ static int large_build(LargeCrf *c, LargeLattice &L, const LatticeFeat &F, hipSt
 // `unary` / `im` / outputs may be host or device pointers (hipMemcpyDefault resolves the kind): the test-time pipeline
 // keeps its scores on the GPU, the Cython-style callers pass numpy memory.
 int large_crf_set_unary(LargeCrf *c, const float *unary) {
-    DSRG_HIP_CHECK(hipMemcpyAsync(c->stage, unary, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault, c->stream));
+    DSRG_HIP_CHECK(hipMemcpyAsync(c->stage, unary, sizeof(float) * (size_t)c->nimg * c->Nimg * c->C, hipMemcpyDefault, c->stream));
     hipLaunchKernelGGL(lg_pad_rows_kernel, dim3(blocks_for((size_t)c->N * c->CP, 256)), dim3(256), 0, c->stream, c->N, c->C,
-                       c->CP, c->stage, c->neg_unary, 1);
+                       c->CP, c->stage, c->neg_unary, 1, c->Nimg, c->Npimg);
     DSRG_LAUNCH_CHECK();
     if (!c->async) DSRG_HIP_CHECK(hipStreamSynchronize(c->stream));         // the caller may reuse its (host) buffer
     return DSRG_OK;
@@ -865,7 +923,7 @@ int large_crf_zero_unary(LargeCrf *c) {
     return DSRG_OK;
 }
 int large_crf_set_image(LargeCrf *c, const unsigned char *im) {
-    DSRG_HIP_CHECK(hipMemcpyAsync(c->im, im, (size_t)c->N * 3, hipMemcpyDefault, c->stream));
+    DSRG_HIP_CHECK(hipMemcpyAsync(c->im, im, (size_t)c->nimg * c->Nimg * 3, hipMemcpyDefault, c->stream));
     if (!c->async) DSRG_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->lattices_valid = false;
     return DSRG_OK;
@@ -948,21 +1006,23 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
 
 int large_crf_read_q(LargeCrf *c, float *out_host) {
     hipLaunchKernelGGL(lg_unpad_rows_kernel, dim3(blocks_for((size_t)c->N * c->C, 256)), dim3(256), 0, c->stream, c->N, c->C,
-                       c->CP, c->q, c->stage);
+                       c->CP, c->q, c->stage, c->Nimg, c->Npimg);
     DSRG_LAUNCH_CHECK();
-    DSRG_HIP_CHECK(hipMemcpyAsync(out_host, c->stage, sizeof(float) * (size_t)c->N * c->C, hipMemcpyDefault, c->stream));
+    DSRG_HIP_CHECK(hipMemcpyAsync(out_host, c->stage, sizeof(float) * (size_t)c->nimg * c->Nimg * c->C, hipMemcpyDefault, c->stream));
     if (!c->async) DSRG_HIP_CHECK(hipStreamSynchronize(c->stream));    // the result is the caller's when the call returns
     return DSRG_OK;
 }
 int large_crf_read_map(LargeCrf *c, int32_t *labels_host) {
-    hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, c->stream, c->N, c->C, c->CP, c->q, c->lab);
+    hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, c->stream, c->N, c->C, c->CP, c->q, c->lab,
+                       c->Nimg, c->Npimg);
     DSRG_LAUNCH_CHECK();
-    DSRG_HIP_CHECK(hipMemcpyAsync(labels_host, c->lab, sizeof(int32_t) * (size_t)c->N, hipMemcpyDefault, c->stream));
+    DSRG_HIP_CHECK(hipMemcpyAsync(labels_host, c->lab, sizeof(int32_t) * (size_t)c->nimg * c->Nimg, hipMemcpyDefault, c->stream));
     if (!c->async) DSRG_HIP_CHECK(hipStreamSynchronize(c->stream));
     return DSRG_OK;
 }
 void large_crf_set_stream(LargeCrf *c, hipStream_t s, bool async) { c->stream = s; c->async = async; }
 int large_crf_lattice_size(LargeCrf *c, int k) { return k == 0 ? c->Lg.M_host : c->Lb.M_host; }
+int large_crf_images(LargeCrf *c) { return c->nimg; }
 Profiler *large_crf_profiler(LargeCrf *c) { return &c->prof; }
 
 }  // namespace dsrg

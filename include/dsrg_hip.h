@@ -53,6 +53,15 @@ typedef struct dsrg_crf_s *dsrg_crf_t;
 
 /* DenseCRFWrapper::DenseCRFWrapper(int W, int H, int nlabels)  densecrf_wrapper.cpp:5-8 */
 int dsrg_crf_create(int W, int H, int nlabels, dsrg_crf_t *out);
+/* The same object for `nimages` (1 .. 8) same-sized images per call: what the reference's test-time loops do one image at
+ * a time (training/tools/test-ms.py:84-111, generate_train_gt.py:78-106: CRF() per image over 10 582 images) as ONE set of
+ * launches — the lattices of the batch are built together (every key carries its image's number, so images share no vertex)
+ * and every splat / blur / slice launch of the mean-field loop carries all of them.  The unary, image, result and label
+ * buffers of the calls below then hold the images back to back ((nimages, H, W, nlabels) / (nimages, H, W, 3) / (nimages, H,
+ * W)); dsrg_crf_npixels returns nimages * W * H.  Results equal nimages single-image calls bit for bit.  Always the
+ * global-memory path; DSRG_ERR_UNSUPPORTED at inference when a spatial kernel is so narrow that the image number does not fit
+ * beside its lattice coordinates (theta_gamma below ~0.3 pixel at 500 pixels a side): filter such images one at a time. */
+int dsrg_crf_create_batch(int W, int H, int nlabels, int nimages, dsrg_crf_t *out);
 /* DenseCRFWrapper::~DenseCRFWrapper                             densecrf_wrapper.cpp:10-12 */
 int dsrg_crf_destroy(dsrg_crf_t h);
 /* The four data pointers of this object API (`unary_host`, `im_host`, `out_host`, `labels_host`) may be host OR device

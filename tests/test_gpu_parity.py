@@ -1096,3 +1096,68 @@ def test_crf_objects_on_their_own_streams(ops, O):
     q = many[0].cpu().numpy()
     want_q = O.CRF(pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy(), scale_factor=1.0)
     assert np.abs(q - want_q).max() < CRF_TOL
+
+
+def _fullres_case(seed, H, W, C, kind="smooth"):
+    rng = np.random.default_rng(seed)
+    img = S.make_images(rng, 1, size=max(H, W), kind=kind)[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]
+    im = torch.from_numpy(np.ascontiguousarray(np.transpose(img, (1, 2, 0))).astype(np.uint8)).cuda()
+    logits = S.make_logits(rng, 1, C, H, W, gain=12.0, sigma=6.0)[0]
+    e = np.exp(logits - logits.max(0, keepdims=True))
+    un = torch.from_numpy(np.log(np.maximum(e / e.sum(0, keepdims=True), 1e-5)).transpose(1, 2, 0).astype(np.float32).copy()).cuda()
+    return im, un
+
+
+@pytest.mark.parametrize("H,W,C,B", [(97, 123, 21, 4),      # N % 4 = 3: every image brings its own SSE padding pixel and phantom vertices
+                                     (100, 120, 21, 3),     # N % 4 = 0
+                                     (61, 47, 5, 8),        # the largest batch an object takes; N % 4 = 3
+                                     (123, 186, 21, 2)])    # one of the shapes of the round-3 allocation bug
+def test_crf_batch_equals_single_image_calls_bit_for_bit(ops, O, H, W, C, B):
+    """dsrg_crf_create_batch (round-4 review item 4): B same-sized images through ONE set of launches — lattices built together
+    (every key carries its image's number), every splat / blur / slice launch carrying all of them — against B calls of the
+    one-image object on the same (global-memory) path: marginals and labels equal bit for bit, image by image; and the batch
+    against the oracle.  Cases: a dark-corner image (many pixels in the origin simplex, where the SSE padding's phantom vertices
+    sit) next to smooth and noise images."""
+    from dsrg_amd.crf import CRF_device_batch, DenseCRF
+    kinds = ["smooth", "dark_corner", "noise", "smooth"]
+    cases = [_fullres_case(900 + 7 * k + H, H, W, C, kinds[k % 4]) for k in range(B)]
+    ims, uns = torch.stack([c[0] for c in cases]), torch.stack([c[1] for c in cases])
+    for want in ("marginals", "map"):
+        got = CRF_device_batch(ims, uns, scale_factor=1.0, want=want)
+        for k in range(B):
+            # the one-image object of the same path (a batched object of one image: no image number in any key)
+            crf = DenseCRF(W, H, C, nimages=1)
+            crf.set_unary_energy((-uns[k]).contiguous())
+            crf.add_pairwise_energy(10, 80.0, 80.0, 13, 13, 13, 3, 3.0, 3.0, ims[k].contiguous())
+            one = crf.map(10, out=torch.empty((H, W), dtype=torch.int32, device="cuda")) if want == "map" else \
+                crf.inference(10, out=torch.empty((H, W, C), dtype=torch.float32, device="cuda"))
+            assert torch.equal(got[k], one), (want, k)
+    q = got if want == "marginals" else CRF_device_batch(ims, uns, scale_factor=1.0)
+    for k in (0, B - 1):
+        want_q = O.CRF(ims[k].cpu().numpy(), uns[k].cpu().numpy(), scale_factor=1.0)
+        assert np.abs(q[k].cpu().numpy() - want_q).max() < CRF_TOL
+
+
+def test_crf_batch_through_the_many_images_loop_and_its_limits(ops, O):
+    """CRF_device_many(batch=k): consecutive same-sized images share batched calls, results in order and bit-equal to the
+    one-at-a-time results (mixed sizes break the runs); a batched object refuses more than eight images, and refuses — at
+    inference, loudly — a spatial kernel so narrow that the image number does not fit beside its lattice coordinates"""
+    from dsrg_amd.crf import CRF_device, CRF_device_many, CRF_device_batch, DenseCRF
+    from dsrg_amd._lib import DsrgError
+    shapes = [(97, 131, 21)] * 5 + [(120, 90, 5)] * 2 + [(97, 131, 21)] * 3 + [(41, 41, 21)]
+    pairs = [_fullres_case(700 + k, H, W, C) for k, (H, W, C) in enumerate(shapes)]
+    one = [CRF_device(im, un, scale_factor=1.0, want="map") for im, un in pairs]
+    for batch, in_flight in ((4, 2), (3, 1), (8, 3)):
+        many = list(CRF_device_many(pairs, scale_factor=1.0, want="map", in_flight=in_flight, batch=batch))
+        assert len(many) == len(one)
+        for k, (a, b) in enumerate(zip(one, many)):
+            assert torch.equal(a, b), (batch, k)
+    with pytest.raises(DsrgError):
+        DenseCRF(50, 50, 21, nimages=9)
+    # scale_factor 12 at 400 pixels a side: sigma_gamma = 0.25 px, lattice coordinates reach ~2800 > 2040
+    im, un = _fullres_case(5, 400, 400, 3)
+    with pytest.raises(DsrgError):
+        CRF_device_batch(torch.stack([im, im]), torch.stack([un, un]), scale_factor=12.0)
+    # ... while the same two images at the test-time scale pass, and the one-image call never has the limit
+    assert CRF_device_batch(torch.stack([im, im]), torch.stack([un, un]), scale_factor=1.0).shape == (2, 400, 400, 3)
+    assert CRF_device(im, un, scale_factor=12.0).shape == (400, 400, 3)
