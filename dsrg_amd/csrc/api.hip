@@ -75,7 +75,9 @@ extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *o
     const int N = H * W;
     if (!lattice_supported(2, N) || !lattice_supported(5, N))
         return set_error(DSRG_ERR_UNSUPPORTED,
-                         "%dx%d map: lattices do not fit the LDS-resident path of this build", H, W);
+                         "%dx%d map: %d pixels, the LDS-resident path takes at most %d (a function of the map size alone, "
+                         "never of the images); use the object API (dsrg_crf_create / dsrg_crf_create_batch) for such maps",
+                         H, W, N, DSRG_CTX_MAX_PIXELS);
     if (dsrg_device_count() < 1) return set_error(DSRG_ERR_HIP, "no HIP device visible");
     dsrg_ctx_s *c = new (std::nothrow) dsrg_ctx_s();
     if (!c) return set_error(DSRG_ERR_NOMEM, "host allocation failed");

@@ -193,11 +193,26 @@ __device__ __forceinline__ void seed_stats(int C, int HW, const float *__restric
                                            const float *__restrict__ Sb, double (&st)[4], double *scratch) {
     st[0] = st[1] = st[2] = st[3] = 0.0;
     const int n = C * HW;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float s = Sb[i];
-        if (s != 0.0f) {
-            const double t = (double)s * (double)logf(pb[i]);
-            if (i < HW) { st[0] += s; st[2] += t; } else { st[1] += s; st[3] += t; }
+    // four elements of a thread per round, their loads issued together (one workgroup walks a whole image — or, in the forward
+    // kernel, the batch: with one load in flight per thread the stand-alone forward took 0.3 ms for 16 images); a thread adds its
+    // elements in index order, as before
+    constexpr int U = 4;
+    for (int i0 = threadIdx.x; i0 < n; i0 += U * blockDim.x) {
+        float sv[U], pv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(i0 + u * (int)blockDim.x, n - 1);
+            sv[u] = Sb[i];
+            pv[u] = pb[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * (int)blockDim.x;
+            const float s = i < n ? sv[u] : 0.0f;
+            if (s != 0.0f) {
+                const double t = (double)s * (double)logf(pv[u]);
+                if (i < HW) { st[0] += s; st[2] += t; } else { st[1] += s; st[3] += t; }
+            }
         }
     }
     block_reduce_sum<4>(st, scratch);
@@ -261,9 +276,20 @@ __global__ __launch_bounds__(1024) void constrain_fwd_kernel(size_t n, double in
                                                              float *__restrict__ loss) {
     __shared__ double scratch[16];
     double acc[1] = {0.0};
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-        float dp, dlq;
-        acc[0] += (double)constrain_term(p[i], lq[i], dp, dlq);
+    constexpr int U = 4;                                   // as seed_stats: four loads of a thread in flight together
+    for (size_t i0 = threadIdx.x; i0 < n; i0 += U * (size_t)blockDim.x) {
+        float pv[U], lv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = min(i0 + (size_t)u * blockDim.x, n - 1);
+            pv[u] = p[i];
+            lv[u] = lq[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float dp, dlq;
+            if (i0 + (size_t)u * blockDim.x < n) acc[0] += (double)constrain_term(pv[u], lv[u], dp, dlq);
+        }
     }
     block_reduce_sum<1>(acc, scratch);
     if (threadIdx.x == 0) *loss = (float)(acc[0] * inv);

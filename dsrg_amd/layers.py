@@ -38,76 +38,263 @@ def _check_labels(n, who):
         raise Exception("%s: %d label planes, but this build of libdsrg_hip.so supports at most %d" % (who, n, MAX_LABELS))
 
 
-# ---- blobs resident on the device between the layers of one iteration ---------------------------------------------------
-# Caffe hands every layer numpy views of its blobs; the protocol forces a host copy of every top.  What it does not force is
-# sending the same bytes up again: a blob one of these layers has just written (or uploaded) is still in HBM when the next
-# layer receives it as a bottom.  `_dev` therefore keeps, per host buffer (address, shape, dtype), the device tensor together
-# with a 64-bit digest (xxh3) of the host bytes it mirrors, and re-uploads only when the host bytes no longer hash to it —
-# any write by Caffe or by another layer in between is seen.  Without the xxhash module every call uploads, as before.
-# Blobs up to _EXACT_BYTES (every blob of the path but the images: 2.3 MB of probabilities take 0.15 ms) are hashed in full.
-# The image blob (20 MB, 1.3 ms per pass — as long as the upload it would save) is fingerprinted by its address, shape, both
-# ends and every 16th 64-byte line instead: it is written once per iteration by the data layer, BEFORE the two layers that
-# read it, so the question "is this still the buffer CRFLayer saw a moment ago" does not need every byte;
-# DSRG_PYLAYERS_EXACT=1 hashes everything.
+# ---- host blobs <-> HBM --------------------------------------------------------------------------------------------------
+# Caffe hands every layer numpy views of its blobs; the protocol forces a host copy of every top and diff.  What it does not
+# force, and what this section avoids (round 5; the per-layer cost table is in INTEGRATION.md, tools/pylayers_route_cost.py):
+#   * sending the same bytes up again — a blob one of these layers has just written (or uploaded) is still in HBM when the next
+#     layer receives it as a bottom: `_dev` keeps, per host buffer (address, shape, dtype), the device tensor together with a
+#     64-bit digest (xxh3) of the host bytes it mirrors and re-uploads only when the host bytes no longer hash to it;
+#   * hashing the same bytes again and again inside one iteration — a blob that was hashed IN FULL (or written by us) in the
+#     current epoch is re-checked by a sampled digest (both ends + every 16th 64-byte line) when the next layer of the same
+#     iteration receives it; an epoch begins at SoftmaxLayer.forward (CRFLayer.forward for a driver that starts there: the heads
+#     of the path, train-s.prototxt:746-775), so anything written between iterations is hashed in full — except a buffer that
+#     held other bytes at each of its last two first sights (the net's scores, a data layer's tops): it is simply uploaded.  DSRG_PYLAYERS_EXACT=1: every
+#     check hashes every byte.  The image blob (20 MB: a full pass costs as much as its upload) is sampled as before unless EXACT;
+#   * pageable copies — a host buffer seen twice at the same address (Caffe's blobs never move) is page-locked in place
+#     (hipHostRegister through torch), so uploads and downloads are single DMA transfers into the blob itself; the registry
+#     holds a reference to the array and is bounded (least recently used entries are unregistered and dropped);
+#   * one device synchronisation per blob — downloads of a layer call are queued and waited for ONCE, when the call ends;
+#   * downloads nobody reads — CRFLayer.result (float64, 4.5 MB per 16 images) is fetched when it is first read.
+# Without the xxhash module every call uploads, as before.
 import os as _os
-_EXACT_BYTES = 1 << 62 if _os.environ.get("DSRG_PYLAYERS_EXACT") == "1" else 4 << 20
+import time as _time
+from collections import OrderedDict as _OrderedDict
+
+_EXACT = _os.environ.get("DSRG_PYLAYERS_EXACT") == "1"
+_EXACT_BYTES = 1 << 62 if _EXACT else 4 << 20
 try:
     import xxhash as _xxhash
 
-    def _digest(a):
-        m = memoryview(a).cast("B")
-        if m.nbytes <= _EXACT_BYTES:
-            return _xxhash.xxh3_64_intdigest(m)
+    def _sampled(m):
         lines = np.frombuffer(m, dtype=np.uint8, count=(m.nbytes // 64) * 64).reshape(-1, 64)
         h = _xxhash.xxh3_64()
         h.update(m[:4096]); h.update(m[-4096:]); h.update(np.ascontiguousarray(lines[::16]))
         return h.intdigest() ^ m.nbytes
+
+    def _digest(a, sampled_ok=False):
+        """64-bit digest of a's bytes: all of them, or (sampled_ok, or a blob beyond _EXACT_BYTES) the sampled form"""
+        t0 = _time.perf_counter()
+        m = memoryview(a).cast("B")
+        if m.nbytes < 16384 or (m.nbytes <= _EXACT_BYTES and not (sampled_ok and not _EXACT)):
+            d = ("full", _xxhash.xxh3_64_intdigest(m))
+        else:
+            d = ("sampled", _sampled(m))
+        _tick("digest", t0)
+        return d
 except ImportError:                      # pragma: no cover - the image ships xxhash
     _digest = None
 
-_resident = {}                           # (address, shape, dtype) -> (digest of the host bytes, device tensor)
-# DSRG_PYLAYERS_TRUST=1: no digests at all — a resident copy is taken for valid until the next iteration begins
-# (SoftmaxLayer.forward, the first layer of the path, train-s.prototxt:746-759).  Right for a Caffe net, whose blobs are written
-# only by their producing layer once per iteration; wrong for a driver that rewrites a blob between two of these layers.
+# DSRG_PYLAYERS_TRUST=1: no digests at all — a resident copy is taken for valid until the next iteration begins.  Right for a
+# Caffe net, whose blobs are written only by their producing layer once per iteration; wrong for a driver that rewrites a blob
+# between two of these layers.
 _TRUST = _os.environ.get("DSRG_PYLAYERS_TRUST") == "1"
 _epoch = [0]
+_MAX_RESIDENT = 64
+_resident = _OrderedDict()               # (address, shape, dtype) -> [epoch of the last full check, {form: digest}, device tensor]
+_pinned = _OrderedDict()                 # (address, nbytes) -> [the array (kept alive), sightings, registered?]
+_PIN = _os.environ.get("DSRG_PYLAYERS_PIN", "1") == "1"
+_pending = []                            # downloads of the current layer call: (host array, device tensor, remember?)
+
+# ---- cost accounting (tools/pylayers_route_cost.py): seconds per (layer call, category) while `profile` is a dict
+profile = None
+_call_name = ["?"]
+
+
+def _tick(cat, t0):
+    if profile is not None:
+        k = (_call_name[0], cat)
+        profile[k] = profile.get(k, 0.0) + (_time.perf_counter() - t0)
+
+
+def _sync_for(cat):
+    """profiling only: wait for the device so that the time spent so far is booked under `cat`"""
+    if profile is not None:
+        t0 = _time.perf_counter()
+        torch.cuda.synchronize()
+        _tick(cat, t0)
 
 
 def _key(a):
     return (a.ctypes.data, a.shape, a.dtype.str)
 
 
-def _dev(a, dtype=torch.float32):
-    """the device copy of host array `a` (uploaded, or the resident one when the host bytes are unchanged)"""
-    a = np.ascontiguousarray(a)
-    if _digest is None or a.dtype != np.float32 or dtype != torch.float32:
-        return torch.from_numpy(a).to(device="cuda", dtype=dtype)
+def _pin(a):
+    """page-lock the memory of a C-contiguous host array in place once it has been seen twice at the same address; -> pinned?"""
+    if not _PIN or a.nbytes < 65536:
+        return False
+    k = (a.ctypes.data, a.nbytes)
+    e = _pinned.get(k)
+    if e is None:
+        _pinned[k] = e = [a, 0, False]
+        while len(_pinned) > _MAX_RESIDENT:
+            _, old = _pinned.popitem(last=False)
+            if old[2]:
+                torch.cuda.cudart().cudaHostUnregister(old[0].ctypes.data)
+    else:
+        _pinned.move_to_end(k)
+    e[1] += 1
+    if not e[2] and e[1] >= 2:
+        t0 = _time.perf_counter()
+        try:
+            rc = torch.cuda.cudart().cudaHostRegister(a.ctypes.data, a.nbytes, 0)
+            e[2] = int(rc) == 0
+        except Exception:                # an overlapping registration, a driver without the call: stay pageable
+            e[2] = False
+        if not e[2]:
+            e[1] = -(1 << 30)            # do not try again
+        _tick("pin", t0)
+    return e[2]
+
+
+_async_uploads = [False]
+
+
+def _upload(a, dtype):
+    t0 = _time.perf_counter()
+    t = torch.from_numpy(a)
+    pinned = _pin(a)
+    _async_uploads[0] = _async_uploads[0] or pinned      # the blob must not change before the DMA has read it: _finish waits
+    t = t.to(device="cuda", dtype=dtype, non_blocking=pinned)
+    _tick("h2d", t0)
+    _sync_for("h2d")
+    return t
+
+
+def _dev(a, dtype=torch.float32, cache=True):
+    """the device copy of host array `a` (uploaded, or the resident one when the host bytes are unchanged); cache=False: a
+    blob that is consumed once (a diff): uploaded, neither hashed nor kept"""
+    c = np.ascontiguousarray(a)
+    if _digest is None or c.dtype != np.float32 or dtype != torch.float32 or not cache or c is not a:
+        return _upload(c, dtype)         # (a non-contiguous input was copied: its address means nothing)
     k = _key(a)
     hit = _resident.get(k)
     if _TRUST:
-        if hit is not None and hit[0] == ("epoch", _epoch[0]):
-            return hit[1]
-        d = ("epoch", _epoch[0])
-    else:
-        d = _digest(a)
-        if hit is not None and hit[0] == d:
-            return hit[1]
-    t = torch.from_numpy(a).to(device="cuda", dtype=dtype)
-    _resident[k] = (d, t)
+        if hit is not None and hit[0] == _epoch[0]:
+            return hit[2]
+        t = _upload(a, dtype)
+        _remember(k, {}, t, 0)
+        return t
+    misses, full = 0, None
+    if hit is not None:
+        _resident.move_to_end(k)
+        in_epoch = hit[0] == _epoch[0]
+        if in_epoch or hit[3] < 2:
+            # fully checked (or written by us) in this epoch: the sampled form decides; otherwise every byte
+            d = _digest(a, sampled_ok=in_epoch)
+            if hit[1].get(d[0]) == d[1]:
+                if d[0] == "full":
+                    hit[0], hit[3] = _epoch[0], 0
+                return hit[2]
+            full = d if d[0] == "full" else None
+        # (a buffer that held other bytes at each of its last two first sights — the net's scores, a data layer's tops — is
+        # not hashed in full a third time: it is uploaded, which is what the hash would have said)
+        misses = hit[3] + (0 if in_epoch else 1)
+    t = _upload(a, dtype)
+    samp = _digest(a, sampled_ok=True)
+    forms = {samp[0]: samp[1]}
+    if full is not None:
+        forms[full[0]] = full[1]
+    elif hit is None or misses < 2:
+        full = _digest(a)
+        forms[full[0]] = full[1]
+    _remember(k, forms, t, misses)
     return t
+
+
+def _remember(k, forms, t, misses=0):
+    _resident[k] = [_epoch[0], forms, t, misses]
+    _resident.move_to_end(k)
+    while len(_resident) > _MAX_RESIDENT:
+        _resident.popitem(last=False)
 
 
 def _blob_id(a):
     """what identifies a blob's content for the CRF reuse: its digest, or under DSRG_PYLAYERS_TRUST its buffer and the iteration"""
     a = np.ascontiguousarray(a)
-    return (_key(a), _epoch[0]) if _TRUST else _digest(a)
+    if _TRUST:
+        return (_key(a), _epoch[0])
+    hit = _resident.get(_key(a))
+    d = _digest(a, sampled_ok=hit is not None and hit[0] == _epoch[0])
+    return d
 
 
-def _publish(host, tensor):
-    """host[...] = tensor (a top blob, or a bottom clipped in place) and remember that `tensor` mirrors it"""
-    host[...] = tensor.detach().cpu().numpy().reshape(host.shape)
-    if _digest is not None and host.dtype == np.float32 and tensor.dtype == torch.float32 and host.flags.c_contiguous:
-        _resident[_key(host)] = (("epoch", _epoch[0]) if _TRUST else _digest(host), tensor)
+def _publish(host, tensor, remember=True):
+    """host[...] = tensor (a top blob, a diff, or a bottom clipped in place), queued: the copies of a layer call are waited for
+    once, in _finish(); remember: `tensor` mirrors the blob afterwards (the next layer's _dev finds it)"""
+    t0 = _time.perf_counter()
+    src = tensor.detach()
+    if host.flags.c_contiguous and host.dtype == np.float32 and src.dtype == torch.float32 and _pin(host):
+        torch.from_numpy(host).copy_(src.reshape(host.shape), non_blocking=True)      # DMA straight into the blob
+        _pending.append((host, None, src if remember else None))
+    else:
+        stage = src.to("cpu", non_blocking=False) if not src.is_cuda else src.cpu()
+        _pending.append((host, stage, src if remember else None))
+    _tick("d2h", t0)
+
+
+def _finish():
+    """end of a layer call: wait for the queued downloads, complete the pageable ones, note what now mirrors what"""
+    if not _pending and not _async_uploads[0]:
+        return
+    t0 = _time.perf_counter()
+    torch.cuda.current_stream().synchronize()
+    _async_uploads[0] = False
+    _tick("sync", t0)
+    for host, stage, src in _pending:
+        if stage is not None:
+            t0 = _time.perf_counter()
+            host[...] = stage.numpy().reshape(host.shape)
+            _tick("d2h", t0)
+        if src is not None and _digest is not None and host.dtype == np.float32 and src.dtype == torch.float32 and host.flags.c_contiguous:
+            # written by us in this epoch: the sampled form is all a later check of the same iteration compares (a blob that
+            # survives into the next epoch is hashed in full there, finds no full digest and is uploaded again)
+            forms = {}
+            if not _TRUST:
+                d = _digest(host, sampled_ok=True)
+                forms[d[0]] = d[1]
+            _remember(_key(host), forms, src)
+    del _pending[:]
+
+
+def _kernels(fn, *a, **kw):
+    """fn(*a, **kw) — the HIP kernels of a layer call; under the cost accounting the device is waited for so that their time is
+    booked as theirs and not as the next download's"""
+    t0 = _time.perf_counter()
+    out = fn(*a, **kw)
+    _tick("kernels", t0)
+    _sync_for("kernels")
+    return out
+
+
+_softmax_ran = [False]
+
+
+class _call(object):
+    """`with _call("CRFLayer.forward"):` — names the layer call for the cost table and flushes its downloads at the end"""
+
+    def __init__(self, name, new_epoch=False):
+        self.name, self.new_epoch = name, new_epoch
+
+    def __enter__(self):
+        _call_name[0] = self.name
+        # an epoch begins at the head of the path: SoftmaxLayer.forward, or CRFLayer.forward when no SoftmaxLayer ran in front of
+        # it (a driver that starts at the CRF) — nothing checked before is taken on a sampled digest any more
+        if self.new_epoch == "softmax":
+            _epoch[0] += 1
+            _softmax_ran[0] = True
+        elif self.new_epoch == "crf":
+            if not _softmax_ran[0]:
+                _epoch[0] += 1
+            _softmax_ran[0] = False
+        self.t0 = _time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        _finish()
+        if profile is not None:
+            k = (self.name, "total")
+            profile[k] = profile.get(k, 0.0) + (_time.perf_counter() - self.t0)
+        return False
 
 
 # the dense CRF of this iteration: CRFLayer.forward and DSRGLayer.refinement run it on the SAME (clipped) probabilities and
@@ -129,12 +316,12 @@ class SoftmaxLayer(_Base):
         top[0].reshape(*bottom[0].data.shape)
 
     def forward(self, bottom, top):
-        _epoch[0] += 1                                       # a new iteration: nothing uploaded before is trusted any more
-        _publish(top[0].data, ops.softmax_forward(_dev(bottom[0].data)))
+        with _call("SoftmaxLayer.forward", new_epoch="softmax"):
+            _publish(top[0].data, _kernels(ops.softmax_forward, _dev(bottom[0].data)))
 
     def backward(self, top, prop_down, bottom):
-        grad = ops.softmax_backward(_dev(bottom[0].data), _dev(top[0].diff))
-        bottom[0].diff[...] = grad.cpu().numpy()
+        with _call("SoftmaxLayer.backward"):
+            _publish(bottom[0].diff, _kernels(ops.softmax_backward, _dev(bottom[0].data), _dev(top[0].diff, cache=False)), remember=False)
 
 
 class CRFLayer(_Base):
@@ -150,18 +337,27 @@ class CRFLayer(_Base):
         top[0].reshape(*bottom[0].data.shape)
 
     def forward(self, bottom, top):
-        probs = _dev(bottom[0].data)
-        refined, logq = ops.crf_refine(probs, _dev(bottom[1].data), scale_factor=12.0)
-        _publish(bottom[0].data, probs)                    # the in-place clip (pylayers.py:65-67)
-        self._result_dev = refined
-        self.result = refined.cpu().numpy()
-        _publish(top[0].data, logq)
-        if _digest is not None:
-            _last_crf.update(probs=_blob_id(bottom[0].data), images=_blob_id(bottom[1].data), scale=12.0, refined=refined)
+        with _call("CRFLayer.forward", new_epoch="crf"):
+            probs = _dev(bottom[0].data)
+            refined, logq = _kernels(ops.crf_refine, probs, _dev(bottom[1].data), scale_factor=12.0)
+            _publish(bottom[0].data, probs)                # the in-place clip (pylayers.py:65-67)
+            self._result_dev, self._result_host = refined, None
+            _publish(top[0].data, logq)
+            _finish()                                      # the blobs hold their final bytes: identify them for DSRGLayer
+            if _digest is not None:
+                _last_crf.update(probs=_blob_id(bottom[0].data), images=_blob_id(bottom[1].data), scale=12.0, refined=refined)
+
+    @property
+    def result(self):
+        """the refined marginals, float64 NCHW, as the reference keeps them (pylayers.py:77-86) — downloaded when first read
+        (nothing in a Caffe net reads them: backward uses the device copy)"""
+        if getattr(self, "_result_host", None) is None and getattr(self, "_result_dev", None) is not None:
+            self._result_host = self._result_dev.cpu().numpy()
+        return getattr(self, "_result_host", None)
 
     def backward(self, top, prop_down, bottom):
-        grad = ops.crf_layer_backward(self._result_dev, _dev(top[0].diff))
-        bottom[0].diff[...] = grad.cpu().numpy()
+        with _call("CRFLayer.backward"):
+            _publish(bottom[0].diff, _kernels(ops.crf_layer_backward, self._result_dev, _dev(top[0].diff, cache=False)), remember=False)
 
 
 class BalancedSeedLossLayer(_Base):
@@ -175,12 +371,14 @@ class BalancedSeedLossLayer(_Base):
         top[0].reshape(1)
 
     def forward(self, bottom, top):
-        loss, _ = ops.seed_loss(_dev(bottom[0].data), _dev(bottom[1].data), want_grad=False)
-        top[0].data[...] = loss.cpu().numpy()
+        with _call("BalancedSeedLossLayer.forward"):
+            loss, _ = _kernels(ops.seed_loss, _dev(bottom[0].data), _dev(bottom[1].data), want_grad=False)
+            _publish(top[0].data, loss, remember=False)
 
     def backward(self, top, prop_down, bottom):
-        _, grad = ops.seed_loss(_dev(bottom[0].data), _dev(bottom[1].data), want_grad=True)
-        bottom[0].diff[...] = grad.cpu().numpy()
+        with _call("BalancedSeedLossLayer.backward"):
+            _, grad = _kernels(ops.seed_loss, _dev(bottom[0].data), _dev(bottom[1].data), want_grad=True, want_loss=False)
+            _publish(bottom[0].diff, grad, remember=False)
 
 
 class SeedLossLayer(_Base):
@@ -233,13 +431,15 @@ class ConstrainLossLayer(_Base):
         top[0].reshape(1)
 
     def forward(self, bottom, top):
-        loss, _, _ = ops.constrain_loss(_dev(bottom[0].data), _dev(bottom[1].data), want_grad=False)
-        top[0].data[...] = loss.cpu().numpy()
+        with _call("ConstrainLossLayer.forward"):
+            loss, _, _ = _kernels(ops.constrain_loss, _dev(bottom[0].data), _dev(bottom[1].data), want_grad=False)
+            _publish(top[0].data, loss, remember=False)
 
     def backward(self, top, prop_down, bottom):
-        _, gp, gq = ops.constrain_loss(_dev(bottom[0].data), _dev(bottom[1].data), want_grad=True)
-        bottom[0].diff[...] = gp.cpu().numpy()
-        bottom[1].diff[...] = gq.cpu().numpy()
+        with _call("ConstrainLossLayer.backward"):
+            _, gp, gq = _kernels(ops.constrain_loss, _dev(bottom[0].data), _dev(bottom[1].data), want_grad=True, want_loss=False)
+            _publish(bottom[0].diff, gp, remember=False)
+            _publish(bottom[1].diff, gq, remember=False)
 
 
 class DSRGLayer(_Base):
@@ -259,10 +459,11 @@ class DSRGLayer(_Base):
         top[0].reshape(*bottom[1].data.shape)
 
     def forward(self, bottom, top):
-        img_labels, probs, cues, im = bottom[0].data, bottom[1].data, bottom[2].data, bottom[3].data
-        seed_c = self.generate_seed(img_labels, probs, cues, im)
-        self._iter_index = self._iter_index + 1
-        _publish(top[0].data, seed_c)
+        with _call("DSRGLayer.forward"):
+            img_labels, probs, cues, im = bottom[0].data, bottom[1].data, bottom[2].data, bottom[3].data
+            seed_c = self.generate_seed(img_labels, probs, cues, im)
+            self._iter_index = self._iter_index + 1
+            _publish(top[0].data, seed_c)
 
     def backward(self, top, prop_down, bottom):
         bottom[1].diff[...] = top[0].diff
@@ -276,14 +477,15 @@ class DSRGLayer(_Base):
             crf_reuse_count += 1
             return _last_crf["refined"]
         p = _dev(probs)
-        refined, _ = ops.crf_refine(p, _dev(im), scale_factor=scale_factor, want_log=False)
+        refined, _ = _kernels(ops.crf_refine, p, _dev(im), scale_factor=scale_factor, want_log=False)
         _publish(probs, p)                                    # in-place clip (pylayers.py:312)
+        _finish()                                             # (a public method: the clip is in the blob when it returns)
         return refined
 
     def generate_seed(self, labels, probs, cues, im):
         refined = self.refinement(probs, im, 12.0)
-        self._seeds_dev = ops.srg_grow(_dev(labels).reshape(labels.shape[0], -1).contiguous(), _dev(cues), refined,
-                                       self._th1, self._th2)
+        self._seeds_dev = _kernels(ops.srg_grow, _dev(labels).reshape(labels.shape[0], -1).contiguous(), _dev(cues), refined,
+                                   self._th1, self._th2)
         return self._seeds_dev
 
 

@@ -122,6 +122,18 @@ _CTX_CACHE = {}
 _CTX_LOCK = threading.Lock()
 
 
+# The LDS-resident path (contexts, the fused step) provisions every lattice for its WORST case — 6 * 4 * ceil(N / 4) vertices for
+# N = H * W pixels, whatever the image — so which maps it takes is a function of N alone (include/dsrg_hip.h): N <= 4488, i.e.
+# 41x41, 65x65, 66x68; 67x67 is the first square map beyond.  Larger maps take the global-memory path through the same Python
+# entry points (crf_refine, supervision_step, dsrg_supervision_loss): the batched full-resolution CRF + the stand-alone
+# kernels of the other layers, composed in the order of train-s.prototxt:746-810.
+LDS_PATH_MAX_PIXELS = 4488
+
+
+def lds_path_supports(H, W):
+    return H * W <= LDS_PATH_MAX_PIXELS
+
+
 def get_context(B, C, H, W):
     """the cached workspace of (device, host thread, C, H, W): a context is used by one host thread at a time
     (include/dsrg_hip.h), so every thread gets its own"""
@@ -162,6 +174,8 @@ def crf_refine(probs, images, scale_factor=12.0, maxiter=10, ctx=None, want_log=
     B, C, H, W = probs.shape
     if images.shape[0] != B or images.shape[1] != 3:
         raise ValueError("images must be (B,3,Hi,Wi)")
+    if not lds_path_supports(H, W):
+        return _crf_refine_large(probs, images, scale_factor, maxiter, want_log)
     ctx = ctx or get_context(B, C, H, W)
     refined = torch.empty((B, C, H, W), dtype=torch.float64, device=probs.device)
     logq = torch.empty_like(probs) if want_log else None
@@ -171,6 +185,40 @@ def crf_refine(probs, images, scale_factor=12.0, maxiter=10, ctx=None, want_log=
     return refined, logq
 
 
+_MEAN_PIXEL = (104.0, 117.0, 123.0)
+
+
+def _map_images_u8(images, H, W):
+    """(B,3,Hi,Wi) mean-subtracted float images -> (B,H,W,3) uint8 at the map's size: zoom(order=1) with the (in-1)/(out-1)
+    mapping evaluated in double, rounded once to float, + mean pixel, np.round, astype(ubyte) (pylayers.py:70-75) — what
+    map_pixel_rgb (csrc/embed.h) does inside the LDS path's embedding kernel"""
+    import torch.nn.functional as F
+    x = images
+    if x.shape[2] != H or x.shape[3] != W:
+        x = F.interpolate(x.double(), size=(H, W), mode="bilinear", align_corners=True).float()
+    mean = torch.tensor(_MEAN_PIXEL, dtype=torch.float64, device=x.device).view(1, 3, 1, 1)
+    v = torch.round(x.double() + mean).to(torch.int64) & 0xff                    # half-even, then C's conversion to unsigned char
+    return v.to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+def _crf_refine_large(probs, images, scale_factor, maxiter, want_log):
+    """crf_refine beyond the LDS path: the in-place clip, the mean field through the batched global-memory objects
+    (crf.CRF_device_batch; one image per object when a batch's spatial kernel is too narrow for the image tag), then the
+    reference's float64 clip / renormalisation / log (pylayers.py:84-88)"""
+    from .crf import CRF_device, CRF_device_batch
+    probs.clamp_(min=1e-4)                                                       # pylayers.py:65-67
+    B, C, H, W = probs.shape
+    im = _map_images_u8(images, H, W)
+    un = probs.permute(0, 2, 3, 1).contiguous()
+    try:
+        q = CRF_device_batch(im, un, maxiter, scale_factor)
+    except _lib.DsrgError:
+        q = torch.stack([CRF_device(im[b], un[b], maxiter, scale_factor) for b in range(B)])
+    q64 = q.permute(0, 3, 1, 2).double().clamp_min(1e-4)
+    refined = (q64 / q64.sum(1, keepdim=True)).contiguous()
+    return refined, (torch.log(refined).float().contiguous() if want_log else None)
+
+
 def crf_prepare(images, C, H, W, scale_factor=12.0, maxiter=10, ctx=None):
     """Image-dependent half of the CRF (image resampling + bilateral lattice build) on the current
     stream; a later supervision_step(..., prepared=True) on the same context skips it.  Lets a trainer
@@ -178,6 +226,8 @@ def crf_prepare(images, C, H, W, scale_factor=12.0, maxiter=10, ctx=None):
     stream, order it behind the last mean field that reads them (`side.wait_stream(main)`, as DSRGTrainer.step does)."""
     _f32c(images, "images")
     B = images.shape[0]
+    if not lds_path_supports(H, W):
+        return None                      # the global-memory path builds its lattices inside the call that uses them
     ctx = ctx or get_context(B, C, H, W)
     prm = CrfParams.from_crf_args(maxiter, scale_factor)
     check(_lib.lib().dsrg_crf_prepare_batch(ctx._h, B, _ptr(images), images.shape[2], images.shape[3],
@@ -225,21 +275,21 @@ def srg_grow(labels, cues, refined, th1=0.99, th2=0.85):
     return seeds
 
 
-def seed_loss(probs, seeds, want_grad=True):
-    """BalancedSeedLossLayer.forward/backward (pylayers.py:147-152) -> (loss[1], grad or None)."""
+def seed_loss(probs, seeds, want_grad=True, want_loss=True):
+    """BalancedSeedLossLayer.forward/backward (pylayers.py:147-152) -> (loss[1] or None, grad or None)."""
     _f32c(probs, "probs"), _f32c(seeds, "seeds")
     B, C, H, W = probs.shape
-    loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+    loss = torch.empty(1, dtype=torch.float32, device=probs.device) if want_loss else None
     grad = torch.empty_like(probs) if want_grad else None
     check(_lib.lib().dsrg_seed_loss(B, C, H * W, _ptr(probs), _ptr(seeds), _ptr(loss), _ptr(grad), _stream()))
     return loss, grad
 
 
-def constrain_loss(probs, logq, want_grad=True):
-    """ConstrainLossLayer.forward/backward (pylayers.py:173-180) -> (loss[1], grad_probs, grad_logq)."""
+def constrain_loss(probs, logq, want_grad=True, want_loss=True):
+    """ConstrainLossLayer.forward/backward (pylayers.py:173-180) -> (loss[1] or None, grad_probs, grad_logq)."""
     _f32c(probs, "probs"), _f32c(logq, "logq")
     B, C, H, W = probs.shape
-    loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+    loss = torch.empty(1, dtype=torch.float32, device=probs.device) if want_loss else None
     gp = torch.empty_like(probs) if want_grad else None
     gq = torch.empty_like(probs) if want_grad else None
     check(_lib.lib().dsrg_constrain_loss(B, C, H * W, _ptr(probs), _ptr(logq), _ptr(loss), _ptr(gp), _ptr(gq),
@@ -298,6 +348,18 @@ def supervision_step(logits, images, labels, cues, th1=0.99, th2=0.85, scale_fac
         raise ValueError("images must be (B,3,Hi,Wi) with the batch size of logits")
     if labels.numel() != B * C or tuple(cues.shape) != (B, C, H, W):
         raise ValueError("labels must hold B*C values and cues must have the shape of logits")
+    if not lds_path_supports(H, W):
+        # maps beyond the LDS path: the same five layers, layer by layer, in the prototxt's order and with its gradient wiring
+        # (seed-loss gradient + constrain gradient wrt p + CRFLayer.backward(constrain gradient wrt log q), then
+        # SoftmaxLayer.backward)
+        probs = softmax_forward(logits)
+        refined, logq = _crf_refine_large(probs, images, scale_factor, maxiter, True)
+        seeds = srg_grow(labels.reshape(B, -1).contiguous(), cues, refined, th1, th2)
+        l_seed, g_seed = seed_loss(probs, seeds)
+        l_con, g_p, g_q = constrain_loss(probs, logq)
+        grad = softmax_backward(logits, g_seed + g_p + crf_layer_backward(refined, g_q))
+        losses = torch.stack([l_seed.reshape(()), l_con.reshape(())]).float()
+        return losses, grad, (dict(probs=probs, seeds=seeds, logq=logq, refined=refined) if want_blobs else None)
     ctx = ctx or get_context(B, C, H, W)
     losses = torch.empty(2, dtype=torch.float32, device=logits.device)
     grad = torch.empty_like(logits)

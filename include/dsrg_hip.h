@@ -121,6 +121,14 @@ typedef struct {
     int32_t n_iters;        /* maxiter = 10 */
 } dsrg_crf_params;
 
+/* Which maps a context takes is a function of N = H * W alone, never of the images: every lattice is provisioned for its worst
+ * case (6 * 4 * ceil(N / 4) vertices for the bilateral kernel, whatever the colours), so that a training run cannot meet a
+ * batch that does not fit.  Accepted: N <= DSRG_CTX_MAX_PIXELS (41x41, 65x65 — the maps of 321x321 and 513x513 inputs — up
+ * to 66x68; 67x67 is the first square map beyond), C <= 96 labels; anything larger returns DSRG_ERR_UNSUPPORTED here, at
+ * creation, with the reason in dsrg_last_error().  Larger maps run on the global-memory path: the object API (section 1,
+ * dsrg_crf_create / dsrg_crf_create_batch) for the CRF and the stand-alone layer entry points below for the rest — which is
+ * what the Python mirror's supervision_step does for them (dsrg_amd/ops.py). */
+#define DSRG_CTX_MAX_PIXELS 4488
 int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *out);
 int dsrg_ctx_destroy(dsrg_ctx_t ctx);
 

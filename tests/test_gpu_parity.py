@@ -388,9 +388,13 @@ def _check_fused_step(ops, O, logits, images, labels, cues, tag):
     """dsrg_supervision_step against the oracle layer by layer in the order of train-s.prototxt:746-810 / SURVEY A.3:
     softmax blob, CRF marginals (1e-4), seeds bit-exact (borderline-proof otherwise), both losses, the fc8 gradient"""
     B, C, H, W = logits.shape
-    ctx = ops.get_context(B, C, H, W)
-    losses, grad, blobs = ops.supervision_step(dev(logits), dev(images), dev(labels), dev(cues), want_blobs=True, ctx=ctx)
-    hip_refined = ctx.read_refined(B).cpu().numpy()
+    if ops.lds_path_supports(H, W):
+        ctx = ops.get_context(B, C, H, W)
+        losses, grad, blobs = ops.supervision_step(dev(logits), dev(images), dev(labels), dev(cues), want_blobs=True, ctx=ctx)
+        hip_refined = ctx.read_refined(B).cpu().numpy()
+    else:                                                                   # the global-memory composition hands its marginals out
+        losses, grad, blobs = ops.supervision_step(dev(logits), dev(images), dev(labels), dev(cues), want_blobs=True)
+        hip_refined = blobs["refined"].cpu().numpy()
     probs = O.softmax_forward(logits)
     refined, logq = O.crf_refine_batch(probs, images, 12.0, 10)           # clips probs in place
     gp = blobs["probs"].cpu().numpy()
@@ -468,9 +472,29 @@ def test_crf_label_permutation_equivariance_on_gpu(ops, O):
 
 
 def test_unsupported_sizes_fail_loudly(ops):
+    """a context's size limit is a function of the map size alone (include/dsrg_hip.h: DSRG_CTX_MAX_PIXELS) and is met at
+    creation, with a message — never by an unlucky batch in the middle of a run"""
     from dsrg_amd import _lib
     with pytest.raises(_lib.DsrgError):
-        ops.Context(1, 21, 321, 321)          # full-resolution lattice: not on the LDS-resident path yet
+        ops.Context(1, 21, 321, 321)          # full-resolution lattice: not on the LDS-resident path
+    assert ops.LDS_PATH_MAX_PIXELS == 4488
+    ops.Context(1, 21, 66, 68)                # 4488 pixels: the largest map of the path
+    with pytest.raises(_lib.DsrgError, match="4489 pixels"):
+        ops.Context(1, 21, 67, 67)
+    # ... whatever the image: a noise image (largest lattice a map can have) at the limit runs
+    b = S.make_batch(3, 1, H=66, W=68, size=66 * 8 - 7, image_kind="noise")
+    refined, _ = ops.crf_refine(ops.softmax_forward(dev(b["logits"])), dev(b["images"]))
+    assert torch.isfinite(refined).all()
+
+
+def test_supervision_step_beyond_the_lds_path_vs_oracle(ops, O):
+    """maps beyond DSRG_CTX_MAX_PIXELS (round-4 review, weak 11): supervision_step / crf_refine no longer fail there — the same
+    five layers run on the global-memory path (batched full-resolution CRF + the stand-alone layer kernels, dsrg_amd/ops.py) —
+    against the oracle layer by layer, as the fused step is checked: 70x70 maps of 553x553 images, and a 75x69 map"""
+    for seed, B, H, W in [(11, 2, 70, 70), (12, 1, 75, 69)]:
+        b = S.make_batch(seed, B, H=H, W=W, size=max(H, W) * 8 - 7)
+        b["images"] = np.ascontiguousarray(b["images"][:, :, :H * 8 - 7, :W * 8 - 7])
+        _check_fused_step(ops, O, b["logits"], b["images"], b["labels"], b["cues"], "large %dx%d" % (H, W))
 
 
 def test_gemm_conv_matches_miopen_conv():
@@ -1161,3 +1185,45 @@ def test_crf_batch_through_the_many_images_loop_and_its_limits(ops, O):
     # ... while the same two images at the test-time scale pass, and the one-image call never has the limit
     assert CRF_device_batch(torch.stack([im, im]), torch.stack([un, un]), scale_factor=1.0).shape == (2, 400, 400, 3)
     assert CRF_device(im, un, scale_factor=12.0).shape == (400, 400, 3)
+
+
+def test_pylayers_resident_blobs_follow_host_writes():
+    """dsrg_amd.layers keeps blobs resident in HBM between the layers of an iteration (cost table): a host blob
+    whose bytes are unchanged is not uploaded again; any write between iterations is seen (full digest at the first sight of an
+    epoch), a write at a sampled position also inside an iteration; the registries stay bounded; a non-contiguous input is
+    never cached under its temporary's address"""
+    from dsrg_amd import layers as L
+    if L._digest is None or L._TRUST:
+        pytest.skip("xxhash absent or DSRG_PYLAYERS_TRUST set")
+    rng = np.random.default_rng(0)
+    a = rng.random((16, 21, 41, 41), dtype=np.float32)
+    with L._call("t", new_epoch="softmax"):
+        t0 = L._dev(a)
+        assert L._dev(a) is t0                                   # same bytes, same epoch: the resident copy (sampled check)
+    with L._call("t", new_epoch="softmax"):
+        assert L._dev(a) is t0                                   # next iteration, unchanged: full digest, still resident
+        a[7, 3, 20, 20] += 1.0                                   # a write in the middle of the blob, inside the iteration ...
+    with L._call("t", new_epoch="softmax"):
+        t1 = L._dev(a)                                           # ... is seen at the next iteration's first sight
+        assert t1 is not t0 and torch.equal(t1.cpu(), torch.from_numpy(a))
+        a[0, 0, 0, 0] += 1.0                                     # a write at a sampled position: seen at once
+        t2 = L._dev(a)
+        assert t2 is not t1 and float(t2[0, 0, 0, 0]) == float(a[0, 0, 0, 0])
+    # a blob we wrote mirrors the tensor it was written from
+    host = np.zeros_like(a)
+    with L._call("t", new_epoch="softmax"):
+        L._publish(host, t2)
+    assert np.array_equal(host, a)
+    with L._call("t"):
+        assert L._dev(host) is t2
+    # non-contiguous input: uploaded from a temporary, never cached
+    n0 = len(L._resident)
+    with L._call("t"):
+        v = L._dev(a[:, ::2])
+    assert v.shape == (16, 11, 41, 41) and len(L._resident) == n0
+    # bounded registries
+    with L._call("t", new_epoch="softmax"):
+        keep = [rng.random((1, 21, 41, 41), dtype=np.float32) for _ in range(L._MAX_RESIDENT + 8)]
+        for x in keep:
+            L._dev(x); L._dev(x)
+    assert len(L._resident) <= L._MAX_RESIDENT and len(L._pinned) <= L._MAX_RESIDENT

@@ -28,4 +28,4 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print("batch %d: %.3f ms per image (%.1f images/s), %d distinct images" % (nb, dt / reps / nb * 1e3, nb * reps / dt, nb))
-sys.stdout.flush(); os._exit(0)
+sys.stdout.flush()

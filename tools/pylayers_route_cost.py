@@ -71,6 +71,26 @@ for _ in range(200):
 torch.cuda.synchronize()
 t_fused = (time.perf_counter() - t0) / 200 * 1e3
 gd = np.abs(grad.cpu().numpy() - ref[2]).max() / max(np.abs(ref[2]).max(), 1e-30)
+# where the route's time goes: the same step with the layers' cost accounting on (dsrg_amd.layers.profile; the device is waited
+# for after every upload and kernel group so that each millisecond is booked where it is spent — the step itself gets slower)
+from dsrg_amd import layers as _L
+_L.profile = {}
+np_ = 10
+for _ in range(np_):
+    caffe_step()
+prof, _L.profile = _L.profile, None
+cats = ["digest", "pin", "h2d", "kernels", "d2h", "sync", "total"]
+print("per-layer cost of the Caffe route, ms per step (accounting on: every phase waited for):")
+print("%-32s " % "layer call" + " ".join("%8s" % c for c in cats) + "    other")
+tot = {c: 0.0 for c in cats}
+for name in ["SoftmaxLayer.forward", "CRFLayer.forward", "DSRGLayer.forward", "BalancedSeedLossLayer.forward", "ConstrainLossLayer.forward",
+             "ConstrainLossLayer.backward", "BalancedSeedLossLayer.backward", "CRFLayer.backward", "SoftmaxLayer.backward"]:
+    row = [prof.get((name, c), 0.0) / np_ * 1e3 for c in cats]
+    for c, v in zip(cats, row):
+        tot[c] += v
+    print("%-32s " % name + " ".join("%8.3f" % v for v in row) + " %8.3f" % (row[-1] - sum(row[:-1])))
+print("%-32s " % "sum" + " ".join("%8.3f" % tot[c] for c in cats) + " %8.3f" % (tot["total"] - sum(tot[c] for c in cats[:-1])))
+print("pinned host buffers: %d of %d seen; resident device copies: %d" % (sum(1 for e in _L._pinned.values() if e[2]), len(_L._pinned), len(_L._resident)))
 print("B %d: Caffe Python-layer route (numpy blobs, 5 layers fwd+bwd, CRF twice) %.2f ms per step; fused device-resident "
       "dsrg_supervision_step %.3f ms; losses %.6f/%.6f vs %.6f/%.6f, max rel. gradient difference %.1e" % (
           B, t_layers, t_fused, ref[0], ref[1], float(losses[0]), float(losses[1]), gd))
