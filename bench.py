@@ -159,7 +159,7 @@ def _counter_file(stem, kernel):
     (tools/gpu_pmc.sh) and their figures are replayed here — only while the kernel's sources hash to what the file was
     collected against (dsrg_amd/provenance.py); -> (record or None, provenance dict for the bench line)"""
     from dsrg_amd import provenance
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         rec = _load_json("%s_%s.json" % (rnd, stem))
         if rec is not None:
             src = provenance.check(rec, kernel)

@@ -471,7 +471,21 @@ def _igemm_route(conv, x, groups=1):
 class GemmConv2d(nn.Conv2d):
     """nn.Conv2d (same parameters, same init, same state_dict) whose CUDA forward is im2col + GEMM, optionally
     with the following ReLU (`fuse_relu`) and Dropout (`fuse_dropout` = p, needs fuse_relu) fused; on the CPU it is the
-    plain convolution (+ ReLU (+ Dropout))."""
+    plain convolution (+ ReLU (+ Dropout)).
+
+    Contract of the fused forms (what a user of these modules may and may not rely on):
+      * `fuse_dropout` = p is realised in steps of 1/256 on the implicit-GEMM route (keep a value iff its random byte >= round(256 p);
+        scale 256 / (256 - round(256 p))): p = 0.5 is exact, p = 0.3 becomes 77/256 = 0.3008.  The mask is a pure function of (seed,
+        branch, position) drawn per forward from torch's generator (ops.dropout_seed), so torch.manual_seed reproduces it;
+      * `chain_input=True` is the caller's PROMISE that this layer's input is the fused-ReLU output of the GemmConv2d in front of it
+        and feeds nothing else.  Then the data gradient this layer returns for that activation is ALREADY masked by the lower layer's
+        ReLU (and scaled by its Dropout): it is the gradient with respect to the lower layer's pre-activation, not dL/dy.  Such
+        chained activations are therefore not autograd inspection points — `retain_grad()`, `torch.autograd.grad` or a tensor hook
+        on them sees the masked value; a hook that RETURNS a new tensor makes the lower node fall back to its own ReLU backward
+        (right on a masked gradient too) or, when a Dropout scale rides in the mask, raise (`_GradLink.take`).  Without the
+        promise (the default) every activation is an ordinary autograd tensor;
+      * `fuse_pool`: the node returns the pooled tensor only; the un-pooled ReLU output is not kept (the window codes carry its
+        mask) and cannot be asked for."""
 
     def __init__(self, *args, fuse_relu=False, gemm=True, fuse_dropout=0.0, fuse_pool=None, chain_input=False, **kw):
         super().__init__(*args, **kw)
@@ -644,6 +658,11 @@ class _HeadsFn(torch.autograd.Function):
 
 
 class VGG16ASPP(nn.Module):
+    """features (conv1_1 .. conv5_3, pools, pool5a) + four ASPP branches fc6_k -> fc7_k -> fc8-SEC_k, summed.  On a GPU under
+    bf16 autocast conv1_2, conv2_2, conv3_2 .. conv5_3, fc7_k and the classifiers are built with `chain_input` (see GemmConv2d):
+    the activations between them are not autograd inspection points, and Dropout's p is rounded to a multiple of 1/256 (the
+    prototxt's 0.5 is exact).  `DSRG_FUSE_CHAIN=0` restores one ordinary autograd node per layer."""
+
     def __init__(self, num_classes=21, dropout=0.5, gemm_convs=True):
         super().__init__()
         L = []

@@ -479,7 +479,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel_32x4(IgemmArgs a) { 
 // write-through stores and published by a flag: cdna_hip_programming.md Guideline 16, recipe R1) are there long before it
 // looks; it adds them in workgroup order (deterministic) and runs the ordinary epilogue.  Dependencies point to higher
 // workgroup ids only and nobody waits before having done all its own work, so the launch cannot deadlock however the
-// dispatcher places the workgroups; every wait is bounded all the same (error word, the tile is then left unwritten).
+// dispatcher places the workgroups; every wait is bounded all the same (error word set, the tile is then filled with NaNs:
+// a timeout under a debugger or profiler turns the step's loss into NaN instead of feeding stale memory to the next layer).
 struct IgemmSkArgs {
     IgemmArgs base;
     float *ws;              // [units][32][512] float4: a workgroup's accumulators of its first segment
@@ -669,7 +670,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_sk_kernel(IgemmSkArgs k) {
                 ok = sk_ok != 0;
                 __syncthreads();                              // the flag word is an epilogue row again
             }
-            if (ok && active) {
+            if (active) {
+                // (a share that never arrived within the bounded wait — error word set — poisons the tile: every value gets a NaN
+                // added, so the step's loss is NaN instead of stale memory feeding the next layer silently)
+                const float poison = ok ? 0.0f : __builtin_nanf("");
                 // ---- epilogue of the complete tile (as conv_igemm_body), the other workgroups' shares of a cut tile added group
                 // by group in workgroup order: the up to kSkParts 16-byte loads of group gi + 1 are in flight while group gi is
                 // finished (a share beyond nparts gets an out-of-range offset = zeros, so the code has no branch per share)
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_sk_kernel(IgemmSkArgs k) {
                         s0 += __uint_as_float(pv[0]); s1 += __uint_as_float(pv[1]); s2 += __uint_as_float(pv[2]); s3 += __uint_as_float(pv[3]);
                     }
                     float v0 = s0 + bq[gi & 1][0], v1 = s1 + bq[gi & 1][1], v2 = s2 + bq[gi & 1][2], v3 = s3 + bq[gi & 1][3];
-                    v0 = fmaxf(v0, floor_); v1 = fmaxf(v1, floor_); v2 = fmaxf(v2, floor_); v3 = fmaxf(v3, floor_);
+                    v0 = fmaxf(v0, floor_) + poison; v1 = fmaxf(v1, floor_) + poison; v2 = fmaxf(v2, floor_) + poison; v3 = fmaxf(v3, floor_) + poison;
                     if (a.drop_thresh) {
                         const uint32_t m = (uint32_t)(m0 + wm * 64 + j * 32 + l31);
                         const uint32_t h = dropout_bytes((m * (uint32_t)a.Cout + (uint32_t)(nw + nl)) >> 2, seed_g, a.seed_hi);
@@ -959,15 +963,23 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
         }
 }
 
-// gw[e] = sum over the splits of part[s][e], e over [n][tap][c], in split order; float4 per thread
+// gw[e] = sum over the splits of part[s][e], e over [n][tap][c], in split order; float4 per thread; blockIdx.y = the group
+// (the four branches of a grouped launch share ONE reduction launch: 17 -> 11 reduction launches per train step)
+struct WgradReduceArgs {
+    const float *part[4];
+    void *gw[4];
+    int ksplit;
+    size_t n4;
+};
 template <bool BF16_OUT>
-__global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(const float *part, void *gw, int ksplit, size_t n4) {
+__global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(WgradReduceArgs a) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n4) return;
-    const float4 *p = reinterpret_cast<const float4 *>(part) + e;
+    if (e >= a.n4) return;
+    const float4 *p = reinterpret_cast<const float4 *>(a.part[blockIdx.y]) + e;
+    void *gw = a.gw[blockIdx.y];
     float4 s = p[0];
-    for (int k = 1; k < ksplit; k++) {
-        const float4 v = p[(size_t)k * n4];
+    for (int k = 1; k < a.ksplit; k++) {
+        const float4 v = p[(size_t)k * a.n4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     if (BF16_OUT) reinterpret_cast<uint2 *>(gw)[e] = make_uint2(pack2(s.x, s.y), pack2(s.z, s.w));
@@ -1240,16 +1252,15 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_wgrad_kernel), lds, grant)) return rc;
     hipLaunchKernelGGL(conv_igemm_wgrad_kernel, dim3(a.tiles_per_group * ngroups), dim3(512), lds, stream, a);
     DSRG_LAUNCH_CHECK();
-    const size_t n4 = (size_t)cout * k * k * cin / 4;
-    for (int q = 0; q < ngroups; q++) {
-        if (out_bf16)
-            hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a.g[q].part, gw[q],
-                               a.ksplit, n4);
-        else
-            hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a.g[q].part, gw[q],
-                               a.ksplit, n4);
-        DSRG_LAUNCH_CHECK();
-    }
+    WgradReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.ksplit = a.ksplit;
+    r.n4 = (size_t)cout * k * k * cin / 4;
+    for (int q = 0; q < ngroups; q++) { r.part[q] = a.g[q].part; r.gw[q] = gw[q]; }
+    const dim3 rgrid((unsigned)((r.n4 + 255) / 256), (unsigned)ngroups);
+    if (out_bf16) hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, r);
+    DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
 

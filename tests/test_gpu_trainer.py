@@ -322,6 +322,31 @@ def test_bf16_route_computes_the_float32_gradient():
     assert all(c >= 0.999 for n, c in r["cos"]["bf16"].items() if n.startswith("branches.") and n.split(".")[2] in ("3", "6"))
 
 
+def test_train_step_with_dropout_on_trains_like_the_float32_leg():
+    """the shipped configuration — Dropout 0.5 drawn inside the convolution epilogues, ReLU / Dropout backward riding in the data
+    gradients — repeated on one batch: the total loss falls as the float32 backbone's does (torch's own Dropout there: other
+    masks, same statistics).  The Dropout-off comparison of the two legs' arithmetic is bench.py's `legs.loss_gap_300_steps`
+    and profiles/r05_overfit_two_legs.txt; this is the default-test-set check that the fused mask path trains at all."""
+    from dsrg_amd import synthetic as S
+    from dsrg_amd.backbone import VGG16ASPP
+    from dsrg_amd.trainer import DSRGTrainer
+    dev = torch.device("cuda", 0)
+    b = S.make_batch(7, 4)
+    images, labels, cues = (torch.from_numpy(b[k]).to(dev) for k in ("images", "labels", "cues"))
+    tot = {}
+    for tag, amp in (("bf16", torch.bfloat16), ("fp32", None)):
+        torch.manual_seed(0)
+        tr = DSRGTrainer(dev, amp_dtype=amp, seed=0, net=VGG16ASPP(dropout=0.5))
+        hist = torch.stack([tr.step(images, labels, cues).detach() for _ in range(60)]).sum(1).cpu().numpy()
+        assert np.isfinite(hist).all()
+        tot[tag] = hist
+        del tr
+    for tag, h in tot.items():
+        assert h[-1] < 0.85 * h[0], (tag, h[0], h[-1])
+    gap = np.abs(tot["bf16"] - tot["fp32"]) / np.abs(tot["fp32"])
+    assert gap.max() < 0.02, float(gap.max())                  # (observed at batch 8, 300 steps: 6e-4)
+
+
 def test_bench_gpus_beyond_the_visible_ones_fails_in_one_line():
     """`python bench.py --gpus N` with fewer than N GPUs on the node: no traceback, one line naming the reason"""
     n = torch.cuda.device_count() + 1
