@@ -119,6 +119,38 @@ def test_igemm_border_taps_are_skipped_bit_identically(ops, B, H, W):
     assert (skip_w[i] - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max() + 1e-4
 
 
+def test_igemm_skipping_on_random_shapes(ops):
+    """the tap / row skipping and the XCD-interleaved tile maps on shapes nobody tuned for: random maps (1 .. 70 a side), batch
+    sizes, dilations up to beyond the map (every tap but the centre dead), one to four groups — fewer pixel tiles than XCDs,
+    tiles that straddle images, pixel chunks of a single step: forward, data-gradient form and weight gradient must equal the
+    every-step launch bit for bit, and the forward must be right against torch"""
+    g = torch.Generator().manual_seed(99)
+    rnd = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))          # noqa: E731
+    for case in range(24):
+        B, H, W = rnd(1, 5), rnd(1, 70), rnd(1, 70)
+        n = rnd(1, 4)
+        dils = [rnd(3, 40) if case % 3 else rnd(1, 12) for _ in range(n)]
+        cin, cout = (256, 256) if case % 2 else (256, 512)
+        xs = [torch.randn(B, cin, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(n)]
+        w32 = [(torch.randn(cout, cin, 3, 3, device="cuda") * 0.03).bfloat16() for _ in range(n)]
+        ws = [ops.pack_conv_weight(w) for w in w32]
+        gs = [torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(n)]
+        try:
+            ops.set_igemm_variant(6)
+            full = ops.conv_igemm(xs, ws, [None] * n, dils, 3, False, stream_k=False)
+            full_w = ops.conv_igemm_wgrad(xs, gs, dils, 3)
+            ops.set_igemm_variant(3)
+            skip = ops.conv_igemm(xs, ws, [None] * n, dils, 3, False, stream_k=False)
+            skip_w = ops.conv_igemm_wgrad(xs, gs, dils, 3)
+        finally:
+            ops.set_igemm_variant(-1)
+        for i in range(n):
+            assert torch.equal(full[i], skip[i]), (case, B, H, W, dils, i)
+            assert torch.equal(full_w[i], skip_w[i]), (case, B, H, W, dils, i)
+        want = F.conv2d(xs[0].float(), w32[0].float(), None, padding=dils[0], dilation=dils[0])
+        _close(skip[0], want, "case %d: %dx%dx%d dilation %d" % (case, B, H, W, dils[0]))
+
+
 def _unpack(p):
     o, cc, taps, _ = p.shape
     k = int(round(taps ** 0.5))
