@@ -86,6 +86,7 @@ struct IgemmArgs {
     uint32_t seed_lo, seed_hi;
     float out_scale;        // every output times this (1 unless a mask carries a Dropout scale)
     int xcd_mix;            // 1: XCD-interleaved tile map (see the kernel); the grid is 8 * ngroups * ceil(tiles_m / 8) * tiles_n blocks
+    int row_tiles, rows_per_tile, bands;      // 1: a pixel tile = rows_per_tile whole rows of one image (bands of them per image)
     int skip_taps;          // 1: a K-step whose tap reaches no pixel of the tile (a dilated kernel near the map's border: all of
                             // its operand rows would be the zeros of the padding) is not loaded and not multiplied
 };
@@ -155,7 +156,18 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         tm = t / a.tiles_n;
         tn = t - tm * a.tiles_n;
     }
-    const int m0 = tm * kBM, n0 = tn * kBN;
+    // the tile's pixels: 256 consecutive ones — or (row_tiles: launches that skip taps) whole map rows of ONE image, as many as fit
+    // 256: a tile that straddles two images reaches every vertical tap through one of them and skips nothing, a tile aligned to
+    // rows skips more (41-wide map, six rows = 246 pixels per tile: 5 % fewer K-steps over the four fc6_k than flattened tiles)
+    int m0 = tm * kBM, mvalid;
+    if (a.row_tiles) {
+        const int bimg = tm / a.bands, band = tm - bimg * a.bands, row0 = band * a.rows_per_tile;
+        m0 = (bimg * a.H + row0) * a.W;
+        mvalid = min(a.rows_per_tile, a.H - row0) * a.W;
+    } else {
+        mvalid = min(kBM, a.M - m0);
+    }
+    const int n0 = tn * kBN;
     const IgemmGroup G = a.g[grp];
     const int taps = a.taps, Cin = a.Cin, W = a.W, H = a.H;
     const int ktot = taps * Cin;
@@ -170,7 +182,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         const int r = wv * 32 + i * C::RPI + lane / C::CPR;
         const int c = (lane % C::CPR) ^ C::swz(r);         // source chunk that lands at chunk position lane % CPR
         const int m = m0 + r;
-        const bool in = m < a.M;
+        const bool in = r < mvalid;
         const int mm = in ? m : 0;
         const int hw = H * W;
         const int b = mm / hw, rem = mm - b * hw, y = rem / W, x = rem - y * W;
@@ -401,7 +413,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
             const int p = it * 4 + (lane >> 4), ch = lane & 15;
             const int m = m0 + wm * 64 + p;
             const uint4 v = *reinterpret_cast<const uint4 *>(O + p * kOutRow + ch * 16);
-            if (m < a.M) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
+            if (wm * 64 + p < mvalid) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
         }
         return;
     }
@@ -413,7 +425,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const int m = m0 + wm * 64 + it * 4 + (lane >> 4);
-            mk[it] = m < a.M ? *reinterpret_cast<const uint4 *>(G.mask + (size_t)m * a.Cout + nw + (lane & 15) * 8)
+            mk[it] = wm * 64 + it * 4 + (lane >> 4) < mvalid ? *reinterpret_cast<const uint4 *>(G.mask + (size_t)m * a.Cout + nw + (lane & 15) * 8)
                              : make_uint4(0, 0, 0, 0);
         }
     } else {
@@ -436,7 +448,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
             cs[2 * e] += __uint_as_float(w4[e] << 16);
             cs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
         }
-        if (m < a.M) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        if (wm * 64 + p < mvalid) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
     if (G.colsum) {                                          // uniform for the workgroup
 #pragma unroll
@@ -1088,9 +1100,26 @@ int launch_igemm_colsum(const float *const *parts, float *const *outs, int ngrou
     return DSRG_OK;
 }
 
-size_t conv_igemm_colsum_workspace(int ngroups, int B, int H, int W, int cout) {
+// row-aligned pixel tiles (IgemmArgs::row_tiles) when at least two rows fit a tile and the rows a band leaves empty cost less
+// than a tenth of the tiles
+static bool conv_igemm_row_tiles(int H, int W) {
+    if (W > kBM / 2) return false;
+    const int r = kBM / W, bands = (H + r - 1) / r;
+    return (long long)bands * kBM * 10 <= (long long)H * W * 11 + 10LL * kBM;
+}
+// most pixel tiles a launch over B maps of H x W can have per group (flattened or row-aligned): sizes the column-sum scratch
+static size_t conv_igemm_pixel_tiles(int B, int H, int W) {
     const long long M = (long long)B * H * W;
-    return (size_t)ngroups * (size_t)((M + kBM - 1) / kBM) * (size_t)cout * sizeof(float);
+    size_t t = (size_t)((M + kBM - 1) / kBM);
+    if (W <= kBM && conv_igemm_row_tiles(H, W)) {
+        const int r = kBM / W;
+        const size_t tr = (size_t)B * ((H + r - 1) / r);
+        if (tr > t) t = tr;
+    }
+    return t;
+}
+size_t conv_igemm_colsum_workspace(int ngroups, int B, int H, int W, int cout) {
+    return (size_t)ngroups * conv_igemm_pixel_tiles(B, H, W) * (size_t)cout * sizeof(float);
 }
 
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
@@ -1115,7 +1144,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
         a.g[g].y = static_cast<uint16_t *>(y[g]);
         a.g[g].dil = dil ? dil[g] : 1;
         a.g[g].mask = mask ? static_cast<const uint16_t *>(mask[g]) : nullptr;
-        a.g[g].colsum = colsum ? static_cast<float *>(colsum_ws) + (size_t)g * ((M + kBM - 1) / kBM) * cout : nullptr;
+        a.g[g].colsum = colsum ? static_cast<float *>(colsum_ws) + (size_t)g * conv_igemm_pixel_tiles(B, H, W) * cout : nullptr;
         if (!a.g[g].x || !a.g[g].w || !a.g[g].y || (mask && !mask[g]) || (colsum && !colsum[g]))
             return set_error(DSRG_ERR_INVALID, "conv_igemm: null pointer");
     }
@@ -1134,11 +1163,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     static LdsGrant grant[3];
     const int variant = igemm_variant() == 2 ? 1 : 0;       // 1, 3: two stages of 64; 2: ring of four stages of 32
     a.stagger = igemm_variant() >= 3;
-    // tap skipping makes tiles unequal: spread every group's tiles over all XCDs (conv_igemm_body).  Only then: the layers
-    // whose tiles all run the same steps keep the map they were tuned with (neighbouring pixel tiles share rows in one L2)
-    for (int g = 0; g < ngroups; g++)
-        if (a.skip_taps && k == 3 && a.g[g].dil >= 3) a.xcd_mix = 1;
-    const dim3 grid(a.xcd_mix ? 8 * ngroups * ((a.tiles_m + 7) / 8) * a.tiles_n : a.tiles_per_group * ngroups), block(512);
+    const dim3 block(512);
     // stream-K only where it was measured to win (profiles/r04_igemm_stream_k.txt): a single round that fills at most 60 % of
     // the chip (conv4_1's data gradient: 106 tiles, 115 -> 88 us).  A cut tile costs its workgroups ~25 us (256 KB of
     // accumulators written through, read back, one acquire), which eats the sixth of the chip that 212 tiles leave idle (131 ->
@@ -1162,6 +1187,21 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
         DSRG_LAUNCH_CHECK();
         return DSRG_OK;
     }
+    // tap skipping makes tiles unequal: spread every group's tiles over all XCDs (conv_igemm_body).  Only then: the layers
+    // whose tiles all run the same steps keep the map they were tuned with (neighbouring pixel tiles share rows in one L2)
+    for (int g = 0; g < ngroups; g++)
+        if (a.skip_taps && k == 3 && a.g[g].dil >= 3) a.xcd_mix = 1;
+    static const bool row_tiles_on = [] { const char *e = getenv("DSRG_IGEMM_ROW_TILES"); return !e || atoi(e) != 0; }();      // tools: A/B
+    if (a.xcd_mix && row_tiles_on && W <= kBM && conv_igemm_row_tiles(H, W)) {
+        // ... and cut them along map rows (see the kernel); tiles_m grows by the rows a band leaves empty (112 against 106 tiles
+        // for sixteen 41x41 maps), which the skipped steps more than pay for
+        a.row_tiles = 1;
+        a.rows_per_tile = kBM / W;
+        a.bands = (H + a.rows_per_tile - 1) / a.rows_per_tile;
+        a.tiles_m = B * a.bands;
+        a.tiles_per_group = a.tiles_m * a.tiles_n;
+    }
+    const dim3 grid(a.xcd_mix ? 8 * ngroups * ((a.tiles_m + 7) / 8) * a.tiles_n : a.tiles_per_group * ngroups);
     if (igemm_variant() == 5) {                              // early barrier (see conv_igemm_body)
         static LdsGrant grant_e;
         constexpr size_t lds = ICfg<64, 2>::LDS;
