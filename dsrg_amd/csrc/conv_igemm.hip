@@ -772,6 +772,7 @@ struct IgemmWgradArgs {
     WgradGroup g[4];
     int ngroups, B, H, W, Cin, Cout, taps, M, tiles_n, tiles_c, ksplit, kchunk, tiles_per_group;
     int stagger;            // as IgemmArgs::stagger
+    int compact;            // 1: a tile sums over the pixels its tap reaches only (see the kernel); every split takes an equal share of THEM
     int xcd_mix;            // 1: XCD-interleaved map of the (group, pixel chunk, tile) workgroups (see the kernel); needs 8 | ksplit
     int skip_rows;          // 1: a K-step (64 pixels) whose rows the tile's tap shifts out of the map entirely is not loaded and
                             // not multiplied (its x rows would all be padding zeros)
@@ -824,14 +825,27 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     const bool two = Cin == 128;
     const int ncb = two ? 1 : Cin >> 8;                     // 256-channel blocks of x per tap
     const int tap = two ? 2 * tc : tc / ncb, c0 = two ? 0 : (tc - tap * ncb) << 8, n0 = tn << 8;
-    const int mbeg = split * a.kchunk, mend = min(a.M, mbeg + a.kchunk);
+    // ---- the pixels this tile sums over.  The reduction index q runs over the pixels of a RECTANGLE of every image, image-major,
+    // raster order inside: the whole map — or (compact: dilated kernels) exactly the pixels whose tap lands inside the map: a tap of
+    // dilation 24 on a 41 x 41 map reaches 17 x 17 (corner tap) or 17 x 41 (edge tap) pixels, everything else would multiply padding
+    // zeros.  The K loop then holds no dead element at all (36 % of the four fc6_k's pixel x tap pairs are dead; skipping whole
+    // 64-pixel steps of the flat order catches 22 %), and the terms that remain are summed in the order they had before.
+    const int tdy = (taps == 9 && !two) ? (tap / 3 - 1) * G.dil : 0, tdx = (taps == 9 && !two) ? (tap % 3 - 1) * G.dil : 0;
+    const bool compact = a.compact && !two && taps == 9;
+    const int ry0 = compact ? max(0, -tdy) : 0, rx0 = compact ? max(0, -tdx) : 0;
+    const int rh_ = compact ? H - abs(tdy) : H, rw_ = compact ? W - abs(tdx) : W;
+    const int rh = max(rh_, 1), rw = max(rw_, 1);                         // (an empty rectangle: no steps at all, see Kc)
+    const int area = rh * rw;
+    const int Kc = (rh_ > 0 && rw_ > 0) ? a.B * area : 0;
+    const int kchunk = compact ? (((Kc + a.ksplit - 1) / a.ksplit + 63) >> 6) << 6 : a.kchunk;
+    const int mbeg = split * kchunk, mend = min(Kc, mbeg + kchunk);      // [mbeg, mend) of the reduction index
     const int nsteps = mend > mbeg ? (mend - mbeg + 63) >> 6 : 0;
 
     const rsrc_t rx = make_rsrc(G.x, (size_t)a.M * Cin * 2);
     const rsrc_t rg = make_rsrc(G.g, (size_t)a.M * Cout * 2);
 
     // ---- DMA geometry: per step a wave moves rows [wv*8 + i*2, +2) of both tiles, i = 0..3; lane -> (row, 16-byte piece)
-    int pm[4], py[4], px[4], ldy[4], ldx[4], ltapoff[4];
+    int pm[4], pb[4], py[4], px[4], ldy[4], ldx[4], ltapoff[4];       // reduction index, image, row and column inside the rectangle
     uint32_t srcoff[4], xsrcoff[4];                         // byte offset of the lane's source piece inside a row of g / of x
     bool ltap[4];                                           // the lane's tap exists (a two-tap tile may hold the tenth)
 #pragma unroll
@@ -847,12 +861,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
         ltapoff[i] = (ldy[i] * W + ldx[i]) * Cin * 2 + c0 * 2;
         const int m = mbeg + r;
         pm[i] = m;
-        const int hw = H * W, mm = m < a.M ? m : 0;
-        const int rem = mm - (mm / hw) * hw;
-        py[i] = rem / W;
-        px[i] = rem - py[i] * W;
+        const int mm = m < Kc ? m : 0;
+        pb[i] = mm / area;
+        const int rem = mm - pb[i] * area;
+        py[i] = rem / rw;
+        px[i] = rem - py[i] * rw;
     }
-    const int qW = 64 / W, rW = 64 - qW * W;                // a step advances every row by 64 pixels
+    const int qW = 64 / rw, rW = 64 - qW * rw;              // a step advances every row by 64 elements of the reduction index
 
     auto advance = [&]() {                                   // the lanes' pixels move on by one step
 #pragma unroll
@@ -860,24 +875,27 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
             pm[i] += 64;
             px[i] += rW;
             py[i] += qW;
-            if (px[i] >= W) { px[i] -= W; py[i] += 1; }
-            while (py[i] >= H) py[i] -= H;
+            if (px[i] >= rw) { px[i] -= rw; py[i] += 1; }
+            while (py[i] >= rh) { py[i] -= rh; pb[i] += 1; }
         }
     };
     auto issue = [&](int stage) {
         unsigned char *A = ig_lds + stage * kWStage + wv * (8 * kWRow);
         unsigned char *Bt = A + kWTile;
+        int pix[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) pix[i] = compact ? (pb[i] * H + ry0 + py[i]) * W + rx0 + px[i] : pm[i];       // the pixel of the map
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool live = pm[i] < mend;
-            const uint32_t vo = live ? (uint32_t)pm[i] * (uint32_t)(Cout * 2) + (uint32_t)(n0 * 2) + srcoff[i] : kOob;
+            const uint32_t vo = live ? (uint32_t)pix[i] * (uint32_t)(Cout * 2) + (uint32_t)(n0 * 2) + srcoff[i] : kOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(A + i * (2 * kWRow)), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int yy = py[i] + ldy[i], xx = px[i] + ldx[i];
+            const int yy = ry0 + py[i] + ldy[i], xx = rx0 + px[i] + ldx[i];
             const bool live = ltap[i] && pm[i] < mend && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const uint32_t vo = live ? (uint32_t)(pm[i] * (Cin * 2) + ltapoff[i]) + xsrcoff[i] : kOob;
+            const uint32_t vo = live ? (uint32_t)(pix[i] * (Cin * 2) + ltapoff[i]) + xsrcoff[i] : kOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(Bt + i * (2 * kWRow)), 16, vo, 0, 0, 0);
         }
         advance();                                           // the next step's pixels
@@ -909,8 +927,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     // bit-identical.  Decided per step from the rows its first and last pixel lie in (wave-uniform, scalar): a step inside one
     // image is dead when no row in [y_first, y_last] lands in [0, H) after the shift; a step that crosses into the next image
     // always holds live rows of one of the two (|shift| < H), and so does any tile without a vertical shift.
-    const int tdy = (taps == 9 && !two) ? (tap / 3 - 1) * G.dil : 0;
-    const bool may_skip = a.skip_rows && tdy != 0 && tdy > -H && tdy < H;
+    // (a step of 64 pixels spans at least 64 / W rows: below that shift no step can be dead, and the test is not free)
+    const bool may_skip = a.skip_rows && !compact && abs(tdy) * W >= 64 && tdy > -H && tdy < H;
     const int hw_ = H * W;
     auto step_dead = [&](int st) -> bool {
         const int p0 = mbeg + st * 64, p1 = min(p0 + 63, mend - 1);
@@ -1285,8 +1303,12 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
         a.g[q].dil = dil ? dil[q] : 1;
         if (!a.g[q].x || !a.g[q].g || !gw[q]) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: null pointer");
     }
-    for (int q = 0; q < ngroups; q++)
+    static const bool compact_on = [] { const char *e = getenv("DSRG_WGRAD_COMPACT"); return !e || atoi(e) != 0; }();      // tools: A/B
+    static const int compact_min_dil = [] { const char *e = getenv("DSRG_WGRAD_COMPACT_MIN_DIL"); return e ? atoi(e) : 3; }();
+    for (int q = 0; q < ngroups; q++) {
         if (a.skip_rows && k == 3 && a.g[q].dil >= 3 && a.ksplit % 8 == 0) a.xcd_mix = 1;
+        if (a.skip_rows && compact_on && igemm_variant() != 7 && k == 3 && cin != 128 && a.g[q].dil >= compact_min_dil) a.compact = 1;      // 7: tests — dead steps skipped in the flat pixel order
+    }
     static LdsGrant grant;
     constexpr size_t lds = 2 * kWStage;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_wgrad_kernel), lds, grant)) return rc;

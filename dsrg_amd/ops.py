@@ -545,8 +545,11 @@ def conv_igemm_supported(cin, cout, k):
 
 
 def set_igemm_variant(v):
-    """tests / tools: pipeline of conv_igemm: 1 = two LDS stages of 64 (default), 2 = ring of four stages of 32, -1 = environment /
-    default; identical results"""
+    """tests / tools: the launch form of the implicit-GEMM kernels: 1 = two LDS stages of 64, 2 = ring of four stages of 32, 3 = 1 +
+    staggered DMA issue + stream-K where it wins (the default), 4 = stream-K wherever legal, 5 = early barrier, 6 = round 4's launches
+    (every K-step multiplied, flat tile maps), 7 = 3 with the weight gradient skipping dead steps of the flat pixel order instead of
+    summing over each tap's live pixels; -1 = DSRG_IGEMM_VARIANT or the default.  Same results (6 / 7 / 3: forward bit-identical;
+    weight gradient bit-identical between 6 and 7, equal up to fp32 reassociation for 3)"""
     _lib.lib().dsrg_debug_set_igemm_variant(int(v))
 
 

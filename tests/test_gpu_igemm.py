@@ -103,14 +103,19 @@ def test_igemm_border_taps_are_skipped_bit_identically(ops, B, H, W):
         ops.set_igemm_variant(6)
         full = ops.conv_igemm(xs, ws, bs, dils, 3, True, stream_k=False)      # (stream-K cuts the K range: another summation order)
         full_w = ops.conv_igemm_wgrad([xs[0]] * 4, gs, dils, 3)
-        ops.set_igemm_variant(3)
+        ops.set_igemm_variant(7)                                 # the weight gradient skips dead 64-pixel steps of the flat pixel order
+        flat_w = ops.conv_igemm_wgrad([xs[0]] * 4, gs, dils, 3)
+        ops.set_igemm_variant(3)                                 # ... or sums over the pixels each tap reaches only (the default)
         skip = ops.conv_igemm(xs, ws, bs, dils, 3, True, stream_k=False)
         skip_w = ops.conv_igemm_wgrad([xs[0]] * 4, gs, dils, 3)
     finally:
         ops.set_igemm_variant(-1)
     for i in range(4):
         assert torch.equal(full[i], skip[i]), dils[i]
-        assert torch.equal(full_w[i], skip_w[i]), dils[i]
+        assert torch.equal(full_w[i], flat_w[i]), dils[i]
+        # the compact reduction adds the same non-zero terms in the same order but cuts them into other partial sums (every
+        # split takes an equal share of the LIVE pixels): equal up to fp32 reassociation
+        assert (full_w[i] - skip_w[i]).abs().max() <= 2e-5 * full_w[i].abs().max(), dils[i]
     i = 3
     want = torch.relu(F.conv2d(xs[i].float(), ws32[i].float(), bs[i], padding=dils[i], dilation=dils[i]))
     _close(skip[i], want, "dilation 24 forward")
@@ -139,6 +144,8 @@ def test_igemm_skipping_on_random_shapes(ops):
             ops.set_igemm_variant(6)
             full = ops.conv_igemm(xs, ws, [None] * n, dils, 3, False, stream_k=False)
             full_w = ops.conv_igemm_wgrad(xs, gs, dils, 3)
+            ops.set_igemm_variant(7)
+            flat_w = ops.conv_igemm_wgrad(xs, gs, dils, 3)
             ops.set_igemm_variant(3)
             skip = ops.conv_igemm(xs, ws, [None] * n, dils, 3, False, stream_k=False)
             skip_w = ops.conv_igemm_wgrad(xs, gs, dils, 3)
@@ -146,7 +153,8 @@ def test_igemm_skipping_on_random_shapes(ops):
             ops.set_igemm_variant(-1)
         for i in range(n):
             assert torch.equal(full[i], skip[i]), (case, B, H, W, dils, i)
-            assert torch.equal(full_w[i], skip_w[i]), (case, B, H, W, dils, i)
+            assert torch.equal(full_w[i], flat_w[i]), (case, B, H, W, dils, i)
+            assert (full_w[i] - skip_w[i]).abs().max() <= 2e-5 * full_w[i].abs().max() + 1e-6, (case, B, H, W, dils, i)
         want = F.conv2d(xs[0].float(), w32[0].float(), None, padding=dils[0], dilation=dils[0])
         _close(skip[0], want, "case %d: %dx%dx%d dilation %d" % (case, B, H, W, dils[0]))
 
