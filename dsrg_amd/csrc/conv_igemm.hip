@@ -829,7 +829,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     // raster order inside: the whole map — or (compact: dilated kernels) exactly the pixels whose tap lands inside the map: a tap of
     // dilation 24 on a 41 x 41 map reaches 17 x 17 (corner tap) or 17 x 41 (edge tap) pixels, everything else would multiply padding
     // zeros.  The K loop then holds no dead element at all (36 % of the four fc6_k's pixel x tap pairs are dead; skipping whole
-    // 64-pixel steps of the flat order catches 22 %), and the terms that remain are summed in the order they had before.
+    // 64-pixel steps of the flat order catches 22 %), and the terms that remain are summed in the order they had before.  Every
+    // 3x3 layer takes this form: with dilation 1 / 2 the rectangle only loses the one or two border rows and columns (2-10 % of
+    // the pixels), and every split of a tile gets an equal share of the LIVE pixels.
     const int tdy = (taps == 9 && !two) ? (tap / 3 - 1) * G.dil : 0, tdx = (taps == 9 && !two) ? (tap % 3 - 1) * G.dil : 0;
     const bool compact = a.compact && !two && taps == 9;
     const int ry0 = compact ? max(0, -tdy) : 0, rx0 = compact ? max(0, -tdx) : 0;
@@ -1304,7 +1306,7 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
         if (!a.g[q].x || !a.g[q].g || !gw[q]) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: null pointer");
     }
     static const bool compact_on = [] { const char *e = getenv("DSRG_WGRAD_COMPACT"); return !e || atoi(e) != 0; }();      // tools: A/B
-    static const int compact_min_dil = [] { const char *e = getenv("DSRG_WGRAD_COMPACT_MIN_DIL"); return e ? atoi(e) : 3; }();
+    static const int compact_min_dil = [] { const char *e = getenv("DSRG_WGRAD_COMPACT_MIN_DIL"); return e ? atoi(e) : 1; }();     // tools: A/B (3: dilated kernels only — 1 776-1 782 against 1 800-1 807 images/s)
     for (int q = 0; q < ngroups; q++) {
         if (a.skip_rows && k == 3 && a.g[q].dil >= 3 && a.ksplit % 8 == 0) a.xcd_mix = 1;
         if (a.skip_rows && compact_on && igemm_variant() != 7 && k == 3 && cin != 128 && a.g[q].dil >= compact_min_dil) a.compact = 1;      // 7: tests — dead steps skipped in the flat pixel order
