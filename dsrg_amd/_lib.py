@@ -99,6 +99,7 @@ SIGNATURES = {
     "dsrg_pack_conv_weight_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "dsrg_conv_igemm_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "dsrg_conv_igemm_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dsrg_conv_igemm_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_conv3x3_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dsrg_conv3x3_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "dsrg_conv3x3_wgrad_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),

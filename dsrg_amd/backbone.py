@@ -245,6 +245,7 @@ class _GradLink:
 
 
 _FUSE_CHAIN = _os.environ.get("DSRG_FUSE_CHAIN", "1") != "0"
+_MERGED_BWD = _os.environ.get("DSRG_MERGED_BWD", "1") != "0"     # data + weight gradient of a single-group 3x3 layer in one launch
 # (measured and dropped in round 5: the weight gradient of an implicit-GEMM layer on a second stream beside its data gradient,
 # to fill the sixth of the chip a 212-tile data-gradient launch leaves idle — 1 761 -> 1 715 images/s, the two 139 KB-LDS kernels
 # only take CUs from each other; profiles/r05_wgrad_side_stream_ab.txt)
@@ -338,6 +339,17 @@ class _IgemmConvFn(torch.autograd.Function):
         # inputs that are another node's ReLU outputs with no other consumer: that node's backward rides in this data gradient
         absorb = _FUSE_CHAIN and ctx.links_in is not None and all(need_x) and conv_igemm_supported(cout, cin, ctx.k) and \
             cin >= 256 and all(x.is_contiguous(memory_format=cl) for x in xs)
+        if _MERGED_BWD and n == 1 and ctx.k == 3 and need_x[0] and conv_igemm_supported(cout, cin, 3) and \
+                conv_igemm_wgrad_supported(cin, cout, 3) and cin % 256 == 0 and xs[0].is_contiguous(memory_format=cl):
+            # one launch for both gradients of the layer (ops.conv_igemm_backward): the data gradient's tiles and the weight gradient's
+            # workgroups share a grid, so the CUs a 212-tile data gradient leaves idle do weight-gradient work
+            from .ops import conv_igemm_backward
+            pd = ctx.packs_d[0] if ctx.packs_d[0] is not None else pack_conv_weight(ws[0], for_dgrad=True)
+            gx, gw, gb_below = conv_igemm_backward(gms[0], pd, xs[0], ctx.dils[0], xs[0] if absorb else None,
+                                                   ctx.links_in[0].scale if absorb else 1.0)
+            if absorb:
+                ctx.links_in[0].leave(gx, gb_below)
+            return (None,) * 8 + (gx, gw) + tuple(gbs)
         if absorb:
             packs_d = [p if p is not None else pack_conv_weight(w, for_dgrad=True) for p, w in zip(ctx.packs_d, ws)]
             gxs, gb_below = conv_igemm_dgrad(gms, packs_d, list(xs), ctx.dils, ctx.k, ctx.links_in[0].scale)

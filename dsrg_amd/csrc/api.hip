@@ -540,6 +540,21 @@ extern "C" int dsrg_conv_igemm_wgrad_bf16(const void *const *x_dev, const void *
     return launch_conv_igemm_wgrad(x_dev, g_dev, gw_dev, dilation, ngroups, workspace_dev, workspace_bytes, B, H, W, cin, cout, ksize,
                                    out_bf16, static_cast<hipStream_t>(stream));
 }
+namespace dsrg {
+int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, const void *mask, void *gx, void *gw, int dil, float *bias_grad,
+                               float mask_scale, void *colsum_ws, size_t colsum_ws_bytes, void *wgrad_ws, size_t wgrad_ws_bytes, int B, int H,
+                               int W, int cin, int cout, int k, hipStream_t stream);
+}
+extern "C" int dsrg_conv_igemm_backward_bf16(const void *g_dev, const void *w_dgrad_dev, const void *x_dev, const void *mask_dev, void *gx_dev,
+                                             float *gw_dev, int dilation, float *bias_grad_dev, float mask_scale, void *colsum_workspace_dev,
+                                             size_t colsum_workspace_bytes, void *wgrad_workspace_dev, size_t wgrad_workspace_bytes, int B,
+                                             int H, int W, int cin, int cout, int ksize, void *stream) {
+    if (!g_dev || !w_dgrad_dev || !x_dev || !gx_dev || !gw_dev || B < 1 || H < 1 || W < 1 || (bias_grad_dev && !mask_dev))
+        return set_error(DSRG_ERR_INVALID, "conv_igemm_backward: bad arguments");
+    return dsrg::launch_conv_igemm_backward(g_dev, w_dgrad_dev, x_dev, mask_dev, gx_dev, gw_dev, dilation, bias_grad_dev, mask_scale,
+                                            colsum_workspace_dev, colsum_workspace_bytes, wgrad_workspace_dev, wgrad_workspace_bytes, B, H,
+                                            W, cin, cout, ksize, static_cast<hipStream_t>(stream));
+}
 extern "C" size_t dsrg_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
     return conv3x3_wgrad_workspace(B, H, W, cin, cout);
 }

@@ -124,7 +124,7 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 // behind the barrier.  All fragment reads of the current stage have been issued by then (the last slice is prefetched during
 // the one before) and are waited for in front of the barrier, so the stage is free for the DMA of step s + 2 as before.
 template <int BK, int NST, bool EARLY = false>
-__device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
+__device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bid, const int nblk) {      // block bid of nblk (a merged launch passes a sub-range)
     using C = ICfg<BK, NST>;
     extern __shared__ __attribute__((aligned(16))) unsigned char ig_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
     // order group, pixel tile, n-tile), so that all XCDs hold the same mix; blocks beyond an XCD's share exit at once.
     int grp, tm, tn;
     if (a.xcd_mix) {
-        const int id = (int)blockIdx.x, xcd = id & 7, k = id >> 3;
+        const int id = bid, xcd = id & 7, k = id >> 3;
         const int cm = (a.tiles_m - xcd + 7) >> 3, per_group = cm * a.tiles_n;
         if (cm <= 0 || k >= per_group * a.ngroups) return;
         grp = k / per_group;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
         tn = r - tml * a.tiles_n;
         tm = xcd + 8 * tml;
     } else {
-        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int total = nblk, id = bid;
         const int q = total >> 3, r = total & 7, xcd = id & 7, k = id >> 3;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
         grp = t / a.tiles_per_group;
@@ -477,9 +477,9 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a) {
 }
 
 
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_64x2(IgemmArgs a) { conv_igemm_body<64, 2>(a); }
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_64x2e(IgemmArgs a) { conv_igemm_body<64, 2, true>(a); }
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_32x4(IgemmArgs a) { conv_igemm_body<32, 4>(a); }
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_64x2(IgemmArgs a) { conv_igemm_body<64, 2>(a, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_64x2e(IgemmArgs a) { conv_igemm_body<64, 2, true>(a, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel_32x4(IgemmArgs a) { conv_igemm_body<32, 4>(a, (int)blockIdx.x, (int)gridDim.x); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // The same convolution with the K-steps of ALL tiles dealt out evenly ("stream-K"): the 41x41 layers have 212 tiles of 72
@@ -789,7 +789,7 @@ __device__ __forceinline__ bf16x8 tr_frag8(lds_u8 *p) {    // pixels 0-3 and 4-7
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs a) {
+__device__ __forceinline__ void conv_igemm_wgrad_body(const IgemmWgradArgs &a, const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ig_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -803,14 +803,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
     const int tiles = a.tiles_n * a.tiles_c;
     int grp, split, t;
     if (a.xcd_mix) {
-        const int id = (int)blockIdx.x, xcd = id & 7, k = id >> 3;
+        const int id = bid, xcd = id & 7, k = id >> 3;
         const int per_group = (a.ksplit >> 3) * tiles;
         grp = k / per_group;
         const int r = k - grp * per_group, sl = r / tiles;
         t = r - sl * tiles;
         split = xcd + 8 * sl;
     } else {
-        const int total = (int)gridDim.x, id = (int)blockIdx.x;
+        const int total = nblk, id = bid;
         const int q = total >> 3, r = total & 7, xcd = id & 7, k = id >> 3;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
         grp = t / a.tiles_per_group;
@@ -995,6 +995,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs
         }
 }
 
+__global__ __launch_bounds__(512, 2) void conv_igemm_wgrad_kernel(IgemmWgradArgs a) { conv_igemm_wgrad_body(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// One launch for the whole backward of a layer's convolution: both gradients need nothing but the (masked) output gradient, and a
+// 41x41 layer's data gradient is 212 tiles for 256 CUs — one round with a sixth of the chip idle — while its weight gradient is
+// 252 workgroups.  Blocks [0, nd) are the data gradient's tiles, blocks [nd_pad, nd_pad + nw) the weight gradient's workgroups
+// (nd_pad = nd rounded up to a multiple of 8, so that both halves keep their block-id -> XCD relation; the padding blocks exit):
+// the dispatcher hands the weight gradient's first workgroups to the CUs the data gradient leaves idle, no stream, no join.
+// (The two kernels on two streams lost: 1 761 -> 1 715 images/s, profiles/r05_wgrad_side_stream_ab.txt.)
+struct IgemmBwdArgs {
+    IgemmArgs d;
+    IgemmWgradArgs w;
+    int nd, nd_pad, nw;
+};
+__global__ __launch_bounds__(512, 2) void conv_igemm_bwd_kernel(IgemmBwdArgs a) {
+    const int id = (int)blockIdx.x;
+    if (id < a.nd_pad) {
+        if (id < a.nd) conv_igemm_body<64, 2>(a.d, id, a.nd);
+    } else {
+        conv_igemm_wgrad_body(a.w, id - a.nd_pad, a.nw);
+    }
+}
+
 // gw[e] = sum over the splits of part[s][e], e over [n][tap][c], in split order; float4 per thread; blockIdx.y = the group
 // (the four branches of a grouped launch share ONE reduction launch: 17 -> 11 reduction launches per train step)
 struct WgradReduceArgs {
@@ -1142,6 +1164,12 @@ size_t conv_igemm_colsum_workspace(int ngroups, int B, int H, int W, int cout) {
     return (size_t)ngroups * conv_igemm_pixel_tiles(B, H, W) * (size_t)cout * sizeof(float);
 }
 
+// set by launch_conv_igemm_backward around its calls of the two launchers below: they then validate, fill the argument block
+// and return it instead of launching
+static thread_local IgemmArgs *t_prep_d = nullptr;
+static thread_local IgemmWgradArgs *t_prep_w = nullptr;
+static thread_local int *t_prep_grid = nullptr;
+
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
                       int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
                       void *workspace, size_t workspace_bytes, hipStream_t stream, const void *const *mask, float out_scale,
@@ -1222,6 +1250,11 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
         a.tiles_per_group = a.tiles_m * a.tiles_n;
     }
     const dim3 grid(a.xcd_mix ? 8 * ngroups * ((a.tiles_m + 7) / 8) * a.tiles_n : a.tiles_per_group * ngroups);
+    if (t_prep_d) {                                          // launch_conv_igemm_backward: arguments only, it launches the merged kernel
+        *t_prep_d = a;
+        *t_prep_grid = (int)grid.x;
+        return DSRG_OK;
+    }
     if (igemm_variant() == 5) {                              // early barrier (see conv_igemm_body)
         static LdsGrant grant_e;
         constexpr size_t lds = ICfg<64, 2>::LDS;
@@ -1276,6 +1309,19 @@ size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int
     return (size_t)ngroups * ks * cout * k * k * cin * sizeof(float);
 }
 
+static int launch_wgrad_reduce(const IgemmWgradArgs &a, void *const *gw, int ngroups, int cin, int cout, int k, int out_bf16, hipStream_t stream) {
+    WgradReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.ksplit = a.ksplit;
+    r.n4 = (size_t)cout * k * k * cin / 4;
+    for (int q = 0; q < ngroups; q++) { r.part[q] = a.g[q].part; r.gw[q] = gw[q]; }
+    const dim3 rgrid((unsigned)((r.n4 + 255) / 256), (unsigned)ngroups);
+    if (out_bf16) hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, r);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
 int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *const *gw, const int *dil, int ngroups, void *workspace,
                             size_t workspace_bytes, int B, int H, int W, int cin, int cout, int k, int out_bf16, hipStream_t stream) {
     if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: 1..4 groups");
@@ -1311,21 +1357,69 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
         if (a.skip_rows && k == 3 && a.g[q].dil >= 3 && a.ksplit % 8 == 0) a.xcd_mix = 1;
         if (a.skip_rows && compact_on && igemm_variant() != 7 && k == 3 && cin != 128 && a.g[q].dil >= compact_min_dil) a.compact = 1;      // 7: tests — dead steps skipped in the flat pixel order
     }
+    if (t_prep_w) {
+        *t_prep_w = a;
+        *t_prep_grid = a.tiles_per_group * ngroups;
+    } else {
+        static LdsGrant grant;
+        constexpr size_t lds = 2 * kWStage;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_wgrad_kernel), lds, grant)) return rc;
+        hipLaunchKernelGGL(conv_igemm_wgrad_kernel, dim3(a.tiles_per_group * ngroups), dim3(512), lds, stream, a);
+        DSRG_LAUNCH_CHECK();
+    }
+    if (t_prep_w) return DSRG_OK;                            // (the caller runs the reduction below itself, after its merged launch)
+    return launch_wgrad_reduce(a, gw, ngroups, cin, cout, k, out_bf16, stream);
+}
+
+
+// The backward of ONE 3x3 convolution as one launch (conv_igemm_bwd_kernel): data gradient of g with the flipped kernel `wd` (+ the
+// ReLU / Dropout backward and bias gradient of the layer below when `mask` is given, as launch_conv_igemm's fused form) and the
+// weight gradient from (x, g).  Falls back to the two launches where the merged kernel does not apply (grouped launches, the
+// XCD-interleaved or stream-K forms, a 128-channel x): same results either way — the two halves run the very code of the
+// separate kernels on the very argument blocks.
+int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, const void *mask, void *gx, void *gw, int dil, float *bias_grad,
+                               float mask_scale, void *colsum_ws, size_t colsum_ws_bytes, void *wgrad_ws, size_t wgrad_ws_bytes, int B, int H,
+                               int W, int cin, int cout, int k, hipStream_t stream) {
+    // (forward convolution: cin -> cout; g has cout channels, gx and x have cin, gw is (cout, cin, k, k) in float32)
+    const void *gp[1] = {g}, *wp[1] = {wd}, *xp[1] = {x}, *mp[1] = {mask};
+    void *gxp[1] = {gx}, *gwp[1] = {gw};
+    float *bgp[1] = {bias_grad};
+    const int dils[1] = {dil};
+    static const bool merged_on = [] { const char *e = getenv("DSRG_IGEMM_MERGED_BWD"); return !e || atoi(e) != 0; }();      // tools: A/B
+    const bool can_merge = merged_on && k == 3 && cin != 128 && dil < 3 && (igemm_variant() == 3 || igemm_variant() == 1);
+    IgemmBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    int nd = 0, nw = 0, rc = DSRG_OK;
+    if (can_merge) {
+        t_prep_d = &a.d; t_prep_grid = &nd;
+        rc = launch_conv_igemm(gp, wp, nullptr, gxp, dils, 1, B, H, W, cout, cin, k, 0, 0.0f, 0ull, nullptr, 0, stream, mask ? mp : nullptr,
+                               mask_scale, bias_grad ? bgp : nullptr, colsum_ws, colsum_ws_bytes);
+        t_prep_d = nullptr;
+        if (!rc) {
+            t_prep_w = &a.w; t_prep_grid = &nw;
+            rc = launch_conv_igemm_wgrad(xp, gp, gwp, dils, 1, wgrad_ws, wgrad_ws_bytes, B, H, W, cin, cout, k, 0, stream);
+            t_prep_w = nullptr;
+        }
+        t_prep_grid = nullptr;
+        if (rc) return rc;
+    }
+    if (!can_merge || a.d.xcd_mix || nd < 1 || nw < 1) {
+        rc = launch_conv_igemm(gp, wp, nullptr, gxp, dils, 1, B, H, W, cout, cin, k, 0, 0.0f, 0ull, nullptr, 0, stream, mask ? mp : nullptr,
+                               mask_scale, bias_grad ? bgp : nullptr, colsum_ws, colsum_ws_bytes);
+        if (rc) return rc;
+        return launch_conv_igemm_wgrad(xp, gp, gwp, dils, 1, wgrad_ws, wgrad_ws_bytes, B, H, W, cin, cout, k, 0, stream);
+    }
+    a.nd = nd; a.nd_pad = (nd + 7) & ~7; a.nw = nw;
     static LdsGrant grant;
-    constexpr size_t lds = 2 * kWStage;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_wgrad_kernel), lds, grant)) return rc;
-    hipLaunchKernelGGL(conv_igemm_wgrad_kernel, dim3(a.tiles_per_group * ngroups), dim3(512), lds, stream, a);
+    constexpr size_t lds = ICfg<64, 2>::LDS > (size_t)(2 * kWStage) ? ICfg<64, 2>::LDS : (size_t)(2 * kWStage);
+    if (int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_bwd_kernel), lds, grant)) return rc2;
+    hipLaunchKernelGGL(conv_igemm_bwd_kernel, dim3(a.nd_pad + a.nw), dim3(512), lds, stream, a);
     DSRG_LAUNCH_CHECK();
-    WgradReduceArgs r;
-    memset(&r, 0, sizeof(r));
-    r.ksplit = a.ksplit;
-    r.n4 = (size_t)cout * k * k * cin / 4;
-    for (int q = 0; q < ngroups; q++) { r.part[q] = a.g[q].part; r.gw[q] = gw[q]; }
-    const dim3 rgrid((unsigned)((r.n4 + 255) / 256), (unsigned)ngroups);
-    if (out_bf16) hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, r);
-    else hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, r);
-    DSRG_LAUNCH_CHECK();
-    return DSRG_OK;
+    if (bias_grad) {
+        const float *parts[1] = {a.d.g[0].colsum};
+        if (int rc2 = launch_igemm_colsum(parts, bgp, 1, a.d.tiles_m, cin, stream)) return rc2;
+    }
+    return launch_wgrad_reduce(a.w, gwp, 1, cin, cout, k, 0, stream);
 }
 
 

@@ -645,6 +645,41 @@ def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias
     return outs, gb
 
 
+def conv_igemm_backward(g, packed_d, x, dilation, mask=None, mask_scale=1.0, ksize=3):
+    """the whole backward of one 3x3 convolution (forward geometry cin -> cout) in one launch (dsrg_conv_igemm_backward_bf16): g
+    (B,cout,H,W) and x (B,cin,H,W) bf16 channels_last, packed_d = pack_conv_weight(w, for_dgrad=True); mask: the layer's input when
+    it is the sole-consumer ReLU output of the layer below (then that layer's ReLU / Dropout backward and bias gradient ride in
+    the data gradient, as conv_igemm_dgrad) -> (gx (B,cin,H,W) bf16 channels_last, gw (cout,cin,k,k) float32 channels_last, bias
+    gradient of the layer below (cin) f32 or None).  Same results as conv_igemm(_dgrad) + conv_igemm_wgrad, bit for bit."""
+    B, cout, H, W = g.shape
+    cin = x.shape[1]
+    cl = torch.channels_last
+    if not (g.is_cuda and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and tuple(x.shape) == (B, cin, H, W)
+            and packed_d.dtype == torch.bfloat16 and tuple(packed_d.shape) == (cin, cout // 64, ksize * ksize, 64)
+            and packed_d.is_contiguous() and x.is_contiguous(memory_format=cl)
+            and (mask is None or (mask.dtype == torch.bfloat16 and tuple(mask.shape) == (B, cin, H, W) and mask.is_contiguous(memory_format=cl)))):
+        raise ValueError("conv_igemm_backward needs bf16 channels_last g / x (/ mask) of one geometry and the data-gradient packing")
+    g = g if g.is_contiguous(memory_format=cl) else g.contiguous(memory_format=cl)
+    L = _lib.lib()
+    need = L.dsrg_conv_igemm_wgrad_workspace(1, B, H, W, cin, cout, ksize)
+    if need == 0:
+        raise ValueError("conv_igemm_backward: 256 | cin, 256 | cout required (got %d, %d)" % (cin, cout))
+    key = (g.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _igemm_ws.get(key)                                          # per-stream scratch, shared with conv_igemm_wgrad
+    if ws is None or ws.numel() < need:
+        ws = _igemm_ws[key] = torch.empty(need, dtype=torch.uint8, device=g.device)
+    gx = torch.empty((B, cin, H, W), dtype=torch.bfloat16, device=g.device, memory_format=cl)
+    gw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=g.device, memory_format=cl)
+    gb = cws = None
+    if mask is not None:
+        gb = torch.empty(cin, dtype=torch.float32, device=g.device)
+        cws = torch.empty(L.dsrg_conv_igemm_dgrad_workspace(1, B, H, W, cin), dtype=torch.uint8, device=g.device)
+    check(L.dsrg_conv_igemm_backward_bf16(_ptr(g), _ptr(packed_d), _ptr(x), _ptr(mask), _ptr(gx), _ptr(gw), int(dilation), _ptr(gb),
+                                          float(mask_scale), _ptr(cws), cws.numel() if cws is not None else 0, _ptr(ws), ws.numel(),
+                                          B, H, W, cin, cout, ksize, _stream()))
+    return gx, gw, gb
+
+
 _igemm_sk_ws = {}
 
 

@@ -349,6 +349,19 @@ size_t dsrg_conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin
 int dsrg_conv_igemm_wgrad_bf16(const void *const *x_dev, const void *const *g_dev, void *const *gw_dev, const int *dilation,
                                int ngroups, void *workspace_dev, size_t workspace_bytes, int B, int H, int W, int cin, int cout,
                                int ksize, int out_bf16, void *stream);
+/* The whole backward of ONE 3x3 convolution of the forward geometry cin -> cout as one launch: the data gradient gx (B,H,W,cin) of g
+ * (B,H,W,cout) with the data-gradient packing w_dgrad_dev (dsrg_pack_conv_weight_f32) — with mask_dev (the layer's INPUT = the ReLU
+ * output of the layer below, (B,H,W,cin) bf16) and bias_grad_dev given also that layer's ReLU (+ Dropout: mask_scale) backward and
+ * bias gradient, as dsrg_conv_igemm_dgrad_bf16 — and the weight gradient gw (cout, cin, k, k; float32, channels_last) from x_dev
+ * (B,H,W,cin) and g.  The data gradient's tiles and the weight gradient's workgroups share a grid, so the CUs a 212-tile data
+ * gradient leaves idle take weight-gradient work; where that form does not apply (dilation >= 3, a 128-channel x) the two launches
+ * run one after the other.  Results equal dsrg_conv_igemm_dgrad_bf16 / dsrg_conv_igemm_bf16 + dsrg_conv_igemm_wgrad_bf16 bit for bit.
+ * Workspaces: dsrg_conv_igemm_dgrad_workspace(1, B, H, W, cin) bytes (only with bias_grad_dev) and
+ * dsrg_conv_igemm_wgrad_workspace(1, B, H, W, cin, cout, ksize) bytes. */
+int dsrg_conv_igemm_backward_bf16(const void *g_dev, const void *w_dgrad_dev, const void *x_dev, const void *mask_dev, void *gx_dev,
+                                  float *gw_dev, int dilation, float *bias_grad_dev, float mask_scale, void *colsum_workspace_dev,
+                                  size_t colsum_workspace_bytes, void *wgrad_workspace_dev, size_t wgrad_workspace_bytes, int B, int H,
+                                  int W, int cin, int cout, int ksize, void *stream);
 /* The four fc8-SEC_k 1x1 classifiers and their Eltwise SUM (train-s.prototxt:461-744) in one pass with float32 weights,
  * float32 accumulation and a float32 NCHW result: out[b][o][hw] = sum_k ( x_k[(b,hw)][:] . w[k][o][:] + bias[k][o] ).
  * x_dev: host array of n_branches (<= 4) device pointers to (B*HW, K) bf16 row-major (NHWC) activations; w_dev

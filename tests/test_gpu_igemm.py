@@ -159,6 +159,39 @@ def test_igemm_skipping_on_random_shapes(ops):
         _close(skip[0], want, "case %d: %dx%dx%d dilation %d" % (case, B, H, W, dils[0]))
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,dil,absorb", [
+    (16, 41, 41, 512, 512, 1, True),      # conv4_2 / conv4_3: 212 data-gradient tiles + 252 weight-gradient workgroups in one grid
+    (2, 41, 41, 512, 512, 2, True),       # conv5_x
+    (3, 41, 41, 256, 512, 1, False),      # conv4_1: the layer below sits behind a pool (no absorbed ReLU backward)
+    (1, 81, 81, 256, 256, 1, True),       # conv3_2 / conv3_3
+    (2, 20, 30, 256, 512, 1, True),       # a ragged last tile on both sides
+    (2, 41, 41, 512, 1024, 12, True),     # a dilated layer: the entry point runs the two launches one after the other
+])
+def test_igemm_merged_backward_equals_the_two_launches(ops, B, H, W, cin, cout, dil, absorb):
+    """dsrg_conv_igemm_backward_bf16: the data gradient's tiles and the weight gradient's workgroups of one layer in ONE grid
+    (conv_igemm_bwd_kernel) — the same argument blocks, the same device code per block: data gradient (+ the absorbed ReLU
+    backward and bias gradient of the layer below) and weight gradient bit-equal to the separate launches"""
+    x = torch.relu(torch.randn(B, cin, H, W, device="cuda")).bfloat16().contiguous(memory_format=CL)     # the layer's input = a ReLU output
+    g = torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.03)
+    pd = ops.pack_conv_weight(w, for_dgrad=True)
+    gx, gw, gb = ops.conv_igemm_backward(g, pd, x, dil, x if absorb else None, 2.0 if absorb else 1.0)
+    if absorb:
+        (gx_ref,), (gb_ref,) = ops.conv_igemm_dgrad([g], [pd], [x], [dil], 3, 2.0)
+        assert torch.equal(gb, gb_ref)
+    else:
+        (gx_ref,) = ops.conv_igemm([g], [pd], [None], [dil], 3, False, stream_k=False)
+        assert gb is None
+    (gw_ref,) = ops.conv_igemm_wgrad([x], [g], [dil], 3)
+    assert torch.equal(gx, gx_ref) and torch.equal(gw, gw_ref)
+    gx2, gw2, _ = ops.conv_igemm_backward(g, pd, x, dil, x if absorb else None, 2.0 if absorb else 1.0)
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2)                                                   # deterministic
+    # and right: the weight gradient against torch
+    wr = torch.zeros(cout, cin, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(x.float(), wr, None, padding=dil, dilation=dil).backward(g.float())
+    assert (gw - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max() + 1e-4
+
+
 def _unpack(p):
     o, cc, taps, _ = p.shape
     k = int(round(taps ** 0.5))
