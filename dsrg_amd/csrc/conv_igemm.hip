@@ -26,8 +26,12 @@
 //     a launch, so that the 424 tiles of one fc6 become 1696 and fill 256 CUs to 95 % instead of 83 %;
 //   * epilogue: bias (+ ReLU) on the fp32 accumulators, bf16 pack, through LDS for 16-byte coalesced NHWC stores.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <queue>
+#include <vector>
 
 namespace dsrg {
 namespace {
@@ -1169,6 +1173,7 @@ size_t conv_igemm_colsum_workspace(int ngroups, int B, int H, int W, int cout) {
 static thread_local IgemmArgs *t_prep_d = nullptr;
 static thread_local IgemmWgradArgs *t_prep_w = nullptr;
 static thread_local int *t_prep_grid = nullptr;
+static thread_local int t_force_ksplit = 0;              // launch_conv_igemm_backward: the pixel split it picked for its merged grid
 
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
                       int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
@@ -1301,11 +1306,22 @@ static int wgrad_ksplit(long long M, int tiles, int cus) {
     return best;
 }
 
+// the finest pixel split launch_conv_igemm_backward may pick for a layer whose stand-alone split is ks: twice as fine, never beyond
+// one 64-pixel step per split
+static int wgrad_ksplit_cap(long long M, int ks) {
+    const long long most = (M + 63) / 64;
+    long long c = 2LL * ks;
+    if (c > most) c = most;
+    if (c > 128) c = 128;
+    return (int)(c < ks ? ks : c);
+}
+
 size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k) {
     if (!conv_igemm_wgrad_supported(cin, cout, k) || ngroups < 1 || ngroups > 4) return 0;
     const long long M = (long long)B * H * W;
     const int tiles = ngroups * (cout / 256) * wgrad_col_tiles(cin, k);
-    const int ks = wgrad_ksplit(M, tiles, 256);
+    int ks = wgrad_ksplit(M, tiles, 256);
+    if (ngroups == 1) ks = wgrad_ksplit_cap(M, ks);         // (the merged backward launch may cut a single layer's pixels finer)
     return (size_t)ngroups * ks * cout * k * k * cin * sizeof(float);
 }
 
@@ -1338,7 +1354,7 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.M = (int)M;
     a.tiles_n = cout / 256;
     a.tiles_c = wgrad_col_tiles(cin, k);
-    a.ksplit = wgrad_ksplit(M, ngroups * a.tiles_n * a.tiles_c, 256);
+    a.ksplit = t_force_ksplit > 0 ? t_force_ksplit : wgrad_ksplit(M, ngroups * a.tiles_n * a.tiles_c, 256);
     a.kchunk = (int)(((M + a.ksplit - 1) / a.ksplit + 63) / 64 * 64);
     a.tiles_per_group = a.tiles_n * a.tiles_c * a.ksplit;
     a.stagger = igemm_variant() >= 3;
@@ -1372,6 +1388,28 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
 }
 
 
+// when the last block of a merged backward grid ends (us): blocks go to the 8 XCDs round-robin by id, an XCD's CUs take its
+// blocks in id order as they free up — nd data-gradient tiles of td us first, then (from the next multiple of 8) nw weight-gradient
+// workgroups of tw us
+static double merged_makespan(int nd, double td, int nw, double tw) {
+    const int per_xcd = igemm_cus() / 8 > 0 ? igemm_cus() / 8 : 32;
+    double worst = 0.0;
+    for (int x = 0; x < 8; x++) {
+        std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
+        for (int c = 0; c < per_xcd; c++) cu.push(0.0);
+        const int ndx = (nd - x + 7) / 8 > 0 ? (nd - x + 7) / 8 : 0, nwx = (nw - x + 7) / 8 > 0 ? (nw - x + 7) / 8 : 0;
+        double end = 0.0;
+        for (int b = 0; b < ndx + nwx; b++) {
+            const double t = cu.top() + (b < ndx ? td : tw);
+            cu.pop();
+            cu.push(t);
+            if (t > end) end = t;
+        }
+        if (end > worst) worst = end;
+    }
+    return worst;
+}
+
 // The backward of ONE 3x3 convolution as one launch (conv_igemm_bwd_kernel): data gradient of g with the flipped kernel `wd` (+ the
 // ReLU / Dropout backward and bias gradient of the layer below when `mask` is given, as launch_conv_igemm's fused form) and the
 // weight gradient from (x, g).  Falls back to the two launches where the merged kernel does not apply (grouped launches, the
@@ -1395,10 +1433,27 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
         rc = launch_conv_igemm(gp, wp, nullptr, gxp, dils, 1, B, H, W, cout, cin, k, 0, 0.0f, 0ull, nullptr, 0, stream, mask ? mp : nullptr,
                                mask_scale, bias_grad ? bgp : nullptr, colsum_ws, colsum_ws_bytes);
         t_prep_d = nullptr;
-        if (!rc) {
+        if (!rc && !a.d.xcd_mix && nd > 0) {
+            // the pixel split of the weight gradient half, chosen for THIS grid: its workgroups fill the CUs the data gradient's
+            // tiles leave idle and then the whole chip; what counts is when the last of them ends (merged_makespan)
+            const long long M = (long long)B * H * W;
+            const int tiles = (cout / 256) * wgrad_col_tiles(cin, k), ks0 = wgrad_ksplit(M, tiles, 256), cap = wgrad_ksplit_cap(M, ks0);
+            const double td = ((cout / 64) * k * k + 6) * 1.85;                  // us per data-gradient tile: K-steps + prologue / epilogue
+            double best = -1.0;
+            int best_ks = ks0;
+            for (int ks = 1; ks <= cap; ks++) {
+                const long long chunk = ((M + ks - 1) / ks + 63) / 64 * 64;
+                if ((long long)(ks - 1) * chunk >= M) continue;                  // an empty last split
+                const double tw = (chunk / 64 + 8) * 2.3;                        // us per weight-gradient workgroup: steps + partial tile out
+                const double t = merged_makespan(nd, td, tiles * ks, tw) + 3.0 + 2.4 * ks * ((double)cout * k * k * cin / (512.0 * 4608.0));
+                if (best < 0.0 || t < best) { best = t; best_ks = ks; }
+            }
+            static const bool pick_on = [] { const char *e = getenv("DSRG_MERGED_KS"); return !e || atoi(e) != 0; }();      // tools: A/B
+            t_force_ksplit = pick_on ? best_ks : 0;
             t_prep_w = &a.w; t_prep_grid = &nw;
             rc = launch_conv_igemm_wgrad(xp, gp, gwp, dils, 1, wgrad_ws, wgrad_ws_bytes, B, H, W, cin, cout, k, 0, stream);
             t_prep_w = nullptr;
+            t_force_ksplit = 0;
         }
         t_prep_grid = nullptr;
         if (rc) return rc;

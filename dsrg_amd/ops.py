@@ -650,7 +650,8 @@ def conv_igemm_backward(g, packed_d, x, dilation, mask=None, mask_scale=1.0, ksi
     (B,cout,H,W) and x (B,cin,H,W) bf16 channels_last, packed_d = pack_conv_weight(w, for_dgrad=True); mask: the layer's input when
     it is the sole-consumer ReLU output of the layer below (then that layer's ReLU / Dropout backward and bias gradient ride in
     the data gradient, as conv_igemm_dgrad) -> (gx (B,cin,H,W) bf16 channels_last, gw (cout,cin,k,k) float32 channels_last, bias
-    gradient of the layer below (cin) f32 or None).  Same results as conv_igemm(_dgrad) + conv_igemm_wgrad, bit for bit."""
+    gradient of the layer below (cin) f32 or None).  gx and the bias gradient equal conv_igemm(_dgrad)'s bit for bit, gw equals
+    conv_igemm_wgrad's up to fp32 reassociation (another pixel split)."""
     B, cout, H, W = g.shape
     cin = x.shape[1]
     cl = torch.channels_last

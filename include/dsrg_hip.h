@@ -355,7 +355,8 @@ int dsrg_conv_igemm_wgrad_bf16(const void *const *x_dev, const void *const *g_de
  * bias gradient, as dsrg_conv_igemm_dgrad_bf16 — and the weight gradient gw (cout, cin, k, k; float32, channels_last) from x_dev
  * (B,H,W,cin) and g.  The data gradient's tiles and the weight gradient's workgroups share a grid, so the CUs a 212-tile data
  * gradient leaves idle take weight-gradient work; where that form does not apply (dilation >= 3, a 128-channel x) the two launches
- * run one after the other.  Results equal dsrg_conv_igemm_dgrad_bf16 / dsrg_conv_igemm_bf16 + dsrg_conv_igemm_wgrad_bf16 bit for bit.
+ * run one after the other.  The data gradient equals dsrg_conv_igemm_dgrad_bf16 / dsrg_conv_igemm_bf16 bit for bit; the weight gradient
+ * equals dsrg_conv_igemm_wgrad_bf16 up to fp32 reassociation (its pixel split is chosen for the merged grid); both deterministic.
  * Workspaces: dsrg_conv_igemm_dgrad_workspace(1, B, H, W, cin) bytes (only with bias_grad_dev) and
  * dsrg_conv_igemm_wgrad_workspace(1, B, H, W, cin, cout, ksize) bytes. */
 int dsrg_conv_igemm_backward_bf16(const void *g_dev, const void *w_dgrad_dev, const void *x_dev, const void *mask_dev, void *gx_dev,

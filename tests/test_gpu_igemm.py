@@ -169,8 +169,9 @@ def test_igemm_skipping_on_random_shapes(ops):
 ])
 def test_igemm_merged_backward_equals_the_two_launches(ops, B, H, W, cin, cout, dil, absorb):
     """dsrg_conv_igemm_backward_bf16: the data gradient's tiles and the weight gradient's workgroups of one layer in ONE grid
-    (conv_igemm_bwd_kernel) — the same argument blocks, the same device code per block: data gradient (+ the absorbed ReLU
-    backward and bias gradient of the layer below) and weight gradient bit-equal to the separate launches"""
+    (conv_igemm_bwd_kernel) — the same device code per block: data gradient (+ the absorbed ReLU backward and bias gradient of
+    the layer below) bit-equal to the separate launch, weight gradient equal up to fp32 reassociation (its pixel split is chosen
+    for the merged grid), deterministic"""
     x = torch.relu(torch.randn(B, cin, H, W, device="cuda")).bfloat16().contiguous(memory_format=CL)     # the layer's input = a ReLU output
     g = torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL)
     w = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.03)
@@ -183,7 +184,10 @@ def test_igemm_merged_backward_equals_the_two_launches(ops, B, H, W, cin, cout, 
         (gx_ref,) = ops.conv_igemm([g], [pd], [None], [dil], 3, False, stream_k=False)
         assert gb is None
     (gw_ref,) = ops.conv_igemm_wgrad([x], [g], [dil], 3)
-    assert torch.equal(gx, gx_ref) and torch.equal(gw, gw_ref)
+    assert torch.equal(gx, gx_ref)
+    # the weight-gradient half may cut the pixels finer than the stand-alone launch does (its split is chosen for the merged grid):
+    # the same terms in the same order, other partial sums
+    assert (gw - gw_ref).abs().max() <= 2e-5 * gw_ref.abs().max()
     gx2, gw2, _ = ops.conv_igemm_backward(g, pd, x, dil, x if absorb else None, 2.0 if absorb else 1.0)
     assert torch.equal(gx, gx2) and torch.equal(gw, gw2)                                                   # deterministic
     # and right: the weight gradient against torch
