@@ -246,6 +246,8 @@ class _GradLink:
 
 _FUSE_CHAIN = _os.environ.get("DSRG_FUSE_CHAIN", "1") != "0"
 _MERGED_BWD = _os.environ.get("DSRG_MERGED_BWD", "1") != "0"     # data + weight gradient of a single-group 3x3 layer in one launch
+# (measured and dropped in round 5: packing every wide layer's kernels on a second stream at the start of the step, under the
+# HBM-bound conv1_x / conv2_x — 1 822 -> 1 798 images/s: the packs then compete with those kernels for the same HBM)
 # (measured and dropped in round 5: the weight gradient of an implicit-GEMM layer on a second stream beside its data gradient,
 # to fill the sixth of the chip a 212-tile data-gradient launch leaves idle — 1 761 -> 1 715 images/s, the two 139 KB-LDS kernels
 # only take CUs from each other; profiles/r05_wgrad_side_stream_ab.txt)

@@ -1424,7 +1424,7 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
     float *bgp[1] = {bias_grad};
     const int dils[1] = {dil};
     static const bool merged_on = [] { const char *e = getenv("DSRG_IGEMM_MERGED_BWD"); return !e || atoi(e) != 0; }();      // tools: A/B
-    const bool can_merge = merged_on && k == 3 && cin != 128 && dil < 3 && (igemm_variant() == 3 || igemm_variant() == 1);
+    const bool can_merge = merged_on && k == 3 && dil < 3 && (igemm_variant() == 3 || igemm_variant() == 1);
     IgemmBwdArgs a;
     memset(&a, 0, sizeof(a));
     int nd = 0, nw = 0, rc = DSRG_OK;

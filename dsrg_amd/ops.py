@@ -664,7 +664,7 @@ def conv_igemm_backward(g, packed_d, x, dilation, mask=None, mask_scale=1.0, ksi
     L = _lib.lib()
     need = L.dsrg_conv_igemm_wgrad_workspace(1, B, H, W, cin, cout, ksize)
     if need == 0:
-        raise ValueError("conv_igemm_backward: 256 | cin, 256 | cout required (got %d, %d)" % (cin, cout))
+        raise ValueError("conv_igemm_backward: 256 | cin (or cin = 128), 256 | cout required (got %d, %d)" % (cin, cout))
     key = (g.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _igemm_ws.get(key)                                          # per-stream scratch, shared with conv_igemm_wgrad
     if ws is None or ws.numel() < need:

@@ -165,6 +165,7 @@ def test_igemm_skipping_on_random_shapes(ops):
     (3, 41, 41, 256, 512, 1, False),      # conv4_1: the layer below sits behind a pool (no absorbed ReLU backward)
     (1, 81, 81, 256, 256, 1, True),       # conv3_2 / conv3_3
     (2, 20, 30, 256, 512, 1, True),       # a ragged last tile on both sides
+    (2, 81, 81, 128, 256, 1, False),      # conv3_1: a 128-channel x (two taps per weight-gradient tile, half an n-tile in the data gradient)
     (2, 41, 41, 512, 1024, 12, True),     # a dilated layer: the entry point runs the two launches one after the other
 ])
 def test_igemm_merged_backward_equals_the_two_launches(ops, B, H, W, cin, cout, dil, absorb):
