@@ -342,7 +342,7 @@ class _IgemmConvFn(torch.autograd.Function):
         absorb = _FUSE_CHAIN and ctx.links_in is not None and all(need_x) and conv_igemm_supported(cout, cin, ctx.k) and \
             cin >= 256 and all(x.is_contiguous(memory_format=cl) for x in xs)
         if _MERGED_BWD and n == 1 and ctx.k == 3 and need_x[0] and conv_igemm_supported(cout, cin, 3) and \
-                conv_igemm_wgrad_supported(cin, cout, 3) and cin % 256 == 0 and xs[0].is_contiguous(memory_format=cl):
+                conv_igemm_wgrad_supported(cin, cout, 3) and xs[0].is_contiguous(memory_format=cl):
             # one launch for both gradients of the layer (ops.conv_igemm_backward): the data gradient's tiles and the weight gradient's
             # workgroups share a grid, so the CUs a 212-tile data gradient leaves idle do weight-gradient work
             from .ops import conv_igemm_backward
