@@ -808,11 +808,18 @@ __device__ __forceinline__ void conv_igemm_wgrad_body(const IgemmWgradArgs &a, c
     int grp, split, t;
     if (a.xcd_mix) {
         const int id = bid, xcd = id & 7, k = id >> 3;
-        const int per_group = (a.ksplit >> 3) * tiles;
-        grp = k / per_group;
-        const int r = k - grp * per_group, sl = r / tiles;
-        t = r - sl * tiles;
-        split = xcd + 8 * sl;
+        if (a.ksplit >= 8) {                                // 8 | ksplit: XCD x owns the chunks x, x + 8, ..
+            const int per_group = (a.ksplit >> 3) * tiles;
+            grp = k / per_group;
+            const int r = k - grp * per_group, sl = r / tiles;
+            t = r - sl * tiles;
+            split = xcd + 8 * sl;
+        } else {                                            // ksplit | 8: a chunk belongs to 8 / ksplit XCDs, its tiles dealt out among them in turn
+            const int xpc = 8 / a.ksplit, sub = xcd % xpc, per_group = tiles / xpc;      // (xpc | tiles: the launcher checked)
+            split = xcd / xpc;
+            grp = k / per_group;
+            t = sub + xpc * (k - grp * per_group);
+        }
     } else {
         const int total = nblk, id = bid;
         const int q = total >> 3, r = total & 7, xcd = id & 7, k = id >> 3;
@@ -1291,7 +1298,10 @@ static int wgrad_col_tiles(int cin, int k) { return cin == 128 ? (k * k + 1) / 2
 
 // pixel split of the weight-gradient launch: the number of workgroups per output tile that minimises
 // rounds of the chip x (K-steps per workgroup + a fixed cost per workgroup for prologue and the partial tile's write-out)
-static int wgrad_ksplit(long long M, int tiles, int cus) {
+// out_bytes: the gradient tensors of all groups — every split writes and the reduction reads that much again, ~2.3 us (one
+// K-step of a workgroup) per 9.2 MB at the rate the reduction kernel streams (the four fc6_k: 75 MB, 8 K-steps per split)
+// xcd_mix_only: only the splits the XCD-interleaved workgroup map takes (a divisor or a multiple of 8)
+static int wgrad_ksplit(long long M, int tiles, int cus, double out_bytes = 0.0, bool xcd_mix_only = false) {
     long long best_cost = -1;
     int best = 1;
     static const int forced = [] { const char *e = getenv("DSRG_WGRAD_KSPLIT"); return e ? atoi(e) : 0; }();     // tools only
@@ -1299,8 +1309,9 @@ static int wgrad_ksplit(long long M, int tiles, int cus) {
     for (int ks = 1; ks <= 128; ks++) {
         const long long chunk = ((M + ks - 1) / ks + 63) / 64 * 64;
         if ((long long)(ks - 1) * chunk >= M) continue;                 // an empty last split
+        if (xcd_mix_only && ks % 8 != 0 && 8 % ks != 0) continue;
         const long long steps = chunk / 64, rounds = ((long long)tiles * ks + cus - 1) / cus;
-        const long long cost = rounds * (steps + 8);
+        const long long cost = rounds * (steps + 8) + (long long)(ks * out_bytes / 9.2e6);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ks; }
     }
     return best;
@@ -1320,7 +1331,9 @@ size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int
     if (!conv_igemm_wgrad_supported(cin, cout, k) || ngroups < 1 || ngroups > 4) return 0;
     const long long M = (long long)B * H * W;
     const int tiles = ngroups * (cout / 256) * wgrad_col_tiles(cin, k);
-    int ks = wgrad_ksplit(M, tiles, 256);
+    int ks = wgrad_ksplit(M, tiles, 256, (double)ngroups * cout * k * k * cin * 4.0);
+    const int ks_mix = wgrad_ksplit(M, tiles, 256, (double)ngroups * cout * k * k * cin * 4.0, true);      // (a launch of dilated kernels picks among these)
+    if (ks_mix > ks) ks = ks_mix;
     if (ngroups == 1) ks = wgrad_ksplit_cap(M, ks);         // (the merged backward launch may cut a single layer's pixels finer)
     return (size_t)ngroups * ks * cout * k * k * cin * sizeof(float);
 }
@@ -1354,7 +1367,12 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.M = (int)M;
     a.tiles_n = cout / 256;
     a.tiles_c = wgrad_col_tiles(cin, k);
-    a.ksplit = t_force_ksplit > 0 ? t_force_ksplit : wgrad_ksplit(M, ngroups * a.tiles_n * a.tiles_c, 256);
+    bool wants_mix = false;                                  // dilated kernels: workgroups of unequal length, see xcd_mix
+    for (int q = 0; q < ngroups; q++) wants_mix = wants_mix || (k == 3 && dil && dil[q] >= 3);      // (whatever the variant: tests compare them bit for bit)
+    a.ksplit = t_force_ksplit > 0 ? t_force_ksplit
+                                  : wgrad_ksplit(M, ngroups * a.tiles_n * a.tiles_c, 256, (double)ngroups * cout * k * k * cin * 4.0, wants_mix);
+    static const int grouped_ks = [] { const char *e = getenv("DSRG_WGRAD_KSPLIT_GROUPED"); return e ? atoi(e) : 0; }();        // tools: A/B
+    if (grouped_ks > 0 && ngroups == 4 && k == 3 && grouped_ks <= a.ksplit) a.ksplit = grouped_ks;
     a.kchunk = (int)(((M + a.ksplit - 1) / a.ksplit + 63) / 64 * 64);
     a.tiles_per_group = a.tiles_n * a.tiles_c * a.ksplit;
     a.stagger = igemm_variant() >= 3;
@@ -1370,7 +1388,8 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     static const bool compact_on = [] { const char *e = getenv("DSRG_WGRAD_COMPACT"); return !e || atoi(e) != 0; }();      // tools: A/B
     static const int compact_min_dil = [] { const char *e = getenv("DSRG_WGRAD_COMPACT_MIN_DIL"); return e ? atoi(e) : 1; }();     // tools: A/B (3: dilated kernels only — 1 776-1 782 against 1 800-1 807 images/s)
     for (int q = 0; q < ngroups; q++) {
-        if (a.skip_rows && k == 3 && a.g[q].dil >= 3 && a.ksplit % 8 == 0) a.xcd_mix = 1;
+        if (a.skip_rows && k == 3 && a.g[q].dil >= 3 &&
+            (a.ksplit % 8 == 0 || (8 % a.ksplit == 0 && (a.tiles_n * a.tiles_c) % (8 / a.ksplit) == 0))) a.xcd_mix = 1;
         if (a.skip_rows && compact_on && igemm_variant() != 7 && k == 3 && cin != 128 && a.g[q].dil >= compact_min_dil) a.compact = 1;      // 7: tests — dead steps skipped in the flat pixel order
     }
     if (t_prep_w) {
@@ -1437,7 +1456,7 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
             // the pixel split of the weight gradient half, chosen for THIS grid: its workgroups fill the CUs the data gradient's
             // tiles leave idle and then the whole chip; what counts is when the last of them ends (merged_makespan)
             const long long M = (long long)B * H * W;
-            const int tiles = (cout / 256) * wgrad_col_tiles(cin, k), ks0 = wgrad_ksplit(M, tiles, 256), cap = wgrad_ksplit_cap(M, ks0);
+            const int tiles = (cout / 256) * wgrad_col_tiles(cin, k), ks0 = wgrad_ksplit(M, tiles, 256, (double)cout * k * k * cin * 4.0), cap = wgrad_ksplit_cap(M, ks0);
             const double td = ((cout / 64) * k * k + 6) * 1.85;                  // us per data-gradient tile: K-steps + prologue / epilogue
             double best = -1.0;
             int best_ks = ks0;
