@@ -97,6 +97,7 @@ SIGNATURES = {
     "dsrg_conv_igemm_dgrad_bf16": (_i, [_vp] * 6 + [_i] * 7 + [_f, _vp, _sz, _vp]),
     "dsrg_conv_igemm_workspace_status": (_i, [_vp, _vp, _vp]),
     "dsrg_pack_conv_weight_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dsrg_sgd_pack_f32": (_i, [_i] + [_vp] * 9 + [_f, _vp]),
     "dsrg_conv_igemm_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "dsrg_conv_igemm_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsrg_conv_igemm_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _vp]),

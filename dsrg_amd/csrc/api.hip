@@ -530,6 +530,18 @@ extern "C" int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void 
 extern "C" int dsrg_pack_conv_weight_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, int ksize, void *stream) {
     return launch_pack_conv_weight(w_dev, fwd_dev, dgrad_dev, cout, cin, ksize, static_cast<hipStream_t>(stream));
 }
+namespace dsrg {   // sgd_pack.hip
+int launch_sgd_pack(int n, float *const *p, const float *const *g, float *const *buf, void *const *fwd, void *const *dg, const int *shape,
+                    const long long *numel, const float *lr, const float *wd, float momentum, hipStream_t stream);
+}
+extern "C" int dsrg_sgd_pack_f32(int n, float *const *param_dev, const float *const *grad_dev, float *const *momentum_dev, void *const *fwd_dev,
+                                 void *const *dgrad_dev, const int *shape, const long long *numel, const float *lr, const float *weight_decay,
+                                 float momentum, void *stream) {
+    if (n > 0 && (!param_dev || !numel || ((fwd_dev || dgrad_dev) && !shape)))
+        return set_error(DSRG_ERR_INVALID, "sgd_pack: null argument");
+    return launch_sgd_pack(n, param_dev, grad_dev, momentum_dev, fwd_dev, dgrad_dev, shape, numel, lr, weight_decay, momentum,
+                           static_cast<hipStream_t>(stream));
+}
 extern "C" size_t dsrg_conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int ksize) {
     return conv_igemm_wgrad_workspace(ngroups, B, H, W, cin, cout, ksize);
 }

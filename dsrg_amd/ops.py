@@ -500,6 +500,109 @@ WGRAD_CONV_SHAPES = ((3, 64), (64, 64), (64, 128), (128, 128))      # (cin, cout
 _wgrad_ws = {}
 
 
+# ---- the packed bf16 kernels of the float32 master parameters, kept from step to step — only for parameters an optimizer that
+# maintains them has claimed (keep_weight_packs: trainer.CaffeSGD).  A convolution node packs the kernel the first time it sees
+# such a parameter and leaves the buffers here; the optimizer's update (sgd_pack_step) rewrites them in the pass that updates the
+# parameter, so from the second step on a forward finds its packs ready and reads no float32 weight.  An entry is good for exactly
+# one value of the parameter: it records the tensor's version counter, which in-place writes bump (load_state_dict, a broadcast)
+# — then the node packs again, into the same buffers.  NOT every writer bumps it: torch's private fused optimizer ops
+# (torch._fused_sgd_, which torch.optim.SGD(fused=True) calls) leave the counter alone, which is why nothing is kept for a
+# parameter unless its optimizer says it plays along; unclaimed parameters are packed inside every forward as before.
+import weakref as _weakref
+
+
+class _WeightPacks(object):
+    __slots__ = ("ref", "version", "fwd", "dg", "plain")
+
+
+_weight_packs = {}                                                    # parameter.data_ptr() -> _WeightPacks
+
+
+def _packs_entry(weight, plain):
+    """the entry of this parameter (whatever value it was packed from), or None"""
+    e = _weight_packs.get(weight.data_ptr())
+    if e is None:
+        return None
+    t = e.ref()
+    if t is None or t.data_ptr() != weight.data_ptr() or t.shape != weight.shape or e.plain != plain:
+        del _weight_packs[weight.data_ptr()]                          # the parameter is gone, another tensor took its address
+        return None
+    return e
+
+
+def keep_weight_packs(params, on=True):
+    """an optimizer's declaration that every write it makes to these parameters either goes through sgd_pack_step or bumps their
+    version counter: the convolution nodes may then keep the packed kernels between steps"""
+    for p in params:
+        p._dsrg_keep_packs = bool(on)
+        if not on:
+            _weight_packs.pop(p.data_ptr(), None)
+
+
+def _packs_kept(weight):
+    # inside a hipGraph capture the packing launches belong in the graph (a replay must see the weights of its own time)
+    return getattr(weight, "_dsrg_keep_packs", False) and not torch.cuda.is_current_stream_capturing()
+
+
+def _packs_keep(weight, plain, fwd, dg):
+    if not _packs_kept(weight):
+        return
+    if weight.data_ptr() not in _weight_packs:                        # a new parameter (first step of a model): drop those of dead ones
+        for k in [k for k, e in _weight_packs.items() if e.ref() is None]:
+            del _weight_packs[k]
+    e = _WeightPacks()
+    e.ref, e.version, e.fwd, e.dg, e.plain = _weakref.ref(weight), weight._version, fwd, dg, plain
+    _weight_packs[weight.data_ptr()] = e
+
+
+def _packs_for(weight, plain, want_fwd, want_dgrad, fwd_shape, dg_shape, fwd_cl=False):
+    """-> (fwd, dg, fresh): the buffers of the packed forms wanted; fresh = they already hold this value of the parameter"""
+    e = _packs_entry(weight, plain) if _packs_kept(weight) else None
+    if e is not None and e.version == weight._version and (e.fwd is not None or not want_fwd) and (e.dg is not None or not want_dgrad):
+        return (e.fwd if want_fwd else None), (e.dg if want_dgrad else None), True
+    mf = torch.channels_last if fwd_cl else torch.contiguous_format
+    fwd = (e.fwd if e is not None and e.fwd is not None else torch.empty(fwd_shape, dtype=torch.bfloat16, device=weight.device, memory_format=mf)) \
+        if (want_fwd or (e is not None and e.fwd is not None)) else None
+    dg = (e.dg if e is not None and e.dg is not None else torch.empty(dg_shape, dtype=torch.bfloat16, device=weight.device, memory_format=mf)) \
+        if (want_dgrad or (e is not None and e.dg is not None)) else None
+    return fwd, dg, False
+
+
+def sgd_pack_step(params, grads, bufs, lrs, wds, momentum):
+    """Caffe's SGD update B <- momentum B + (g + wd W); W <- W - lr B of float32 CUDA parameters in one launch per sixteen
+    tensors (dsrg_sgd_pack_f32), rewriting the packed bf16 kernels the convolution nodes keep for them in the same pass.
+    params / grads / bufs: dense tensors of one memory layout each; lrs / wds: per-tensor rates."""
+    import numpy as np
+    n = len(params)
+    if n == 0:
+        return
+    ptr = lambda ts: np.array([0 if t is None else t.data_ptr() for t in ts], dtype=np.uint64)
+    fwd, dg, shape, entries = [None] * n, [None] * n, np.zeros((n, 4), dtype=np.int32), []
+    for i, p in enumerate(params):
+        e = _weight_packs.get(p.data_ptr())
+        if e is None or e.ref() is None or e.ref().data_ptr() != p.data_ptr() or e.ref().shape != p.shape:
+            continue
+        fwd[i], dg[i] = e.fwd, e.dg
+        shape[i] = (p.shape[0], p.shape[1], p.shape[2] * p.shape[3], e.plain)
+        entries.append((e, p))
+    pp, gp, bp, fp, dp = ptr(params), ptr(grads), ptr(bufs), ptr(fwd), ptr(dg)
+    numel = np.array([p.numel() for p in params], dtype=np.int64)
+    lr, wd = np.asarray(lrs, dtype=np.float32), np.asarray(wds, dtype=np.float32)
+    a = lambda x: x.ctypes.data
+    check(_lib.lib().dsrg_sgd_pack_f32(n, a(pp), a(gp), a(bp), a(fp), a(dp), a(shape), a(numel), a(lr), a(wd), float(momentum), _stream()))
+    torch.autograd.graph.increment_version(list(params))              # an in-place write autograd has not seen
+    for e, p in entries:
+        e.version = p._version
+
+
+def sgd_pack_eligible(p, g, b):
+    """can dsrg_sgd_pack_f32 update this parameter: float32 CUDA tensors of one dense layout, 16-byte aligned"""
+    return p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and b.dtype == torch.float32 and g.is_cuda and \
+        g.shape == p.shape and all(n == 1 or (sg == sp and sb == sp) for n, sp, sg, sb in zip(p.shape, p.stride(), g.stride(), b.stride())) and \
+        (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))) and \
+        (p.data_ptr() | g.data_ptr() | b.data_ptr()) % 16 == 0
+
+
 def pack_direct_weight_pair(weight, want_dgrad=True):
     """the bf16 kernels of conv3x3_direct from a float32 channels_last (cout, cin, 3, 3) parameter with 64 / 128 channels either
     side, one pass: (weight cast, weight flipped with its channel axes swapped — the data gradient's kernel — or None)"""
@@ -508,10 +611,11 @@ def pack_direct_weight_pair(weight, want_dgrad=True):
     if not (weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous(memory_format=cl) and tuple(weight.shape[2:]) == (3, 3)
             and cin in DIRECT_CONV_CHANNELS and cout in DIRECT_CONV_CHANNELS):
         raise ValueError("pack_direct_weight_pair needs a float32 channels_last (cout,cin,3,3) CUDA parameter with 64 / 128 channels")
-    fwd = torch.empty((cout, cin, 3, 3), dtype=torch.bfloat16, device=weight.device, memory_format=cl)
-    dg = torch.empty((cin, cout, 3, 3), dtype=torch.bfloat16, device=weight.device, memory_format=cl) if want_dgrad else None
-    check(_lib.lib().dsrg_pack_conv_weight_direct_f32(_ptr(weight.detach()), _ptr(fwd), _ptr(dg), cout, cin, _stream()))
-    return fwd, dg
+    fwd, dg, fresh = _packs_for(weight, 1, True, want_dgrad, (cout, cin, 3, 3), (cin, cout, 3, 3), fwd_cl=True)
+    if not fresh:
+        check(_lib.lib().dsrg_pack_conv_weight_direct_f32(_ptr(weight.detach()), _ptr(fwd), _ptr(dg), cout, cin, _stream()))
+        _packs_keep(weight, 1, fwd, dg)
+    return fwd, (dg if want_dgrad else None)
 
 
 def conv3x3_wgrad(x, g, out_dtype=torch.bfloat16):
@@ -578,10 +682,11 @@ def pack_conv_weight_pair(weight, want_fwd=True, want_dgrad=True):
     if not (weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous(memory_format=torch.channels_last)
             and cout % 64 == 0 and cin % 64 == 0 and k in (1, 3)):
         return (pack_conv_weight(weight) if want_fwd else None, pack_conv_weight(weight, for_dgrad=True) if want_dgrad else None)
-    fwd = torch.empty((cout, cin // 64, k * k, 64), dtype=torch.bfloat16, device=weight.device) if want_fwd else None
-    dg = torch.empty((cin, cout // 64, k * k, 64), dtype=torch.bfloat16, device=weight.device) if want_dgrad else None
-    check(_lib.lib().dsrg_pack_conv_weight_f32(_ptr(weight.detach()), _ptr(fwd), _ptr(dg), cout, cin, k, _stream()))
-    return fwd, dg
+    fwd, dg, fresh = _packs_for(weight, 0, want_fwd, want_dgrad, (cout, cin // 64, k * k, 64), (cin, cout // 64, k * k, 64))
+    if not fresh:
+        check(_lib.lib().dsrg_pack_conv_weight_f32(_ptr(weight.detach()), _ptr(fwd), _ptr(dg), cout, cin, k, _stream()))
+        _packs_keep(weight, 0, fwd, dg)
+    return (fwd if want_fwd else None), (dg if want_dgrad else None)
 
 
 def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0, stream_k=True):

@@ -2,10 +2,15 @@
 hot path (libdsrg_hip.so) -> backward -> Caffe-style SGD (solver-s.prototxt).  Data parallel
 over images: one process per GPU, gradients all-reduced by RCCL through DistributedDataParallel.
 """
+import os
+
 import torch
 
 from .backbone import VGG16ASPP
 from .ops import dsrg_supervision_loss
+
+
+_SGD_PACK = os.environ.get("DSRG_SGD_PACK", "1") != "0"     # the update + weight packing kernel of csrc/sgd_pack.hip (0: torch._fused_sgd_)
 
 
 class CaffeSGD(object):
@@ -23,6 +28,11 @@ class CaffeSGD(object):
         for g in self.groups:
             g["bufs"] = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in g["params"]]
             g["buf_lr"] = None
+        if _SGD_PACK:
+            # every write step() makes to a parameter is either dsrg_sgd_pack_f32's (which rewrites the packed bf16 kernels the
+            # convolution nodes keep) or is followed by a bump of its version counter: the nodes may keep their packs
+            from .ops import keep_weight_packs
+            keep_weight_packs([p for g in self.groups for p in g["params"] if p.is_cuda])
 
     def lr(self):
         return self.base_lr * self.gamma ** (self.iter // self.stepsize)
@@ -30,6 +40,7 @@ class CaffeSGD(object):
     @torch.no_grad()
     def step(self):
         lr = self.lr()
+        own = ([], [], [], [], [])                 # params, grads, bufs, lrs, wds of the tensors dsrg_sgd_pack_f32 updates
         for g in self.groups:
             ps = [p for p in g["params"] if p.grad is not None]
             if not ps:
@@ -40,6 +51,22 @@ class CaffeSGD(object):
             if g["buf_lr"] is not None and g["buf_lr"] != local_lr:
                 torch._foreach_mul_(g["bufs"], g["buf_lr"] / local_lr)
             g["buf_lr"] = local_lr
+            if _SGD_PACK and ps[0].is_cuda:
+                # one launch series for all groups (the rates ride per tensor), the packed bf16 kernels of the convolution nodes
+                # rewritten in the same pass (ops.sgd_pack_step); whatever does not fit (another dtype, a gradient laid out
+                # differently) stays with torch below
+                from .ops import sgd_pack_eligible
+                rest = ([], [], [])
+                for p, gr, b in zip(ps, grads, bufs):
+                    if sgd_pack_eligible(p, gr, b):
+                        for lst, v in zip(own, (p, gr, b, local_lr, local_wd)):
+                            lst.append(v)
+                    else:
+                        for lst, v in zip(rest, (p, gr, b)):
+                            lst.append(v)
+                ps, grads, bufs = rest
+                if not ps:
+                    continue
             try:
                 torch._fused_sgd_(ps, grads, bufs, weight_decay=local_wd, momentum=self.momentum, lr=local_lr,
                                   dampening=0.0, nesterov=False, maximize=False, is_first_step=False)
@@ -49,6 +76,10 @@ class CaffeSGD(object):
                 torch._foreach_mul_(bufs, self.momentum)
                 torch._foreach_add_(bufs, grads)
                 torch._foreach_add_(ps, bufs, alpha=-local_lr)
+            torch.autograd.graph.increment_version(ps)           # torch._fused_sgd_ writes without bumping the version counters
+        if own[0]:
+            from .ops import sgd_pack_step
+            sgd_pack_step(own[0], own[1], own[2], own[3], own[4], self.momentum)
         self.iter += 1
 
     def zero_grad(self):

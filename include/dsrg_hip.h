@@ -338,6 +338,18 @@ int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, in
  * (cout, cin / 64, taps, 64) bf16 for the forward; dgrad_dev (may be NULL): (cin, cout / 64, taps, 64) bf16 for the data
  * gradient (kernel flipped, channel axes swapped).  64 | cout, 64 | cin. */
 int dsrg_pack_conv_weight_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, int ksize, void *stream);
+/* Caffe's SGDSolver update (solver-s.prototxt:5-14: momentum 0.9, weight_decay 5e-4, per-blob lr_mult / decay_mult of
+ * train-s.prototxt) of n float32 parameters, sixteen per launch, in the form  B <- momentum B + (g + wd W);  W <- W - lr B
+ * (B = Caffe's history / lr), WITH the packed bf16 kernels of the convolution routes written from the new values in the same
+ * pass (the packs of dsrg_pack_conv_weight_f32 / dsrg_pack_conv_weight_direct_f32 — the next forward then reads no float32
+ * weight).  Host arrays of n entries each: param_dev / grad_dev / momentum_dev device pointers (16-byte aligned, same element
+ * order; grad_dev[i] = NULL: tensor i is only packed); fwd_dev[i] / dgrad_dev[i] packed outputs or NULL (the arrays themselves
+ * may be NULL: nothing packed); shape[4 i ..] = {cout, cin, taps (1 | 9), plain (1: the direct kernels' layouts)} of a packed
+ * tensor, whose memory is (cout, taps, cin), 64 | cout, 64 | cin; numel[i]; lr[i] = base_lr * lr_mult, weight_decay[i] =
+ * weight_decay * decay_mult.  Element-wise, one thread owns an element: deterministic. */
+int dsrg_sgd_pack_f32(int n, float *const *param_dev, const float *const *grad_dev, float *const *momentum_dev, void *const *fwd_dev,
+                      void *const *dgrad_dev, const int *shape, const long long *numel, const float *lr, const float *weight_decay,
+                      float momentum, void *stream);
 /* Weight gradient of the same convolutions, again without an im2col matrix (cin % 256 == 0, cout % 256 == 0, ksize 1 or 3):
  *   gw[o][tap][c] = sum_{b,y,x} g[b,y,x,o] * x[b,y+dy*dil,x+dx*dil,c]      (zero padding; tap = 3 (dy+1) + dx+1)
  * x_dev[g] (B,H,W,cin) and g_dev[g] (B,H,W,cout) NHWC bf16; gw_dev[g] (cout, ksize*ksize, cin) = the memory of a channels_last

@@ -347,6 +347,93 @@ def test_train_step_with_dropout_on_trains_like_the_float32_leg():
     assert gap.max() < 0.02, float(gap.max())                  # (observed at batch 8, 300 steps: 6e-4)
 
 
+def test_sgd_pack_kernel_equals_torch_fused_sgd_and_the_pack_kernel(ops):
+    """dsrg_sgd_pack_f32 on a list of tensors of all the kinds the net has (packed 3x3 / 1x1 implicit-GEMM kernels, a direct-route
+    kernel, a kernel that is not packed, biases, a 21 x 1024 classifier — sizes off every multiple of 4096) against
+    torch._fused_sgd_ with the same rates per group, two steps (momentum history in play): parameters and history agree to the last
+    bit or the one before it (torch's kernel may contract a*b+c), and the packed bf16 forms it leaves are bit for bit those of
+    dsrg_pack_conv_weight_f32 on the updated parameter"""
+    from dsrg_amd import _lib
+    dev_ = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    cl = torch.channels_last
+    shapes = [((256, 128, 3, 3), 0), ((128, 256, 1, 1), 0), ((128, 64, 3, 3), 1), ((64, 3, 3, 3), None), ((256,), None), ((21, 1024, 1, 1), None),
+              ((21,), None), ((4099,), None), ((192, 64, 3, 3), 0)] + [((64,), None)] * 12          # 21 tensors: two launches
+    mk = lambda sh: (torch.randn(sh, generator=g).to(dev_).contiguous(memory_format=cl) if len(sh) == 4 else torch.randn(sh, generator=g).to(dev_))
+    ps = [torch.nn.Parameter(mk(sh)) for sh, _ in shapes]
+    assert ops.pack_conv_weight_pair(ps[0], True, True)[0] is not ops.pack_conv_weight_pair(ps[0], True, True)[0]   # nothing kept unasked
+    ops.keep_weight_packs(ps)
+    ref = [p.detach().clone(memory_format=torch.preserve_format) for p in ps]
+    bufs, rbufs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    lrs = [1e-2 * (1 + (i % 3)) for i in range(len(ps))]
+    wds = [5e-4 if i % 2 == 0 else 0.0 for i in range(len(ps))]
+    for i, (p, (sh, plain)) in enumerate(zip(ps, shapes)):                               # the nodes' first forward leaves the packs
+        if plain == 0:
+            ops.pack_conv_weight_pair(p, True, True)
+        elif plain == 1:
+            ops.pack_direct_weight_pair(p, True)
+    assert sum(1 for p in ps if p.data_ptr() in ops._weight_packs) == 4
+    for step in range(2):
+        grads = [mk(sh) for sh, _ in shapes]
+        v0 = [p._version for p in ps]
+        ops.sgd_pack_step(ps, grads, bufs, lrs, wds, 0.9)
+        assert all(p._version > v for p, v in zip(ps, v0))
+        for i in range(len(ps)):
+            torch._fused_sgd_([ref[i]], [grads[i]], [rbufs[i]], weight_decay=wds[i], momentum=0.9, lr=lrs[i], dampening=0.0,
+                              nesterov=False, maximize=False, is_first_step=False)
+        for p, r, b, rb in zip(ps, ref, bufs, rbufs):
+            assert p.stride() == r.stride()
+            assert torch.allclose(p.detach(), r, rtol=1e-6, atol=1e-6) and torch.allclose(b, rb, rtol=1e-6, atol=1e-6)
+        for p, (sh, plain) in zip(ps, shapes):
+            if plain is None:
+                continue
+            e = ops._weight_packs[p.data_ptr()]
+            assert e.version == p._version
+            w = p.detach().clone(memory_format=torch.preserve_format)                    # not a Parameter: packed afresh
+            want = ops.pack_conv_weight_pair(w, True, True) if plain == 0 else ops.pack_direct_weight_pair(w, True)
+            assert torch.equal(e.fwd, want[0]) and torch.equal(e.dg, want[1])
+            got = ops.pack_conv_weight_pair(p, True, True) if plain == 0 else ops.pack_direct_weight_pair(p, True)
+            assert got[0] is e.fwd and got[1] is e.dg                                    # the next forward takes them as they are
+    # a write the optimizer did not make (load_state_dict, a broadcast): the node packs again
+    with torch.no_grad():
+        ps[0].mul_(0.5)
+    fwd, dgp = ops.pack_conv_weight_pair(ps[0], True, True)
+    want = ops.pack_conv_weight_pair(ps[0].detach().clone(memory_format=torch.preserve_format), True, True)
+    assert torch.equal(fwd, want[0]) and torch.equal(dgp, want[1])
+    # malformed lists are refused
+    lib = _lib.lib()
+    import ctypes
+    arr = (ctypes.c_void_p * 1)(ps[4].data_ptr() + 4)
+    one = (ctypes.c_longlong * 1)(8)
+    assert lib.dsrg_sgd_pack_f32(1, arr, arr, arr, None, None, None, one, None, None, 0.9, None) != 0     # not 16-byte aligned
+
+
+def test_trainer_steps_with_the_sgd_pack_kernel_equal_torch_fused_sgd(ops, monkeypatch):
+    """three DSRGTrainer steps with the update + packing kernel (the default) against the same steps with torch._fused_sgd_ and
+    the packs made inside each forward: same losses and weights up to the last-bit differences of the two update kernels carried
+    through three steps; from the second step on no convolution node packs a kernel (every pack is found fresh)"""
+    from dsrg_amd import trainer as T
+    from dsrg_amd.backbone import VGG16ASPP
+    device = torch.device("cuda", 0)
+    images, labels, cues = _batch(4, seed=9)
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(T, "_SGD_PACK", on)
+        tr = T.DSRGTrainer(device, seed=0, net=VGG16ASPP(dropout=0.0))
+        losses = [tr.step(images, labels, cues).detach().cpu() for _ in range(3)]
+        params = [p for g in tr.opt.groups for p in g["params"]]
+        kept = [e for e, p in ((ops._weight_packs.get(p.data_ptr()), p) for p in params) if e is not None and e.ref() is p]
+        if on:
+            assert len(kept) >= 8 and all(e.version == e.ref()._version for e in kept)   # (which layers take a packed route depends on the batch)
+        else:
+            assert not kept
+        out[on] = (torch.stack(losses), [p.detach().clone() for p in params])
+        del tr
+    assert torch.allclose(out[True][0], out[False][0], rtol=2e-3), (out[True][0], out[False][0])
+    for a, b in zip(out[True][1], out[False][1]):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-5)
+
+
 def test_bench_gpus_beyond_the_visible_ones_fails_in_one_line():
     """`python bench.py --gpus N` with fewer than N GPUs on the node: no traceback, one line naming the reason"""
     n = torch.cuda.device_count() + 1
