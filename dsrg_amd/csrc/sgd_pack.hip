@@ -36,7 +36,8 @@ struct SgdTensor {
     uint32_t cout, cin, taps;   // of a packed kernel
     uint32_t first_block;   // this tensor's first block in the launch
     float lr, wd;           // the tensor's group: base_lr * lr_mult, weight_decay * decay_mult
-    int plain;              // packed layouts of the direct kernels instead of the implicit-GEMM ones
+    int plain;              // packed layouts of the direct kernels instead of the implicit-GEMM ones; tensor not packed: 1 = take the scalar path
+    int g_split;            // the gradient is only 4-byte aligned (a view into a DistributedDataParallel bucket): dword loads
 };
 struct SgdArgs {
     SgdTensor t[kSgdTensors];
@@ -49,6 +50,11 @@ __device__ __forceinline__ float4 sgd4(float4 w, float4 g, float4 &b, float m, f
     float4 d = make_float4(g.x + wd * w.x, g.y + wd * w.y, g.z + wd * w.z, g.w + wd * w.w);
     b = make_float4(m * b.x + d.x, m * b.y + d.y, m * b.z + d.z, m * b.w + d.w);
     return make_float4(w.x - lr * b.x, w.y - lr * b.y, w.z - lr * b.z, w.w - lr * b.w);
+}
+
+__device__ __forceinline__ float4 load_grad4(const float *g, int split) {
+    if (split) return make_float4(g[0], g[1], g[2], g[3]);    // a lane still reads its own 16 contiguous bytes: the lines are used whole
+    return *reinterpret_cast<const float4 *>(g);
 }
 
 __global__ __launch_bounds__(256) void sgd_pack_kernel(SgdArgs a) {
@@ -65,11 +71,19 @@ __global__ __launch_bounds__(256) void sgd_pack_kernel(SgdArgs a) {
         // ---- a plain tensor (bias, classifier, first layer): 4096 elements per block, float4 per thread and pass
         if (!T.g) return;
         const size_t base = (size_t)blk * 4096;
+        if (T.plain) {                                       // a slice of a larger buffer that is not 16-byte aligned: one float at a time
+            for (size_t q = base + t; q < T.n && q < base + 4096; q += 256) {
+                const float d = T.g[q] + wd * T.p[q], b = m * T.buf[q] + d;
+                T.buf[q] = b;
+                T.p[q] = T.p[q] - lr * b;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const size_t e = base + (size_t)(i * 256 + t) * 4;
             if (e + 3 < T.n) {
-                const float4 w = *reinterpret_cast<const float4 *>(T.p + e), g = *reinterpret_cast<const float4 *>(T.g + e);
+                const float4 w = *reinterpret_cast<const float4 *>(T.p + e), g = load_grad4(T.g + e, T.g_split);
                 float4 b = *reinterpret_cast<const float4 *>(T.buf + e);
                 const float4 nw = sgd4(w, g, b, m, lr, wd);
                 *reinterpret_cast<float4 *>(T.buf + e) = b;
@@ -95,7 +109,7 @@ __global__ __launch_bounds__(256) void sgd_pack_kernel(SgdArgs a) {
         const size_t src = ((size_t)(ob * 64 + o) * T.taps + tap) * T.cin + cb * 64 + q * 4;
         float4 w = *reinterpret_cast<const float4 *>(T.p + src);
         if (T.g) {
-            const float4 g = *reinterpret_cast<const float4 *>(T.g + src);
+            const float4 g = load_grad4(T.g + src, T.g_split);
             float4 b = *reinterpret_cast<const float4 *>(T.buf + src);
             w = sgd4(w, g, b, m, lr, wd);
             *reinterpret_cast<float4 *>(T.buf + src) = b;
@@ -138,8 +152,10 @@ int launch_sgd_pack(int n, float *const *p, const float *const *g, float *const 
             T.lr = lr ? lr[i] : 0.0f; T.wd = wd ? wd[i] : 0.0f;
             if (!T.p || numel[i] < 1 || numel[i] > 0x7fffffffLL || (T.g && !T.buf))
                 return set_error(DSRG_ERR_INVALID, "sgd_pack: tensor %d: null parameter, bad size or a gradient without a momentum buffer", i);
-            if ((reinterpret_cast<uintptr_t>(T.p) | reinterpret_cast<uintptr_t>(T.g) | reinterpret_cast<uintptr_t>(T.buf)) & 15)
-                return set_error(DSRG_ERR_INVALID, "sgd_pack: tensor %d is not 16-byte aligned", i);
+            const uintptr_t low = reinterpret_cast<uintptr_t>(T.p) | reinterpret_cast<uintptr_t>(T.buf);
+            if (((low | reinterpret_cast<uintptr_t>(T.g)) & 3) || ((low & 15) && (T.fwd || T.dg)))
+                return set_error(DSRG_ERR_INVALID, "sgd_pack: tensor %d is not aligned (4 bytes; parameter and momentum of a packed kernel: 16)", i);
+            T.g_split = (reinterpret_cast<uintptr_t>(T.g) & 15) != 0;
             T.n = (uint32_t)numel[i];
             T.first_block = blocks;
             if (T.fwd || T.dg) {
@@ -150,6 +166,7 @@ int launch_sgd_pack(int n, float *const *p, const float *const *g, float *const 
                                      i, T.cout, T.cin, T.taps);
                 blocks += (T.cout / 64) * (T.cin / 64) * T.taps;
             } else {
+                T.plain = (low & 15) != 0;
                 blocks += (uint32_t)((numel[i] + 4095) / 4096);
             }
         }

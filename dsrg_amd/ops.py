@@ -596,11 +596,11 @@ def sgd_pack_step(params, grads, bufs, lrs, wds, momentum):
 
 
 def sgd_pack_eligible(p, g, b):
-    """can dsrg_sgd_pack_f32 update this parameter: float32 CUDA tensors of one dense layout, 16-byte aligned"""
+    """can dsrg_sgd_pack_f32 update this parameter: float32 CUDA tensors of one dense layout"""
     return p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and b.dtype == torch.float32 and g.is_cuda and \
         g.shape == p.shape and all(n == 1 or (sg == sp and sb == sp) for n, sp, sg, sb in zip(p.shape, p.stride(), g.stride(), b.stride())) and \
         (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))) and \
-        (p.data_ptr() | g.data_ptr() | b.data_ptr()) % 16 == 0
+        ((p.data_ptr() | b.data_ptr()) % 16 == 0 or p.data_ptr() not in _weight_packs)
 
 
 def pack_direct_weight_pair(weight, want_dgrad=True):

@@ -342,7 +342,7 @@ int dsrg_pack_conv_weight_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev
  * train-s.prototxt) of n float32 parameters, sixteen per launch, in the form  B <- momentum B + (g + wd W);  W <- W - lr B
  * (B = Caffe's history / lr), WITH the packed bf16 kernels of the convolution routes written from the new values in the same
  * pass (the packs of dsrg_pack_conv_weight_f32 / dsrg_pack_conv_weight_direct_f32 — the next forward then reads no float32
- * weight).  Host arrays of n entries each: param_dev / grad_dev / momentum_dev device pointers (16-byte aligned, same element
+ * weight).  Host arrays of n entries each: param_dev / grad_dev / momentum_dev device pointers (4-byte aligned; parameter and momentum of a packed kernel 16, same element
  * order; grad_dev[i] = NULL: tensor i is only packed); fwd_dev[i] / dgrad_dev[i] packed outputs or NULL (the arrays themselves
  * may be NULL: nothing packed); shape[4 i ..] = {cout, cin, taps (1 | 9), plain (1: the direct kernels' layouts)} of a packed
  * tensor, whose memory is (cout, taps, cin), 64 | cout, 64 | cin; numel[i]; lr[i] = base_lr * lr_mult, weight_decay[i] =
