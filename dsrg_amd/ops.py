@@ -530,18 +530,21 @@ def _packs_entry(weight, plain):
     return e
 
 
-def keep_weight_packs(params, on=True):
+def keep_weight_packs(params, owner):
     """an optimizer's declaration that every write it makes to these parameters either goes through sgd_pack_step or bumps their
-    version counter: the convolution nodes may then keep the packed kernels between steps"""
+    version counter: the convolution nodes may then keep the packed kernels between steps.  The claim lasts as long as `owner`
+    (the optimizer object) does — a parameter handed to another optimizer afterwards is packed inside every forward again;
+    owner=None withdraws it"""
+    ref = _weakref.ref(owner) if owner is not None else None
     for p in params:
-        p._dsrg_keep_packs = bool(on)
-        if not on:
-            _weight_packs.pop(p.data_ptr(), None)
+        p._dsrg_keep_packs = ref
+        _weight_packs.pop(p.data_ptr(), None)     # whatever an earlier owner left may have missed writes made since
 
 
 def _packs_kept(weight):
     # inside a hipGraph capture the packing launches belong in the graph (a replay must see the weights of its own time)
-    return getattr(weight, "_dsrg_keep_packs", False) and not torch.cuda.is_current_stream_capturing()
+    ref = getattr(weight, "_dsrg_keep_packs", None)
+    return ref is not None and ref() is not None and not torch.cuda.is_current_stream_capturing()
 
 
 def _packs_keep(weight, plain, fwd, dg):

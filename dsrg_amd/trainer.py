@@ -32,7 +32,7 @@ class CaffeSGD(object):
             # every write step() makes to a parameter is either dsrg_sgd_pack_f32's (which rewrites the packed bf16 kernels the
             # convolution nodes keep) or is followed by a bump of its version counter: the nodes may keep their packs
             from .ops import keep_weight_packs
-            keep_weight_packs([p for g in self.groups for p in g["params"] if p.is_cuda])
+            keep_weight_packs([p for g in self.groups for p in g["params"] if p.is_cuda], self)
 
     def lr(self):
         return self.base_lr * self.gamma ** (self.iter // self.stepsize)

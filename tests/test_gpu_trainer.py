@@ -365,7 +365,10 @@ def test_sgd_pack_kernel_equals_torch_fused_sgd_and_the_pack_kernel(ops):
     ps[6] = torch.nn.Parameter(odd[1:22])                             # a slice that is not 16-byte aligned (the scalar path)
     assert ps[6].data_ptr() % 16 == 4
     assert ops.pack_conv_weight_pair(ps[0], True, True)[0] is not ops.pack_conv_weight_pair(ps[0], True, True)[0]   # nothing kept unasked
-    ops.keep_weight_packs(ps)
+    class _Owner(object):
+        pass
+    owner = _Owner()
+    ops.keep_weight_packs(ps, owner)
     ref = [p.detach().clone(memory_format=torch.preserve_format) for p in ps]
     bufs, rbufs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
     lrs = [1e-2 * (1 + (i % 3)) for i in range(len(ps))]
@@ -409,6 +412,9 @@ def test_sgd_pack_kernel_equals_torch_fused_sgd_and_the_pack_kernel(ops):
     fwd, dgp = ops.pack_conv_weight_pair(ps[0], True, True)
     want = ops.pack_conv_weight_pair(ps[0].detach().clone(memory_format=torch.preserve_format), True, True)
     assert torch.equal(fwd, want[0]) and torch.equal(dgp, want[1])
+    # the claim ends with its owner: nothing is kept for the parameter afterwards
+    del owner
+    assert ops.pack_conv_weight_pair(ps[8], True, True)[0] is not ops.pack_conv_weight_pair(ps[8], True, True)[0]
     # malformed lists are refused
     lib = _lib.lib()
     import ctypes
