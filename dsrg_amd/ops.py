@@ -541,10 +541,14 @@ def keep_weight_packs(params, owner):
         _weight_packs.pop(p.data_ptr(), None)     # whatever an earlier owner left may have missed writes made since
 
 
+def _packs_claimed(weight):
+    ref = getattr(weight, "_dsrg_keep_packs", None)
+    return ref is not None and ref() is not None
+
+
 def _packs_kept(weight):
     # inside a hipGraph capture the packing launches belong in the graph (a replay must see the weights of its own time)
-    ref = getattr(weight, "_dsrg_keep_packs", None)
-    return ref is not None and ref() is not None and not torch.cuda.is_current_stream_capturing()
+    return _packs_claimed(weight) and weight.is_cuda and not torch.cuda.is_current_stream_capturing()
 
 
 def _packs_keep(weight, plain, fwd, dg):

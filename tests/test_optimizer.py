@@ -33,3 +33,45 @@ def test_caffe_sgd_skips_parameters_without_gradient():
     a.grad = torch.ones(3)
     opt.step()
     assert torch.allclose(a.detach(), torch.full((3,), 0.5)) and torch.equal(b.detach(), torch.ones(3))
+
+
+def test_caffe_sgd_bumps_version_counters_and_packs_are_kept_only_while_their_owner_lives():
+    """the contract the kept weight packs rest on (dsrg_amd/ops.py): (a) torch._fused_sgd_ itself leaves a parameter's version
+    counter alone — the reason a counter cannot be the only staleness test — while every CaffeSGD.step() bumps it; (b) packs are
+    kept only for parameters claimed by a live owner, and a new claim forgets what an earlier one left"""
+    import gc
+    from dsrg_amd import ops
+    p = torch.nn.Parameter(torch.randn(8))
+    g, b = torch.randn(8), torch.zeros(8)
+    v0 = p._version
+    try:
+        with torch.no_grad():
+            torch._fused_sgd_([p], [g], [b], weight_decay=0.0, momentum=0.9, lr=0.1, dampening=0.0, nesterov=False, maximize=False,
+                              is_first_step=False)
+        fused_bumps = p._version > v0                  # False on torch 2.10; if a later torch bumps it, all the better
+    except (RuntimeError, NotImplementedError):
+        fused_bumps = None
+    assert fused_bumps in (False, True, None)
+    opt = CaffeSGD([dict(params=[p], lr_mult=1.0, decay_mult=1.0)], base_lr=0.1)
+    p.grad = g.clone()
+    v1 = p._version
+    opt.step()
+    assert p._version > v1
+
+    class Owner(object):
+        pass
+    w = torch.nn.Parameter(torch.randn(64, 64, 3, 3))
+    assert not ops._packs_claimed(w)
+    o1 = Owner()
+    ops.keep_weight_packs([w], o1)
+    assert ops._packs_claimed(w)
+    e = ops._WeightPacks()
+    e.ref, e.version, e.fwd, e.dg, e.plain = ops._weakref.ref(w), w._version, torch.zeros(1), None, 0
+    ops._weight_packs[w.data_ptr()] = e
+    assert ops._packs_entry(w, 0) is e and ops._packs_entry(w, 1) is None     # another layout: the entry goes
+    ops._weight_packs[w.data_ptr()] = e
+    del o1
+    gc.collect()
+    assert not ops._packs_claimed(w)
+    ops.keep_weight_packs([w], Owner())                # the owner dies at once; the claim forgot the old entry
+    assert w.data_ptr() not in ops._weight_packs and not ops._packs_claimed(w)
