@@ -507,7 +507,9 @@ _wgrad_ws = {}
 # one value of the parameter: it records the tensor's version counter, which in-place writes bump (load_state_dict, a broadcast)
 # — then the node packs again, into the same buffers.  NOT every writer bumps it: torch's private fused optimizer ops
 # (torch._fused_sgd_, which torch.optim.SGD(fused=True) calls) leave the counter alone, which is why nothing is kept for a
-# parameter unless its optimizer says it plays along; unclaimed parameters are packed inside every forward as before.
+# parameter unless its optimizer says it plays along; unclaimed parameters are packed inside every forward as before.  Writes
+# through `param.data` (whose version counter is its own) or by foreign kernels are equally invisible: code that does that to a
+# claimed parameter calls forget_weight_packs afterwards.
 import weakref as _weakref
 
 
@@ -539,6 +541,12 @@ def keep_weight_packs(params, owner):
     for p in params:
         p._dsrg_keep_packs = ref
         _weight_packs.pop(p.data_ptr(), None)     # whatever an earlier owner left may have missed writes made since
+
+
+def forget_weight_packs(params):
+    """drop the kept packed kernels of these parameters (after a write that neither sgd_pack_step made nor a version counter saw)"""
+    for p in params:
+        _weight_packs.pop(p.data_ptr(), None)
 
 
 def _packs_claimed(weight):
