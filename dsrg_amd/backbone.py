@@ -671,6 +671,22 @@ class _HeadsFn(torch.autograd.Function):
         return (None, gw, gb1.unsqueeze(0).expand(n, O).contiguous()) + (tuple(gxs) if gxs is not None else (None,) * n)
 
 
+class _StackKernels(torch.autograd.Function):
+    """the (cout, cin, 1, 1) classifier kernels as one (n, cout, cin) tensor; backward hands every kernel its slice of the gradient
+    in the PARAMETER's strides (a channels_last 1x1 kernel has strides (cin, 1, cin, cin); the plain reshape's gradient has
+    (cin, 1, 1, 1) — the same memory, but DistributedDataParallel compares strides, warns and copies the gradient into its bucket)"""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.layouts = [(tuple(w.shape), tuple(w.stride())) for w in ws]
+        return torch.stack([w.reshape(w.shape[0], w.shape[1]) for w in ws])
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[i].as_strided(shape, stride) if g[i].is_contiguous() else g[i].reshape(shape)
+                     for i, (shape, stride) in enumerate(ctx.layouts))
+
+
 class VGG16ASPP(nn.Module):
     """features (conv1_1 .. conv5_3, pools, pool5a) + four ASPP branches fc6_k -> fc7_k -> fc8-SEC_k, summed.  On a GPU under
     bf16 autocast conv1_2, conv2_2, conv3_2 .. conv5_3, fc7_k and the classifiers are built with `chain_input` (see GemmConv2d):
@@ -741,7 +757,7 @@ class VGG16ASPP(nn.Module):
         heads = [br[-1] for br in self.branches]
         if hs[0].is_cuda and hs[0].dtype == torch.bfloat16 and len(hs) <= 4 and heads[0].out_channels <= 32 \
                 and heads[0].in_channels % 256 == 0:
-            w = torch.stack([m.weight.reshape(m.out_channels, m.in_channels) for m in heads])
+            w = _StackKernels.apply(*[m.weight for m in heads])
             b = torch.stack([m.bias for m in heads])
             # (on the grouped route the fc7_k outputs feed these classifiers and nothing else)
             links = [getattr(h, "_dsrg_grad_link", None) for h in hs]
