@@ -32,6 +32,9 @@ import time
 os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
 os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/dsrg_tunableop_%s.csv" % os.environ.get("LOCAL_RANK", "0"))   # one file per rank
 os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+# dmabuf IPC between the ranks of a node (the image exports this already; RCCL's intra-node transport fails with
+# `hipIpcGetMemHandle: invalid argument` without it): set before the HIP runtime starts, inherited by the ranks bench.py launches
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
