@@ -43,6 +43,8 @@ _vp, _i, _f, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_d
 SIGNATURES = {
     "dsrg_last_error": (ctypes.c_char_p, []),
     "dsrg_device_count": (_i, []),
+    "dsrg_host_register": (_i, [_vp, _sz]),
+    "dsrg_host_unregister": (_i, [_vp]),
     "dsrg_crf_create": (_i, [_i, _i, _i, ctypes.POINTER(_vp)]),
     "dsrg_crf_create_batch": (_i, [_i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "dsrg_crf_destroy": (_i, [_vp]),

@@ -214,6 +214,15 @@ def load_weights(net, path, rename=None):
     """--weights: .caffemodel (by layer name), .npz ("<layer>/<blob index>"), or a torch file (state_dict or a snapshot
     written by save_snapshot; loaded non-strictly by key, like Caffe by name).  -> names copied.  A file that matches no
     layer raises; layers left at their initial values are reported by a warning."""
+    try:
+        return _load_weights(net, path, rename)
+    finally:
+        if any(p.is_cuda for p in net.parameters()):         # kept bf16 kernels of the old values (ops.keep_weight_packs)
+            from .ops import forget_weight_packs
+            forget_weight_packs(net.parameters())
+
+
+def _load_weights(net, path, rename=None):
     if path.endswith(".caffemodel"):
         layers = read_caffemodel(path)
         return _report_copied(net, path, load_layers(net, layers, rename), len(layers))

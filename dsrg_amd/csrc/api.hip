@@ -69,6 +69,34 @@ extern "C" int dsrg_device_count(void) {
     return n;
 }
 
+extern "C" int dsrg_host_register(void *host, size_t bytes) {
+    if (!host || !bytes) return 0;
+    // memory the runtime already knows (its owner page-locked it, or it lies inside an earlier registration) is left alone:
+    // registering it again fails AND leaves the failure as the thread's last error for an unrelated launch check to report
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, host) == hipSuccess) {
+        if (at.type != hipMemoryTypeUnregistered) return 0;
+    } else {
+        (void)hipGetLastError();                             // (older runtimes answer "invalid value" for plain host memory)
+    }
+    const char *last = static_cast<const char *>(host) + bytes - 1;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, last) == hipSuccess) {
+        if (at.type != hipMemoryTypeUnregistered) return 0;
+    } else {
+        (void)hipGetLastError();
+    }
+    if (hipHostRegister(host, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return 1;
+}
+
+extern "C" int dsrg_host_unregister(void *host) {
+    if (!host) return 0;
+    if (hipHostUnregister(host) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return 1;
+}
+
 extern "C" int dsrg_ctx_create(int max_batch, int C, int H, int W, dsrg_ctx_t *out) {
     if (!out || max_batch < 1 || C < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "bad ctx shape");
     if (C > kMaxLabels) return set_error(DSRG_ERR_UNSUPPORTED, "at most %d labels", kMaxLabels);
@@ -698,6 +726,7 @@ void large_crf_set_stream(LargeCrf *c, hipStream_t s, bool async);
 struct dsrg_crf_s {
     int W, H, M;
     int nimg;                    // images per call: 1, or the batch size of dsrg_crf_create_batch (global-memory path only)
+    bool forced_large;           // made by dsrg_crf_create_batch: on the global-memory path whatever the map size
     dsrg::LargeCrf *large;
     dsrg_ctx_t ctx;
     float *neg_unary;            // device (M,N) planes = -U
@@ -735,7 +764,9 @@ static int crf_create(int W, int H, int nlabels, int nimages, dsrg_crf_t *out) {
         std::lock_guard<std::mutex> lock(g_crf_cache_mutex);
         for (int i = 0; i < kCrfCacheSlots; i++) {
             dsrg_crf_s *c = g_crf_cache[i];
-            if (c && c->W == W && c->H == H && c->M == nlabels && c->nimg == nimages && (!force_large || c->large)) {
+            // (an object is handed back only to the entry point that made it: a one-image object of dsrg_crf_create_batch lives on
+            // the global-memory path also for a map the LDS path takes, and dsrg_crf_create must not get that other implementation)
+            if (c && c->W == W && c->H == H && c->M == nlabels && c->nimg == nimages && c->forced_large == force_large) {
                 g_crf_cache[i] = nullptr;
                 c->have_unary = c->have_pairwise = false;
                 c->stream = nullptr; c->async = false;
@@ -748,7 +779,7 @@ static int crf_create(int W, int H, int nlabels, int nimages, dsrg_crf_t *out) {
     dsrg_crf_s *h = new (std::nothrow) dsrg_crf_s();
     if (!h) return set_error(DSRG_ERR_NOMEM, "host allocation failed");
     memset(h, 0, sizeof(*h));
-    h->W = W; h->H = H; h->M = nlabels; h->nimg = nimages;
+    h->W = W; h->H = H; h->M = nlabels; h->nimg = nimages; h->forced_large = force_large;
     if (nlabels > kMaxLabels) { delete h; return set_error(DSRG_ERR_UNSUPPORTED, "at most %d labels", kMaxLabels); }
     if (dsrg_device_count() < 1) { delete h; return set_error(DSRG_ERR_HIP, "no HIP device visible"); }
     if (force_large || !lattice_supported(2, W * H) || !lattice_supported(5, W * H)) {

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import yaml
 
-from . import ops
+from . import _lib, ops
 
 try:                                    # inside Caffe the layers derive from caffe.Layer (pylayers.py:23)
     import caffe as _caffe
@@ -90,7 +90,8 @@ except ImportError:                      # pragma: no cover - the image ships xx
 _TRUST = _os.environ.get("DSRG_PYLAYERS_TRUST") == "1"
 _epoch = [0]
 _MAX_RESIDENT = 64
-_resident = _OrderedDict()               # (address, shape, dtype) -> [epoch of the last full check, {form: digest}, device tensor]
+_resident = _OrderedDict()               # (address, shape, dtype) -> [epoch of the last full check, {form: digest}, device tensor,
+                                         #                              misses, epoch in which WE wrote the blob (or -1)]
 _pinned = _OrderedDict()                 # (address, nbytes) -> [the array (kept alive), sightings, registered?]
 _PIN = _os.environ.get("DSRG_PYLAYERS_PIN", "1") == "1"
 _pending = []                            # downloads of the current layer call: (host array, device tensor, remember?)
@@ -129,17 +130,15 @@ def _pin(a):
         while len(_pinned) > _MAX_RESIDENT:
             _, old = _pinned.popitem(last=False)
             if old[2]:
-                torch.cuda.cudart().cudaHostUnregister(old[0].ctypes.data)
+                _lib.lib().dsrg_host_unregister(old[0].ctypes.data)      # (the entry kept the array alive: still mapped)
     else:
         _pinned.move_to_end(k)
     e[1] += 1
     if not e[2] and e[1] >= 2:
         t0 = _time.perf_counter()
-        try:
-            rc = torch.cuda.cudart().cudaHostRegister(a.ctypes.data, a.nbytes, 0)
-            e[2] = int(rc) == 0
-        except Exception:                # an overlapping registration, a driver without the call: stay pageable
-            e[2] = False
+        # inside the library: memory HIP already knows (page-locked by its owner, overlapping an earlier registration) is
+        # skipped, and a refused registration leaves no HIP error behind for the next launch check
+        e[2] = _lib.lib().dsrg_host_register(a.ctypes.data, a.nbytes) == 1
         if not e[2]:
             e[1] = -(1 << 30)            # do not try again
         _tick("pin", t0)
@@ -179,8 +178,10 @@ def _dev(a, dtype=torch.float32, cache=True):
         _resident.move_to_end(k)
         in_epoch = hit[0] == _epoch[0]
         if in_epoch or hit[3] < 2:
-            # fully checked (or written by us) in this epoch: the sampled form decides; otherwise every byte
-            d = _digest(a, sampled_ok=in_epoch)
+            # written by US in this epoch (_publish: nobody else writes a top of ours inside an iteration): the sampled form
+            # decides; a blob the host provided is hashed in full at every sight — a sparse host write between two layer calls
+            # of one iteration must not be missed (a gradient checker, a unit driver that edits a blob and calls a layer again)
+            d = _digest(a, sampled_ok=hit[4] == _epoch[0])
             if hit[1].get(d[0]) == d[1]:
                 if d[0] == "full":
                     hit[0], hit[3] = _epoch[0], 0
@@ -194,15 +195,17 @@ def _dev(a, dtype=torch.float32, cache=True):
     forms = {samp[0]: samp[1]}
     if full is not None:
         forms[full[0]] = full[1]
-    elif hit is None or misses < 2:
+    elif hit is None or misses < 2 or a.nbytes <= (1 << 20):
+        # (a small blob keeps its full digest whatever its history: the images are seen by CRFLayer and again by DSRGLayer in
+        # every iteration, and the second sight of a host-provided blob compares every byte)
         full = _digest(a)
         forms[full[0]] = full[1]
     _remember(k, forms, t, misses)
     return t
 
 
-def _remember(k, forms, t, misses=0):
-    _resident[k] = [_epoch[0], forms, t, misses]
+def _remember(k, forms, t, misses=0, ours=False):
+    _resident[k] = [_epoch[0], forms, t, misses, _epoch[0] if ours else -1]
     _resident.move_to_end(k)
     while len(_resident) > _MAX_RESIDENT:
         _resident.popitem(last=False)
@@ -214,7 +217,7 @@ def _blob_id(a):
     if _TRUST:
         return (_key(a), _epoch[0])
     hit = _resident.get(_key(a))
-    d = _digest(a, sampled_ok=hit is not None and hit[0] == _epoch[0])
+    d = _digest(a, sampled_ok=hit is not None and hit[4] == _epoch[0])
     return d
 
 
@@ -252,7 +255,7 @@ def _finish():
             if not _TRUST:
                 d = _digest(host, sampled_ok=True)
                 forms[d[0]] = d[1]
-            _remember(_key(host), forms, src)
+            _remember(_key(host), forms, src, ours=True)
     del _pending[:]
 
 
@@ -267,6 +270,7 @@ def _kernels(fn, *a, **kw):
 
 
 _softmax_ran = [False]
+_forwards_seen = set()                   # the forward calls of the current epoch, by name
 
 
 class _call(object):
@@ -279,13 +283,24 @@ class _call(object):
         _call_name[0] = self.name
         # an epoch begins at the head of the path: SoftmaxLayer.forward, or CRFLayer.forward when no SoftmaxLayer ran in front of
         # it (a driver that starts at the CRF) — nothing checked before is taken on a sampled digest any more
+        # ... and so does it when a layer's forward runs a SECOND time inside one epoch: a driver that calls a loss layer or
+        # DSRGLayer on its own again and again (numeric gradient checks) never passes the head of the path, and the blobs we
+        # wrote in "this" iteration may have been edited by it since
+        bump = False
         if self.new_epoch == "softmax":
-            _epoch[0] += 1
+            bump = True
             _softmax_ran[0] = True
         elif self.new_epoch == "crf":
-            if not _softmax_ran[0]:
-                _epoch[0] += 1
+            bump = not _softmax_ran[0]
             _softmax_ran[0] = False
+        if self.name.endswith(".forward"):
+            if self.name in _forwards_seen:
+                bump = True
+            if bump:
+                _forwards_seen.clear()
+            _forwards_seen.add(self.name)
+        if bump:
+            _epoch[0] += 1
         self.t0 = _time.perf_counter()
         return self
 

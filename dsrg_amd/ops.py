@@ -212,7 +212,9 @@ def _crf_refine_large(probs, images, scale_factor, maxiter, want_log):
     un = probs.permute(0, 2, 3, 1).contiguous()
     try:
         q = CRF_device_batch(im, un, maxiter, scale_factor)
-    except _lib.DsrgError:
+    except _lib.DsrgError as e:
+        if e.code != _lib.ERR_UNSUPPORTED:                                       # out of memory, a HIP fault: not ours to retry
+            raise
         q = torch.stack([CRF_device(im[b], un[b], maxiter, scale_factor) for b in range(B)])
     q64 = q.permute(0, 3, 1, 2).double().clamp_min(1e-4)
     refined = (q64 / q64.sum(1, keepdim=True)).contiguous()
@@ -583,6 +585,29 @@ def _packs_for(weight, plain, want_fwd, want_dgrad, fwd_shape, dg_shape, fwd_cl=
     return fwd, dg, False
 
 
+# DSRG_CHECK_PACKS=N (debugging aid): every N-th time a forward takes kept packs for good, the parameter is packed again into
+# scratch buffers and compared — a writer the version counter cannot see (`p.data.copy_`, an EMA through `.data`, a foreign
+# kernel, torch's private fused optimizer ops) then fails loudly instead of training on kernels one update behind.  0 = off.
+_CHECK_PACKS = int(__import__("os").environ.get("DSRG_CHECK_PACKS", "0") or 0)
+_check_packs_calls = [0]
+
+
+def _check_kept_packs(weight, fwd, dg, pack):
+    """pack(fwd_buffer_or_None, dg_buffer_or_None) packs `weight` into the buffers given"""
+    if _CHECK_PACKS <= 0:
+        return
+    _check_packs_calls[0] += 1
+    if _check_packs_calls[0] % _CHECK_PACKS:
+        return
+    f2 = torch.empty_like(fwd) if fwd is not None else None
+    d2 = torch.empty_like(dg) if dg is not None else None
+    pack(f2, d2)
+    if (f2 is not None and not torch.equal(f2, fwd)) or (d2 is not None and not torch.equal(d2, dg)):
+        raise RuntimeError("DSRG_CHECK_PACKS: the kept bf16 kernels of a %s parameter no longer match its float32 value — it was "
+                           "written behind the version counter's back (param.data, a foreign kernel, torch._fused_sgd_); call "
+                           "dsrg_amd.ops.forget_weight_packs([param]) after such a write" % (tuple(weight.shape),))
+
+
 def sgd_pack_step(params, grads, bufs, lrs, wds, momentum):
     """Caffe's SGD update B <- momentum B + (g + wd W); W <- W - lr B of float32 CUDA parameters in one launch per sixteen
     tensors (dsrg_sgd_pack_f32), rewriting the packed bf16 kernels the convolution nodes keep for them in the same pass.
@@ -627,9 +652,12 @@ def pack_direct_weight_pair(weight, want_dgrad=True):
             and cin in DIRECT_CONV_CHANNELS and cout in DIRECT_CONV_CHANNELS):
         raise ValueError("pack_direct_weight_pair needs a float32 channels_last (cout,cin,3,3) CUDA parameter with 64 / 128 channels")
     fwd, dg, fresh = _packs_for(weight, 1, True, want_dgrad, (cout, cin, 3, 3), (cin, cout, 3, 3), fwd_cl=True)
+    pack = lambda f, d: check(_lib.lib().dsrg_pack_conv_weight_direct_f32(_ptr(weight.detach()), _ptr(f), _ptr(d), cout, cin, _stream()))
     if not fresh:
-        check(_lib.lib().dsrg_pack_conv_weight_direct_f32(_ptr(weight.detach()), _ptr(fwd), _ptr(dg), cout, cin, _stream()))
+        pack(fwd, dg)
         _packs_keep(weight, 1, fwd, dg)
+    else:
+        _check_kept_packs(weight, fwd, dg, pack)
     return fwd, (dg if want_dgrad else None)
 
 
@@ -698,9 +726,12 @@ def pack_conv_weight_pair(weight, want_fwd=True, want_dgrad=True):
             and cout % 64 == 0 and cin % 64 == 0 and k in (1, 3)):
         return (pack_conv_weight(weight) if want_fwd else None, pack_conv_weight(weight, for_dgrad=True) if want_dgrad else None)
     fwd, dg, fresh = _packs_for(weight, 0, want_fwd, want_dgrad, (cout, cin // 64, k * k, 64), (cin, cout // 64, k * k, 64))
+    pack = lambda f, d: check(_lib.lib().dsrg_pack_conv_weight_f32(_ptr(weight.detach()), _ptr(f), _ptr(d), cout, cin, k, _stream()))
     if not fresh:
-        check(_lib.lib().dsrg_pack_conv_weight_f32(_ptr(weight.detach()), _ptr(fwd), _ptr(dg), cout, cin, k, _stream()))
+        pack(fwd, dg)
         _packs_keep(weight, 0, fwd, dg)
+    else:
+        _check_kept_packs(weight, fwd, dg, pack)
     return (fwd if want_fwd else None), (dg if want_dgrad else None)
 
 

@@ -125,6 +125,12 @@ def params_checksum(tensors):
     return acc
 
 
+def distributed_rank():
+    """this process's rank in the default process group (0 outside one)"""
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 class DSRGTrainer(object):
     def __init__(self, device, world_size=1, seed=0, amp_dtype=torch.bfloat16, channels_last=True,
                  loss_fn=None, net=None, ddp=None, weights=None, snapshot=None, bucket_cap_mb=32):
@@ -158,7 +164,11 @@ class DSRGTrainer(object):
         self.opt = CaffeSGD(net.caffe_param_groups())
         if snapshot is not None:
             self.load(snapshot)
-        torch.manual_seed(seed + 1 + (device.index or 0))      # per-rank dropout stream
+        # per-rank dropout stream: seeded with the DISTRIBUTED rank, not the device ordinal — under a launcher that shows every
+        # process one GPU (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per rank) all of them are cuda:0, and they must still draw
+        # different masks for their different images
+        self.dropout_stream_seed = seed + 1 + distributed_rank()
+        torch.manual_seed(self.dropout_stream_seed)
 
     def save(self, prefix="models/model-s"):
         """solver-s.prototxt:16-17 `snapshot_prefix`: <prefix>_iter_N.caffemodel + .solverstate.pt (rank 0 writes)"""
@@ -167,7 +177,11 @@ class DSRGTrainer(object):
 
     def load(self, state_path):
         from .checkpoint import load_snapshot
-        return load_snapshot(self, state_path)
+        it = load_snapshot(self, state_path)
+        if self.device.type == "cuda":                       # (load_state_dict bumps the version counters; belt and braces)
+            from .ops import forget_weight_packs
+            forget_weight_packs(self.net.parameters())
+        return it
 
     def reduce_losses(self, losses):
         """the logging all-reduce of SURVEY 8e: `losses` of step() are this rank's shard means; their mean over ranks is the

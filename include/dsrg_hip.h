@@ -42,6 +42,14 @@ extern "C" {
 const char *dsrg_last_error(void);
 /* number of visible HIP devices (0 when there is none); never fails */
 int dsrg_device_count(void);
+/* Page-lock `bytes` of ordinary host memory at `host` in place (hipHostRegister), so that the copies between a Caffe blob
+ * (pylayers.py: bottom[i].data / top[i].data are host arrays the framework owns) and HBM run as DMA instead of through a
+ * bounce buffer.  Returns 1 = registered by this call, 0 = left alone: memory HIP already knows (page-locked by its owner —
+ * a hipHostMalloc'ed blob of a GPU-mode Caffe, a pinned torch tensor — or overlapping an earlier registration) or a refused
+ * registration.  Never fails and never leaves a HIP error behind for the next launch check to trip over.
+ * dsrg_host_unregister undoes a registration made here (call it only for pointers that returned 1); same guarantees. */
+int dsrg_host_register(void *host, size_t bytes);
+int dsrg_host_unregister(void *host);
 
 /* ------------------------------------------------------------------------ */
 /* 1. Single-image dense-CRF object: mirrors the C++ class DenseCRFWrapper     */

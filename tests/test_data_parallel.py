@@ -64,6 +64,9 @@ def _worker(rank, world, port, out_dir):
     # a bucket cap of ~1 KB splits TinyNet's 14 tensors over several buckets, as 32 MB does with the 37.9 M parameters of VGG16
     tr = DSRGTrainer(torch.device("cpu"), world_size=world, seed=0, amp_dtype=None, channels_last=False,
                      loss_fn=torch_loss, net=TinyNet(), bucket_cap_mb=0.001)
+    # the first thing the trainer's dropout stream yields on this rank (both ranks sit on "cpu": no device ordinal tells them apart,
+    # as with one visible GPU per process)
+    mask = torch.nn.functional.dropout(torch.ones(256), 0.5).clone()
     # the overlap of the gradient all-reduce with backward, observed: a communication hook (the default all-reduce, plus a
     # log line) fires per bucket as soon as the bucket's gradients exist; the first layer's weight gradient is the LAST thing
     # backward computes, so bucket events in front of it are all-reduces issued while backward was still running
@@ -89,7 +92,7 @@ def _worker(rank, world, port, out_dir):
     equal_after_drift, words_drift = tr.weights_equal_across_ranks()
     torch.save({"w": [p.detach().clone() for p in tr.net.parameters()], "events": events, "shard": shard_losses,
                 "reduced": reduced, "equal": equal, "words": words, "equal_after_drift": equal_after_drift,
-                "words_drift": words_drift}, os.path.join(out_dir, "w%d.pt" % rank))
+                "words_drift": words_drift, "mask": mask, "dropout_seed": tr.dropout_stream_seed}, os.path.join(out_dir, "w%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -110,6 +113,8 @@ def test_two_rank_gloo_equals_single_process_global_batch(tmp_path):
         assert r["equal"] is True and r["words"][0] == r["words"][1] and len(r["words"]) == 2
         assert r["equal_after_drift"] is False and r["words_drift"][0] != r["words_drift"][1]
     assert r0["words"] == r1["words"] and r0["words_drift"] == r1["words_drift"]
+    # per-rank dropout streams: seeded by the distributed rank (not by the device ordinal), so the ranks' masks differ
+    assert r1["dropout_seed"] == r0["dropout_seed"] + 1 and not torch.equal(r0["mask"], r1["mask"])
     torch.manual_seed(0)
     tr = DSRGTrainer(torch.device("cpu"), world_size=1, seed=0, amp_dtype=None, channels_last=False,
                      loss_fn=torch_loss, net=TinyNet())

@@ -1199,23 +1199,34 @@ def test_pylayers_resident_blobs_follow_host_writes():
     a = rng.random((16, 21, 41, 41), dtype=np.float32)
     with L._call("t", new_epoch="softmax"):
         t0 = L._dev(a)
-        assert L._dev(a) is t0                                   # same bytes, same epoch: the resident copy (sampled check)
+        assert L._dev(a) is t0                                   # same bytes, same epoch: the resident copy (every byte compared)
     with L._call("t", new_epoch="softmax"):
         assert L._dev(a) is t0                                   # next iteration, unchanged: full digest, still resident
-        a[7, 3, 20, 20] += 1.0                                   # a write in the middle of the blob, inside the iteration ...
-    with L._call("t", new_epoch="softmax"):
-        t1 = L._dev(a)                                           # ... is seen at the next iteration's first sight
+        a[7, 3, 20, 20] += 1.0                                   # a sparse write to a HOST-PROVIDED blob inside the iteration, at
+        t1 = L._dev(a)                                           # a position the sampled digest does not cover: seen at once
         assert t1 is not t0 and torch.equal(t1.cpu(), torch.from_numpy(a))
-        a[0, 0, 0, 0] += 1.0                                     # a write at a sampled position: seen at once
+    with L._call("t", new_epoch="softmax"):
+        assert L._dev(a) is t1
+        a[0, 0, 0, 0] += 1.0
         t2 = L._dev(a)
         assert t2 is not t1 and float(t2[0, 0, 0, 0]) == float(a[0, 0, 0, 0])
-    # a blob we wrote mirrors the tensor it was written from
+    # a blob we wrote mirrors the tensor it was written from: inside the iteration the sampled digest vouches for it ...
     host = np.zeros_like(a)
     with L._call("t", new_epoch="softmax"):
         L._publish(host, t2)
     assert np.array_equal(host, a)
     with L._call("t"):
         assert L._dev(host).data_ptr() == t2.data_ptr()          # (no upload: the tensor the blob was written from)
+    # ... and a layer whose forward runs a second time without the head of the path in between (a stand-alone driver: numeric
+    # gradient checks on a loss layer) begins a new iteration: every byte of a blob we wrote is compared again
+    e0 = L._epoch[0]
+    with L._call("X.forward"):
+        assert L._dev(host).data_ptr() == t2.data_ptr() and L._epoch[0] == e0
+    host[7, 3, 20, 21] += 1.0                                    # not a sampled position
+    with L._call("X.forward"):
+        assert L._epoch[0] == e0 + 1
+        t3 = L._dev(host)
+        assert t3.data_ptr() != t2.data_ptr() and torch.equal(t3.cpu(), torch.from_numpy(host))
     # non-contiguous input: uploaded from a temporary, never cached
     n0 = len(L._resident)
     with L._call("t"):
