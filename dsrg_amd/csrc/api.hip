@@ -55,7 +55,10 @@ extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_filter_opt
 // tests / tools only: pipeline of the implicit-GEMM convolution: 1 = two LDS stages of 64 reduction elements, every wave issuing
 // its DMA right behind the barrier; 3 (default) = the same with waves 4-7 issuing behind their first MFMA cluster; 2 = a ring of
 // four stages of 32 with three steps in flight; 4 = as 3 with the stream-K form wherever it is legal (by default only where it
-// wins); 5 = as 3 with the step's barrier in front of its last MFMA cluster and the next step's first fragments read before it; -1 = back to DSRG_IGEMM_VARIANT / the default; identical results up to the summation order of a cut tile
+// wins); 5 = as 3 with the step's barrier in front of its last MFMA cluster and the next step's first fragments read before it; 6 / 7 =
+// round 4's launches (every K-step multiplied) / 3 with flat-order skipping in the weight gradient; 8 = 3 with round 5's row-aligned
+// pixel tiles for the dilated launches, 9 = 3 with the class-ordered tiles wherever legal (by default only where they run fewer
+// K-steps); -1 = back to DSRG_IGEMM_VARIANT / the default; identical results up to the summation order of a cut tile
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_igemm_variant(int v) { dsrg::g_igemm_variant = v; }
 extern "C" __attribute__((visibility("default"))) void dsrg_debug_set_build_trace(void *dev_buf) { dsrg::g_build_dbg = dev_buf; }
 // tools only (not in the public header): device buffer of 16 u64 per filter block receiving phase timestamps

@@ -30,6 +30,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <queue>
 #include <vector>
 
@@ -45,6 +47,8 @@ constexpr int kBM = 256, kBN = 256;
 constexpr int kOutRow = 128 * 2 + 16;                      // epilogue: a wave's 64 pixels x 128 channels, padded rows
 constexpr int kOutWave = 64 * kOutRow;
 constexpr uint32_t kOob = 0x80000000u;                     // beyond any descriptor of this kernel: the load returns zeros
+constexpr int kRowTab = 8 * kOutWave;                      // cls_tiles: the pixel of each of the tile's 256 rows (int32, -1 = none), behind
+constexpr int kRowTabBytes = kBM * 4;                      // the stages and the epilogue's staging rows
 
 // BK = reduction elements per K-step, NST = LDS stages.  (64, 2): one step in flight behind the one being multiplied;
 // (32, 4): a ring with three steps in flight (counted vmcnt: the DMA of steps s + 1, s + 2 stays in flight across the barrier of
@@ -63,12 +67,20 @@ template <int BK, int NST> struct ICfg {
     static constexpr int KS = BK / 16;                     // MFMA k-slices per step
     static constexpr int SPC = 64 / BK;                    // steps per 64-channel chunk of a tap
     static constexpr int AHEAD = NST - 1;
-    static constexpr size_t LDS = (size_t)(NST * STAGE > 8 * kOutWave ? NST * STAGE : 8 * kOutWave);
+    static_assert(NST * STAGE <= kRowTab, "the row table sits behind the stages");
+    static constexpr size_t LDS = (size_t)kRowTab + kRowTabBytes;
     // chunk c of row r is stored at chunk position c ^ swz(r): the 16 rows a ds_read_b128 lane group touches then cover
     // all 64 banks (rows of 128 B: 2 rows per 256-byte bank line -> 3 bits from r >> 1; rows of 64 B: 4 per line -> r >> 2)
     __device__ static constexpr int swz(int r) { return BK == 64 ? (r >> 1) & 7 : (r >> 2) & 3; }
 };
 
+// a rectangle [y0, y0 + h) x [x0, x0 + w) of every image of the batch; its pixels (image-major, raster order inside) take the
+// indices q0 .. q0 + B h w - 1 of the launch's pixel order (IgemmArgs::cls_tiles)
+struct IgemmClass {
+    uint32_t rect;          // y0 | h << 8 | x0 << 16 | w << 24
+    int q0;
+};
+constexpr int kMaxClasses = 9;
 struct IgemmGroup {
     const uint16_t *x;      // (B, H, W, Cin) bf16
     const uint16_t *w;      // (Cout, Cin / 64, taps, 64) bf16
@@ -78,7 +90,8 @@ struct IgemmGroup {
                             // the ReLU (+ Dropout) backward of the layer below, when this launch is a data gradient
     float *colsum;          // (tiles_m, Cout) fp32 or nullptr: per 256-row tile, the column sums of what was stored —
                             // the partial bias gradient of the layer below (summed in fixed order by igemm_colsum_kernel)
-    int dil, pad_;
+    int dil, ncls;
+    IgemmClass cls[kMaxClasses];    // cls_tiles: the group's pixel order, classes by ascending q0
 };
 struct IgemmArgs {
     IgemmGroup g[4];
@@ -93,6 +106,10 @@ struct IgemmArgs {
     int row_tiles, rows_per_tile, bands;      // 1: a pixel tile = rows_per_tile whole rows of one image (bands of them per image)
     int skip_taps;          // 1: a K-step whose tap reaches no pixel of the tile (a dilated kernel near the map's border: all of
                             // its operand rows would be the zeros of the padding) is not loaded and not multiplied
+    int cls_tiles;          // 1: a pixel tile = 256 consecutive indices of the group's CLASS order (IgemmGroup::cls) instead of 256
+                            // consecutive pixels: a dilated tap (dy, dx) d reaches exactly the pixels of a rectangle of the map, so the
+                            // map falls into <= 3 x 3 rectangles inside each of which every pixel has the SAME live taps; ordered
+                            // class by class (most taps first), a tile multiplies padding only where it straddles two classes
 };
 
 // the random bytes of the four consecutive channels starting at element 4 * e4 of a launch's output: a counter-based
@@ -172,9 +189,32 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
         mvalid = min(kBM, a.M - m0);
     }
     const int n0 = tn * kBN;
-    const IgemmGroup G = a.g[grp];
+    const IgemmGroup &G = a.g[grp];
     const int taps = a.taps, Cin = a.Cin, W = a.W, H = a.H;
     const int ktot = taps * Cin;
+    // cls_tiles: row r of the tile is index m0 + r of the group's class order; its pixel goes to the row table (one row per
+    // thread: a search over <= 9 classes and two divisions), which the DMA geometry and the epilogue read
+    volatile int32_t *rowpix = reinterpret_cast<volatile int32_t *>(ig_lds + kRowTab);
+    const bool cls = a.cls_tiles != 0;
+    if (cls) {
+        if (tid < kBM) {
+            const int q = m0 + tid;
+            int m = -1;
+            if (q < a.M) {
+                uint32_t rect = G.cls[0].rect;
+                int q0 = G.cls[0].q0;
+#pragma unroll
+                for (int k = 1; k < kMaxClasses; k++)
+                    if (k < G.ncls && q >= G.cls[k].q0) { rect = G.cls[k].rect; q0 = G.cls[k].q0; }
+                const int cy0 = (int)(rect & 255u), ch = (int)((rect >> 8) & 255u), cx0 = (int)((rect >> 16) & 255u), cw = (int)(rect >> 24);
+                const int qq = q - q0, area = ch * cw, b = qq / area, rem = qq - b * area, yy = rem / cw, xx = rem - yy * cw;
+                m = (b * H + cy0 + yy) * W + cx0 + xx;
+            }
+            rowpix[tid] = m;
+        }
+        __syncthreads();
+    }
+    auto row_pixel = [&](int r) -> int { return cls ? rowpix[r] : (r < mvalid ? m0 + r : -1); };      // -1: the tile has no such row
 
     const rsrc_t rx = make_rsrc(G.x, (size_t)a.M * Cin * 2);
     const rsrc_t rw = make_rsrc(G.w, (size_t)a.Cout * ktot * 2);
@@ -185,8 +225,8 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
     for (int i = 0; i < C::IPW; i++) {
         const int r = wv * 32 + i * C::RPI + lane / C::CPR;
         const int c = (lane % C::CPR) ^ C::swz(r);         // source chunk that lands at chunk position lane % CPR
-        const int m = m0 + r;
-        const bool in = r < mvalid;
+        const int m = row_pixel(r);
+        const bool in = m >= 0;
         const int mm = in ? m : 0;
         const int hw = H * W;
         const int b = mm / hw, rem = mm - b * hw, y = rem / W, x = rem - y * W;
@@ -399,7 +439,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
                 v0 = fmaxf(v0, floor_) * a.out_scale; v1 = fmaxf(v1, floor_) * a.out_scale;
                 v2 = fmaxf(v2, floor_) * a.out_scale; v3 = fmaxf(v3, floor_) * a.out_scale;
                 if (a.drop_thresh) {                                             // uniform
-                    const uint32_t m = (uint32_t)(m0 + wm * 64 + j * 32 + l31);
+                    const uint32_t m = cls ? (uint32_t)rowpix[wm * 64 + j * 32 + l31] : (uint32_t)(m0 + wm * 64 + j * 32 + l31);
                     const uint32_t h = dropout_bytes((m * (uint32_t)a.Cout + (uint32_t)(nw + nl)) >> 2, seed_g, a.seed_hi);
                     v0 = (h & 0xffu) >= a.drop_thresh ? v0 * a.drop_scale : 0.0f;
                     v1 = ((h >> 8) & 0xffu) >= a.drop_thresh ? v1 * a.drop_scale : 0.0f;
@@ -415,9 +455,9 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
 #pragma unroll 4
         for (int it = 0; it < 16; it++) {
             const int p = it * 4 + (lane >> 4), ch = lane & 15;
-            const int m = m0 + wm * 64 + p;
+            const int m = row_pixel(wm * 64 + p);
             const uint4 v = *reinterpret_cast<const uint4 *>(O + p * kOutRow + ch * 16);
-            if (wm * 64 + p < mvalid) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
+            if (m >= 0) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
         }
         return;
     }
@@ -428,9 +468,8 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
     if (G.mask) {
 #pragma unroll
         for (int it = 0; it < 16; it++) {
-            const int m = m0 + wm * 64 + it * 4 + (lane >> 4);
-            mk[it] = wm * 64 + it * 4 + (lane >> 4) < mvalid ? *reinterpret_cast<const uint4 *>(G.mask + (size_t)m * a.Cout + nw + (lane & 15) * 8)
-                             : make_uint4(0, 0, 0, 0);
+            const int m = row_pixel(wm * 64 + it * 4 + (lane >> 4));
+            mk[it] = m >= 0 ? *reinterpret_cast<const uint4 *>(G.mask + (size_t)m * a.Cout + nw + (lane & 15) * 8) : make_uint4(0, 0, 0, 0);
         }
     } else {
 #pragma unroll
@@ -440,7 +479,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
 #pragma unroll
     for (int it = 0; it < 16; it++) {
         const int p = it * 4 + (lane >> 4), ch = lane & 15;
-        const int m = m0 + wm * 64 + p;
+        const int m = row_pixel(wm * 64 + p);
         const uint4 v = *reinterpret_cast<const uint4 *>(O + p * kOutRow + ch * 16);
         uint32_t w4[4] = {v.x, v.y, v.z, v.w};
         const uint32_t y4[4] = {mk[it].x, mk[it].y, mk[it].z, mk[it].w};
@@ -452,7 +491,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
             cs[2 * e] += __uint_as_float(w4[e] << 16);
             cs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
         }
-        if (wm * 64 + p < mvalid) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        if (m >= 0) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
     if (G.colsum) {                                          // uniform for the workgroup
 #pragma unroll
@@ -1175,6 +1214,70 @@ size_t conv_igemm_colsum_workspace(int ngroups, int B, int H, int W, int cout) {
     return (size_t)ngroups * conv_igemm_pixel_tiles(B, H, W) * (size_t)cout * sizeof(float);
 }
 
+// ---- class order of a dilated launch's pixels (IgemmArgs::cls_tiles)
+static uint32_t tap_mask_rect(int H, int W, int d, int y0, int y1, int x0, int x1) {      // the taps that reach a pixel of [y0, y1) x [x0, x1)
+    uint32_t m = 0;
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = (tap / 3 - 1) * d, dx = (tap % 3 - 1) * d;
+        if (std::max(y0, -dy) < std::min(y1, H - dy) && std::max(x0, -dx) < std::min(x1, W - dx)) m |= 1u << tap;
+    }
+    return m;
+}
+// the bands of an axis of n pixels inside each of which the taps -d / +d are either valid for every pixel or for none
+static int axis_bands(int n, int d, int (*out)[2]) {
+    if (d >= n) { out[0][0] = 0; out[0][1] = n; return 1; }
+    const int lo = std::min(d, n - d), hi = std::max(d, n - d), cut[4] = {0, lo, hi, n};
+    int k = 0;
+    for (int i = 0; i < 3; i++)
+        if (cut[i + 1] > cut[i]) { out[k][0] = cut[i]; out[k][1] = cut[i + 1]; k++; }
+    return k;
+}
+struct HostClass { int y0, y1, x0, x1; uint32_t mask; };
+static int build_classes(int H, int W, int d, HostClass *c) {      // most live taps first (ties: map order)
+    int yb[3][2], xb[3][2];
+    const int ny = axis_bands(H, d, yb), nx = axis_bands(W, d, xb);
+    int n = 0;
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) c[n++] = HostClass{yb[i][0], yb[i][1], xb[j][0], xb[j][1], tap_mask_rect(H, W, d, yb[i][0], yb[i][1], xb[j][0], xb[j][1])};
+    std::stable_sort(c, c + n, [](const HostClass &a, const HostClass &b) { return __builtin_popcount(a.mask) > __builtin_popcount(b.mask); });
+    return n;
+}
+// K-steps per 64-channel chunk (= live taps summed over the pixel tiles) of one group: class order / row-aligned / flattened tiles
+static long long tile_taps(int B, int H, int W, int d, int mode) {
+    const long long M = (long long)B * H * W;
+    long long tot = 0;
+    if (mode == 2) {                                         // class order
+        HostClass c[kMaxClasses];
+        const int n = build_classes(H, W, d, c);
+        long long q0[kMaxClasses + 1];
+        q0[0] = 0;
+        for (int k = 0; k < n; k++) q0[k + 1] = q0[k] + (long long)B * (c[k].y1 - c[k].y0) * (c[k].x1 - c[k].x0);
+        for (long long t0 = 0; t0 < M; t0 += kBM) {
+            const long long t1 = std::min(M, t0 + kBM);
+            uint32_t m = 0;
+            for (int k = 0; k < n; k++)
+                if (q0[k] < t1 && q0[k + 1] > t0) m |= c[k].mask;
+            tot += __builtin_popcount(m);
+        }
+    } else if (mode == 1) {                                  // whole rows of one image
+        const int r = kBM / W;
+        for (int y0 = 0; y0 < H; y0 += r) tot += (long long)B * __builtin_popcount(tap_mask_rect(H, W, d, y0, std::min(H, y0 + r), 0, W));
+    } else {                                                 // 256 consecutive pixels
+        for (long long t0 = 0; t0 < M; t0 += kBM) {
+            const long long t1 = std::min(M, t0 + kBM);
+            uint32_t m = 0;
+            for (long long p = t0; p < t1;) {                // row by row (a row piece is a rectangle)
+                const int rem = (int)(p % ((long long)H * W)), y = rem / W, x = rem % W;
+                const int x1 = (int)std::min<long long>(W, x + (t1 - p));
+                m |= tap_mask_rect(H, W, d, y, y + 1, x, x1);
+                p += x1 - x;
+            }
+            tot += __builtin_popcount(m);
+        }
+    }
+    return tot;
+}
+
 // set by launch_conv_igemm_backward around its calls of the two launchers below: they then validate, fill the argument block
 // and return it instead of launching
 static thread_local IgemmArgs *t_prep_d = nullptr;
@@ -1223,6 +1326,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     static LdsGrant grant[3];
     const int variant = igemm_variant() == 2 ? 1 : 0;       // 1, 3: two stages of 64; 2: ring of four stages of 32
     a.stagger = igemm_variant() >= 3;
+    const bool default_form = igemm_variant() == 3 || igemm_variant() == 8 || igemm_variant() == 9;      // (8 / 9: 3 with one tiling forced)
     const dim3 block(512);
     // stream-K only where it was measured to win (profiles/r04_igemm_stream_k.txt): a single round that fills at most 60 % of
     // the chip (conv4_1's data gradient: 106 tiles, 115 -> 88 us).  A cut tile costs its workgroups ~25 us (256 KB of
@@ -1231,7 +1335,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     // different rounds overlap: fc6 x 4, 6.6 rounds, 810 us whole against 902 us dealt out).
     const int units = igemm_cus(), tiles_total = a.tiles_per_group * ngroups, nsteps = (cin / 64) * k * k;
     const bool sk_wins = tiles_total * 100 <= units * 60, sk_forced = igemm_variant() == 4;      // 4: tests / tools, wherever legal
-    if (!fused_bwd && workspace && workspace_bytes >= conv_igemm_workspace() && ((igemm_variant() == 3 && sk_wins) || sk_forced) &&
+    if (!fused_bwd && workspace && workspace_bytes >= conv_igemm_workspace() && ((default_form && sk_wins) || sk_forced) &&
         (long long)tiles_total * nsteps >= (long long)units * 8 && tiles_total * 3 >= units) {
         IgemmSkArgs sk;
         sk.base = a;
@@ -1252,7 +1356,45 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     for (int g = 0; g < ngroups; g++)
         if (a.skip_taps && k == 3 && a.g[g].dil >= 3) a.xcd_mix = 1;
     static const bool row_tiles_on = [] { const char *e = getenv("DSRG_IGEMM_ROW_TILES"); return !e || atoi(e) != 0; }();      // tools: A/B
-    if (a.xcd_mix && row_tiles_on && W <= kBM && conv_igemm_row_tiles(H, W)) {
+    static const bool cls_tiles_on = [] { const char *e = getenv("DSRG_IGEMM_CLASS_TILES"); return !e || atoi(e) != 0; }();    // tools: A/B
+    const bool rows_ok = a.xcd_mix && row_tiles_on && W <= kBM && conv_igemm_row_tiles(H, W);
+    if (a.xcd_mix && cls_tiles_on && igemm_variant() != 8 && H <= 255 && W <= 255) {       // 8: tests — round 5's row-aligned tiles
+        // the class order pays where its tiles run fewer K-steps than the tiling it replaces (a map of few tiles has most of them
+        // straddle classes); decided once per geometry
+        struct Key { int B, H, W, d[4], n, rows; bool operator<(const Key &o) const { return memcmp(this, &o, sizeof(Key)) < 0; } };
+        static std::map<Key, bool> memo;
+        static std::mutex memo_mutex;
+        Key key;
+        memset(&key, 0, sizeof(key));
+        key.B = B; key.H = H; key.W = W; key.n = ngroups; key.rows = rows_ok;
+        for (int g = 0; g < ngroups; g++) key.d[g] = a.g[g].dil;
+        bool pays;
+        {
+            std::lock_guard<std::mutex> lock(memo_mutex);
+            auto it = memo.find(key);
+            if (it == memo.end()) {
+                long long now = 0, then = 0;
+                for (int g = 0; g < ngroups; g++) { now += tile_taps(B, H, W, a.g[g].dil, 2); then += tile_taps(B, H, W, a.g[g].dil, rows_ok ? 1 : 0); }
+                it = memo.emplace(key, now * 100 < then * 97).first;
+            }
+            pays = it->second;
+        }
+        if (pays || igemm_variant() == 9) {                  // 9: tests — the class order wherever it is legal
+            a.cls_tiles = 1;
+            for (int g = 0; g < ngroups; g++) {
+                HostClass c[kMaxClasses];
+                const int n = build_classes(H, W, a.g[g].dil, c);
+                long long q0 = 0;
+                a.g[g].ncls = n;
+                for (int k = 0; k < n; k++) {
+                    a.g[g].cls[k].rect = (uint32_t)c[k].y0 | (uint32_t)(c[k].y1 - c[k].y0) << 8 | (uint32_t)c[k].x0 << 16 | (uint32_t)(c[k].x1 - c[k].x0) << 24;
+                    a.g[g].cls[k].q0 = (int)q0;
+                    q0 += (long long)B * (c[k].y1 - c[k].y0) * (c[k].x1 - c[k].x0);
+                }
+            }
+        }
+    }
+    if (!a.cls_tiles && rows_ok) {
         // ... and cut them along map rows (see the kernel); tiles_m grows by the rows a band leaves empty (112 against 106 tiles
         // for sixteen 41x41 maps), which the skipped steps more than pay for
         a.row_tiles = 1;
@@ -1443,7 +1585,7 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
     float *bgp[1] = {bias_grad};
     const int dils[1] = {dil};
     static const bool merged_on = [] { const char *e = getenv("DSRG_IGEMM_MERGED_BWD"); return !e || atoi(e) != 0; }();      // tools: A/B
-    const bool can_merge = merged_on && k == 3 && dil < 3 && (igemm_variant() == 3 || igemm_variant() == 1);
+    const bool can_merge = merged_on && k == 3 && dil < 3 && (igemm_variant() == 3 || igemm_variant() == 1 || igemm_variant() == 8 || igemm_variant() == 9);
     IgemmBwdArgs a;
     memset(&a, 0, sizeof(a));
     int nd = 0, nw = 0, rc = DSRG_OK;

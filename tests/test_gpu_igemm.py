@@ -159,6 +159,42 @@ def test_igemm_skipping_on_random_shapes(ops):
         _close(skip[0], want, "case %d: %dx%dx%d dilation %d" % (case, B, H, W, dils[0]))
 
 
+@pytest.mark.parametrize("B,H,W", [(16, 41, 41), (1, 41, 41), (3, 65, 65), (2, 30, 50), (5, 7, 100), (2, 23, 9)])
+def test_igemm_class_ordered_tiles_are_bit_identical(ops, B, H, W):
+    """The dilated launches order their pixels class by class (the <= 3 x 3 rectangles of the map inside each of which every
+    pixel has the same live taps, most taps first) and cut THAT order into tiles of 256, so that a tile multiplies padding
+    only where it straddles two classes (conv_igemm.hip, IgemmArgs::cls_tiles; variant 9 forces it, 8 = round 5's row-aligned
+    tiles, 6 = every step of flat tiles).  Every output element still sums its live taps in the same order: forward (bias,
+    ReLU, Dropout: the mask is a function of the PIXEL, not of the tile row) and the masked data gradient are the same bits;
+    the bias gradient sums other partial rows (fp32 reassociation)."""
+    cin, cout = 256, 512
+    dils = [6, 12, 18, 24] if (H, W) != (23, 9) else [3, 5, 30, 4]
+    xs, ws, bs = [], [], []
+    for i in range(4):
+        x, w, b = _case(B, H, W, cin, cout, 3, 80 + i)
+        xs.append(x); ws.append(ops.pack_conv_weight(w)); bs.append(b)
+    gs = [torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=CL) for _ in range(4)]
+    wd = [ops.pack_conv_weight(torch.randn(cout, cin, 3, 3, device="cuda") * 0.02, for_dgrad=True) for _ in range(4)]
+    ys = [torch.relu(torch.randn(B, cin, H, W, device="cuda")).bfloat16().contiguous(memory_format=CL) for _ in range(4)]
+    out = {}
+    try:
+        for v in (6, 8, 9, 3):
+            ops.set_igemm_variant(v)
+            f = ops.conv_igemm(xs, ws, bs, dils, 3, True, 0.5, 4321, stream_k=False)
+            d, gb = ops.conv_igemm_dgrad(gs, wd, ys, dils, 3, 2.0)
+            out[v] = (f, d, gb)
+    finally:
+        ops.set_igemm_variant(-1)
+    for v in (8, 9, 3):
+        for i in range(4):
+            assert torch.equal(out[6][0][i], out[v][0][i]), (v, i)
+            assert torch.equal(out[6][1][i], out[v][1][i]), (v, i)
+            assert float((out[6][2][i] - out[v][2][i]).abs().max()) <= 1e-4 * float(out[6][2][i].abs().max()) + 1e-5, (v, i)
+    want = torch.relu(F.conv2d(xs[1].float(), _unpack(ws[1]), bs[1], padding=dils[1], dilation=dils[1]))
+    kept = out[9][0][1] != 0
+    assert ((out[9][0][1].float() - 2.0 * want)[kept].abs() <= 0.02 * want[kept].abs() + 2e-2).all()
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,dil,absorb", [
     (16, 41, 41, 512, 512, 1, True),      # conv4_2 / conv4_3: 212 data-gradient tiles + 252 weight-gradient workgroups in one grid
     (2, 41, 41, 512, 512, 2, True),       # conv5_x
