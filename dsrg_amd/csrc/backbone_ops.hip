@@ -5,6 +5,10 @@
 //   maxpool3x3    : 3x3 max pooling (stride 1 or 2, pad 1, optional ceil mode) forward with a 1-byte window code,
 //                   and the gather-form backward that reads the codes (no atomics, deterministic)
 #include "common.h"
+#include <algorithm>
+#ifndef DSRG_EXP
+#define DSRG_EXP 0                // experiment builds (Makefile EXP= EXPSRC=backbone_ops; tools only)
+#endif
 #include <cstdlib>
 #include <cstring>
 
@@ -711,6 +715,92 @@ __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float *__restri
     }
 }
 
+// The same data gradient for the shape the net has (O == 21 classes, K a multiple of 1024), bound by its 8 bytes per element (the
+// bf16 store + the bf16 mask read) instead of by the latency chain of the tiled form above: one workgroup = one branch, a STRIP of
+// consecutive rows, a block of 1024 channels; thread t keeps W_k[0..O)[4 t .. 4 t + 3] in registers for the whole strip (84
+// VGPRs), a row's O gradient values are workgroup-uniform (scalar loads: the row index is a function of the block and the loop
+// counter only), so a row costs O x 4 fmas per thread, one 8-byte mask load and one 8-byte store per thread — a wave reads and
+// writes 512 contiguous bytes, a workgroup the row's whole 2 KB.  Four rows per iteration are in flight.  Same fma order over the
+// outputs as heads_bwd_dx_kernel: identical bits.  Column sums: a thread adds up what it stored, one partial row per workgroup.
+template <int O, bool MASK>
+__global__ __launch_bounds__(256) void heads_bwd_dx_rows_kernel(const float *__restrict__ g, const float *__restrict__ w,
+                                                                unsigned char *__restrict__ gx, int M, int K, int HW, size_t branch_stride,
+                                                                HeadMask hm, int rows_per_wg) {
+    constexpr int OP = (O + 3) & ~3;                                 // a row of the strip's gradient in LDS: O floats padded to 16 bytes
+    extern __shared__ __attribute__((aligned(16))) float gs_rows[];  // [rows_per_wg][OP]
+    const int k = blockIdx.y, t = threadIdx.x;
+    const int c = blockIdx.z * 1024 + 4 * t;
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg), nr = r1 - r0;
+    for (int e = t; e < nr * OP; e += 256) {                         // (NCHW gradient: for one output, consecutive rows are contiguous)
+        const int o = e / nr, r = e - o * nr, m = r0 + r;
+        float v = 0.0f;
+        if (o < O) { const int b = m / HW, hw = m - b * HW; v = g[((size_t)b * O + o) * HW + hw]; }
+        gs_rows[r * OP + o] = v;
+    }
+    float wr[O][4];
+#pragma unroll
+    for (int o = 0; o < O; o++) {
+        const float4 v = *reinterpret_cast<const float4 *>(w + ((size_t)k * O + o) * K + c);
+        wr[o][0] = v.x; wr[o][1] = v.y; wr[o][2] = v.z; wr[o][3] = v.w;
+    }
+    __syncthreads();
+    unsigned char *dst = gx + (size_t)k * branch_stride;
+    const uint16_t *yk = MASK ? hm.y[k] : nullptr;
+    float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int R = 4;
+    // the mask rows of iteration i + 1 are on their way while iteration i computes (8 x 8 bytes per lane in flight: what stands
+    // between this kernel and its bandwidth is the latency of those loads, nothing else reads HBM here)
+    uint2 yn[R];
+    auto fetch_masks = [&](int r) {
+#pragma unroll
+        for (int j = 0; j < R; j++) yn[j] = r + j < nr ? *reinterpret_cast<const uint2 *>(yk + (size_t)(r0 + r + j) * K + c) : make_uint2(0u, 0u);
+    };
+    if (MASK) fetch_masks(0);
+    for (int r = 0; r < nr; r += R) {
+        uint2 y[R];
+        if (MASK) {
+#pragma unroll
+            for (int j = 0; j < R; j++) y[j] = yn[j];
+            if (r + R < nr) fetch_masks(r + R);
+        }
+        float acc[R][4];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const float *gr = gs_rows + min(r + j, nr - 1) * OP;    // (uniform address: every lane reads the same words — a broadcast)
+            float gv[OP];
+#pragma unroll
+            for (int q = 0; q < OP / 4; q++) {
+                const float4 v = *reinterpret_cast<const float4 *>(gr + 4 * q);
+                gv[4 * q] = v.x; gv[4 * q + 1] = v.y; gv[4 * q + 2] = v.z; gv[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[j][e] = 0.0f;
+#pragma unroll
+            for (int o = 0; o < O; o++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[j][e] = __builtin_fmaf(gv[o], wr[o][e], acc[j][e]);
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            uint32_t o2[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (MASK) {
+                    const uint32_t yy = e == 0 ? y[j].x : y[j].y;
+                    const uint32_t keep = ((int16_t)(yy & 0xffffu) > 0 ? 0x0000ffffu : 0u) | ((int32_t)yy >= 0x10000 ? 0xffff0000u : 0u);
+                    o2[e] = pack_bf16(acc[j][2 * e] * hm.scale, acc[j][2 * e + 1] * hm.scale) & keep;
+                    cs[2 * e] += __uint_as_float(o2[e] << 16);                     // (rows past the strip: mask 0)
+                    cs[2 * e + 1] += __uint_as_float(o2[e] & 0xffff0000u);
+                } else {
+                    o2[e] = pack_bf16(acc[j][2 * e], acc[j][2 * e + 1]);
+                }
+            }
+            if (r + j < nr) *reinterpret_cast<uint2 *>(dst + ((size_t)(r0 + r + j) * K + c) * 2) = make_uint2(o2[0], o2[1]);
+        }
+    }
+    if (MASK) *reinterpret_cast<float4 *>(hm.part + ((size_t)k * gridDim.x + blockIdx.x) * K + c) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+}
+
 // weight gradient, stage 1: partial[rc][k][o][c] = sum over the rows of chunk rc of g[m][o] x_k[m][c].  One workgroup = one
 // (branch, row chunk); wave q = channels [256 q, 256 q + 256): 8 MFMA tiles, tile t holding channels c0 + 8 j + t so that a lane's
 // 16-byte load of x feeds all eight.  g^T chunk through LDS.
@@ -859,9 +949,13 @@ __global__ __launch_bounds__(256) void heads_fwd_split_kernel(HeadArgs a) {
                 const float wf[8] = {wv[u][0].x, wv[u][0].y, wv[u][0].z, wv[u][0].w, wv[u][1].x, wv[u][1].y, wv[u][1].z, wv[u][1].w};
                 const int kn = kb + 16 * G + u * 16;
                 if (kn < a.K) {
+#if !(DSRG_EXP & 1)
                     xv[u] = *reinterpret_cast<const uint4 *>(xp + kn);
+#endif
+#if !(DSRG_EXP & 2)
                     wv[u][0] = *reinterpret_cast<const float4 *>(wp + kn);
                     wv[u][1] = *reinterpret_cast<const float4 *>(wp + kn + 4);
+#endif
                 }
                 hbf16x8 w0, w1, w2;
                 split3(wf, w0, w1, w2);
@@ -1000,9 +1094,18 @@ static int head_mask_tiles() {
     static const int t = [] { const char *e = getenv("DSRG_HEAD_TILES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 8; }();
     return t;
 }
+// rows per workgroup of the row-strip form (heads_bwd_dx_rows_kernel): long enough to amortise the 84 KB of W a workgroup loads,
+// short enough for a few rounds of the chip (DSRG_HEAD_ROWS overrides, tools only; 0 = the tiled kernel)
+static int head_strip_rows() {
+    static const int r = [] { const char *e = getenv("DSRG_HEAD_ROWS"); const int v = e ? atoi(e) : -1; return v >= 0 && v <= 512 ? v : 64; }();
+    return r;
+}
+static bool head_strips(int K, int O) { return head_strip_rows() > 0 && O == 21 && K % 1024 == 0; }
 size_t heads_bwd_relu_workspace(int nbr, int M, int K) {
     const int kHeadMaskTiles = head_mask_tiles();
-    return (size_t)nbr * ((M + 16 * kHeadMaskTiles - 1) / (16 * kHeadMaskTiles)) * (size_t)K * sizeof(float);
+    size_t rows = (size_t)((M + 16 * kHeadMaskTiles - 1) / (16 * kHeadMaskTiles));
+    if (head_strip_rows() > 0) rows = std::max(rows, (size_t)((M + head_strip_rows() - 1) / head_strip_rows()));
+    return (size_t)nbr * rows * (size_t)K * sizeof(float);
 }
 
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
@@ -1020,18 +1123,31 @@ int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float 
         if (!bias_grad || !colsum_ws || colsum_ws_bytes < heads_bwd_relu_workspace(nbr, M, K))
             return set_error(DSRG_ERR_INVALID, "heads backward: bias gradient / scratch of the absorbed ReLU missing or too small");
         hm.part = static_cast<float *>(colsum_ws);
-        hipLaunchKernelGGL(heads_bwd_dx_kernel<true>, dim3(nblk, nbr), dim3(256), 0, stream, g, w, static_cast<uint4 *>(gx), M, K, O, HW,
-                           gx_branch_stride, hm);
+        int nblk_s = nblk;
+        if (head_strips(K, O)) {
+            nblk_s = (M + head_strip_rows() - 1) / head_strip_rows();
+            hipLaunchKernelGGL((heads_bwd_dx_rows_kernel<21, true>), dim3(nblk_s, nbr, K / 1024), dim3(256),
+                               (size_t)head_strip_rows() * 24 * sizeof(float), stream, g, w, static_cast<unsigned char *>(gx), M, K, HW,
+                               gx_branch_stride, hm, head_strip_rows());
+        } else {
+            hipLaunchKernelGGL(heads_bwd_dx_kernel<true>, dim3(nblk, nbr), dim3(256), 0, stream, g, w, static_cast<uint4 *>(gx), M, K, O, HW,
+                               gx_branch_stride, hm);
+        }
         DSRG_LAUNCH_CHECK();
         const float *parts[4];
         float *outs[4];
-        for (int k = 0; k < nbr; k++) { parts[k] = hm.part + (size_t)k * nblk * K; outs[k] = bias_grad + (size_t)k * K; }
-        if (int rc2 = launch_igemm_colsum(parts, outs, nbr, nblk, K, stream)) return rc2;
+        for (int k = 0; k < nbr; k++) { parts[k] = hm.part + (size_t)k * nblk_s * K; outs[k] = bias_grad + (size_t)k * K; }
+        if (int rc2 = launch_igemm_colsum(parts, outs, nbr, nblk_s, K, stream)) return rc2;
     } else if (gx) {
         HeadMask hm;
         memset(&hm, 0, sizeof(hm));
-        hipLaunchKernelGGL(heads_bwd_dx_kernel<false>, dim3((M + 15) / 16, nbr), dim3(256), 0, stream, g, w, static_cast<uint4 *>(gx), M,
-                           K, O, HW, gx_branch_stride, hm);
+        if (head_strips(K, O))
+            hipLaunchKernelGGL((heads_bwd_dx_rows_kernel<21, false>), dim3((M + head_strip_rows() - 1) / head_strip_rows(), nbr, K / 1024),
+                               dim3(256), (size_t)head_strip_rows() * 24 * sizeof(float), stream, g, w, static_cast<unsigned char *>(gx), M, K, HW,
+                               gx_branch_stride, hm, head_strip_rows());
+        else
+            hipLaunchKernelGGL(heads_bwd_dx_kernel<false>, dim3((M + 15) / 16, nbr), dim3(256), 0, stream, g, w, static_cast<uint4 *>(gx), M,
+                               K, O, HW, gx_branch_stride, hm);
         DSRG_LAUNCH_CHECK();
     }
     if (gw) {

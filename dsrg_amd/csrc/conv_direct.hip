@@ -25,6 +25,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#ifndef DSRG_EXP
+#define DSRG_EXP 0                           // experiment builds (Makefile, EXP= / EXPSRC=conv_direct): 1 no halo fetch beyond the first
+#endif                                       // tile, 2 no output stores, 4 no MFMAs — what binds the forward kernel (tools only)
+
 namespace dsrg {
 namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -43,7 +47,11 @@ template <int CIN, int COUT, int TPW_ = (CIN == 64 ? 2 : 1)> struct Cfg {
     static constexpr int NG = COUT / (32 * TPW);           // waves across the output channels
     static constexpr int PG = 4 / NG;                      // waves across the pixels
     static constexpr int MT = 4 / PG;                      // 32-pixel M-tiles per wave
+#if DSRG_EXP & 8
+    static constexpr int KPS = 4;
+#else
     static constexpr int KPS = WGS == 2 ? 2 : 4;           // k-steps per step of the MFMA loop (the operand prefetch unit)
+#endif
     static constexpr int SPT = CG / KPS;                   // steps per tap
     static constexpr int STEPS = 9 * SPT;
     static constexpr int IN_STRIDE = CIN * 2 + 16;         // bytes per halo pixel in LDS
@@ -161,7 +169,11 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
     const rsrc_t rmask = make_rsrc(a.mask, BWD ? (size_t)a.B * a.H * a.W * COUT * 2 : 0);
     for (; t < a.ntiles; t += gridDim.x) {
         const int tn = t + gridDim.x;
+#if DSRG_EXP & 1
+        const bool more = false;
+#else
         const bool more = tn < a.ntiles;
+#endif
         unsigned char *in = conv_lds + cur * C::BUF, *other = conv_lds + (cur ^ 1) * C::BUF;
         if (BWD) {
             int b, y0, x0;
@@ -205,8 +217,14 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
 #pragma unroll
                 for (int i = 0; i < C::KPS; i++)
 #pragma unroll
-                    for (int j = 0; j < C::TPW; j++)
+                    for (int j = 0; j < C::TPW; j++) {
+#if DSRG_EXP & 4
+                        if (s == 0) acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s * C::KPS + i], ar[s & 1][i], acc[mt][j], 0, 0, 0);
+                        else asm volatile("" ::"v"(ar[s & 1][i]), "v"(wf[j][s * C::KPS + i]));
+#else
                         acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s * C::KPS + i], ar[s & 1][i], acc[mt][j], 0, 0, 0);
+#endif
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (more) park(other, mt);
@@ -261,7 +279,11 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
                     }
                     val = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                 }
+#if DSRG_EXP & 2
+                if (yy < a.H && xx < a.W && val.x == 0x12345678u)
+#else
                 if (yy < a.H && xx < a.W)
+#endif
                     *reinterpret_cast<uint4 *>(a.y + (((size_t)b * a.H + yy) * a.W + xx) * COUT + cg * 8) = val;
             }
             if (BWD) {
@@ -270,7 +292,9 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
             }
         }
         __syncthreads();                                         // this buffer is free for the tile after next
+#if !(DSRG_EXP & 1)
         cur ^= 1;
+#endif
     }
     if (BWD) {                                                   // one partial bias row per workgroup, fixed order
         const float *red = reinterpret_cast<const float *>(conv_lds + 2 * C::BUF);        // [256 threads][8]
