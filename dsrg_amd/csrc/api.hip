@@ -507,6 +507,14 @@ extern "C" int dsrg_avgpool3x3_s1_bf16(const void *in, void *out, int B, int H, 
     if (!in || !out) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_avgpool3x3_s1(in, out, B, H, W, C, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_add_relu_bf16(const void *a, const void *b, void *y, size_t n, void *stream) {
+    if (!a || !b || !y) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_add_relu(a, b, y, n, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_relu_mask_bf16(const void *g, const void *g2, const void *y, void *gm, size_t n, void *stream) {
+    if (!g || !y || !gm) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_relu_mask(g, g2, y, gm, n, static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_bias_grad_bf16(const void *g, float *bias_grad, float *partials, int partial_blocks, long rows, int C,
                                    void *stream) {
     if (!g || !bias_grad || !partials) return set_error(DSRG_ERR_INVALID, "NULL argument");

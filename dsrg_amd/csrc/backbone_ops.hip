@@ -429,6 +429,54 @@ int launch_avgpool3x3_s1(const void *in, void *out, int B, int H, int W, int C, 
     return DSRG_OK;
 }
 
+// ---- the tail of a ResNet bottleneck (train-f stage on the DeepLab-v2 ResNet-101, BASELINE.json configs[4]; no reference
+// counterpart): y = relu(a + b) in one pass over bf16 tensors (fp32 sum, one rounding) instead of an add and a threshold pass, and
+// its backward gm = (y > 0 ? g (+ g2) : 0) — g2: a second gradient of y that autograd would otherwise add in a pass of its own
+// (the block's output feeds the next block's first convolution AND its identity path).  Flat arrays, 16 bytes per thread.
+__global__ __launch_bounds__(256) void add_relu_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b, uint4 *__restrict__ y, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 va = a[i], vb = b[i];
+    const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        o[k] = pack_bf16(fmaxf(bf16_lo(wa[k]) + bf16_lo(wb[k]), 0.0f), fmaxf(bf16_hi(wa[k]) + bf16_hi(wb[k]), 0.0f));
+    y[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+__global__ __launch_bounds__(256) void relu_mask_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ g2, const uint4 *__restrict__ y,
+                                                        uint4 *__restrict__ gm, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 vg = g[i], vy = y[i];
+    uint32_t wg[4] = {vg.x, vg.y, vg.z, vg.w};
+    const uint32_t wy[4] = {vy.x, vy.y, vy.z, vy.w};
+    if (g2) {
+        const uint4 v2 = g2[i];
+        const uint32_t w2[4] = {v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) wg[k] = pack_bf16(bf16_lo(wg[k]) + bf16_lo(w2[k]), bf16_hi(wg[k]) + bf16_hi(w2[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)      // bf16 halves compared as signed 16-bit integers: +0, -0 and negatives drop
+        wg[k] &= ((int16_t)(wy[k] & 0xffffu) > 0 ? 0x0000ffffu : 0u) | ((int32_t)wy[k] >= 0x10000 ? 0xffff0000u : 0u);
+    gm[i] = make_uint4(wg[0], wg[1], wg[2], wg[3]);
+}
+int launch_add_relu(const void *a, const void *b, void *y, size_t n, hipStream_t stream) {
+    if (n == 0 || n % 8) return set_error(DSRG_ERR_INVALID, "add_relu: element count must be a positive multiple of 8");
+    hipLaunchKernelGGL(add_relu_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const uint4 *)a, (const uint4 *)b,
+                       (uint4 *)y, n / 8);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+int launch_relu_mask(const void *g, const void *g2, const void *y, void *gm, size_t n, hipStream_t stream) {
+    if (n == 0 || n % 8) return set_error(DSRG_ERR_INVALID, "relu_mask: element count must be a positive multiple of 8");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const uint4 *)g, (const uint4 *)g2,
+                       (const uint4 *)y, (uint4 *)gm, n / 8);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
 // ---- bias gradient of a (rows, C) bf16 matrix for any C <= 256 (the 21-channel fc8 outputs): column sums in f32 -------------
 // lanes walk the flat array, so a wave reads 128 contiguous bytes; thread t always meets channel (t % C) because the row
 // group a block advances by is a whole number of rows.  Partials per block, then bias_finalize_kernel.

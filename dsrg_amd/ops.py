@@ -454,6 +454,35 @@ def avgpool3x3_s1(x):
     return out
 
 
+def add_relu(a, b):
+    """relu(a + b) of two bf16 CUDA tensors of one shape and memory layout in one pass (fp32 sum, one rounding) — the tail of a
+    ResNet bottleneck"""
+    if not (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape == b.shape and a.numel() % 8 == 0):
+        raise ValueError("add_relu needs two bf16 CUDA tensors of one shape, 8 | elements")
+    if a.stride() != b.stride() or not (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last)):
+        a, b = a.contiguous(memory_format=torch.channels_last), b.contiguous(memory_format=torch.channels_last)
+    y = torch.empty_like(a)
+    check(_lib.lib().dsrg_add_relu_bf16(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()))
+    return y
+
+
+def relu_mask(g, y, g2=None):
+    """(g (+ g2)) where y > 0, else 0: the backward of add_relu (y its output); bf16 CUDA tensors of y's layout"""
+    if not (y.is_cuda and y.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and g.shape == y.shape and y.numel() % 8 == 0):
+        raise ValueError("relu_mask needs bf16 CUDA tensors of one shape, 8 | elements")
+    if not (y.is_contiguous() or y.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError("relu_mask: y must be dense")
+    mf = torch.contiguous_format if y.is_contiguous() else torch.channels_last
+
+    def dense(t):
+        return t if t.stride() == y.stride() else t.contiguous(memory_format=mf)
+    g = dense(g)
+    g2 = dense(g2) if g2 is not None else None
+    gm = torch.empty_like(y)
+    check(_lib.lib().dsrg_relu_mask_bf16(_ptr(g), _ptr(g2) if g2 is not None else None, _ptr(y), _ptr(gm), y.numel(), _stream()))
+    return gm
+
+
 DIRECT_CONV_CHANNELS = (64, 128)
 
 

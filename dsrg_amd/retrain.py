@@ -13,8 +13,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os as _os
+
 from .backbone import VGG16ASPP, GemmConv2d, _ConvFn
 from .trainer import CaffeSGD
+
+_IGEMM_BN = _os.environ.get("DSRG_RESNET_IGEMM", "1") == "1"      # tools: A/B against round 5's im2col + library-GEMM bottlenecks
 
 
 def interp_shrink(label, factor=8):
@@ -44,18 +48,105 @@ def poly_lr(base_lr, it, max_iter, power=0.9):
 
 
 class _FrozenBN(nn.Module):
-    """BatchNorm with fixed statistics (DeepLab-v2 trains ResNet-101 with use_global_stats)"""
+    """BatchNorm with fixed statistics (DeepLab-v2 trains ResNet-101 with use_global_stats).  train_affine=False (the default of
+    ResNet101DeepLab): gamma and beta are fixed too — the layer is a constant per-channel affine map, which the implicit-GEMM
+    route folds into the convolution in front of it (scale into the packed kernel, shift as the epilogue's bias)"""
 
-    def __init__(self, c):
+    def __init__(self, c, train_affine=True):
         super().__init__()
-        self.weight, self.bias = nn.Parameter(torch.ones(c)), nn.Parameter(torch.zeros(c))
+        self.weight, self.bias = nn.Parameter(torch.ones(c), requires_grad=train_affine), nn.Parameter(torch.zeros(c), requires_grad=train_affine)
         self.register_buffer("running_mean", torch.zeros(c))
         self.register_buffer("running_var", torch.ones(c))
+        self._folded = None                       # (versions, scale, shift) of the frozen map
+
+    def affine(self):
+        scale = self.weight * torch.rsqrt(self.running_var + 1e-5)
+        return scale, self.bias - self.running_mean * scale
+
+    def frozen_affine(self):
+        """(scale, shift) float32, computed once per value of the four tensors (their version counters)"""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version, self.weight.device)
+        if self._folded is None or self._folded[0] != key:
+            with torch.no_grad():
+                scale, shift = self.affine()
+                self._folded = (key, scale.float().contiguous(), shift.float().contiguous())
+        return self._folded[1], self._folded[2]
 
     def forward(self, x):
-        scale = self.weight * torch.rsqrt(self.running_var + 1e-5)
-        shift = self.bias - self.running_mean * scale
+        scale, shift = self.affine()
         return x * scale.view(1, -1, 1, 1).to(x.dtype) + shift.view(1, -1, 1, 1).to(x.dtype)
+
+
+class _FoldedIgemmFn(torch.autograd.Function):
+    """conv (1x1 or dilated 3x3, stride 1, 'same') -> constant per-channel affine (-> ReLU) of a ResNet bottleneck on the
+    implicit-GEMM kernels of the VGG path (ops.conv_igemm): the scale rides in the packed bf16 kernel (packed from w * scale, both
+    the forward and the flipped / transposed data-gradient form in one pass), the shift is the epilogue's bias.  Backward: ReLU
+    mask, data gradient by the same kernel, weight gradient by the implicit-GEMM weight-gradient kernel where its tiling takes the
+    shape (both sides multiples of 256 channels) and by the library otherwise; d/dw = scale * d/d(w * scale).
+    x: bf16 channels_last; w: the float32 master parameter (channels_last); scale, shift: float32 (cout), no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, dil, relu):
+        from .ops import conv_igemm, pack_conv_weight_pair
+        k = w.shape[2]
+        x = x if x.dtype == torch.bfloat16 else x.bfloat16()
+        wf = (w.detach() * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+        need_d = ctx.needs_input_grad[0]
+        pf, pd = pack_conv_weight_pair(wf, True, need_d)
+        (y,) = conv_igemm([x], [pf], [shift], [dil], k, relu)
+        ctx.save_for_backward(x, w, scale, y if relu else None)
+        ctx.pd, ctx.dil, ctx.relu, ctx.k = pd, dil, relu, k
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import conv_igemm, conv_igemm_wgrad, conv_igemm_wgrad_supported, relu_mask
+        x, w, scale, y = ctx.saved_tensors
+        cout, cin, k, d = w.shape[0], w.shape[1], ctx.k, ctx.dil
+        cl = torch.channels_last
+        g = g if g.dtype == torch.bfloat16 else g.bfloat16()
+        gm = relu_mask(g, y) if ctx.relu else (g if g.is_contiguous(memory_format=cl) else g.contiguous(memory_format=cl))
+        gx = conv_igemm([gm], [ctx.pd], None, [d], k, False)[0] if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            if conv_igemm_wgrad_supported(cin, cout, k):
+                (gwf,) = conv_igemm_wgrad([x], [gm], [d], k)                    # float32, channels_last
+            else:
+                p = d * (k // 2)
+                gwf = torch.ops.aten.convolution_backward(gm, x, w.to(torch.bfloat16), None, [1, 1], [p, p], [d, d], False, [0, 0], 1,
+                                                          [False, True, False])[1].float()
+            gw = gwf * scale.view(-1, 1, 1, 1)
+        return gx, gw, None, None, None, None
+
+
+class _AddReLUFn(torch.autograd.Function):
+    """relu(a + b) in one pass (ops.add_relu); both inputs receive the same masked gradient (one pass, ops.relu_mask)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        from .ops import add_relu
+        y = add_relu(a, b)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import relu_mask
+        (y,) = ctx.saved_tensors
+        gm = relu_mask(g if g.dtype == torch.bfloat16 else g.bfloat16(), y)
+        return gm, gm
+
+
+def _igemm_bn_route(x, conv, bn):
+    """conv + frozen affine on the implicit-GEMM kernels?  bf16 CUDA activations, stride 1, 'same' padding, channel counts the
+    forward AND the data-gradient launch take (conv_igemm: 64 | cin, 128 | cout, both ways round), a constant affine map"""
+    from .ops import conv_igemm_supported
+    k = conv.kernel_size[0]
+    return (x.is_cuda and conv.stride == (1, 1) and k in (1, 3) and conv.kernel_size == (k, k) and
+            conv.padding[0] == conv.dilation[0] * (k // 2) and conv.padding[0] == conv.padding[1] and conv.groups == 1 and conv.bias is None and
+            not bn.weight.requires_grad and not bn.bias.requires_grad and
+            conv_igemm_supported(conv.in_channels, conv.out_channels, k) and conv_igemm_supported(conv.out_channels, conv.in_channels, k) and
+            x.shape[0] * x.shape[2] * x.shape[3] >= 2048)
 
 
 def _conv_bn(x, conv, bn, relu):
@@ -63,6 +154,10 @@ def _conv_bn(x, conv, bn, relu):
     weights (W * scale per output channel, bias = shift) and the whole thing is one im2col + GEMM with the bias (and ReLU)
     in the epilogue (backbone._ConvFn; 1x1 convolutions need no im2col at all).  gamma / beta still train: their
     gradients flow through the weight-sized products instead of activation-sized reductions."""
+    if _IGEMM_BN and x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)) \
+            and _igemm_bn_route(x, conv, bn):
+        scale, shift = bn.frozen_affine()
+        return _FoldedIgemmFn.apply(x, conv.weight, scale, shift, conv.dilation[0], relu)
     if x.is_cuda and conv.stride == (1, 1) and conv.kernel_size[0] in (1, 3) and conv.in_channels % 8 == 0 and \
             conv.padding[0] == conv.dilation[0] * (conv.kernel_size[0] // 2):
         scale = bn.weight * torch.rsqrt(bn.running_var + 1e-5)
@@ -73,19 +168,22 @@ def _conv_bn(x, conv, bn, relu):
 
 
 class _Bottleneck(nn.Module):
-    def __init__(self, cin, mid, stride, dilation, down):
+    def __init__(self, cin, mid, stride, dilation, down, train_bn_affine=True):
         super().__init__()
         cout = mid * 4
-        self.c1, self.b1 = nn.Conv2d(cin, mid, 1, stride=stride, bias=False), _FrozenBN(mid)
-        self.c2, self.b2 = nn.Conv2d(mid, mid, 3, padding=dilation, dilation=dilation, bias=False), _FrozenBN(mid)
-        self.c3, self.b3 = nn.Conv2d(mid, cout, 1, bias=False), _FrozenBN(cout)
-        self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), _FrozenBN(cout)) if down else None
+        bn = lambda c: _FrozenBN(c, train_bn_affine)                      # noqa: E731
+        self.c1, self.b1 = nn.Conv2d(cin, mid, 1, stride=stride, bias=False), bn(mid)
+        self.c2, self.b2 = nn.Conv2d(mid, mid, 3, padding=dilation, dilation=dilation, bias=False), bn(mid)
+        self.c3, self.b3 = nn.Conv2d(mid, cout, 1, bias=False), bn(cout)
+        self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), bn(cout)) if down else None
 
     def forward(self, x):
         y = _conv_bn(x, self.c1, self.b1, True)
         y = _conv_bn(y, self.c2, self.b2, True)
         y = _conv_bn(y, self.c3, self.b3, False)
         idn = _conv_bn(x, self.down[0], self.down[1], False) if self.down is not None else x
+        if _IGEMM_BN and y.is_cuda and y.dtype == torch.bfloat16 and idn.dtype == torch.bfloat16 and y.numel() % 8 == 0:
+            return _AddReLUFn.apply(y, idn)                               # one pass each way instead of add + threshold
         return F.relu(y + idn)
 
 
@@ -93,15 +191,18 @@ class ResNet101DeepLab(nn.Module):
     """DeepLab-v2 ResNet-101: output stride 8 (res4 dilation 2, res5 dilation 4), ASPP 6/12/18/24
     summed; 513x513 -> 65x65 (BASELINE.json configs[4])."""
 
-    def __init__(self, num_classes=21, blocks=(3, 4, 23, 3)):
+    def __init__(self, num_classes=21, blocks=(3, 4, 23, 3), train_bn_affine=False):
+        """train_bn_affine=False: the BatchNorm layers are constant affine maps (fixed statistics AND fixed gamma / beta, the usual
+        DeepLab-v2 fine-tuning set-up), which lets the bottlenecks run on the implicit-GEMM kernels with the map folded in; True:
+        gamma and beta train (their gradients flow through the folded weights), on the im2col + library-GEMM route"""
         super().__init__()
-        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), _FrozenBN(64), nn.ReLU(inplace=True),
+        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), _FrozenBN(64, train_bn_affine), nn.ReLU(inplace=True),
                                   nn.MaxPool2d(3, 2, 1, ceil_mode=True))
         cfg = [(64, blocks[0], 1, 1), (128, blocks[1], 2, 1), (256, blocks[2], 1, 2), (512, blocks[3], 1, 4)]
         layers, cin = [], 64
         for mid, n, stride, dil in cfg:
             for i in range(n):
-                layers.append(_Bottleneck(cin, mid, stride if i == 0 else 1, dil, down=(i == 0)))
+                layers.append(_Bottleneck(cin, mid, stride if i == 0 else 1, dil, down=(i == 0), train_bn_affine=train_bn_affine))
                 cin = mid * 4
         self.layers = nn.Sequential(*layers)
         self.aspp = nn.ModuleList([nn.Conv2d(2048, num_classes, 3, padding=d, dilation=d) for d in (6, 12, 18, 24)])
@@ -119,6 +220,8 @@ class ResNet101DeepLab(nn.Module):
     def caffe_param_groups(self):
         groups = {}
         for name, p in self.named_parameters():
+            if not p.requires_grad:
+                continue
             is_head, is_bias = name.startswith("aspp"), name.endswith("bias")
             key = ((10.0 if is_head else 1.0) * (2.0 if is_bias else 1.0), 0.0 if is_bias else 1.0)
             groups.setdefault(key, []).append(p)

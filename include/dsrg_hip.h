@@ -274,6 +274,12 @@ int dsrg_relu_bwd_bias_bf16(const void *g_dev, const void *y_dev, void *gm_dev, 
  * e.g. the 21-channel fc8 outputs).  partials: device scratch of partial_blocks * C floats. */
 int dsrg_bias_grad_bf16(const void *g_dev, float *bias_grad_dev, float *partials_dev, int partial_blocks, long rows, int C,
                         void *stream);
+/* The tail of a ResNet bottleneck (the train-f stage on the DeepLab-v2 ResNet-101 of BASELINE.json configs[4]; the reference
+ * trains VGG16 only, train-f.prototxt:15-720 — backbone plumbing): y = relu(a + b) over n bf16 elements (fp32 sum, one
+ * rounding), n % 8 == 0; and its backward gm = (y > 0) ? g (+ g2) : 0 — g2_dev (may be NULL): a second gradient of y to be
+ * added first (the sum autograd would otherwise take in a pass of its own). */
+int dsrg_add_relu_bf16(const void *a_dev, const void *b_dev, void *y_dev, size_t n, void *stream);
+int dsrg_relu_mask_bf16(const void *g_dev, const void *g2_dev, const void *y_dev, void *gm_dev, size_t n, void *stream);
 /* 3x3 / stride 1 / pad 1 average pooling over padded windows (Caffe AVE pooling, pool5a of train-s.prototxt), NHWC bf16,
  * C % 8 == 0.  The stencil is symmetric: the backward pass is the same call on the output gradient. */
 int dsrg_avgpool3x3_s1_bf16(const void *in_dev, void *out_dev, int B, int H, int W, int C, void *stream);

@@ -1014,34 +1014,68 @@ def test_fused_relu_dropout_backward_matches_unfused_sequence():
     assert torch.equal(y1, y2)                                      # no dropout in eval mode
 
 
-def test_resnet_folded_bn_path_matches_unfused_reference():
+@pytest.mark.parametrize("train_affine,size", [(True, 65), (False, 257)])
+def test_resnet_folded_bn_path_matches_unfused_reference(train_affine, size):
     """train-f's ResNet-101: conv + frozen BN (+ ReLU) folded into one GEMM on the GPU against the plain
-    conv -> affine -> relu sequence in fp32 on the CPU, forward and the gradients of conv weights, gamma and beta"""
+    conv -> affine -> relu sequence in fp32 on the CPU, forward and the gradients.  train_affine: gamma and beta train (im2col +
+    library GEMM, the affine folded into the weights by autograd); otherwise (the default) the BatchNorm layers are constant maps
+    and the bottlenecks whose channel counts the kernels take run on the implicit-GEMM kernels — scale in the packed kernel,
+    shift as the epilogue's bias, relu(y + identity) in one pass: at 257 x 257 the res3 .. res5 maps have 2 178 pixels, enough
+    for that route to be taken (checked: the nodes are in the graph)"""
     from dsrg_amd import retrain as R
     torch.manual_seed(0)
-    ref = R.ResNet101DeepLab(blocks=(1, 1, 1, 1))
+    ref = R.ResNet101DeepLab(blocks=(1, 1, 1, 1), train_bn_affine=train_affine)
     with torch.no_grad():
         for m in ref.modules():                      # non-trivial statistics and affine parameters
             if isinstance(m, R._FrozenBN):
                 m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
                 m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
-    net = R.ResNet101DeepLab(blocks=(1, 1, 1, 1))
+    net = R.ResNet101DeepLab(blocks=(1, 1, 1, 1), train_bn_affine=train_affine)
     net.load_state_dict(ref.state_dict())
     net = net.cuda().to(memory_format=torch.channels_last)
-    x = torch.randn(2, 3, 65, 65)
-    g = torch.randn(2, 21, 9, 9)
+    x = torch.randn(2, 3, size, size)
+    h = (size - 1) // 8 + 1
+    g = torch.randn(2, 21, h, h)
     yr = ref(x)
     (yr * g).sum().backward()
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        yg = net(x.cuda().contiguous(memory_format=torch.channels_last)).float()
+        out = net(x.cuda().contiguous(memory_format=torch.channels_last))
+        yg = out.float()
+    if not train_affine:                             # the implicit-GEMM nodes and the fused block tails are what ran
+        seen, todo = set(), [out.grad_fn]
+        while todo:
+            f = todo.pop()
+            if f is None or f in seen:
+                continue
+            seen.add(f)
+            todo.extend(nf for nf, _ in f.next_functions)
+        names = [type(f).__name__ for f in seen]
+        assert sum(n.startswith("_FoldedIgemmFn") for n in names) >= 7 and sum(n.startswith("_AddReLUFn") for n in names) == 4, names
     (yg * g.cuda()).sum().backward()
     assert yg.shape == yr.shape
     assert (yg.cpu() - yr).norm() < 0.05 * yr.norm()
     pr, pg = dict(ref.named_parameters()), dict(net.named_parameters())
-    for name in ["layers.3.c3.weight", "layers.3.b3.weight", "layers.3.b3.bias", "layers.2.c2.weight", "layers.2.b2.weight",
-                 "layers.1.c1.weight", "layers.1.b1.bias", "layers.0.down.0.weight", "layers.0.b2.weight", "aspp.2.weight"]:
+    affine = ["layers.3.b3.weight", "layers.3.b3.bias", "layers.2.b2.weight", "layers.1.b1.bias", "layers.0.b2.weight"]
+    for name in ["layers.3.c3.weight", "layers.3.c1.weight", "layers.3.down.0.weight", "layers.2.c2.weight", "layers.2.c3.weight",
+                 "layers.1.c1.weight", "layers.1.c2.weight", "layers.0.down.0.weight", "aspp.2.weight"] + (affine if train_affine else []):
         a, b = pg[name].grad.float().cpu(), pr[name].grad
         assert torch.isfinite(a).all() and (a - b).norm() < 0.15 * b.norm(), (name, float((a - b).norm() / b.norm()))
+    if not train_affine:
+        assert all(pg[n].grad is None and not pg[n].requires_grad for n in affine)
+
+
+def test_add_relu_and_its_backward(ops):
+    """ops.add_relu / ops.relu_mask (the fused tail of a ResNet bottleneck): relu(a + b) with one rounding, and (g (+ g2)) where y > 0"""
+    torch.manual_seed(3)
+    for shape, cl in [((2, 64, 9, 7), True), ((3, 8, 5, 5), False), ((1, 256, 33, 33), True)]:
+        mk = lambda: (torch.randn(*shape, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last) if cl  # noqa: E731
+                      else torch.randn(*shape, device="cuda").bfloat16())
+        a, b, g, g2 = mk(), mk(), mk(), mk()
+        y = ops.add_relu(a, b)
+        assert torch.equal(y, torch.relu(a.float() + b.float()).bfloat16()) and y.stride() == a.stride()
+        assert torch.equal(ops.relu_mask(g, y), torch.where(y > 0, g, torch.zeros_like(g)))
+        want = torch.where(y > 0, (g.float() + g2.float()).bfloat16(), torch.zeros_like(g))
+        assert torch.equal(ops.relu_mask(g, y, g2), want)
 
 
 def test_col2im_is_the_adjoint_of_im2col(ops):

@@ -474,12 +474,13 @@ def test_config5_retrain_step_resnet101_513():
     label = label.to(device)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         assert tr.net(images.contiguous(memory_format=torch.channels_last)).shape == (2, 21, 65, 65)
-    w0 = [p.detach().clone() for p in tr.net.parameters()]
+    params = [p for p in tr.net.parameters() if p.requires_grad]      # (the BatchNorm maps are constants: gamma / beta do not train)
+    w0 = [p.detach().clone() for p in params]
     l0 = tr.step(images, label)
     l1 = tr.step(images, label)
     torch.cuda.synchronize()
     assert torch.isfinite(l0) and torch.isfinite(l1) and 2.0 < float(l0) < 4.5          # ~log(21) at initialisation
-    moved = sum(int(not torch.equal(a, b.detach())) for a, b in zip(w0, tr.net.parameters()))
-    assert moved == len(w0), (moved, len(w0))
+    moved = sum(int(not torch.equal(a, b.detach())) for a, b in zip(w0, params))
+    assert moved == len(w0) and len(w0) == 104 + 4 * 2, (moved, len(w0))
     assert tr.opt.iter == 2 and abs(tr.opt.base_lr - poly_lr(tr.base_lr, 1, tr.max_iter)) < 1e-12
     print("train-f ResNet-101 513x513 losses:", float(l0), float(l1))
