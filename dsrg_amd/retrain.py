@@ -86,7 +86,9 @@ class _FoldedIgemmFn(torch.autograd.Function):
     x: bf16 channels_last; w: the float32 master parameter (channels_last); scale, shift: float32 (cout), no gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, shift, dil, relu):
+    def forward(ctx, x, w, scale, shift, dil, relu, link_in=None, link_out=None):
+        """link_in / link_out (backbone._GradLink or None): x is the ReLU output of the node in front and feeds nothing but this
+        node (its ReLU backward then rides in this node's data-gradient store) / this node's output is such an x for the next"""
         from .ops import conv_igemm, pack_conv_weight_pair
         k = w.shape[2]
         x = x if x.dtype == torch.bfloat16 else x.bfloat16()
@@ -96,17 +98,30 @@ class _FoldedIgemmFn(torch.autograd.Function):
         (y,) = conv_igemm([x], [pf], [shift], [dil], k, relu)
         ctx.save_for_backward(x, w, scale, y if relu else None)
         ctx.pd, ctx.dil, ctx.relu, ctx.k = pd, dil, relu, k
+        ctx.link_in = link_in if (need_d and x.is_contiguous(memory_format=torch.channels_last)) else None
+        ctx.link_out = link_out if relu else None
+        if ctx.link_out is not None:
+            ctx.link_out.scale, ctx.link_out.gb = 1.0, None
         return y
 
     @staticmethod
     def backward(ctx, g):
-        from .ops import conv_igemm, conv_igemm_wgrad, conv_igemm_wgrad_supported, relu_mask
+        from .ops import conv_igemm, conv_igemm_dgrad, conv_igemm_wgrad, conv_igemm_wgrad_supported, relu_mask
         x, w, scale, y = ctx.saved_tensors
         cout, cin, k, d = w.shape[0], w.shape[1], ctx.k, ctx.dil
         cl = torch.channels_last
         g = g if g.dtype == torch.bfloat16 else g.bfloat16()
-        gm = relu_mask(g, y) if ctx.relu else (g if g.is_contiguous(memory_format=cl) else g.contiguous(memory_format=cl))
-        gx = conv_igemm([gm], [ctx.pd], None, [d], k, False)[0] if ctx.needs_input_grad[0] else None
+        masked = ctx.link_out.take(g) is not None if ctx.link_out is not None else False      # the consumer's data gradient came masked
+        gm = (g if masked else relu_mask(g, y)) if ctx.relu else g
+        gm = gm if gm.is_contiguous(memory_format=cl) else gm.contiguous(memory_format=cl)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.link_in is not None:
+                # x = relu(...) of the node in front, read by this node only: its backward is a mask in this launch's store
+                (gx,), _ = conv_igemm_dgrad([gm], [ctx.pd], [x], [d], k, 1.0, bias_grad=False)
+                ctx.link_in.leave(gx, True)
+            else:
+                gx = conv_igemm([gm], [ctx.pd], None, [d], k, False)[0]
         gw = None
         if ctx.needs_input_grad[1]:
             if conv_igemm_wgrad_supported(cin, cout, k):
@@ -116,7 +131,7 @@ class _FoldedIgemmFn(torch.autograd.Function):
                 gwf = torch.ops.aten.convolution_backward(gm, x, w.to(torch.bfloat16), None, [1, 1], [p, p], [d, d], False, [0, 0], 1,
                                                           [False, True, False])[1].float()
             gw = gwf * scale.view(-1, 1, 1, 1)
-        return gx, gw, None, None, None, None
+        return gx, gw, None, None, None, None, None, None
 
 
 class _AddReLUFn(torch.autograd.Function):
@@ -149,7 +164,7 @@ def _igemm_bn_route(x, conv, bn):
             x.shape[0] * x.shape[2] * x.shape[3] >= 2048)
 
 
-def _conv_bn(x, conv, bn, relu):
+def _conv_bn(x, conv, bn, relu, link_in=None, link_out=None):
     """conv -> frozen-statistics BN (-> ReLU).  On the GPU, for stride-1 convolutions, the BN affine is folded into the
     weights (W * scale per output channel, bias = shift) and the whole thing is one im2col + GEMM with the bias (and ReLU)
     in the epilogue (backbone._ConvFn; 1x1 convolutions need no im2col at all).  gamma / beta still train: their
@@ -157,7 +172,7 @@ def _conv_bn(x, conv, bn, relu):
     if _IGEMM_BN and x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)) \
             and _igemm_bn_route(x, conv, bn):
         scale, shift = bn.frozen_affine()
-        return _FoldedIgemmFn.apply(x, conv.weight, scale, shift, conv.dilation[0], relu)
+        return _FoldedIgemmFn.apply(x, conv.weight, scale, shift, conv.dilation[0], relu, link_in, link_out)
     if x.is_cuda and conv.stride == (1, 1) and conv.kernel_size[0] in (1, 3) and conv.in_channels % 8 == 0 and \
             conv.padding[0] == conv.dilation[0] * (conv.kernel_size[0] // 2):
         scale = bn.weight * torch.rsqrt(bn.running_var + 1e-5)
@@ -178,13 +193,75 @@ class _Bottleneck(nn.Module):
         self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), bn(cout)) if down else None
 
     def forward(self, x):
-        y = _conv_bn(x, self.c1, self.b1, True)
-        y = _conv_bn(y, self.c2, self.b2, True)
-        y = _conv_bn(y, self.c3, self.b3, False)
+        # c1's and c2's outputs are ReLU outputs with one reader each (c2, c3): on the implicit-GEMM route their ReLU backward is a
+        # mask in the store of the reader's data gradient (a _GradLink per pair, as in the VGG chain) instead of a pass of its own
+        from .backbone import _GradLink, _FUSE_CHAIN
+        l1, l2 = (_GradLink(), _GradLink()) if (_IGEMM_BN and _FUSE_CHAIN and torch.is_grad_enabled()) else (None, None)
+        routed = lambda t, conv, bn: t.is_cuda and _igemm_bn_route(t, conv, bn)      # noqa: E731
+        y1 = _conv_bn(x, self.c1, self.b1, True, None, l1 if l1 is not None and routed(x, self.c1, self.b1) else None)
+        use1 = l1 is not None and routed(x, self.c1, self.b1) and routed(y1, self.c2, self.b2)
+        use2 = l2 is not None and routed(y1, self.c2, self.b2)
+        y2 = _conv_bn(y1, self.c2, self.b2, True, l1 if use1 else None, l2 if use2 else None)
+        use2 = use2 and routed(y2, self.c3, self.b3)
+        y = _conv_bn(y2, self.c3, self.b3, False, l2 if use2 else None, None)
         idn = _conv_bn(x, self.down[0], self.down[1], False) if self.down is not None else x
         if _IGEMM_BN and y.is_cuda and y.dtype == torch.bfloat16 and idn.dtype == torch.bfloat16 and y.numel() % 8 == 0:
             return _AddReLUFn.apply(y, idn)                               # one pass each way instead of add + threshold
         return F.relu(y + idn)
+
+
+class _AsppFn(torch.autograd.Function):
+    """the DeepLab-v2 ASPP head, sum over four dilated 3x3 classifiers (2048 -> 21, dilation 6 / 12 / 18 / 24) of one feature map, on
+    the implicit-GEMM kernels: the classifiers' 21 outputs are padded to the kernels' 128-channel tile (zero kernels: 6x the
+    flops of the unpadded product, still 4x faster than the library's 64 x 32-tile forward at this shape) and the four branches
+    share ONE launch each way (class-ordered pixel tiles skip the taps the dilation pushes off the 65 x 65 map).
+    apply(f, w_1..w_4, b_1..b_4): f bf16 channels_last; w, b the float32 master parameters -> (B, 21, H, W) float32."""
+
+    @staticmethod
+    def forward(ctx, dils, f, *t):
+        from .ops import conv_igemm, pack_conv_weight_pair
+        n = len(dils)
+        ws, bs = t[:n], t[n:2 * n]
+        O, cin = ws[0].shape[0], ws[0].shape[1]
+        f = f if f.dtype == torch.bfloat16 else f.bfloat16()
+        f = f if f.is_contiguous(memory_format=torch.channels_last) else f.contiguous(memory_format=torch.channels_last)
+        packs = []
+        for w in ws:
+            wp = F.pad(w.detach().float(), (0, 0, 0, 0, 0, 0, 0, 128 - O)).contiguous(memory_format=torch.channels_last)
+            packs.append(pack_conv_weight_pair(wp, True, False)[0])
+        zero = torch.zeros(128, dtype=torch.float32, device=f.device)
+        outs = conv_igemm([f] * n, packs, [zero] * n, list(dils), 3, False)
+        out = outs[0][:, :O].float()
+        for o in outs[1:]:
+            out = out + o[:, :O].float()
+        out = out + sum(b.detach().float() for b in bs).view(1, -1, 1, 1)
+        ctx.save_for_backward(f, *ws)
+        ctx.dils, ctx.O = tuple(dils), O
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import conv_igemm, pack_conv_weight
+        f, *ws = ctx.saved_tensors
+        n, O = len(ws), ctx.O
+        cl = torch.channels_last
+        gb = g.float().sum((0, 2, 3))                                                  # the same for every branch
+        g16 = g.to(torch.bfloat16)
+        gf = None
+        if ctx.needs_input_grad[1]:
+            # data gradient: the same launch on the flipped / transposed kernels, the 21 gradient channels padded to one 64-channel chunk
+            gp = F.pad(g16, (0, 0, 0, 0, 0, 64 - O)).contiguous(memory_format=cl)
+            packs_d = [pack_conv_weight(F.pad(w.detach().to(torch.bfloat16), (0, 0, 0, 0, 0, 0, 0, 64 - O)), for_dgrad=True) for w in ws]
+            gxs = conv_igemm([gp] * n, packs_d, None, list(ctx.dils), 3, False)
+            gf = gxs[0]
+            for gx in gxs[1:]:
+                gf = gf + gx                                                           # (bf16 sums, as autograd's own accumulation)
+        gws = []
+        g16 = g16.contiguous(memory_format=cl)
+        for w, d in zip(ws, ctx.dils):
+            gws.append(torch.ops.aten.convolution_backward(g16, f, w.to(torch.bfloat16), None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                                                           [False, True, False])[1].float())
+        return (None, gf) + tuple(gws) + (gb,) * n
 
 
 class ResNet101DeepLab(nn.Module):
@@ -212,6 +289,12 @@ class ResNet101DeepLab(nn.Module):
 
     def forward(self, x):
         f = self.layers(self.stem(x))
+        from .ops import conv_igemm_supported
+        if _IGEMM_BN and f.is_cuda and (f.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)) \
+                and len(self.aspp) <= 4 and self.aspp[0].out_channels <= 64 and conv_igemm_supported(f.shape[1], 128, 3) and \
+                f.shape[0] * f.shape[2] * f.shape[3] >= 2048 and all(m.kernel_size == (3, 3) and m.padding == m.dilation and m.stride == (1, 1)
+                                                                      for m in self.aspp):
+            return _AsppFn.apply(tuple(m.dilation[0] for m in self.aspp), f, *[m.weight for m in self.aspp], *[m.bias for m in self.aspp])
         out = self.aspp[0](f)
         for m in self.aspp[1:]:
             out = out + m(f)
