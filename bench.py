@@ -19,7 +19,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   grad_cosine_min / loss_gap_300_steps: how close the two legs' gradients and 300-step trajectories are
   modes         — (N=1, --mode train) bounded sub-records of the other quoted configurations, each with its own roofline and
                   cpu_baseline: supervision (hot path alone, 16 images), supervision_b1, infer_b1 (BASELINE.json configs[1]),
-                  crf_fullres
+                  crf_fullres, train_f (the reference's stage 2: VGG16-ASPP 321x321, batch 16), train_f_resnet101_513
+                  (BASELINE.json configs[4] on one GPU, batch 10)
 """
 import argparse
 import json
@@ -162,7 +163,7 @@ def _counter_file(stem, kernel):
     (tools/gpu_pmc.sh) and their figures are replayed here — only while the kernel's sources hash to what the file was
     collected against (dsrg_amd/provenance.py); -> (record or None, provenance dict for the bench line)"""
     from dsrg_amd import provenance
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         rec = _load_json("%s_%s.json" % (rnd, stem))
         if rec is not None:
             src = provenance.check(rec, kernel)
@@ -425,6 +426,9 @@ def filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead_ms):
     traffic = (tj or {}).get("mf_filter_kernel_bytes_per_launch")       # None when the kernel changed after the PMC pass
     counters = None
     cj, counters_src = _counter_file("lds_counters", "mf_filter_kernel")
+    if cj and int(cj.get("batch", 16)) != B:
+        # the PMC pass ran the 16-image step: its per-launch counters say nothing about a launch over B images
+        cj, counters_src = None, dict(counters_src or {}, dropped="counters collected at batch %d, this record is batch %d" % (int(cj.get("batch", 16)), B))
     if cj:
         ck = sorted((v for k, v in cj.get("kernels", {}).items() if "mf_filter_kernel" in k),
                     key=lambda v: -v.get("launches", 0))          # the loop's instantiation, not the build's norm pass
@@ -759,6 +763,18 @@ def main():
                           "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
                           "traffic": None, "note": "3 x forward flops of the conv stack / step time (supervision, "
                                                    "pooling, optimizer included in the time)"})
+        if args.mode == "train-f":
+            from dsrg_amd.retrain import count_flops_per_image_resnet101
+            fl = count_flops_per_image(args.size) if args.backbone == "vgg16" else count_flops_per_image_resnet101(args.size)
+            tf = fl * 3 * B * world * args.steps / dt / 1e12 / world
+            trainf_roofline = {"kernel": "backbone convolutions of the train-f step (implicit-GEMM / direct MFMA kernels of this repo; "
+                                         "%s), whole step per GPU" % ("every convolution" if args.backbone == "vgg16" else
+                                                                      "7x7 stem, stride-2 projections, res2 and the 21-output weight "
+                                                                      "gradients stay on MIOpen / hipBLASLt"),
+                               "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+                               "flops_per_image_forward": fl,
+                               "note": "3 x forward flops of the conv stack / step time (loss, pooling, residual adds, optimizer "
+                                       "included in the time); per-kernel times: profiles/r06_train_f_*_kernel_stats.txt"}
         out = {
             "metric": "images/sec DSRG train step (VGG16 321x321, 21-class)" if args.mode == "train"
                       else "images/sec train-f retrain step (%s %dx%d, softmax loss on pseudo-labels)" % (args.backbone, args.size, args.size),
@@ -782,9 +798,15 @@ def main():
             "losses": [float(x) for x in losses.detach().cpu()],
             "supervision_ms_per_step": sup_ms,
             "backbone_tflops": (count_flops_per_image() * 3 * B * world * args.steps / dt / 1e12) if args.mode == "train" else None,
-            "roofline": filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead) if filt_n else None,
+            "roofline": (filter_roofline(ctx, B, C, N, filt_ms, filt_n, ev_overhead) if filt_n else None) if args.mode == "train" else trainf_roofline,
             "other_rooflines": other,
         }
+        if args.mode == "train-f":
+            out["config"]["baseline_config"] = ("configs[4] (ResNet-101 DeepLab-v2, 513x513, train-f) on one GPU" if args.backbone == "resnet101"
+                                                else "the reference's own stage 2: train-f.prototxt:3-14,721-755 + solver-f.prototxt:1-17 (VGG16-ASPP, 321x321)")
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = ("no CPU leg: the reference runs this step entirely inside Caffe on a GPU (no Python layer on "
+                                        "the path, train-f.prototxt) — there is no reference CPU path to time")
         if args.mode == "train" and world == 1:
             out["legs"] = {"bf16": {"value": out["value"], "ms_per_step": out["ms_per_step"], "steps": args.steps,
                                     "dtype": out["dtype"], "backbone_tflops": out["backbone_tflops"],
@@ -838,7 +860,11 @@ def main():
             for name, argv in (("supervision", ["--mode", "supervision", "--batch", "16", "--steps", "200", "--warmup", "20", "--no-cpu-baseline"]),
                                ("supervision_b1", ["--mode", "supervision", "--batch", "1", "--steps", "200", "--warmup", "20", "--sub"] + nocpu),
                                ("infer_b1", ["--mode", "infer", "--batch", "1", "--steps", "300", "--warmup", "30"]),
-                               ("crf_fullres", ["--mode", "crf-fullres", "--steps", "20", "--warmup", "5"] + nocpu)):
+                               ("crf_fullres", ["--mode", "crf-fullres", "--steps", "20", "--warmup", "5"] + nocpu),
+                               ("train_f", ["--mode", "train-f", "--backbone", "vgg16", "--size", "321", "--batch", "16", "--steps", "20",
+                                            "--warmup", "6", "--no-cpu-baseline"]),
+                               ("train_f_resnet101_513", ["--mode", "train-f", "--backbone", "resnet101", "--size", "513", "--batch", "10",
+                                                          "--steps", "10", "--warmup", "5", "--no-cpu-baseline"])):
                 try:
                     r = subprocess.run(base + argv, capture_output=True, text=True, timeout=420)
                     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -253,6 +253,12 @@ _MERGED_BWD = _os.environ.get("DSRG_MERGED_BWD", "1") != "0"     # data + weight
 # only take CUs from each other; profiles/r05_wgrad_side_stream_ab.txt)
 
 
+def _landed(g, slot):
+    """the gradient a backward returns for a parameter: when the kernel wrote it into the reducer's slot, a FRESH alias of the slot
+    (autograd adopts a gradient as `.grad` without a copy only if nobody else holds the tensor object)"""
+    return g.detach() if (slot is not None and g is slot) else g
+
+
 class _IgemmConvFn(torch.autograd.Function):
     """n convolutions of one geometry (n = 1, or the four ASPP branches) + bias (+ ReLU (+ Dropout) (+ the stride-2 max pool)):
     apply(k, dils, relu, drop_p, pool, n, links_in, links_out, x_1..x_n, w_1..w_n, b_1..b_n) (links: lists of _GradLink or None —
@@ -303,6 +309,8 @@ class _IgemmConvFn(torch.autograd.Function):
             pooled, code = maxpool3x3_fwd(outs[0], pool[0], pool[1], relu_input=True)    # the codes carry the ReLU mask
         ctx.save_for_backward(code, *xs, *ws, *(outs if (relu and pool is None) else ()))
         ctx.out_shape = tuple(outs[0].shape)
+        # where a data-parallel reducer wants the weight gradients written (dsrg_amd/reducer.py: the parameters' bucket slots)
+        ctx.gw_out = [getattr(w, "_dsrg_grad_out", None) for w in ws]
         ctx.packs_d = packs_d                  # not an input or output of the node: kept outside save_for_backward
         ctx.dils, ctx.relu, ctx.scale, ctx.pool, ctx.n, ctx.k = dils, relu, scale, pool, n, k
         ctx.links_in = links_in
@@ -348,10 +356,10 @@ class _IgemmConvFn(torch.autograd.Function):
             from .ops import conv_igemm_backward
             pd = ctx.packs_d[0] if ctx.packs_d[0] is not None else pack_conv_weight(ws[0], for_dgrad=True)
             gx, gw, gb_below = conv_igemm_backward(gms[0], pd, xs[0], ctx.dils[0], xs[0] if absorb else None,
-                                                   ctx.links_in[0].scale if absorb else 1.0)
+                                                   ctx.links_in[0].scale if absorb else 1.0, gw_out=ctx.gw_out[0])
             if absorb:
                 ctx.links_in[0].leave(gx, gb_below)
-            return (None,) * 8 + (gx, gw) + tuple(gbs)
+            return (None,) * 8 + (gx, _landed(gw, ctx.gw_out[0])) + tuple(gbs)
         if absorb:
             packs_d = [p if p is not None else pack_conv_weight(w, for_dgrad=True) for p, w in zip(ctx.packs_d, ws)]
             gxs, gb_below = conv_igemm_dgrad(gms, packs_d, list(xs), ctx.dils, ctx.k, ctx.links_in[0].scale)
@@ -365,7 +373,7 @@ class _IgemmConvFn(torch.autograd.Function):
                     g2d = gms[i].permute(0, 2, 3, 1).reshape(-1, cout)
                     B_, _, H_, W_ = xs[i].shape
                     gxs[i] = torch.mm(g2d, ws[i].to(torch.bfloat16).reshape(cout, cin)).view(B_, H_, W_, cin).permute(0, 3, 1, 2)
-            gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 1)
+            gws = [_landed(gw, o) for gw, o in zip(conv_igemm_wgrad(list(xs), gms, ctx.dils, 1, outs=ctx.gw_out), ctx.gw_out)]
             return (None,) * 8 + tuple(gxs) + tuple(gws) + tuple(gbs)
         if any(need_x) and not absorb:
             if conv_igemm_supported(cout, cin, 3):
@@ -377,7 +385,8 @@ class _IgemmConvFn(torch.autograd.Function):
                     gxs[i] = torch.ops.aten.convolution_backward(gms[i], xs[i], ws[i].to(torch.bfloat16), None, [1, 1], [d, d], [d, d],
                                                                  False, [0, 0], 1, [True, False, False])[0]
         if conv_igemm_wgrad_supported(cin, cout, 3):
-            gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 3)                           # float32, the parameters' own layout
+            gws = conv_igemm_wgrad(list(xs), gms, ctx.dils, 3, outs=ctx.gw_out)          # float32, the parameters' own layout
+            gws = [_landed(gw, o) for gw, o in zip(gws, ctx.gw_out)]
         else:
             gws = []
             for i in range(n):
@@ -411,6 +420,7 @@ class _DirectConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, out if (relu and pool is None) else None, code)
         ctx.out_shape = tuple(out.shape)
         ctx.wd = wd                                    # not an input or output of the node: kept outside save_for_backward
+        ctx.gw_out = getattr(weight, "_dsrg_grad_out", None)      # a reducer's slot for the weight gradient (dsrg_amd/reducer.py)
         ctx.relu, ctx.pool = relu, pool
         ctx.link_in = link_in if (link_in is not None and link_in.scale == 1.0 and wd is not None) else None
         ctx.link_out = link_out if (relu and pool is None) else None
@@ -439,8 +449,8 @@ class _DirectConvFn(torch.autograd.Function):
                 ctx.link_in.leave(gx, gb_below)
             else:
                 gx = conv3x3_direct(g, ctx.wd, None, False)
-        gw = conv3x3_wgrad(x, g, torch.float32)
-        return gx, gw, gb, None, None, None, None
+        gw = conv3x3_wgrad(x, g, torch.float32, out=ctx.gw_out)
+        return gx, _landed(gw, ctx.gw_out), gb, None, None, None, None
 
 
 def _direct_route(conv, x, p, pool):

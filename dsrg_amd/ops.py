@@ -406,7 +406,18 @@ _PARTIAL_BLOCKS = 512
 _partials = {}
 
 
-def relu_bwd_bias(g, y, scale=1.0):
+def _dest(out, shape, dtype, device, channels_last=False):
+    """`out` if it can take a kernel's result of this shape / dtype in place (a reducer's gradient slot: dense, the layout the
+    kernel writes), else a fresh tensor"""
+    if out is not None and out.dtype == dtype and tuple(out.shape) == tuple(shape) and out.device == device and (
+            out.is_contiguous(memory_format=torch.channels_last) if channels_last else out.is_contiguous()):
+        return out
+    if channels_last:
+        return torch.empty(shape, dtype=dtype, device=device, memory_format=torch.channels_last)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def relu_bwd_bias(g, y, scale=1.0, gb_out=None):
     """ReLU backward fused with the bias-gradient reduction of the convolution before it.
     g, y: (B,C,H,W) bf16 channels_last (y = the ReLU output, or the output of ReLU + Dropout with scale = 1/(1-p)).
     Returns (scale * g * (y > 0), its sum over B,H,W as f32 (C,))."""
@@ -416,7 +427,7 @@ def relu_bwd_bias(g, y, scale=1.0):
         raise ValueError("relu_bwd_bias needs bf16 channels_last CUDA tensors")
     g = g.contiguous(memory_format=cl)
     gm = torch.empty_like(y)
-    gb = torch.empty(C, dtype=torch.float32, device=y.device)
+    gb = _dest(gb_out, (C,), torch.float32, y.device)
     key = (y.device, C)
     part = _partials.get(key)
     if part is None:
@@ -690,7 +701,7 @@ def pack_direct_weight_pair(weight, want_dgrad=True):
     return fwd, (dg if want_dgrad else None)
 
 
-def conv3x3_wgrad(x, g, out_dtype=torch.bfloat16):
+def conv3x3_wgrad(x, g, out_dtype=torch.bfloat16, out=None):
     """weight gradient of the 3x3 / stride 1 / pad 1 convolution y = conv(x, w): x (B,cin,H,W) and g = dL/dy (B,cout,H,W) bf16
     channels_last, (cin, cout) in WGRAD_CONV_SHAPES -> (cout,cin,3,3) bf16 (or float32: out_dtype) channels_last; fp32
     accumulation, deterministic"""
@@ -709,7 +720,7 @@ def conv3x3_wgrad(x, g, out_dtype=torch.bfloat16):
         ws = _wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
     if out_dtype not in (torch.bfloat16, torch.float32):
         raise ValueError("conv3x3_wgrad: bf16 or float32 output")
-    gw = torch.empty((cout, cin, 3, 3), dtype=out_dtype, device=x.device, memory_format=cl)
+    gw = _dest(out, (cout, cin, 3, 3), out_dtype, x.device, True)
     fn = _lib.lib().dsrg_conv3x3_wgrad_f32 if out_dtype == torch.float32 else _lib.lib().dsrg_conv3x3_wgrad_bf16
     check(fn(_ptr(x), _ptr(g), _ptr(gw), _ptr(ws), ws.numel(), B, H, W, cin, cout, _stream()))
     return gw
@@ -793,7 +804,7 @@ def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0
     return ys
 
 
-def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias_grad=True):
+def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias_grad=True, gb_outs=None):
     """the data gradient of 1 .. 4 convolutions whose inputs were ReLU (+ Dropout) outputs, with that layer's backward folded
     in: gs[g] (B,cout_fwd,H,W) bf16 channels_last, packed_t[g] the flipped + transposed packing, masks[g] (B,cin_fwd,H,W) bf16
     the outputs of the layer below -> (list of (B,cin_fwd,H,W) bf16 = conv_T(g) * mask_scale where mask > 0, list of (cin_fwd)
@@ -815,7 +826,7 @@ def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias
     L = _lib.lib()
     gb = ws = None
     if bias_grad:
-        gb = [torch.empty(cout, dtype=torch.float32, device=gs[0].device) for _ in range(n)]
+        gb = [_dest(gb_outs[i] if gb_outs is not None else None, (cout,), torch.float32, gs[0].device) for i in range(n)]
         ws = torch.empty(L.dsrg_conv_igemm_dgrad_workspace(n, B, H, W, cout), dtype=torch.uint8, device=gs[0].device)
     check(L.dsrg_conv_igemm_dgrad_bf16(vp(*[g.data_ptr() for g in gs]), vp(*[p.data_ptr() for p in packed_t]),
                                        vp(*[m.data_ptr() for m in masks]), vp(*[o.data_ptr() for o in outs]),
@@ -825,7 +836,7 @@ def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias
     return outs, gb
 
 
-def conv_igemm_backward(g, packed_d, x, dilation, mask=None, mask_scale=1.0, ksize=3):
+def conv_igemm_backward(g, packed_d, x, dilation, mask=None, mask_scale=1.0, ksize=3, gw_out=None, gb_out=None):
     """the whole backward of one 3x3 convolution (forward geometry cin -> cout) in one launch (dsrg_conv_igemm_backward_bf16): g
     (B,cout,H,W) and x (B,cin,H,W) bf16 channels_last, packed_d = pack_conv_weight(w, for_dgrad=True); mask: the layer's input when
     it is the sole-consumer ReLU output of the layer below (then that layer's ReLU / Dropout backward and bias gradient ride in
@@ -850,10 +861,10 @@ def conv_igemm_backward(g, packed_d, x, dilation, mask=None, mask_scale=1.0, ksi
     if ws is None or ws.numel() < need:
         ws = _igemm_ws[key] = torch.empty(need, dtype=torch.uint8, device=g.device)
     gx = torch.empty((B, cin, H, W), dtype=torch.bfloat16, device=g.device, memory_format=cl)
-    gw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=g.device, memory_format=cl)
+    gw = _dest(gw_out, (cout, cin, ksize, ksize), torch.float32, g.device, True)
     gb = cws = None
     if mask is not None:
-        gb = torch.empty(cin, dtype=torch.float32, device=g.device)
+        gb = _dest(gb_out, (cin,), torch.float32, g.device)
         cws = torch.empty(L.dsrg_conv_igemm_dgrad_workspace(1, B, H, W, cin), dtype=torch.uint8, device=g.device)
     check(L.dsrg_conv_igemm_backward_bf16(_ptr(g), _ptr(packed_d), _ptr(x), _ptr(mask), _ptr(gx), _ptr(gw), int(dilation), _ptr(gb),
                                           float(mask_scale), _ptr(cws), cws.numel() if cws is not None else 0, _ptr(ws), ws.numel(),
@@ -895,7 +906,7 @@ def conv_igemm_wgrad_supported(cin, cout, k):
     return _lib.lib().dsrg_conv_igemm_wgrad_workspace(1, 1, 8, 8, int(cin), int(cout), int(k)) > 0
 
 
-def conv_igemm_wgrad(xs, gs, dilations, ksize, out_dtype=torch.float32):
+def conv_igemm_wgrad(xs, gs, dilations, ksize, out_dtype=torch.float32, outs=None):
     """weight gradients of 1 .. 4 convolutions of one geometry in one launch: xs[g] (B,cin,H,W) the layer inputs and gs[g]
     (B,cout,H,W) the output gradients, bf16 channels_last -> list of (cout,cin,k,k) channels_last tensors in float32 (the
     master weights' gradient) or bf16; cin % 256 == 0, cout % 256 == 0; fp32 accumulation, deterministic, no im2col matrix"""
@@ -919,7 +930,7 @@ def conv_igemm_wgrad(xs, gs, dilations, ksize, out_dtype=torch.float32):
     ws = _igemm_ws.get(key)                                          # per-stream scratch, reused across layers and steps
     if ws is None or ws.numel() < need:
         ws = _igemm_ws[key] = torch.empty(need, dtype=torch.uint8, device=xs[0].device)
-    gws = [torch.empty((cout, cin, ksize, ksize), dtype=out_dtype, device=xs[0].device, memory_format=cl) for _ in range(n)]
+    gws = [_dest(outs[i] if outs is not None else None, (cout, cin, ksize, ksize), out_dtype, xs[0].device, True) for i in range(n)]
     vp = ctypes.c_void_p * n
     check(L.dsrg_conv_igemm_wgrad_bf16(vp(*[x.data_ptr() for x in xs]), vp(*[g.data_ptr() for g in gs]),
                                        vp(*[w.data_ptr() for w in gws]), (ctypes.c_int * n)(*[int(d) for d in dilations]), n,
@@ -1004,7 +1015,7 @@ def maxpool3x3_bwd(gout, code, in_shape, stride):
     return gin
 
 
-def maxpool3x3_bwd_relu(gout, code, relu_out, stride=2):
+def maxpool3x3_bwd_relu(gout, code, relu_out, stride=2, gb_out=None):
     """3x3 / stride 2 / pad 1 max-pool backward + the ReLU backward and bias gradient of the convolution in front of the pool:
     relu_out (B,C,H,W) bf16 channels_last = the pool's input -> (masked input gradient (B,C,H,W) bf16 channels_last,
     bias gradient (C) f32); the same values as maxpool3x3_bwd followed by relu_bwd_bias.
@@ -1019,7 +1030,7 @@ def maxpool3x3_bwd_relu(gout, code, relu_out, stride=2):
         raise ValueError("maxpool3x3_bwd_relu: stride 2, bf16 channels_last, channels / 8 a divisor of 256")
     gout = gout.contiguous(memory_format=cl)
     gin = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=gout.device, memory_format=cl)
-    gb = torch.empty(C, dtype=torch.float32, device=gout.device)
+    gb = _dest(gb_out, (C,), torch.float32, gout.device)
     key = (gout.device, C)                                          # shared with relu_bwd_bias (same stream-ordering rule)
     part = _partials.get(key)
     if part is None:

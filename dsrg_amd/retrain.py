@@ -311,6 +311,24 @@ class ResNet101DeepLab(nn.Module):
         return [dict(params=ps, lr_mult=k[0], decay_mult=k[1]) for k, ps in groups.items()]
 
 
+def count_flops_per_image_resnet101(size=513, blocks=(3, 4, 23, 3), num_classes=21):
+    """forward multiply-accumulates x2 of ResNet101DeepLab's convolutions at size x size (output stride 8)"""
+    def half(n): return (n - 1) // 2 + 1
+    h = half(size)                                                   # 7x7 / 2 stem
+    macs = 3 * 64 * 49 * h * h
+    h = half(h)                                                      # 3x3 / 2 max pool (ceil mode)
+    cin = 64
+    for mid, n, stride in ((64, blocks[0], 1), (128, blocks[1], 2), (256, blocks[2], 1), (512, blocks[3], 1)):
+        for i in range(n):
+            ho = half(h) if (i == 0 and stride == 2) else h
+            macs += cin * mid * ho * ho + mid * mid * 9 * ho * ho + mid * 4 * mid * ho * ho
+            if i == 0:
+                macs += cin * mid * 4 * ho * ho
+            cin, h = mid * 4, ho
+    macs += 4 * cin * num_classes * 9 * h * h
+    return 2 * macs
+
+
 class RetrainTrainer(object):
     """one train-f step: backbone -> (logits, labels shrunk by 8) -> softmax loss -> SGD with poly LR"""
 
@@ -328,10 +346,10 @@ class RetrainTrainer(object):
         if device.type == "cuda":
             net = net.to(memory_format=torch.channels_last)
         self.net = self.model = net
+        self.reducer = None
         if (world_size > 1) if ddp is None else ddp:
-            from torch.nn.parallel import DistributedDataParallel as DDP
-            self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=32,
-                             gradient_as_bucket_view=True)
+            from .reducer import BucketedAllReduce           # as DSRGTrainer: gradients land in their all-reduce buckets
+            self.reducer = BucketedAllReduce(list(net.parameters()), bucket_cap_mb=32)
         self.opt = CaffeSGD(net.caffe_param_groups(), base_lr=base_lr, gamma=1.0, stepsize=1 << 30)
         if snapshot is not None:
             self.load(snapshot)
@@ -346,12 +364,17 @@ class RetrainTrainer(object):
         return load_snapshot(self, state_path)          # the poly rate is recomputed from opt.iter at every step
 
     def step(self, images, label):
-        self.opt.zero_grad()
+        if self.reducer is not None:
+            self.reducer.prepare()
+        else:
+            self.opt.zero_grad()
         self.opt.base_lr = poly_lr(self.base_lr, self.opt.iter, self.max_iter)
         x = images.contiguous(memory_format=torch.channels_last) if self.device.type == "cuda" else images
         with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             logits = self.model(x)
         loss = seg_softmax_loss(logits, interp_shrink(label, 8))
         loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
         self.opt.step()
         return loss.detach()

@@ -156,11 +156,18 @@ class DSRGTrainer(object):
             net = net.to(memory_format=torch.channels_last)
         self.net = net
         self.model = net
+        self.reducer = None
         if (world_size > 1) if ddp is None else ddp:
-            from torch.nn.parallel import DistributedDataParallel as DDP
-            # 151.5 MB of fp32 gradients per step; 32 MB buckets -> 5 all-reduces overlapped with backward
-            self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=bucket_cap_mb,
-                             gradient_as_bucket_view=True)
+            # 151.5 MB of fp32 gradients per step; 32 MB buckets -> 5 all-reduces overlapped with backward, the weight-gradient
+            # kernels writing straight into the buckets (dsrg_amd/reducer.py; torch's DistributedDataParallel copies every
+            # gradient into its bucket: 47 launches per step, +3.8 % at one rank — DSRG_TORCH_DDP=1 restores it for A/B runs)
+            if os.environ.get("DSRG_TORCH_DDP") == "1":
+                from torch.nn.parallel import DistributedDataParallel as DDP
+                self.model = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=bucket_cap_mb,
+                                 gradient_as_bucket_view=True)
+            else:
+                from .reducer import BucketedAllReduce
+                self.reducer = BucketedAllReduce(list(net.parameters()), bucket_cap_mb=bucket_cap_mb)
         self.opt = CaffeSGD(net.caffe_param_groups())
         if snapshot is not None:
             self.load(snapshot)
@@ -215,7 +222,10 @@ class DSRGTrainer(object):
     def step(self, images, labels, cues):
         """images (B,3,321,321) f32 mean-subtracted, labels (B,1,1,21), cues (B,21,41,41) -> losses[2] (this rank's shard;
         reduce_losses() gives the global-batch figure for logging)"""
-        self.opt.zero_grad()
+        if self.reducer is not None:
+            self.reducer.prepare()                          # gradients unset, every large parameter knows its bucket slot
+        else:
+            self.opt.zero_grad()
         x = images.contiguous(memory_format=torch.channels_last) if self.channels_last else images
         if self.overlap_build:
             from .ops import crf_prepare
@@ -232,5 +242,7 @@ class DSRGTrainer(object):
         else:
             total, losses = self.loss_fn(logits, images, labels, cues)
         total.backward()
+        if self.reducer is not None:
+            self.reducer.finish()                           # the rest of the buckets out, the collectives joined; p.grad = the mean
         self.opt.step()
         return losses

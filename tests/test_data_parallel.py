@@ -62,8 +62,12 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     # a bucket cap of ~1 KB splits TinyNet's 14 tensors over several buckets, as 32 MB does with the 37.9 M parameters of VGG16
+    # (small_numel: TinyNet's kernels count as "large" tensors with slots of their own; its biases share the last bucket)
     tr = DSRGTrainer(torch.device("cpu"), world_size=world, seed=0, amp_dtype=None, channels_last=False,
                      loss_fn=torch_loss, net=TinyNet(), bucket_cap_mb=0.001)
+    tr.reducer.remove()
+    from dsrg_amd.reducer import BucketedAllReduce
+    tr.reducer = BucketedAllReduce(list(tr.net.parameters()), bucket_cap_mb=0.001, small_numel=64)
     # the first thing the trainer's dropout stream yields on this rank (both ranks sit on "cpu": no device ordinal tells them apart,
     # as with one visible GPU per process)
     mask = torch.nn.functional.dropout(torch.ones(256), 0.5).clone()
@@ -71,11 +75,12 @@ def _worker(rank, world, port, out_dir):
     # log line) fires per bucket as soon as the bucket's gradients exist; the first layer's weight gradient is the LAST thing
     # backward computes, so bucket events in front of it are all-reduces issued while backward was still running
     events = []
+    launch = tr.reducer._launch
 
-    def hook(state, bucket):
+    def logged_launch(bi):
         events.append("bucket")
-        return dist.all_reduce(bucket.buffer().div_(world), async_op=True).get_future().then(lambda f: f.value()[0])
-    tr.model.register_comm_hook(None, hook)
+        return launch(bi)
+    tr.reducer._launch = logged_launch
     tr.net.features[0].weight.register_hook(lambda g: events.append("first_layer_grad"))
     images, labels, cues = make_data(4)
     sh = slice(rank * 2, rank * 2 + 2)                       # rank r takes images [2r, 2r+2)
@@ -90,7 +95,10 @@ def _worker(rank, world, port, out_dir):
         with torch.no_grad():
             tr.net.features[0].bias[0] += 1e-7               # one parameter of one replica drifts by an ulp-sized amount
     equal_after_drift, words_drift = tr.weights_equal_across_ranks()
+    # gradients are views of the buckets; the fallback copies are counted (torch ops produce every gradient of this CPU net)
+    assert all(p.grad.data_ptr() == tr.reducer._slot[p][1].data_ptr() for p in tr.net.parameters())
     torch.save({"w": [p.detach().clone() for p in tr.net.parameters()], "events": events, "shard": shard_losses,
+                "nbuckets": len(tr.reducer.buckets), "launch_log": list(tr.reducer.launch_log),
                 "reduced": reduced, "equal": equal, "words": words, "equal_after_drift": equal_after_drift,
                 "words_drift": words_drift, "mask": mask, "dropout_seed": tr.dropout_stream_seed}, os.path.join(out_dir, "w%d.pt" % rank))
     dist.destroy_process_group()
@@ -128,15 +136,14 @@ def test_two_rank_gloo_equals_single_process_global_batch(tmp_path):
         assert torch.allclose(r0["reduced"][it], (r0["shard"][it] + r1["shard"][it]) / 2)
         assert torch.allclose(r0["reduced"][it], global_losses[it], rtol=1e-5, atol=1e-6)
     assert tr.reduce_losses(global_losses[0]) is global_losses[0]            # a single process: no collective
-    # bucketed all-reduce overlapped with backward: from the second step on (DDP sizes its buckets from the order in which
-    # the gradients became ready in the first) there are several buckets per step, and all but the last are issued before
-    # backward has produced the first layer's gradient
+    # bucketed all-reduce overlapped with backward: several buckets per step, launched in bucket order on both ranks, all but the
+    # last ones issued before backward has produced the first layer's gradient; the small-tensor bucket goes last
     for r in (r0, r1):
         steps = " ".join(r["events"]).split("step")[1:]
-        assert len(steps) == 3
-        for st in steps[1:]:
+        assert len(steps) == 3 and r["nbuckets"] >= 3 and r["launch_log"] == list(range(r["nbuckets"]))
+        for st in steps:
             ev = st.split()
-            assert ev.count("first_layer_grad") == 1 and ev.count("bucket") >= 2, ev
+            assert ev.count("first_layer_grad") == 1 and ev.count("bucket") == r["nbuckets"], ev
             assert ev[:ev.index("first_layer_grad")].count("bucket") >= 1, ev
             assert ev[-1] == "bucket", ev
 

@@ -157,7 +157,40 @@ def test_crf_function_vs_oracle(O, kind, scale, HW, C):
     assert hc.lattice_size(0) == oc.lattice_size(0) and hc.lattice_size(1) == oc.lattice_size(1)
     oc.set_unary_energy(-un.ravel())
     wl = oc.map(10)
-    assert (lab != wl).mean() < 1e-3                        # argmax ties at ~1e-7 differences only
+    # the labels may differ only where the oracle's own top two marginals are a near tie: at such a pixel the label we chose must
+    # be within 1e-5 of the oracle's maximum (no budget of "a few flipped pixels")
+    flip = np.flatnonzero(np.asarray(lab).ravel() != np.asarray(wl).ravel())
+    wq = want.reshape(-1, C)
+    assert all(wq[i].max() - wq[i, int(np.asarray(lab).ravel()[i])] < 1e-5 for i in flip), (len(flip), H, W)
+
+
+@pytest.mark.parametrize("seed", [20083, 20173])
+def test_crf_sweep_worst_cases_vs_oracle(O, seed):
+    """the two worst cases the randomised sweep (tools/parity_sweep_crf.py, 240 calls, profiles/r05_parity_sweeps_long.txt) ever
+    found, pinned as tests with the sweep's own generator: seed 20173 = 138 x 163, 21 labels, scale 3, dark_corner — the
+    global-memory path, where a vertex that gathers thousands of equal-coloured pixels sums its row in segments and the oracle
+    sums it pixel by pixel (fp32 reassociation, amplified by ten softmax iterations at weight 10); seed 20083 = 89 x 96, 7 labels,
+    scale 1.  The bar is the contract's 1e-4; the figure reached is printed (round 5: 7.44e-5 and 2.21e-5)."""
+    import krahenbuhl2013
+    it = seed - 20000
+    rng = np.random.default_rng(seed)
+    H, W = (int(rng.integers(1, 71)), int(rng.integers(1, 71))) if it % 2 == 0 else (int(rng.integers(60, 180)), int(rng.integers(60, 220)))
+    C = int(rng.choice([2, 3, 7, 21, 21, 21, 33]))
+    scale = float(rng.choice([1.0, 3.0, 12.0]))
+    kind = ["smooth", "noise", "dark_corner"][it % 3]
+    assert (H, W, C, scale, kind) in ((89, 96, 7, 1.0, "dark_corner"), (138, 163, 21, 3.0, "dark_corner"))
+    img = S.make_images(rng, 1, size=max(H, W, 8), kind=kind)[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]
+    im = np.ascontiguousarray(np.transpose(img, (1, 2, 0)))
+    logits = S.make_logits(rng, 1, C, H, W, gain=float(rng.uniform(2, 40)), sigma=float(rng.uniform(1, 10)))
+    un = np.ascontiguousarray(np.transpose(np.maximum(O.softmax_forward(logits)[0], 1e-5), (1, 2, 0)))
+    if rng.random() < 0.5:
+        un = np.log(un)
+    want = O.CRF(im, un, scale_factor=scale)
+    got = krahenbuhl2013.CRF(im, un, scale_factor=scale)
+    d = float(np.abs(got - want).max())
+    print("sweep worst case seed %d (%dx%d C=%d scale %g): max|dQ| %.2e" % (seed, H, W, C, scale, d))
+    assert np.isfinite(got).all() and d < CRF_TOL
+    assert (got.argmax(2) == want.argmax(2)).all()
 
 
 @pytest.mark.parametrize("kind,scale,HW", [("smooth", 12.0, (41, 41)), ("noise", 12.0, (41, 41)), ("dark_corner", 12.0, (41, 41)),
