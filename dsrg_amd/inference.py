@@ -45,7 +45,9 @@ def _eval_mode(net):
 
 def preprocess(image, size, device="cuda"):
     """image: (H,W,3) RGB uint8/float -> (1,3,size,size) float32 BGR, mean-subtracted (test-ms.py:68-81)"""
-    x = torch.as_tensor(np.asarray(image), dtype=torch.float32, device=device).permute(2, 0, 1)[None]
+    # (uploaded in the image's own dtype and converted on the device: a float32 conversion on the host is a multi-threaded torch op,
+    # and the idle spin of its ~100 worker threads after every call eats a container's CPU quota — 7 ms per image became 95)
+    x = torch.from_numpy(np.ascontiguousarray(np.asarray(image))).to(device).to(torch.float32).permute(2, 0, 1)[None]
     x = _zoom(x, size, size)
     x = x[:, [2, 1, 0]]
     return x - torch.tensor(MEAN_PIXEL, dtype=torch.float32, device=device).view(1, 3, 1, 1)
