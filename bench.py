@@ -573,12 +573,14 @@ def srg_roofline(ops, B, C, N, logits, images, labels, cues, ctx):
                     "growth): the time is two kernel boundaries plus one memory round trip each, not bandwidth"}
 
 
-def supervision_record(device, rank, B, steps, warmup, cpu=True, cpu_target_s=10.0):
-    """the supervision path on fixed fc8 logits: Softmax -> CRF -> SRG -> losses -> backward (dsrg_supervision_step)"""
+def supervision_record(device, rank, B, steps, warmup, cpu=True, cpu_target_s=10.0, size=321):
+    """the supervision path on fixed fc8 logits: Softmax -> CRF -> SRG -> losses -> backward (dsrg_supervision_step); size = the
+    input images' side: 321 -> 41 x 41 score maps (train-s), 513 -> 65 x 65 (the ResNet-101 / 513 configuration's map size)"""
     from dsrg_amd import ops, synthetic as S
-    C, H, W = 21, 41, 41
+    C = 21
+    H = W = (size - 1) // 8 + 1
     N = H * W
-    batch_np = S.make_batch(1000 + rank, B)
+    batch_np = S.make_batch(1000 + rank, B, C, H, W, size=size)
     d = lambda a: torch.from_numpy(a).to(device)                 # noqa: E731
     logits, images, labels, cues = d(batch_np["logits"]), d(batch_np["images"]), d(batch_np["labels"]), d(batch_np["cues"])
     ctx = ops.get_context(B, C, H, W)
@@ -600,7 +602,7 @@ def supervision_record(device, rank, B, steps, warmup, cpu=True, cpu_target_s=10
            "value": B * steps / dt, "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 (thresholds and marginals f64)", "data": "synthetic",
-           "config": {"workload": "supervision path on fixed fc8 logits, 41x41x21, CRF 10 iterations scale 12", "per_gpu_batch": B},
+           "config": {"workload": "supervision path on fixed fc8 logits, %dx%dx21, CRF 10 iterations scale 12" % (H, W), "per_gpu_batch": B},
            "losses": [float(x) for x in losses.detach().cpu()],
            "roofline": filter_roofline(ctx, B, C, N, filt_ms, filt_n, event_overhead_ms()) if filt_n else None,
            "other_rooflines": [srg_roofline(ops, B, C, N, logits, images, labels, cues, ctx)]}
@@ -755,7 +757,8 @@ def main():
             print(json.dumps(rec))
         return finish()
     if args.mode == "supervision":
-        rec = supervision_record(device, rank, args.batch, args.steps, args.warmup, cpu=cpu, cpu_target_s=5.0 if args.sub else 10.0)
+        rec = supervision_record(device, rank, args.batch, args.steps, args.warmup, cpu=cpu, cpu_target_s=5.0 if args.sub else 10.0,
+                                 size=args.size)
         if rank == 0:
             if cpu and not args.sub:
                 try:
@@ -950,6 +953,8 @@ def main():
             nocpu = [] if cpu else ["--no-cpu-baseline"]
             for name, argv in (("supervision", ["--mode", "supervision", "--batch", "16", "--steps", "200", "--warmup", "20", "--no-cpu-baseline"]),
                                ("supervision_b1", ["--mode", "supervision", "--batch", "1", "--steps", "200", "--warmup", "20", "--sub"] + nocpu),
+                               ("supervision_65", ["--mode", "supervision", "--batch", "10", "--size", "513", "--steps", "100", "--warmup", "10",
+                                                   "--no-cpu-baseline"]),
                                ("infer_b1", ["--mode", "infer", "--batch", "1", "--steps", "300", "--warmup", "30"]),
                                ("crf_fullres", ["--mode", "crf-fullres", "--steps", "20", "--warmup", "5"] + nocpu),
                                ("test_ms", ["--mode", "test-ms", "--steps", "30", "--warmup", "6"] + nocpu),

@@ -773,7 +773,9 @@ static int dispatch_vpt(const FilterArgs &a, int nblocks, size_t lds, int vpt, h
     if (vpt <= 4) return launch_filter<CPW_B, CPW_G, 4, 1, SEQ>(a, nblocks, lds, stream, prof);
     if (vpt <= 10) return launch_filter<CPW_B, CPW_G, 10, 2, SEQ>(a, nblocks, lds, stream, prof);
     if (vpt <= 16) return launch_filter<CPW_B, CPW_G, 16, 3, SEQ>(a, nblocks, lds, stream, prof);
-    if (vpt <= 25) return launch_filter<CPW_B, CPW_G, 25, 5, SEQ>(a, nblocks, lds, stream, prof);
+    if constexpr (CPW_B > 1) return set_error(DSRG_ERR_UNSUPPORTED, "plane pairs beyond 16 vertices per thread (vpt=%d): plan_filter picks single planes there", vpt);
+    if (vpt <= 25) return launch_filter<CPW_B, CPW_G, 25, 5, SEQ>(a, nblocks, lds, stream, prof);      // 65 x 65 (513 / 8 + 1): no scratch
+    if (vpt <= 29 && a.N <= 5 * kWG) return launch_filter<CPW_B, CPW_G, 29, 5, SEQ>(a, nblocks, lds, stream, prof);      // (66 .. 70 pixels a side)
     if (vpt <= 32) return launch_filter<CPW_B, CPW_G, 32, 6, SEQ>(a, nblocks, lds, stream, prof);
     return set_error(DSRG_ERR_UNSUPPORTED, "lattice too large for the LDS-resident filter (vpt=%d)", vpt);
 }
@@ -816,7 +818,10 @@ static int plan_filter(const LatticeView &Lg, const LatticeView &Lb, const Meanf
     // up to 12 images of 21 labels, and a one-plane workgroup is the shorter one: measured 14.1 / 14.3 us per launch at 8 / 12
     // images against 16.8-17.4 / 16.3-16.5 with plane pairs)
     const bool one_round_of_single_planes = gauss_local && (filter_opts() & kOptLocalGauss) && (size_t)B * C <= 256;
-    if (lds_for(2, 4) <= kLds && (size_t)B * ((C + 1) / 2) >= 64 && C > 2 && !one_round_of_single_planes) { cpw_b = 2; cpw_g = 4; }
+    // (plane pairs only up to 16 vertices per thread: the 25-vertex instantiation with two planes has no registers left at 1 024
+    // threads — 156 bytes of scratch per lane — where the one-plane one has none; maps of 52 .. 53 pixels a side)
+    const bool pairs_fit_registers = (Lb.Mcap + kWG - 1) / kWG <= 16;
+    if (lds_for(2, 4) <= kLds && (size_t)B * ((C + 1) / 2) >= 64 && C > 2 && !one_round_of_single_planes && pairs_fit_registers) { cpw_b = 2; cpw_g = 4; }
     else if (lds_for(1, 2) <= kLds && C > 2) { cpw_b = 1; cpw_g = 2; }
     else if (lds_for(1, 1) > 158 * 1024) return set_error(DSRG_ERR_UNSUPPORTED, "lattice does not fit LDS");
     const int vpt = (Lb.Mcap + kWG - 1) / kWG;
