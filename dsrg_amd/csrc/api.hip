@@ -507,6 +507,11 @@ extern "C" int dsrg_avgpool3x3_s1_bf16(const void *in, void *out, int B, int H, 
     if (!in || !out) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_avgpool3x3_s1(in, out, B, H, W, C, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_conv_igemm_split_f32(const void *x3_dev, const void *w_dev, const float *bias_dev, float *y_dev, int dilation, int B, int H,
+                                         int W, int cin, int cout, int ksize, int relu, void *stream) {
+    if (!x3_dev || !w_dev || !y_dev) return set_error(DSRG_ERR_INVALID, "NULL argument");
+    return launch_conv_igemm_split(x3_dev, w_dev, bias_dev, y_dev, dilation, B, H, W, cin, cout, ksize, relu, static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_add_relu_bf16(const void *a, const void *b, void *y, size_t n, void *stream) {
     if (!a || !b || !y) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_add_relu(a, b, y, n, static_cast<hipStream_t>(stream));

@@ -106,6 +106,13 @@ struct IgemmArgs {
     int row_tiles, rows_per_tile, bands;      // 1: a pixel tile = rows_per_tile whole rows of one image (bands of them per image)
     int skip_taps;          // 1: a K-step whose tap reaches no pixel of the tile (a dilated kernel near the map's border: all of
                             // its operand rows would be the zeros of the padding) is not loaded and not multiplied
+    int xrow;               // bytes per pixel row of x (Cin * 2 — or, split mode, the three bf16 planes of a float32 activation: 3 * cin * 2)
+    int cpp;                // split mode (0 = off): 64-channel chunks per PLANE.  A float32 convolution as six bf16 products on the fp32
+                            // accumulators: x = x0 + x1 + x2 and w = w0 + w1 + w2 (each term the bf16 rounding of what the terms before
+                            // leave), the products x0 w0, x0 w1, x1 w0, x0 w2, x2 w0, x1 w1 carry 2^-24-grade relative error; the K loop
+                            // runs over 6 * cpp VIRTUAL chunks — virtual chunk v reads plane kSplitXPlane[v / cpp] of x, and the packed
+                            // kernel holds plane kSplitWPlane[v / cpp] of w there (the caller's packing)
+    int out_f32;            // 1: y is float32 (B, H, W, Cout), written straight from the accumulators (split mode's prototype epilogue)
     int cls_tiles;          // 1: a pixel tile = 256 consecutive indices of the group's CLASS order (IgemmGroup::cls) instead of 256
                             // consecutive pixels: a dilated tap (dy, dx) d reaches exactly the pixels of a rectangle of the map, so the
                             // map falls into <= 3 x 3 rectangles inside each of which every pixel has the SAME live taps; ordered
@@ -216,7 +223,8 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
     }
     auto row_pixel = [&](int r) -> int { return cls ? rowpix[r] : (r < mvalid ? m0 + r : -1); };      // -1: the tile has no such row
 
-    const rsrc_t rx = make_rsrc(G.x, (size_t)a.M * Cin * 2);
+    const int xrow = a.xrow;
+    const rsrc_t rx = make_rsrc(G.x, (size_t)a.M * xrow);
     const rsrc_t rw = make_rsrc(G.w, (size_t)a.Cout * ktot * 2);
 
     // ---- DMA geometry: per K-step a wave moves rows [wv*32 + i*RPI, +RPI) of both tiles; lane -> (row, 16-byte chunk)
@@ -242,7 +250,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
                 valid = 1u;
             }
         }
-        pbase[i] = (uint32_t)mm * (uint32_t)(Cin * 2) + (uint32_t)c * 16u;
+        pbase[i] = (uint32_t)mm * (uint32_t)xrow + (uint32_t)c * 16u;
         pvalid[i] = valid;
         wbase[i] = (uint32_t)(n0 + r) * (uint32_t)(ktot * 2) + (uint32_t)c * 16u;   // rows past Cout lie beyond the descriptor
     }
@@ -286,7 +294,9 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
         if (++it_h == C::SPC) { it_h = 0; if (++it_tap == nlive) { it_tap = 0; it_cc++; } }
         int dy = 0, dx = 0;
         if (taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-        const int toff = (dy * G.dil * W + dx * G.dil) * Cin * 2 + cc * 128 + h * C::ROW;      // wave-uniform
+        // (split mode: virtual chunk cc -> chunk cc % cpp of plane 0 0 1 0 2 1 [cc / cpp] of x; two bits per entry of 0x610)
+        const int xc = a.cpp ? (int)((0x610u >> (2 * (cc / a.cpp))) & 3u) * a.cpp + cc % a.cpp : cc;
+        const int toff = (dy * G.dil * W + dx * G.dil) * xrow + xc * 128 + h * C::ROW;      // wave-uniform
         unsigned char *P = ig_lds + stage * C::STAGE + wv * (32 * C::ROW);
         unsigned char *Wt = P + kBM * C::ROW;
 #pragma unroll
@@ -415,6 +425,28 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
     // ---- epilogue: C[row = channel][col = pixel]; a lane holds channels (reg & 3) + 8 (reg >> 2) + 4 kgrp of pixel l31
     unsigned char *O = ig_lds + wv * kOutWave;
     const int nw = n0 + wn * 128;
+    if (a.out_f32) {
+        // float32 result straight from the accumulators: 16 bytes per lane and (i, q, j) — 32-byte runs per pixel row (the layer-level
+        // prototype of the split mode; a production epilogue would stage through LDS as the bf16 one does)
+        float *y32 = reinterpret_cast<float *>(G.y);
+        const float floor32 = a.relu ? 0.0f : -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int m = row_pixel(wm * 64 + j * 32 + l31);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n = nw + i * 32 + q * 8 + kgrp * 4;
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (G.bias) b4 = *reinterpret_cast<const float4 *>(G.bias + n);
+                    const float4 v = make_float4(fmaxf(acc[i][j][q * 4 + 0] + b4.x, floor32), fmaxf(acc[i][j][q * 4 + 1] + b4.y, floor32),
+                                                 fmaxf(acc[i][j][q * 4 + 2] + b4.z, floor32), fmaxf(acc[i][j][q * 4 + 3] + b4.w, floor32));
+                    if (m >= 0) *reinterpret_cast<float4 *>(y32 + (size_t)m * a.Cout + n) = v;
+                }
+        }
+        return;
+    }
     const rsrc_t rb = make_rsrc(G.bias, G.bias ? (size_t)a.Cout * 4 : 0);      // no bias: every load is out of range = 0
     const float floor_ = a.relu ? 0.0f : -__builtin_inff();                    // ReLU without a branch per value
     const uint32_t seed_g = a.seed_lo + (uint32_t)grp * 0x9E3779B9u;              // every branch its own stream
@@ -1284,6 +1316,7 @@ static thread_local IgemmArgs *t_prep_d = nullptr;
 static thread_local IgemmWgradArgs *t_prep_w = nullptr;
 static thread_local int *t_prep_grid = nullptr;
 static thread_local int t_force_ksplit = 0;              // launch_conv_igemm_backward: the pixel split it picked for its merged grid
+static thread_local int t_split_cin = 0;                 // launch_conv_igemm_split: the real input channel count (0: ordinary launch)
 
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
                       int ngroups, int B, int H, int W, int cin, int cout, int k, int relu, float drop_p, unsigned long long seed,
@@ -1312,6 +1345,12 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
             return set_error(DSRG_ERR_INVALID, "conv_igemm: null pointer");
     }
     a.out_scale = out_scale;
+    a.xrow = cin * 2;
+    if (t_split_cin > 0) {                                   // launch_conv_igemm_split: cin here is the VIRTUAL channel count 6 * real
+        a.xrow = 3 * t_split_cin * 2;
+        a.cpp = t_split_cin / 64;
+        a.out_f32 = 1;
+    }
     a.skip_taps = igemm_variant() != 6;                      // 6: tests / tools — every tap of every tile, as before round 5
     const bool fused_bwd = mask || colsum;
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.relu = relu; a.M = (int)M;
@@ -1335,7 +1374,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     // different rounds overlap: fc6 x 4, 6.6 rounds, 810 us whole against 902 us dealt out).
     const int units = igemm_cus(), tiles_total = a.tiles_per_group * ngroups, nsteps = (cin / 64) * k * k;
     const bool sk_wins = tiles_total * 100 <= units * 60, sk_forced = igemm_variant() == 4;      // 4: tests / tools, wherever legal
-    if (!fused_bwd && workspace && workspace_bytes >= conv_igemm_workspace() && ((default_form && sk_wins) || sk_forced) &&
+    if (!fused_bwd && t_split_cin == 0 && workspace && workspace_bytes >= conv_igemm_workspace() && ((default_form && sk_wins) || sk_forced) &&
         (long long)tiles_total * nsteps >= (long long)units * 8 && tiles_total * 3 >= units) {
         IgemmSkArgs sk;
         sk.base = a;
@@ -1432,6 +1471,24 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     return DSRG_OK;
 }
 
+
+// A float32 convolution on the bf16 MFMA (forward, one group; layer-level prototype of round 6): x3 = the three bf16 planes of the
+// float32 activation, (B, H, W, 3 cin) with channel index plane * cin + c; w = the packed kernel over 6 cin VIRTUAL channels,
+// (cout, 6 cin / 64, k k, 64), virtual chunk block q holding plane {0, 1, 0, 2, 0, 1}[q] of the split kernel; y float32 (B, H, W, cout)
+int launch_conv_igemm_split(const void *x3, const void *w, const float *bias, float *y, int dil, int B, int H, int W, int cin, int cout, int k,
+                            int relu, hipStream_t stream) {
+    if (!conv_igemm_supported(cin, cout, k) || (long long)B * H * W * 3 * cin * 2 >= 0x7fffffffLL)
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm_split: shape not supported");
+    const void *xp[1] = {x3}, *wp[1] = {w};
+    const float *bp[1] = {bias};
+    void *yp[1] = {y};
+    const int dils[1] = {dil};
+    t_split_cin = cin;
+    const int rc = launch_conv_igemm(xp, wp, bias ? bp : nullptr, yp, dils, 1, B, H, W, 6 * cin, cout, k, relu, 0.0f, 0ull, nullptr, 0, stream,
+                                     nullptr, 1.0f, nullptr, nullptr, 0);
+    t_split_cin = 0;
+    return rc;
+}
 
 bool conv_igemm_wgrad_supported(int cin, int cout, int k) {
     return (k == 1 || k == 3) && ((cin >= 256 && cin % 256 == 0) || (cin == 128 && k == 3)) && cout >= 256 && cout % 256 == 0;

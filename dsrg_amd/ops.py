@@ -775,6 +775,33 @@ def pack_conv_weight_pair(weight, want_fwd=True, want_dgrad=True):
     return (fwd if want_fwd else None), (dg if want_dgrad else None)
 
 
+def split3_bf16(t, dim):
+    """a float32 tensor as three bf16 planes concatenated along `dim`: t = p0 + p1 + p2 up to 2^-24 relative (each plane the bf16
+    rounding of what the planes before leave)"""
+    p0 = t.to(torch.bfloat16)
+    r1 = t - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    return torch.cat([p0, p1, p2], dim=dim)
+
+
+def conv_igemm_split(x, weight, bias, dilation, relu):
+    """layer-level prototype: a float32 'same' convolution (3x3 or 1x1, stride 1) on the bf16 MFMA with six bf16 products per
+    multiply-add (dsrg_conv_igemm_split_f32): x (B,cin,H,W) float32, weight (cout,cin,k,k) float32, bias (cout) float32 or None ->
+    (B,cout,H,W) float32 channels_last.  The operand splits are torch ops here (a production path would have the producing
+    epilogue write the planes)."""
+    B, cin, H, W = x.shape
+    cout, k = weight.shape[0], weight.shape[2]
+    x3 = split3_bf16(x.permute(0, 2, 3, 1).contiguous().float(), 3)                     # (B,H,W,3 cin)
+    w0, w1, w2 = [pack_conv_weight(p) for p in split3_bf16(weight.float(), 0).split(cout, 0)]
+    wv = torch.cat([w0, w1, w0, w2, w0, w1], dim=1).contiguous()                      # (cout, 6 cin / 64, k k, 64)
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    b = bias.float().contiguous() if bias is not None else None
+    check(_lib.lib().dsrg_conv_igemm_split_f32(_ptr(x3), _ptr(wv), _ptr(b), _ptr(y), int(dilation), B, H, W, cin, cout, k, int(bool(relu)),
+                                               _stream()))
+    return y
+
+
 def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0, stream_k=True):
     """1 .. 4 convolutions of one geometry in one launch (the four ASPP branches): xs[g] (B,cin,H,W) bf16 channels_last,
     packed[g] = pack_conv_weight(w_g), biases[g] (cout) f32 or None -> list of (B,cout,H,W) bf16 channels_last; fp32

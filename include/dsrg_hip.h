@@ -274,6 +274,13 @@ int dsrg_relu_bwd_bias_bf16(const void *g_dev, const void *y_dev, void *gm_dev, 
  * e.g. the 21-channel fc8 outputs).  partials: device scratch of partial_blocks * C floats. */
 int dsrg_bias_grad_bf16(const void *g_dev, float *bias_grad_dev, float *partials_dev, int partial_blocks, long rows, int C,
                         void *stream);
+/* Layer-level prototype (round 6) of a FLOAT32 convolution on the bf16 MFMA — the arithmetic of the reference's Caffe
+ * convolutions (train-s.prototxt:41-744) at six bf16 products per multiply-add: x = x0 + x1 + x2, w = w0 + w1 + w2 (each term the
+ * bf16 rounding of what the terms before leave), products x0 w0, x0 w1, x1 w0, x0 w2, x2 w0, x1 w1 on the fp32 accumulators.
+ *   x3_dev (B,H,W,3*cin) bf16: channel plane * cin + c;  w_dev (cout, 6*cin/64, k*k, 64) bf16: the dsrg_conv_igemm_bf16 packing of
+ *   the six-block virtual kernel [w0 | w1 | w0 | w2 | w0 | w1];  y_dev (B,H,W,cout) float32.  Forward only, one group. */
+int dsrg_conv_igemm_split_f32(const void *x3_dev, const void *w_dev, const float *bias_dev, float *y_dev, int dilation, int B, int H,
+                              int W, int cin, int cout, int ksize, int relu, void *stream);
 /* The tail of a ResNet bottleneck (the train-f stage on the DeepLab-v2 ResNet-101 of BASELINE.json configs[4]; the reference
  * trains VGG16 only, train-f.prototxt:15-720 — backbone plumbing): y = relu(a + b) over n bf16 elements (fp32 sum, one
  * rounding), n % 8 == 0; and its backward gm = (y > 0) ? g (+ g2) : 0 — g2_dev (may be NULL): a second gradient of y to be

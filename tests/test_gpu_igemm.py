@@ -159,6 +159,28 @@ def test_igemm_skipping_on_random_shapes(ops):
         _close(skip[0], want, "case %d: %dx%dx%d dilation %d" % (case, B, H, W, dils[0]))
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,k,dil", [(2, 41, 41, 128, 256, 3, 1), (1, 33, 29, 64, 128, 3, 6), (2, 17, 19, 256, 128, 1, 1)])
+def test_igemm_split_mode_is_float32_grade(ops, B, H, W, cin, cout, k, dil):
+    """dsrg_conv_igemm_split_f32 (the layer-level prototype of a float32 convolution on the bf16 MFMA: operands as three bf16
+    planes, six bf16 products per multiply-add on the fp32 accumulators): against a float64 convolution of the same float32
+    operands the error is that of a float32 convolution (1e-6 of the range), three orders below the bf16 launch's"""
+    g = torch.Generator(device="cuda").manual_seed(7 + cin)
+    x = torch.relu(torch.randn(B, cin, H, W, device="cuda", generator=g)).contiguous(memory_format=CL)
+    w = torch.randn(cout, cin, k, k, device="cuda", generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, device="cuda", generator=g) * 0.1
+    y64 = F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=dil * (k // 2), dilation=dil)
+    for relu in (False, True):
+        y = ops.conv_igemm_split(x, w, b, dil, relu)
+        want = torch.relu(y64) if relu else y64
+        assert y.dtype == torch.float32 and y.is_contiguous(memory_format=CL)
+        err = float((y.double().cpu() - want).abs().max()) / float(y64.abs().max())
+        y32 = F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=dil * (k // 2), dilation=dil)
+        err32 = float((y32.double() - y64).abs().max()) / float(y64.abs().max())
+        assert err < 4e-6 and err < 4 * err32 + 1e-6, (err, err32)
+    yb = ops.conv_igemm([x.bfloat16().contiguous(memory_format=CL)], [ops.pack_conv_weight(w.bfloat16())], [b], [dil], k, False)[0]
+    assert float((yb.double().cpu() - y64).abs().max()) / float(y64.abs().max()) > 100 * err
+
+
 @pytest.mark.parametrize("B,H,W", [(16, 41, 41), (1, 41, 41), (3, 65, 65), (2, 30, 50), (5, 7, 100), (2, 23, 9)])
 def test_igemm_class_ordered_tiles_are_bit_identical(ops, B, H, W):
     """The dilated launches order their pixels class by class (the <= 3 x 3 rectangles of the map inside each of which every
