@@ -11,6 +11,7 @@
 #include <math.h>
 #include <cstring>
 #include "common.h"
+#include <cstdlib>
 #include "embed.h"
 
 namespace dsrg {
@@ -40,7 +41,12 @@ struct LargeLattice {
     int T_host, nmulti_host;
     int seg_len;             // entries per splat segment
 };
-constexpr int kSplatSeg = 64;
+// (4 096 since round 6: a vertex's row is summed WHOLE, entry by entry in the reference's order, unless it is longer than any row of a
+// natural image — a flat region of more than ~4 000 pixels inside one 80-pixel lattice cell.  With 64-entry segments the partial
+// sums' reassociation, amplified by ten softmax iterations at weight 10, put the worst sweep case at 7.4e-5 of the 1e-4 contract
+// (138 x 163, dark corner); whole rows: 4.4e-6, at the same 1.44 ms per natural 321 x 321 image and 0.80 ms batched.  A flat image
+// pays: 2.7 -> 5.0 ms.  profiles/r06_splat_segments.txt; DSRG_SPLAT_SEG overrides, tools only)
+constexpr int kSplatSeg = 4096;
 constexpr int kLargeBatchMax = 8;          // images per batched object: the image number's room in the d = 2 keys (lg_embed_kernel)
 
 
@@ -801,7 +807,7 @@ static size_t large_lattice_carve(LargeLattice &L, unsigned char *p, int d, int 
     L.M = (int *)take(sizeof(int) * 4);
     L.seg_start = L.first; L.seg_cnt = L.scanned; L.seg_v = L.slot_e; L.multi_v = L.key_e;        // dead once lg_vid_kernel has run
     L.T_host = L.nmulti_host = 0;
-    L.seg_len = kSplatSeg;
+    L.seg_len = [] { const char *e = getenv("DSRG_SPLAT_SEG"); const int v = e ? atoi(e) : 0; return v >= 8 && v <= 65536 ? v : kSplatSeg; }();   // (tools: A/B)
     L.nimg = 1; L.Nimg = N; L.Npimg = 0;
     return off;
 }

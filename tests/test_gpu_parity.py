@@ -170,7 +170,8 @@ def test_crf_sweep_worst_cases_vs_oracle(O, seed):
     found, pinned as tests with the sweep's own generator: seed 20173 = 138 x 163, 21 labels, scale 3, dark_corner — the
     global-memory path, where a vertex that gathers thousands of equal-coloured pixels sums its row in segments and the oracle
     sums it pixel by pixel (fp32 reassociation, amplified by ten softmax iterations at weight 10); seed 20083 = 89 x 96, 7 labels,
-    scale 1.  The bar is the contract's 1e-4; the figure reached is printed (round 5: 7.44e-5 and 2.21e-5)."""
+    scale 1.  Round 5 (rows cut into 64-entry segments): 7.44e-5 and 2.21e-5 of the contract's 1e-4; since round 6 a row is summed
+    whole, in the reference's order, up to 4 096 entries (lattice_large.hip, kSplatSeg): 4.4e-6 and 7e-9.  Bar here: 3e-5."""
     import krahenbuhl2013
     it = seed - 20000
     rng = np.random.default_rng(seed)
@@ -189,7 +190,7 @@ def test_crf_sweep_worst_cases_vs_oracle(O, seed):
     got = krahenbuhl2013.CRF(im, un, scale_factor=scale)
     d = float(np.abs(got - want).max())
     print("sweep worst case seed %d (%dx%d C=%d scale %g): max|dQ| %.2e" % (seed, H, W, C, scale, d))
-    assert np.isfinite(got).all() and d < CRF_TOL
+    assert np.isfinite(got).all() and d < 3e-5
     assert (got.argmax(2) == want.argmax(2)).all()
 
 
