@@ -15,7 +15,7 @@ python tools/pmc_parse.py $OUT/pmc/fr_fetch_counter_collection.csv $OUT/pmc/fr_w
 python tools/pmc_lds_parse.py $OUT/pmc/sup_lds_counter_collection.csv $OUT/lds_counters.json $COMMIT > /dev/null 2>>$OUT/pmc_parse.err
 python tools/pmc_mfma.py $OUT/pmc/train_mfma_counter_collection.csv 3 > $OUT/mfma_utilisation.txt 2>>$OUT/pmc_parse.err
 mkdir -p profiles
-for f in pmc_traffic pmc_traffic_fullres lds_counters; do [ -s $OUT/$f.json ] && cp $OUT/$f.json profiles/r05_$f.json; done
+for f in pmc_traffic pmc_traffic_fullres lds_counters; do [ -s $OUT/$f.json ] && cp $OUT/$f.json profiles/r06_$f.json; done
 timeout 1500 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_t -o train -- python $ROOT/bench.py --steps 20 --warmup 8 --no-fp32 --no-cpu-baseline --no-modes --no-profile > $ROOT/$OUT/bench_train_rocprof.json 2> $ROOT/$OUT/rocprof_train.err
@@ -32,6 +32,9 @@ python tools/filter_trace.py 16 2>&1 | grep -v amdgpu > $OUT/filter_trace.txt
 timeout 200 python tools/pylayers_route_cost.py 16 2>&1 | grep -v amdgpu > $OUT/pylayers_route.txt
 timeout 300 python tools/skip_probe.py 16 2>&1 | grep -v amdgpu > $OUT/skip_probe.txt
 timeout 300 python tools/grad_fidelity.py 16 2>&1 | grep -v amdgpu > $OUT/grad_fidelity_b16.txt
+timeout 300 python tools/class_tiles_probe.py 16 2>&1 | grep -v amdgpu > $OUT/class_tiles_probe.txt
+python tools/rocpd_timeline.py /tmp/prof_t/train_results.db avgpool3x3_s1 2 > $OUT/train_timeline.txt 2>&1
+bash tools/gpu_trainf_profiles.sh $OUT > $OUT/trainf_profiles.log 2>&1
 head -3 $OUT/train_kernel_stats.txt | cut -c1-200; tail -12 $OUT/parity_sweeps.txt; python - <<PY
 import json
 d = json.load(open("$OUT/bench_default.json"))
