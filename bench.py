@@ -280,8 +280,9 @@ def crf_fullres_record(device, steps, warmup, cpu=True, size=321):
     tj, traffic_src = _counter_file("pmc_traffic_fullres", "fullres")
     traffic = (tj or {}).get("lg_splat2_kernel_bytes_per_launch")
     achieved = head["alg_bytes_per_splat_launch"] / per_launch_s / 1e9
-    roofline = {"kernel": "lg_splat2_kernel + lg_combine_kernel (permutohedral splat of both lattices: per-vertex ordered gather lists cut "
-                          "into segments of 64 entries, values in HBM/L2)",
+    roofline = {"kernel": "lg_splat2_kernel (+ lg_combine_kernel for rows beyond 4 096 entries) — permutohedral splat of both lattices: one "
+                          "ordered sum per vertex over its gather list, in the reference's order; values in HBM/L2.  One image per launch: "
+                          "the longest row sets the launch's duration; modes.crf_fullres.batch8_splat is the throughput form",
                 "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src,
@@ -725,8 +726,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    # under torch.distributed.run (RANK set) the process group and DDP are used even for one rank, so the
-    # single-GPU run of the driver's launch line exercises the same RCCL/DDP path as the 8-GPU run
+    # under torch.distributed.run (RANK set) the process group and the gradient reducer (dsrg_amd/reducer.py) are set up even for one
+    # rank, so the single-GPU run of the driver's launch line goes through the code the 8-GPU run goes through (at one rank the
+    # bucket all-reduces themselves are skipped — nothing to reduce; barrier, timing gather and the weight checksums use RCCL)
     use_dist = world > 1 or (os.environ.get("RANK") is not None and os.environ.get("DSRG_BENCH_NO_DDP") is None)
     if use_dist:
         import torch.distributed as dist

@@ -531,8 +531,16 @@ __device__ __forceinline__ void filter_lattice(const LatticeView &L, int li, con
 // bilateral ones (CPW_B planes of one image: 6 axes, M ~ 2-6 N vertices, the long ones), then the Gaussian ones (CPW_G planes
 // of one image through the lattice all images share: 3 axes), handed out by the hardware dispatcher (a software unit queue
 // was measured and lost, profiles/r02_filter_queue_ab.txt).
+// (DSRG_EXP & 64, measured and not adopted — profiles/r06_filter_ab.txt: the kernel built for TWO workgroups per CU — 64 VGPRs
+// at 1 024 threads, 112 bytes of scratch per lane for the 10-vertex instantiation — so that the 336 one-plane workgroups of a
+// 16-image batch are resident at once instead of 176 plane pairs on 176 CUs)
+#if DSRG_EXP & 64
+#define DSRG_FILTER_BOUNDS __launch_bounds__(kWG, 8)
+#else
+#define DSRG_FILTER_BOUNDS __launch_bounds__(kWG)
+#endif
 template <int CPW_B, int CPW_G, int VPT_B, int PPT, bool SEQ>
-__global__ __launch_bounds__(kWG) void mf_filter_kernel(FilterArgs a) {
+__global__ DSRG_FILTER_BOUNDS void mf_filter_kernel(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int VPT_G = (VPT_B + 1) / 2;                 // Mcap_gauss = Mcap_bilateral / 2
     unsigned long long *dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr;
@@ -817,7 +825,11 @@ static int plan_filter(const LatticeView &Lg, const LatticeView &Lb, const Meanf
     // (with the Gaussian workgroups out of the launch, one-plane bilateral workgroups still make ONE round of MI355X's 256 CUs
     // up to 12 images of 21 labels, and a one-plane workgroup is the shorter one: measured 14.1 / 14.3 us per launch at 8 / 12
     // images against 16.8-17.4 / 16.3-16.5 with plane pairs)
+#if DSRG_EXP & 64
+    const bool one_round_of_single_planes = gauss_local && (filter_opts() & kOptLocalGauss) && (size_t)B * C <= 512;
+#else
     const bool one_round_of_single_planes = gauss_local && (filter_opts() & kOptLocalGauss) && (size_t)B * C <= 256;
+#endif
     // (plane pairs only up to 16 vertices per thread: the 25-vertex instantiation with two planes has no registers left at 1 024
     // threads — 156 bytes of scratch per lane — where the one-plane one has none; maps of 52 .. 53 pixels a side)
     const bool pairs_fit_registers = (Lb.Mcap + kWG - 1) / kWG <= 16;

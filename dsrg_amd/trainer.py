@@ -1,6 +1,6 @@
 """One DSRG train-s step on MI355X: backbone forward (MIOpen, bf16 autocast) -> supervision
 hot path (libdsrg_hip.so) -> backward -> Caffe-style SGD (solver-s.prototxt).  Data parallel
-over images: one process per GPU, gradients all-reduced by RCCL through DistributedDataParallel.
+over images: one process per GPU, gradients all-reduced by RCCL in buckets the weight-gradient kernels write into (reducer.py).
 """
 import os
 
@@ -138,7 +138,7 @@ class DSRGTrainer(object):
         path.  (Tests inject a torch loss to exercise the data-parallel plumbing on CPU/gloo.)
         weights: `train.py --weights` (run.sh:5: ../../vgg16_20M_mc.caffemodel) — a .caffemodel / .npz / torch file
         copied by layer name before training; snapshot: `train.py --snapshot` — a solverstate written by save()."""
-        torch.manual_seed(seed)            # same initial weights on every rank (DDP also broadcasts)
+        torch.manual_seed(seed)            # same initial weights on every rank (the reducer also broadcasts)
         self.device = device
         self.amp_dtype = amp_dtype
         self.channels_last = channels_last
