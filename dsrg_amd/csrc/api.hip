@@ -507,6 +507,12 @@ extern "C" int dsrg_avgpool3x3_s1_bf16(const void *in, void *out, int B, int H, 
     if (!in || !out) return set_error(DSRG_ERR_INVALID, "NULL argument");
     return launch_avgpool3x3_s1(in, out, B, H, W, C, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_conv_igemm_residual_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, const void *res_dev, const void *mask_dev,
+                                             void *y_dev, int dilation, int B, int H, int W, int cin, int cout, int ksize, int relu, void *stream) {
+    if (!x_dev || !w_dev || !res_dev || !y_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "conv_igemm_residual: bad arguments");
+    return launch_conv_igemm_residual(x_dev, w_dev, bias_dev, res_dev, mask_dev, y_dev, dilation, B, H, W, cin, cout, ksize, relu,
+                                      static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_conv_igemm_split_f32(const void *x3_dev, const void *w_dev, const float *bias_dev, float *y_dev, int dilation, int B, int H,
                                          int W, int cin, int cout, int ksize, int relu, void *stream) {
     if (!x3_dev || !w_dev || !y_dev) return set_error(DSRG_ERR_INVALID, "NULL argument");

@@ -184,6 +184,8 @@ int launch_conv3x3_direct(const void *x, const void *w, const float *bias, void 
                           void *colsum_ws = nullptr, size_t colsum_ws_bytes = 0);
 size_t conv3x3_direct_colsum_workspace(int cout);
 bool conv_igemm_supported(int cin, int cout, int k);
+int launch_conv_igemm_residual(const void *x, const void *w, const float *bias, const void *res, const void *mask, void *y, int dil, int B,
+                               int H, int W, int cin, int cout, int k, int relu, hipStream_t stream);
 int launch_conv_igemm_split(const void *x3, const void *w, const float *bias, float *y, int dil, int B, int H, int W, int cin, int cout, int k,
                             int relu, hipStream_t stream);
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,

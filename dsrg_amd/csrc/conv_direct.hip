@@ -25,6 +25,12 @@
 #include <cstdlib>
 #include <cstring>
 
+#if defined(DSRG_EXP) && (DSRG_EXP & 16)
+#define DSRG_DIRECT_DMA 0
+#endif
+#ifndef DSRG_DIRECT_DMA
+#define DSRG_DIRECT_DMA 1                    // 1: the halo tiles of conv3x3_direct_kernel go global -> LDS by DMA (chunk-major image); 0: through registers (rounds 2-5)
+#endif
 #ifndef DSRG_EXP
 #define DSRG_EXP 0                           // experiment builds (Makefile, EXP= / EXPSRC=conv_direct): 1 no halo fetch beyond the first
 #endif                                       // tile, 2 no output stores, 4 no MFMAs — what binds the forward kernel (tools only)
@@ -54,9 +60,21 @@ template <int CIN, int COUT, int TPW_ = (CIN == 64 ? 2 : 1)> struct Cfg {
 #endif
     static constexpr int SPT = CG / KPS;                   // steps per tap
     static constexpr int STEPS = 9 * SPT;
-    static constexpr int IN_STRIDE = CIN * 2 + 16;         // bytes per halo pixel in LDS
+    // halo by LDS-DMA (buffer_load ... lds) where it pays (measured at batch 16, round 6: 128 -> 128 152 -> 141 us; 64 -> 64 and
+    // 128 -> 64 unchanged; 64 -> 128 slower, its M-tile pair spills): image CHUNK-MAJOR, [16-byte channel chunk c][halo pixel p],
+    // 16 bytes each.  A DMA wave instruction lands 64 consecutive pixels of one chunk (lane-linear, as the instruction requires); a
+    // fragment read's 16-lane group touches 16 (nearly) consecutive pixels of one chunk = consecutive 16-byte slots: conflict-free
+    // without padding or swizzle, and the address is lane part (pixel * 16 + kgrp * PLANE) + compile-time constant (chunk * PLANE +
+    // tap offset * 16): immediate offsets, as the padded pixel-major image has (an XOR-swizzled pixel-major image makes hipcc form
+    // every step's address up front and spill the register-resident weights)
+    static constexpr bool DMA = DSRG_DIRECT_DMA && CIN == 128 && COUT == 128;
+    static constexpr int CPR = CIN / 8;                    // 16-byte chunks per halo pixel (8 / 16)
+    static constexpr int PB = (kHH * kHW + 63) / 64;       // 64-pixel blocks per chunk plane (3)
+    static constexpr int PLANE = PB * 1024;                // bytes per chunk plane
+    static constexpr int NI = CPR * PB;                    // DMA wave instructions per halo tile (24 / 48)
+    static constexpr int IN_STRIDE = CIN * 2 + 16;         // bytes per halo pixel in LDS (pixel-major image, through registers)
     static constexpr int OUT_STRIDE = COUT * 2 + 16;       // bytes per pixel of the output tile in LDS (2-way on the 8-byte stores)
-    static constexpr int IN_BYTES = kHH * kHW * IN_STRIDE, OUT_BYTES = kTH * kTW * OUT_STRIDE;
+    static constexpr int IN_BYTES = DMA && CPR * PLANE > kHH * kHW * IN_STRIDE ? CPR * PLANE : kHH * kHW * IN_STRIDE, OUT_BYTES = kTH * kTW * OUT_STRIDE;
     static constexpr int BUF = IN_BYTES > OUT_BYTES ? IN_BYTES : OUT_BYTES;   // a buffer is a halo tile, then an output tile
     static constexpr int VPP = CIN / 8;                    // 16-byte vectors per input pixel
     static constexpr int HALO_VECS = kHH * kHW * VPP;
@@ -122,7 +140,35 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
         y0 = (r / a.tiles_x) * kTH;
         x0 = (r % a.tiles_x) * kTW;
     };
-    // halo vector v of a tile: pixel (hy, hx) of the 10 x 18 halo, 16-byte channel group cg; chunk c of MT per thread
+    constexpr bool kDma = C::DMA && !BWD;                        // (the masked data-gradient instantiation spills 428 bytes a lane with it)
+    // (kDma) the halo of tile t straight into LDS.  Wave instruction q = chunk * PB + block lands the 64 pixels [64 block, 64 block + 64) of
+    // chunk plane `chunk`; lane = pixel inside the block; a pixel outside the image or beyond the halo reads zeros through the
+    // descriptor's range check.  No staging registers, no ds_write pass; the wait moves to the barrier at the end of the tile.
+    const rsrc_t rxh = make_rsrc(a.x, (size_t)a.B * a.H * a.W * CIN * 2);
+    auto issue_halo = [&](int t, unsigned char *buf) {
+        int b, y0, x0;
+        tile_origin(t, b, y0, x0);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        uint32_t poff[C::PB];                                    // this lane's pixel of each block: byte offset of its row in x, or out of range
+#pragma unroll
+        for (int blk = 0; blk < C::PB; blk++) {
+            const int px = blk * 64 + lane, hy = px / kHW, hx = px - hy * kHW, yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const bool in = px < kHH * kHW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            poff[blk] = in ? (uint32_t)((b * a.H + yy) * a.W + xx) * (uint32_t)(CIN * 2) : 0x80000000u;
+        }
+#pragma unroll
+        for (int u = 0; u < (C::NI + 3) / 4; u++) {
+            const int q = wv + 4 * u;                            // (wave-uniform)
+            if (q < C::NI) {
+                const int c = q / C::PB, blk = q - c * C::PB;
+                uint32_t off = poff[0];
+#pragma unroll
+                for (int k = 1; k < C::PB; k++) off = blk == k ? poff[k] : off;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void *)(buf + q * 1024), 16, off, (uint32_t)(c * 16), 0, 0);
+            }
+        }
+    };
+    // (!kDma) halo vector v of a tile: pixel (hy, hx) of the 10 x 18 halo, 16-byte channel group cg; chunk c of MT per thread
     uint4 pre[C::VPC];
     auto fetch = [&](int t, int c) {
         int b, y0, x0;
@@ -150,10 +196,15 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
 
     int t = blockIdx.x, cur = 0;
     if (t >= a.ntiles) return;
+    if constexpr (kDma) {
+        issue_halo(t, conv_lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int c = 0; c < C::MT; c++) {
-        fetch(t, c);
-        park(conv_lds, c);
+        for (int c = 0; c < C::MT; c++) {
+            fetch(t, c);
+            park(conv_lds, c);
+        }
     }
     __syncthreads();
     // masked launch: the column sums of this thread's channel group (tid % OVP) over all its tiles live in LDS behind the two
@@ -187,10 +238,13 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rmask, (lds_void *)(mtile + (u * 256 + wv * 64) * 16), 16, off, 0, 0, 0);
             }
         }
+        if constexpr (kDma)
+            if (more) issue_halo(tn, other);                     // the next tile's halo on its way while this one is computed
         f32x16 acc[C::MT][C::TPW];
 #pragma unroll
         for (int mt = 0; mt < C::MT; mt++) {
-            if (more) fetch(tn, mt);                             // a slice of the next halo on its way while this M-tile computes
+            if constexpr (!kDma)
+                if (more) fetch(tn, mt);                         // a slice of the next halo on its way while this M-tile computes
 #pragma unroll
             for (int j = 0; j < C::TPW; j++)
 #pragma unroll
@@ -200,18 +254,22 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
             // one wave per SIMD: nothing else hides the LDS latency of the pixel operand, so the four 16-byte reads of step
             // s + 1 are issued before the MFMAs of step s; sched_barrier pins that order (left alone, the scheduler sinks
             // every read next to its use and the wave waits out the LDS latency at every step)
+            // fragment i of step s — chunk-major image: chunk h * 2 KPS + 2 i + kgrp of halo pixel (ty + tap / 3, tx + tap % 3);
+            // pixel-major image: bytes [h * 32 KPS + 32 i + 16 kgrp, + 16) of that pixel's row
+            const unsigned char *lane_base = kDma ? in + (ty * kHW + tx) * 16 + kgrp * C::PLANE : in + (ty * kHW + tx) * C::IN_STRIDE + kgrp * 16;
             auto a_ptr = [&](int s) {
                 const int tap = s / C::SPT, h = s % C::SPT;
-                return in + ((ty + tap / 3) * kHW + (tx + tap % 3)) * C::IN_STRIDE + h * (32 * C::KPS) + kgrp * 16;
+                return lane_base + ((tap / 3) * kHW + tap % 3) * (kDma ? 16 : C::IN_STRIDE) + h * (kDma ? 2 * C::KPS * C::PLANE : 32 * C::KPS);
             };
+            constexpr int kFragStep = kDma ? 2 * C::PLANE : 32;  // fragment i + 1: two chunks further
             bf16x8 ar[2][C::KPS];
 #pragma unroll
-            for (int i = 0; i < C::KPS; i++) ar[0][i] = *reinterpret_cast<const bf16x8 *>(a_ptr(0) + i * 32);
+            for (int i = 0; i < C::KPS; i++) ar[0][i] = *reinterpret_cast<const bf16x8 *>(a_ptr(0) + i * kFragStep);
 #pragma unroll
             for (int s = 0; s < C::STEPS; s++) {
                 if (s + 1 < C::STEPS) {
 #pragma unroll
-                    for (int i = 0; i < C::KPS; i++) ar[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(a_ptr(s + 1) + i * 32);
+                    for (int i = 0; i < C::KPS; i++) ar[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(a_ptr(s + 1) + i * kFragStep);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -227,7 +285,8 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) park(other, mt);
+            if constexpr (!kDma)
+                if (more) park(other, mt);
         }
         __syncthreads();                                         // every wave is done reading the halo in `in`
         // epilogue: the product is taken transposed, C[row = output channel][col = pixel], so a lane holds runs of four
@@ -291,6 +350,7 @@ __global__ __launch_bounds__(256, (TPW_ * CIN <= 64 ? 2 : 1)) void conv3x3_direc
                 for (int e = 0; e < 8; e++) csl[e] += cs[e];
             }
         }
+        if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next halo have landed (the barrier: everybody's)
         __syncthreads();                                         // this buffer is free for the tile after next
 #if !(DSRG_EXP & 1)
         cur ^= 1;
@@ -321,6 +381,8 @@ template <int CIN, int COUT, int TPW_>
 int launch_variant(const ConvArgs &a, int n_cus, hipStream_t stream) {
     using C = Cfg<CIN, COUT, TPW_>;
     static LdsGrant grant, grant_b;
+    // (the DMA halo marks a lane outside the image with byte offset 2^31, which must lie beyond the descriptor's range)
+    if (C::DMA && !a.mask && (size_t)a.B * a.H * a.W * CIN * 2 >= ((size_t)1 << 31)) return DSRG_ERR_UNSUPPORTED;
     const int grid = variant_grid<CIN, COUT, TPW_>(a, n_cus);    // persistent: one or two workgroups per CU
     if (a.mask) {                                                // masked data gradient: + 8 KB of column sums
         const size_t lds = 2 * (size_t)C::BUF + 256 * 8 * sizeof(float) + (size_t)kTH * kTW * COUT * 2;

@@ -90,6 +90,10 @@ struct IgemmGroup {
                             // the ReLU (+ Dropout) backward of the layer below, when this launch is a data gradient
     float *colsum;          // (tiles_m, Cout) fp32 or nullptr: per 256-row tile, the column sums of what was stored —
                             // the partial bias gradient of the layer below (summed in fixed order by igemm_colsum_kernel)
+    const uint16_t *res;    // (B, H, W, Cout) bf16 or nullptr: added to the bf16-rounded result BEFORE the ReLU / the mask — the identity
+                            // branch of a residual block in the forward launch (y = relu(bf16(conv + bias) + res): bit for bit what a separate
+                            // add + ReLU pass over the stored convolution gives), the gradient that reaches the block's input past the
+                            // convolutions in its first convolution's data gradient (gx = (bf16(conv) + res) where mask > 0)
     int dil, ncls;
     IgemmClass cls[kMaxClasses];    // cls_tiles: the group's pixel order, classes by ascending q0
 };
@@ -448,7 +452,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
         return;
     }
     const rsrc_t rb = make_rsrc(G.bias, G.bias ? (size_t)a.Cout * 4 : 0);      // no bias: every load is out of range = 0
-    const float floor_ = a.relu ? 0.0f : -__builtin_inff();                    // ReLU without a branch per value
+    const float floor_ = (a.relu && !G.res) ? 0.0f : -__builtin_inff();        // ReLU without a branch per value (behind the residual, if any)
     const uint32_t seed_g = a.seed_lo + (uint32_t)grp * 0x9E3779B9u;              // every branch its own stream
     float bias_r[4][4][4];
 #pragma unroll
@@ -483,6 +487,40 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
         }
     }
     // the wave reads back its own rows only: LDS operations of one wave complete in order
+    if (G.res) {                                             // (uniform) residual, then ReLU and / or the mask of the layer below
+        const float floor2 = a.relu ? 0.0f : -__builtin_inff();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                        // two batches of eight rows: two latencies, half the registers
+            uint4 rs[8], mk8[8];
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int m = row_pixel(wm * 64 + (h * 8 + it) * 4 + (lane >> 4));
+                const size_t at = (size_t)m * a.Cout + nw + (lane & 15) * 8;
+                rs[it] = m >= 0 ? *reinterpret_cast<const uint4 *>(G.res + at) : make_uint4(0, 0, 0, 0);
+                mk8[it] = !G.mask ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
+                                  : (m >= 0 ? *reinterpret_cast<const uint4 *>(G.mask + at) : make_uint4(0, 0, 0, 0));
+            }
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int p = (h * 8 + it) * 4 + (lane >> 4), ch = lane & 15;
+                const int m = row_pixel(wm * 64 + p);
+                const uint4 v = *reinterpret_cast<const uint4 *>(O + p * kOutRow + ch * 16);
+                uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t r4[4] = {rs[it].x, rs[it].y, rs[it].z, rs[it].w};
+                const uint32_t y4[4] = {mk8[it].x, mk8[it].y, mk8[it].z, mk8[it].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float lo = fmaxf(__uint_as_float(w4[e] << 16) + __uint_as_float(r4[e] << 16), floor2);
+                    const float hi = fmaxf(__uint_as_float(w4[e] & 0xffff0000u) + __uint_as_float(r4[e] & 0xffff0000u), floor2);
+                    const uint32_t klo = (int16_t)(y4[e] & 0xffffu) > 0 ? 0x0000ffffu : 0u;
+                    const uint32_t khi = (int32_t)y4[e] >= 0x10000 ? 0xffff0000u : 0u;
+                    w4[e] = pack2(lo, hi) & (klo | khi);
+                }
+                if (m >= 0) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+        }
+        return;
+    }
     if (!G.mask && !G.colsum) {
 #pragma unroll 4
         for (int it = 0; it < 16; it++) {
@@ -1316,6 +1354,7 @@ static thread_local IgemmArgs *t_prep_d = nullptr;
 static thread_local IgemmWgradArgs *t_prep_w = nullptr;
 static thread_local int *t_prep_grid = nullptr;
 static thread_local int t_force_ksplit = 0;              // launch_conv_igemm_backward: the pixel split it picked for its merged grid
+static thread_local const void *t_res = nullptr;         // launch_conv_igemm_residual: the residual of its single group (nullptr: none)
 static thread_local int t_split_cin = 0;                 // launch_conv_igemm_split: the real input channel count (0: ordinary launch)
 
 int launch_conv_igemm(const void *const *x, const void *const *w, const float *const *bias, void *const *y, const int *dil,
@@ -1341,6 +1380,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
         a.g[g].dil = dil ? dil[g] : 1;
         a.g[g].mask = mask ? static_cast<const uint16_t *>(mask[g]) : nullptr;
         a.g[g].colsum = colsum ? static_cast<float *>(colsum_ws) + (size_t)g * conv_igemm_pixel_tiles(B, H, W) * cout : nullptr;
+        a.g[g].res = static_cast<const uint16_t *>(t_res);
         if (!a.g[g].x || !a.g[g].w || !a.g[g].y || (mask && !mask[g]) || (colsum && !colsum[g]))
             return set_error(DSRG_ERR_INVALID, "conv_igemm: null pointer");
     }
@@ -1352,7 +1392,9 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
         a.out_f32 = 1;
     }
     a.skip_taps = igemm_variant() != 6;                      // 6: tests / tools — every tap of every tile, as before round 5
-    const bool fused_bwd = mask || colsum;
+    const bool fused_bwd = mask || colsum || t_res;
+    if (t_res && (colsum || ngroups != 1 || drop_p != 0.0f || t_split_cin))
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: a residual goes with one group, no column sums, no dropout");
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.relu = relu; a.M = (int)M;
     a.tiles_m = (int)((M + kBM - 1) / kBM);
     a.tiles_n = (cout + kBN - 1) / kBN;
@@ -1487,6 +1529,22 @@ int launch_conv_igemm_split(const void *x3, const void *w, const float *bias, fl
     const int rc = launch_conv_igemm(xp, wp, bias ? bp : nullptr, yp, dils, 1, B, H, W, 6 * cin, cout, k, relu, 0.0f, 0ull, nullptr, 0, stream,
                                      nullptr, 1.0f, nullptr, nullptr, 0);
     t_split_cin = 0;
+    return rc;
+}
+
+// One group with a residual in the store (IgemmGroup::res): y = post(bf16(conv(x, w) + bias) + res), post = ReLU (relu) and / or
+// zero where mask <= 0 (mask may be nullptr).  Forward of a residual block's last convolution; data gradient of its first.
+int launch_conv_igemm_residual(const void *x, const void *w, const float *bias, const void *res, const void *mask, void *y, int dil, int B,
+                               int H, int W, int cin, int cout, int k, int relu, hipStream_t stream) {
+    if (!res) return set_error(DSRG_ERR_INVALID, "conv_igemm_residual: null residual");
+    const void *xp[1] = {x}, *wp[1] = {w}, *mp[1] = {mask};
+    const float *bp[1] = {bias};
+    void *yp[1] = {y};
+    const int dils[1] = {dil};
+    t_res = res;
+    const int rc = launch_conv_igemm(xp, wp, bias ? bp : nullptr, yp, dils, 1, B, H, W, cin, cout, k, relu, 0.0f, 0ull, nullptr, 0, stream,
+                                     mask ? mp : nullptr, 1.0f, nullptr, nullptr, 0);
+    t_res = nullptr;
     return rc;
 }
 

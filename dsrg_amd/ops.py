@@ -831,6 +831,26 @@ def conv_igemm(xs, packed, biases, dilations, ksize, relu, dropout_p=0.0, seed=0
     return ys
 
 
+def conv_igemm_residual(x, packed, bias, res, mask, dilation, ksize, relu):
+    """one convolution with a residual in its store (dsrg_conv_igemm_residual_bf16): x (B,cin,H,W) bf16 channels_last, packed =
+    pack_conv_weight(w), bias (cout) f32 or None, res (B,cout,H,W) bf16 channels_last, mask the same or None ->
+    post(bf16(conv + bias) + res), post = ReLU (relu) and / or zero where mask <= 0.  Forward of a residual block's last
+    convolution (res = the shortcut); data gradient of its first (res = the shortcut's gradient, mask = the block input)."""
+    B, cin, H, W = x.shape
+    cout = packed.shape[0]
+    cl = torch.channels_last
+    ok = lambda t: t.is_cuda and t.dtype == torch.bfloat16 and tuple(t.shape) == (B, cout, H, W) and t.is_contiguous(memory_format=cl)   # noqa: E731
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and packed.dtype == torch.bfloat16 and packed.is_contiguous()
+            and tuple(packed.shape) == (cout, cin // 64, ksize * ksize, 64) and ok(res) and (mask is None or ok(mask))):
+        raise ValueError("conv_igemm_residual needs bf16 channels_last tensors of matching shapes and a kernel packed by pack_conv_weight")
+    x = x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl)
+    b = None if bias is None else _f32c(bias, "bias")
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    check(_lib.lib().dsrg_conv_igemm_residual_bf16(_ptr(x), _ptr(packed), _ptr(b), _ptr(res), _ptr(mask), _ptr(y), int(dilation), B, H, W,
+                                                   cin, cout, ksize, int(bool(relu)), _stream()))
+    return y
+
+
 def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias_grad=True, gb_outs=None):
     """the data gradient of 1 .. 4 convolutions whose inputs were ReLU (+ Dropout) outputs, with that layer's backward folded
     in: gs[g] (B,cout_fwd,H,W) bf16 channels_last, packed_t[g] the flipped + transposed packing, masks[g] (B,cin_fwd,H,W) bf16

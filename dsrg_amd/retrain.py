@@ -19,6 +19,7 @@ from .backbone import VGG16ASPP, GemmConv2d, _ConvFn
 from .trainer import CaffeSGD
 
 _IGEMM_BN = _os.environ.get("DSRG_RESNET_IGEMM", "1") == "1"      # tools: A/B against round 5's im2col + library-GEMM bottlenecks
+_FUSE_RES = _os.environ.get("DSRG_RESNET_FUSE_RES", "1") == "1"   # tools / tests: 0 = the shortcut's add + ReLU and its backward as passes of their own
 
 
 def interp_shrink(label, factor=8):
@@ -86,27 +87,37 @@ class _FoldedIgemmFn(torch.autograd.Function):
     x: bf16 channels_last; w: the float32 master parameter (channels_last); scale, shift: float32 (cout), no gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, shift, dil, relu, link_in=None, link_out=None):
+    def forward(ctx, x, w, scale, shift, dil, relu, link_in=None, link_out=None, res=None, res_link=None):
         """link_in / link_out (backbone._GradLink or None): x is the ReLU output of the node in front and feeds nothing but this
-        node (its ReLU backward then rides in this node's data-gradient store) / this node's output is such an x for the next"""
-        from .ops import conv_igemm, pack_conv_weight_pair
+        node (its ReLU backward then rides in this node's data-gradient store) / this node's output is such an x for the next.
+        res (bf16 channels_last, the output's shape): the block's shortcut, added in the store BEFORE the ReLU (the block's last
+        convolution: y = relu(bf16(conv + shift) + res), ops.conv_igemm_residual).
+        res_link (_ResLink): the block's last node leaves the masked gradient of the block output there instead of returning it for
+        `res` when the block's first node said it would add it in its own data-gradient store (res is the block input itself)."""
+        from .ops import conv_igemm, conv_igemm_residual, pack_conv_weight_pair
         k = w.shape[2]
         x = x if x.dtype == torch.bfloat16 else x.bfloat16()
         wf = (w.detach() * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
         need_d = ctx.needs_input_grad[0]
         pf, pd = pack_conv_weight_pair(wf, True, need_d)
-        (y,) = conv_igemm([x], [pf], [shift], [dil], k, relu)
+        if res is not None:
+            y = conv_igemm_residual(x, pf, shift, res, None, dil, k, relu)
+        else:
+            (y,) = conv_igemm([x], [pf], [shift], [dil], k, relu)
         ctx.save_for_backward(x, w, scale, y if relu else None)
         ctx.pd, ctx.dil, ctx.relu, ctx.k = pd, dil, relu, k
         ctx.link_in = link_in if (need_d and x.is_contiguous(memory_format=torch.channels_last)) else None
         ctx.link_out = link_out if relu else None
         if ctx.link_out is not None:
             ctx.link_out.scale, ctx.link_out.gb = 1.0, None
+        ctx.has_res, ctx.res_link = res is not None, res_link
+        if res_link is not None and res is None:
+            res_link.armed, res_link.gm = bool(need_d), None     # the block's first node: it will add the shortcut's gradient itself
         return y
 
     @staticmethod
     def backward(ctx, g):
-        from .ops import conv_igemm, conv_igemm_dgrad, conv_igemm_wgrad, conv_igemm_wgrad_supported, relu_mask
+        from .ops import conv_igemm, conv_igemm_dgrad, conv_igemm_residual, conv_igemm_wgrad, conv_igemm_wgrad_supported, relu_mask
         x, w, scale, y = ctx.saved_tensors
         cout, cin, k, d = w.shape[0], w.shape[1], ctx.k, ctx.dil
         cl = torch.channels_last
@@ -114,9 +125,24 @@ class _FoldedIgemmFn(torch.autograd.Function):
         masked = ctx.link_out.take(g) is not None if ctx.link_out is not None else False      # the consumer's data gradient came masked
         gm = (g if masked else relu_mask(g, y)) if ctx.relu else g
         gm = gm if gm.is_contiguous(memory_format=cl) else gm.contiguous(memory_format=cl)
+        gres = None
+        if ctx.has_res and ctx.needs_input_grad[8]:
+            if ctx.res_link is not None and ctx.res_link.armed:
+                ctx.res_link.gm = gm                                                    # the block's first node adds it in its store
+            else:
+                gres = gm
+        shortcut = None
+        if not ctx.has_res and ctx.res_link is not None:
+            shortcut, ctx.res_link.gm = ctx.res_link.gm, None
         gx = None
         if ctx.needs_input_grad[0]:
-            if ctx.link_in is not None:
+            if shortcut is not None:
+                # the block's first convolution: data gradient + the gradient along the shortcut, and (x a block output with this
+                # block as its one reader) the ReLU backward of the block in front — one store
+                gx = conv_igemm_residual(gm, ctx.pd, None, shortcut, x if ctx.link_in is not None else None, d, k, False)
+                if ctx.link_in is not None:
+                    ctx.link_in.leave(gx, True)
+            elif ctx.link_in is not None:
                 # x = relu(...) of the node in front, read by this node only: its backward is a mask in this launch's store
                 (gx,), _ = conv_igemm_dgrad([gm], [ctx.pd], [x], [d], k, 1.0, bias_grad=False)
                 ctx.link_in.leave(gx, True)
@@ -131,7 +157,19 @@ class _FoldedIgemmFn(torch.autograd.Function):
                 gwf = torch.ops.aten.convolution_backward(gm, x, w.to(torch.bfloat16), None, [1, 1], [p, p], [d, d], False, [0, 0], 1,
                                                           [False, True, False])[1].float()
             gw = gwf * scale.view(-1, 1, 1, 1)
-        return gx, gw, None, None, None, None, None, None
+        elif shortcut is not None and gx is None:
+            raise RuntimeError("a shortcut gradient was left for a node that computes no data gradient")
+        return gx, gw, None, None, None, None, None, None, gres, None
+
+
+class _ResLink:
+    """side channel inside one bottleneck, from its last node (the shortcut's add + ReLU in the store of the last convolution) to
+    its first: the masked gradient of the block output, which reaches the block input along the identity shortcut and is added
+    in the store of the first convolution's data gradient instead of by autograd's accumulation pass"""
+    __slots__ = ("armed", "gm")
+
+    def __init__(self):
+        self.armed, self.gm = False, None
 
 
 class _AddReLUFn(torch.autograd.Function):
@@ -164,7 +202,7 @@ def _igemm_bn_route(x, conv, bn):
             x.shape[0] * x.shape[2] * x.shape[3] >= 2048)
 
 
-def _conv_bn(x, conv, bn, relu, link_in=None, link_out=None):
+def _conv_bn(x, conv, bn, relu, link_in=None, link_out=None, res=None, res_link=None):
     """conv -> frozen-statistics BN (-> ReLU).  On the GPU, for stride-1 convolutions, the BN affine is folded into the
     weights (W * scale per output channel, bias = shift) and the whole thing is one im2col + GEMM with the bias (and ReLU)
     in the epilogue (backbone._ConvFn; 1x1 convolutions need no im2col at all).  gamma / beta still train: their
@@ -172,7 +210,9 @@ def _conv_bn(x, conv, bn, relu, link_in=None, link_out=None):
     if _IGEMM_BN and x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)) \
             and _igemm_bn_route(x, conv, bn):
         scale, shift = bn.frozen_affine()
-        return _FoldedIgemmFn.apply(x, conv.weight, scale, shift, conv.dilation[0], relu, link_in, link_out)
+        return _FoldedIgemmFn.apply(x, conv.weight, scale, shift, conv.dilation[0], relu, link_in, link_out, res, res_link)
+    if res is not None:
+        raise RuntimeError("_conv_bn: a shortcut in the store needs the implicit-GEMM route")
     if x.is_cuda and conv.stride == (1, 1) and conv.kernel_size[0] in (1, 3) and conv.in_channels % 8 == 0 and \
             conv.padding[0] == conv.dilation[0] * (conv.kernel_size[0] // 2):
         scale = bn.weight * torch.rsqrt(bn.running_var + 1e-5)
@@ -198,13 +238,32 @@ class _Bottleneck(nn.Module):
         from .backbone import _GradLink, _FUSE_CHAIN
         l1, l2 = (_GradLink(), _GradLink()) if (_IGEMM_BN and _FUSE_CHAIN and torch.is_grad_enabled()) else (None, None)
         routed = lambda t, conv, bn: t.is_cuda and _igemm_bn_route(t, conv, bn)      # noqa: E731
-        y1 = _conv_bn(x, self.c1, self.b1, True, None, l1 if l1 is not None and routed(x, self.c1, self.b1) else None)
-        use1 = l1 is not None and routed(x, self.c1, self.b1) and routed(y1, self.c2, self.b2)
+        cl = torch.channels_last
+        bf16 = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16))
+        r1 = bf16 and _IGEMM_BN and routed(x, self.c1, self.b1)
+        # the shortcut: relu(c3(..) + idn) in the store of c3's launch; with an identity shortcut its gradient joins c1's data gradient
+        # in that launch's store (rl), and where x is itself such a block output (x._dsrg_plink, set below) the ReLU backward of the
+        # block in front rides there too — no add / ReLU / mask / accumulate pass between the blocks, either way
+        fuse = _IGEMM_BN and _FUSE_RES and bf16 and self.c3.stride == (1, 1)
+        grad = torch.is_grad_enabled()
+        rl = _ResLink() if (fuse and grad and _FUSE_CHAIN and self.down is None and r1 and x.dtype == torch.bfloat16) else None
+        pin = getattr(x, "_dsrg_plink", None) if rl is not None else None
+        y1 = _conv_bn(x, self.c1, self.b1, True, pin if r1 else None, l1 if l1 is not None and r1 else None, None, rl)
+        use1 = l1 is not None and r1 and routed(y1, self.c2, self.b2)
         use2 = l2 is not None and routed(y1, self.c2, self.b2)
         y2 = _conv_bn(y1, self.c2, self.b2, True, l1 if use1 else None, l2 if use2 else None)
         use2 = use2 and routed(y2, self.c3, self.b3)
-        y = _conv_bn(y2, self.c3, self.b3, False, l2 if use2 else None, None)
         idn = _conv_bn(x, self.down[0], self.down[1], False) if self.down is not None else x
+        if fuse and routed(y2, self.c3, self.b3) and y2.dtype == torch.bfloat16 and idn.dtype == torch.bfloat16 and \
+                idn.is_contiguous(memory_format=cl) and tuple(idn.shape) == (y2.shape[0], self.c3.out_channels, y2.shape[2], y2.shape[3]):
+            pout = _GradLink() if (grad and _FUSE_CHAIN) else None
+            y = _conv_bn(y2, self.c3, self.b3, True, l2 if use2 else None, pout, idn, rl)
+            if pout is not None:
+                y._dsrg_plink = pout                                      # the next block's first convolution may mask its data gradient with y
+            return y
+        if rl is not None:
+            rl.armed = False                                              # (nobody will leave a gradient there)
+        y = _conv_bn(y2, self.c3, self.b3, False, l2 if use2 else None, None)
         if _IGEMM_BN and y.is_cuda and y.dtype == torch.bfloat16 and idn.dtype == torch.bfloat16 and y.numel() % 8 == 0:
             return _AddReLUFn.apply(y, idn)                               # one pass each way instead of add + threshold
         return F.relu(y + idn)

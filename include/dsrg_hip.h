@@ -353,6 +353,14 @@ size_t dsrg_conv_igemm_dgrad_workspace(int ngroups, int B, int H, int W, int cou
 int dsrg_conv_igemm_dgrad_bf16(const void *const *g_dev, const void *const *w_dev, const void *const *mask_dev, void *const *gx_dev,
                                float *const *bias_grad_dev, const int *dilation, int ngroups, int B, int H, int W, int cin,
                                int cout, int ksize, float mask_scale, void *workspace_dev, size_t workspace_bytes, void *stream);
+/* One convolution of the same family with a RESIDUAL in its store (a ResNet bottleneck's shortcut; the reference's stage-2 networks
+ * are DeepLab-v2 VGG16 / ResNet-101 — training/experiment/anti-noise/config/deeplabv2_weak.prototxt — where Caffe runs Eltwise SUM +
+ * ReLU layers of their own):  y = post( bf16(conv(x, w) + bias) + res ),  post = ReLU (relu != 0) and / or zero where mask <= 0
+ * (mask_dev may be NULL).  res, mask, y: (B, H, W, cout) bf16.  Bit for bit what dsrg_conv_igemm_bf16 followed by dsrg_add_relu_bf16
+ * (forward: res = the shortcut) or by a bf16 add and dsrg_relu_mask_bf16 (data gradient of the block's first convolution: res = the
+ * gradient that reaches the block input along the shortcut, mask = the block input, itself a ReLU output) gives, in one launch. */
+int dsrg_conv_igemm_residual_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, const void *res_dev, const void *mask_dev,
+                                  void *y_dev, int dilation, int B, int H, int W, int cin, int cout, int ksize, int relu, void *stream);
 int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, int *status_host);
 /* The two packed forms dsrg_conv_igemm_bf16 reads, from the float32 master kernel in ONE pass (cast included): w_dev
  * (cout, ksize*ksize, cin) f32 = the memory of a channels_last (cout, cin, ksize, ksize) parameter; fwd_dev (may be NULL):

@@ -1084,7 +1084,8 @@ def test_resnet_folded_bn_path_matches_unfused_reference(train_affine, size):
             seen.add(f)
             todo.extend(nf for nf, _ in f.next_functions)
         names = [type(f).__name__ for f in seen]
-        assert sum(n.startswith("_FoldedIgemmFn") for n in names) >= 7 and sum(n.startswith("_AddReLUFn") for n in names) == 4, names
+        # (res2's 64-channel bottleneck keeps the separate add + ReLU pass; res3 .. res5 have the shortcut in the last convolution's store)
+        assert sum(n.startswith("_FoldedIgemmFn") for n in names) >= 7 and sum(n.startswith("_AddReLUFn") for n in names) == 1, names
     (yg * g.cuda()).sum().backward()
     assert yg.shape == yr.shape
     assert (yg.cpu() - yr).norm() < 0.05 * yr.norm()
@@ -1096,6 +1097,71 @@ def test_resnet_folded_bn_path_matches_unfused_reference(train_affine, size):
         assert torch.isfinite(a).all() and (a - b).norm() < 0.15 * b.norm(), (name, float((a - b).norm() / b.norm()))
     if not train_affine:
         assert all(pg[n].grad is None and not pg[n].requires_grad for n in affine)
+
+
+def test_igemm_residual_store_equals_the_separate_passes(ops):
+    """ops.conv_igemm_residual (the shortcut of a residual block in the convolution's store) against the passes it replaces, bit for
+    bit: forward = conv_igemm + add_relu; data gradient = conv_igemm + bf16 add + relu_mask.  1x1 and dilated 3x3 (class-ordered
+    tiles), pixel counts that are no multiple of the 256-pixel tile, a 128-channel output (half-idle channel tile)"""
+    torch.manual_seed(11)
+    cl = torch.channels_last
+    for B, cin, cout, H, W, k, d in [(2, 128, 512, 33, 33, 1, 1), (3, 256, 256, 29, 31, 3, 12), (2, 512, 128, 33, 35, 1, 1), (1, 64, 256, 41, 41, 3, 1)]:
+        x = torch.randn(B, cin, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        w = (torch.randn(cout, cin, k, k, device="cuda") * (1.0 / (cin * k * k) ** 0.5)).contiguous(memory_format=cl)
+        bias = torch.randn(cout, device="cuda")
+        res = torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        below = torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        pk = ops.pack_conv_weight(w)
+        (plain,) = ops.conv_igemm([x], [pk], [bias], [d], k, False)
+        assert torch.equal(ops.conv_igemm_residual(x, pk, bias, res, None, d, k, True), ops.add_relu(plain, res))
+        assert torch.equal(ops.conv_igemm_residual(x, pk, bias, res, None, d, k, False), (plain.float() + res.float()).bfloat16())
+        (nob,) = ops.conv_igemm([x], [pk], None, [d], k, False)
+        want = ops.relu_mask((nob.float() + res.float()).bfloat16(), below)
+        assert torch.equal(ops.conv_igemm_residual(x, pk, None, res, below, d, k, False), want)
+    with pytest.raises(ValueError):
+        ops.conv_igemm_residual(x, pk, None, res[:, :64], None, d, k, False)
+
+
+def test_resnet_shortcut_in_the_store_is_bit_identical_to_the_separate_passes(monkeypatch):
+    """three bottlenecks (projection shortcut, then two identity shortcuts) with the shortcut's add + ReLU in the last convolution's
+    store and its backward in the first convolution's data gradient (retrain._FUSE_RES) against the same blocks with add_relu /
+    relu_mask passes and autograd's accumulation: outputs, input gradient and every weight gradient bit-equal; the fused graph has
+    no _AddReLUFn node"""
+    from dsrg_amd import retrain as R
+    torch.manual_seed(5)
+    blocks = torch.nn.Sequential(R._Bottleneck(256, 128, 1, 2, True, False), R._Bottleneck(512, 128, 1, 2, False, False),
+                                 R._Bottleneck(512, 128, 1, 4, False, False)).cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for m in blocks.modules():
+            if isinstance(m, R._FrozenBN):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    x0 = torch.randn(2, 256, 33, 35, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    g = torch.randn(2, 512, 33, 35, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(R, "_FUSE_RES", fused)
+        for p in blocks.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = blocks(x)
+        seen, todo = set(), [y.grad_fn]
+        while todo:
+            f = todo.pop()
+            if f is not None and f not in seen:
+                seen.add(f)
+                todo.extend(nf for nf, _ in f.next_functions)
+        n_add = sum(type(f).__name__.startswith("_AddReLUFn") for f in seen)
+        assert n_add == (0 if fused else 3)
+        y.backward(g)
+        runs.append((y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blocks.named_parameters() if p.grad is not None}))
+    (ya, xa, ga), (yb, xb, gb) = runs
+    assert torch.equal(ya, yb) and torch.equal(xa, xb)
+    assert set(ga) == set(gb) and len(ga) == 10
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
+    with torch.no_grad():                                # inference takes the fused store too
+        monkeypatch.setattr(R, "_FUSE_RES", True)
+        assert torch.equal(blocks(x0), ya)
 
 
 def test_add_relu_and_its_backward(ops):
