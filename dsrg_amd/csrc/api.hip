@@ -617,6 +617,20 @@ extern "C" int dsrg_conv_igemm_backward_bf16(const void *g_dev, const void *w_dg
                                             colsum_workspace_dev, colsum_workspace_bytes, wgrad_workspace_dev, wgrad_workspace_bytes, B, H,
                                             W, cin, cout, ksize, static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_conv_igemm_backward_residual_bf16(const void *g_dev, const void *w_dgrad_dev, const void *x_dev, const void *mask_dev,
+                                                      const void *res_dev, void *gx_dev, float *gw_dev, const float *gw_scale_dev, int dilation,
+                                                      void *wgrad_workspace_dev, size_t wgrad_workspace_bytes, int B, int H, int W, int cin,
+                                                      int cout, int ksize, void *stream) {
+    if (!g_dev || !w_dgrad_dev || !x_dev || !gx_dev || !gw_dev || B < 1 || H < 1 || W < 1)
+        return set_error(DSRG_ERR_INVALID, "conv_igemm_backward_residual: bad arguments");
+    return launch_conv_igemm_backward_residual(g_dev, w_dgrad_dev, x_dev, mask_dev, res_dev, gx_dev, gw_dev, gw_scale_dev, dilation,
+                                               wgrad_workspace_dev, wgrad_workspace_bytes, B, H, W, cin, cout, ksize,
+                                               static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_pack_conv_weight_scaled_f32(const float *w_dev, const float *scale_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin,
+                                                int ksize, void *stream) {
+    return launch_pack_conv_weight(w_dev, fwd_dev, dgrad_dev, cout, cin, ksize, static_cast<hipStream_t>(stream), 0, scale_dev);
+}
 extern "C" size_t dsrg_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout) {
     return conv3x3_wgrad_workspace(B, H, W, cin, cout);
 }

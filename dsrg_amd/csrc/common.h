@@ -198,7 +198,11 @@ int conv_igemm_workspace_status(const void *workspace, hipStream_t stream, int *
 size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k);
 int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *const *gw, const int *dil, int ngroups, void *workspace,
                             size_t workspace_bytes, int B, int H, int W, int cin, int cout, int k, int out_bf16, hipStream_t stream);
-int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream, int plain = 0);
+int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream, int plain = 0,
+                            const float *scale = nullptr);
+int launch_conv_igemm_backward_residual(const void *g, const void *wd, const void *x, const void *mask, const void *res, void *gx, void *gw,
+                                        const float *gw_scale, int dil, void *wgrad_ws, size_t wgrad_ws_bytes, int B, int H, int W, int cin,
+                                        int cout, int k, hipStream_t stream);
 int heads_bwd_chunks(int M);
 int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float *g, void *gx, size_t gx_branch_stride,
                      float *gw, float *partial, int B, int HW, int K, int O, hipStream_t stream, float relu_scale = 0.0f,

@@ -1144,6 +1144,8 @@ struct WgradReduceArgs {
     void *gw[4];
     int ksplit;
     size_t n4;
+    const float *scale;     // nullptr, or (cout) f32: output channel o's gradient times scale[o] (a constant per-channel factor folded into
+    size_t per_o4;          // the kernel the convolution ran with: d/dw = scale * d/d(w scale)); per_o4 = float4s per output channel
 };
 template <bool BF16_OUT>
 __global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(WgradReduceArgs a) {
@@ -1155,6 +1157,10 @@ __global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(WgradReduc
     for (int k = 1; k < a.ksplit; k++) {
         const float4 v = p[(size_t)k * a.n4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (a.scale) {
+        const float f = a.scale[e / a.per_o4];
+        s.x *= f; s.y *= f; s.z *= f; s.w *= f;
     }
     if (BF16_OUT) reinterpret_cast<uint2 *>(gw)[e] = make_uint2(pack2(s.x, s.y), pack2(s.z, s.w));
     else reinterpret_cast<float4 *>(gw)[e] = s;
@@ -1169,7 +1175,7 @@ __global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(WgradReduc
 // plain = 1: the layouts of the direct kernels (conv_direct.hip) instead — fwd[o][tap][c] (the parameter's own order, cast) and
 // dg[c][T - tap][o] (a channels_last (cin, cout, k, k) tensor: the kernel flipped, channel axes swapped).
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float *w, uint16_t *fwd, uint16_t *dg, int cout, int cin, int taps,
-                                                               int plain) {
+                                                               int plain, const float *scale) {      // scale: nullptr or (cout) — w[o] * scale[o] is packed
     __shared__ uint16_t tile[64][64 + 4];
     const int ob = blockIdx.x, cb = blockIdx.y, tap = blockIdx.z, t = threadIdx.x;
     const int r = t >> 4, q = t & 15;                        // 16 rows x 16 float4 per pass
@@ -1177,7 +1183,11 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float *w, u
     for (int i = 0; i < 4; i++) {
         const int o = r + 16 * i;
         const size_t src = ((size_t)(ob * 64 + o) * taps + tap) * cin + cb * 64 + q * 4;
-        const float4 v = *reinterpret_cast<const float4 *>(w + src);
+        float4 v = *reinterpret_cast<const float4 *>(w + src);
+        if (scale) {
+            const float f = scale[ob * 64 + o];
+            v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        }
         const uint2 pk = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
         if (fwd) *reinterpret_cast<uint2 *>(fwd + (plain ? src : (((size_t)(ob * 64 + o) * (cin >> 6) + cb) * taps + tap) * 64 + q * 4)) = pk;
         *reinterpret_cast<uint2 *>(&tile[o][q * 4]) = pk;
@@ -1354,6 +1364,7 @@ static thread_local IgemmArgs *t_prep_d = nullptr;
 static thread_local IgemmWgradArgs *t_prep_w = nullptr;
 static thread_local int *t_prep_grid = nullptr;
 static thread_local int t_force_ksplit = 0;              // launch_conv_igemm_backward: the pixel split it picked for its merged grid
+static thread_local const float *t_wgrad_scale = nullptr; // launch_conv_igemm_backward_residual: per-output factor of the weight gradient (nullptr: none)
 static thread_local const void *t_res = nullptr;         // launch_conv_igemm_residual: the residual of its single group (nullptr: none)
 static thread_local int t_split_cin = 0;                 // launch_conv_igemm_split: the real input channel count (0: ordinary launch)
 
@@ -1600,6 +1611,8 @@ static int launch_wgrad_reduce(const IgemmWgradArgs &a, void *const *gw, int ngr
     memset(&r, 0, sizeof(r));
     r.ksplit = a.ksplit;
     r.n4 = (size_t)cout * k * k * cin / 4;
+    r.scale = t_wgrad_scale;
+    r.per_o4 = (size_t)k * k * cin / 4;
     for (int q = 0; q < ngroups; q++) { r.part[q] = a.g[q].part; r.gw[q] = gw[q]; }
     const dim3 rgrid((unsigned)((r.n4 + 255) / 256), (unsigned)ngroups);
     if (out_bf16) hipLaunchKernelGGL(conv_igemm_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, r);
@@ -1700,7 +1713,8 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
     float *bgp[1] = {bias_grad};
     const int dils[1] = {dil};
     static const bool merged_on = [] { const char *e = getenv("DSRG_IGEMM_MERGED_BWD"); return !e || atoi(e) != 0; }();      // tools: A/B
-    const bool can_merge = merged_on && k == 3 && dil < 3 && (igemm_variant() == 3 || igemm_variant() == 1 || igemm_variant() == 8 || igemm_variant() == 9);
+    static const bool merged_k1_on = [] { const char *e = getenv("DSRG_IGEMM_MERGED_K1"); return !e || atoi(e) != 0; }();    // tools: A/B (1x1 layers)
+    const bool can_merge = merged_on && ((k == 3 && dil < 3) || (k == 1 && merged_k1_on)) && (igemm_variant() == 3 || igemm_variant() == 1 || igemm_variant() == 8 || igemm_variant() == 9);
     IgemmBwdArgs a;
     memset(&a, 0, sizeof(a));
     int nd = 0, nw = 0, rc = DSRG_OK;
@@ -1754,14 +1768,28 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
 }
 
 
-int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream, int plain) {
+int launch_pack_conv_weight(const float *w, void *fwd, void *dgrad, int cout, int cin, int k, hipStream_t stream, int plain, const float *scale) {
     if (!w || cout < 64 || cout % 64 || cin < 64 || cin % 64 || (k != 1 && k != 3))
         return set_error(DSRG_ERR_INVALID, "pack_conv_weight: 64 | cout, 64 | cin, k in (1, 3) required (got %d, %d, %d)", cout, cin, k);
     if (!fwd && !dgrad) return DSRG_OK;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cout / 64, cin / 64, k * k), dim3(256), 0, stream, w, static_cast<uint16_t *>(fwd),
-                       static_cast<uint16_t *>(dgrad), cout, cin, k * k, plain);
+                       static_cast<uint16_t *>(dgrad), cout, cin, k * k, plain, scale);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
+}
+
+// launch_conv_igemm_backward with a residual in the data gradient's store (IgemmGroup::res; res may be nullptr) and a per-output-channel
+// factor on the weight gradient (gw_scale may be nullptr); no bias gradient.  A ResNet bottleneck convolution's whole backward.
+int launch_conv_igemm_backward_residual(const void *g, const void *wd, const void *x, const void *mask, const void *res, void *gx, void *gw,
+                                        const float *gw_scale, int dil, void *wgrad_ws, size_t wgrad_ws_bytes, int B, int H, int W, int cin,
+                                        int cout, int k, hipStream_t stream) {
+    t_res = res;
+    t_wgrad_scale = gw_scale;
+    const int rc = launch_conv_igemm_backward(g, wd, x, mask, gx, gw, dil, nullptr, 1.0f, nullptr, 0, wgrad_ws, wgrad_ws_bytes, B, H, W, cin, cout,
+                                              k, stream);
+    t_res = nullptr;
+    t_wgrad_scale = nullptr;
+    return rc;
 }
 
 // tests: the error word of the last stream-K launch that used this workspace (1 = a workgroup gave up waiting); synchronises

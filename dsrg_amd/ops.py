@@ -757,11 +757,21 @@ def pack_conv_weight(weight, for_dgrad=False, dtype=torch.bfloat16):
     return out
 
 
-def pack_conv_weight_pair(weight, want_fwd=True, want_dgrad=True):
+def pack_conv_weight_pair(weight, want_fwd=True, want_dgrad=True, scale=None):
     """both packed forms of a float32 channels_last (cout, cin, k, k) parameter in one pass (cast included) ->
     (pack_conv_weight(weight), pack_conv_weight(weight, for_dgrad=True)); an entry is None when not wanted.  Other dtypes /
-    layouts take the torch copies of pack_conv_weight."""
+    layouts take the torch copies of pack_conv_weight.  scale (cout) f32: weight[o] * scale[o] is what is packed (the same pass; fresh
+    buffers every call — the kept packs of a parameter, which the fused optimizer step rewrites, are those of the bare weight)."""
     cout, cin, k, _ = weight.shape
+    if scale is not None:
+        if not (weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous(memory_format=torch.channels_last)
+                and cout % 64 == 0 and cin % 64 == 0 and k in (1, 3)):
+            return pack_conv_weight_pair((weight.detach() * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last), want_fwd, want_dgrad)
+        fwd = torch.empty((cout, cin // 64, k * k, 64), dtype=torch.bfloat16, device=weight.device) if want_fwd else None
+        dg = torch.empty((cin, cout // 64, k * k, 64), dtype=torch.bfloat16, device=weight.device) if want_dgrad else None
+        check(_lib.lib().dsrg_pack_conv_weight_scaled_f32(_ptr(weight.detach()), _ptr(_f32c(scale, "scale")), _ptr(fwd), _ptr(dg), cout, cin, k,
+                                                          _stream()))
+        return fwd, dg
     if not (weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous(memory_format=torch.channels_last)
             and cout % 64 == 0 and cin % 64 == 0 and k in (1, 3)):
         return (pack_conv_weight(weight) if want_fwd else None, pack_conv_weight(weight, for_dgrad=True) if want_dgrad else None)
@@ -917,6 +927,35 @@ def conv_igemm_backward(g, packed_d, x, dilation, mask=None, mask_scale=1.0, ksi
                                           float(mask_scale), _ptr(cws), cws.numel() if cws is not None else 0, _ptr(ws), ws.numel(),
                                           B, H, W, cin, cout, ksize, _stream()))
     return gx, gw, gb
+
+
+def conv_igemm_backward_residual(g, packed_d, x, dilation, ksize, mask=None, res=None, gw_scale=None, gw_out=None):
+    """conv_igemm_backward (3x3 or 1x1) for a convolution inside a residual block (dsrg_conv_igemm_backward_residual_bf16): res
+    (B,cin,H,W) bf16 channels_last or None is added to the bf16-rounded data gradient before the mask (the gradient along the
+    block's shortcut); gw_scale (cout) f32 or None multiplies the weight gradient per output channel (the constant scale the
+    forward's kernel was packed with); no bias gradient -> (gx, gw)"""
+    B, cout, H, W = g.shape
+    cin = x.shape[1]
+    cl = torch.channels_last
+    ok = lambda t: t.dtype == torch.bfloat16 and tuple(t.shape) == (B, cin, H, W) and t.is_contiguous(memory_format=cl)      # noqa: E731
+    if not (g.is_cuda and g.dtype == torch.bfloat16 and ok(x) and packed_d.dtype == torch.bfloat16 and packed_d.is_contiguous()
+            and tuple(packed_d.shape) == (cin, cout // 64, ksize * ksize, 64) and (mask is None or ok(mask)) and (res is None or ok(res))):
+        raise ValueError("conv_igemm_backward_residual needs bf16 channels_last g / x (/ mask / res) of one geometry and the data-gradient packing")
+    g = g if g.is_contiguous(memory_format=cl) else g.contiguous(memory_format=cl)
+    L = _lib.lib()
+    need = L.dsrg_conv_igemm_wgrad_workspace(1, B, H, W, cin, cout, ksize)
+    if need == 0:
+        raise ValueError("conv_igemm_backward_residual: 256 | cin (or cin = 128 with a 3x3 kernel), 256 | cout required (got %d, %d)" % (cin, cout))
+    key = (g.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _igemm_ws.get(key)                                          # per-stream scratch, shared with conv_igemm_wgrad
+    if ws is None or ws.numel() < need:
+        ws = _igemm_ws[key] = torch.empty(need, dtype=torch.uint8, device=g.device)
+    gx = torch.empty((B, cin, H, W), dtype=torch.bfloat16, device=g.device, memory_format=cl)
+    gw = _dest(gw_out, (cout, cin, ksize, ksize), torch.float32, g.device, True)
+    sc = None if gw_scale is None else _f32c(gw_scale, "gw_scale")
+    check(L.dsrg_conv_igemm_backward_residual_bf16(_ptr(g), _ptr(packed_d), _ptr(x), _ptr(mask), _ptr(res), _ptr(gx), _ptr(gw), _ptr(sc),
+                                                   int(dilation), _ptr(ws), ws.numel(), B, H, W, cin, cout, ksize, _stream()))
+    return gx, gw
 
 
 _igemm_sk_ws = {}

@@ -19,6 +19,7 @@ from .backbone import VGG16ASPP, GemmConv2d, _ConvFn
 from .trainer import CaffeSGD
 
 _IGEMM_BN = _os.environ.get("DSRG_RESNET_IGEMM", "1") == "1"      # tools: A/B against round 5's im2col + library-GEMM bottlenecks
+_MERGED = _os.environ.get("DSRG_RESNET_MERGED_BWD", "1") == "1"   # tools / tests: 0 = data and weight gradient of a bottleneck convolution as two launches
 _FUSE_RES = _os.environ.get("DSRG_RESNET_FUSE_RES", "1") == "1"   # tools / tests: 0 = the shortcut's add + ReLU and its backward as passes of their own
 
 
@@ -97,9 +98,8 @@ class _FoldedIgemmFn(torch.autograd.Function):
         from .ops import conv_igemm, conv_igemm_residual, pack_conv_weight_pair
         k = w.shape[2]
         x = x if x.dtype == torch.bfloat16 else x.bfloat16()
-        wf = (w.detach() * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
         need_d = ctx.needs_input_grad[0]
-        pf, pd = pack_conv_weight_pair(wf, True, need_d)
+        pf, pd = pack_conv_weight_pair(w.detach(), True, need_d, scale)               # w * scale, cast and both packings in one pass
         if res is not None:
             y = conv_igemm_residual(x, pf, shift, res, None, dil, k, relu)
         else:
@@ -135,6 +135,18 @@ class _FoldedIgemmFn(torch.autograd.Function):
         if not ctx.has_res and ctx.res_link is not None:
             shortcut, ctx.res_link.gm = ctx.res_link.gm, None
         gx = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _MERGED and conv_igemm_wgrad_supported(cin, cout, k) and \
+                x.is_contiguous(memory_format=cl):
+            # the whole backward in one grid (the weight gradient's workgroups take the CUs the data gradient's tiles leave idle: a
+            # 65 x 65 x 10 map is 166 pixel tiles), the scale on the weight gradient in its reduction, written into the reducer's slot
+            from .backbone import _landed
+            from .ops import conv_igemm_backward_residual
+            from .reducer import grad_destination
+            slot = grad_destination(w, w.shape)
+            gx, gw = conv_igemm_backward_residual(gm, ctx.pd, x, d, k, x if ctx.link_in is not None else None, shortcut, scale, slot)
+            if ctx.link_in is not None:
+                ctx.link_in.leave(gx, True)
+            return gx, _landed(gw, slot), None, None, None, None, None, None, gres, None
         if ctx.needs_input_grad[0]:
             if shortcut is not None:
                 # the block's first convolution: data gradient + the gradient along the shortcut, and (x a block output with this

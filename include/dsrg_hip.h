@@ -367,6 +367,10 @@ int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, in
  * (cout, cin / 64, taps, 64) bf16 for the forward; dgrad_dev (may be NULL): (cin, cout / 64, taps, 64) bf16 for the data
  * gradient (kernel flipped, channel axes swapped).  64 | cout, 64 | cin. */
 int dsrg_pack_conv_weight_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, int ksize, void *stream);
+/* The same with a constant per-output-channel factor folded in: w[o] * scale_dev[o] is what is packed (scale_dev (cout) f32, may be
+ * NULL = dsrg_pack_conv_weight_f32) — a frozen BatchNorm's scale behind the convolution (DeepLab-v2 ResNet-101, use_global_stats). */
+int dsrg_pack_conv_weight_scaled_f32(const float *w_dev, const float *scale_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin,
+                                     int ksize, void *stream);
 /* Caffe's SGDSolver update (solver-s.prototxt:5-14: momentum 0.9, weight_decay 5e-4, per-blob lr_mult / decay_mult of
  * train-s.prototxt) of n float32 parameters, sixteen per launch, in the form  B <- momentum B + (g + wd W);  W <- W - lr B
  * (B = Caffe's history / lr), WITH the packed bf16 kernels of the convolution routes written from the new values in the same
@@ -404,6 +408,14 @@ int dsrg_conv_igemm_backward_bf16(const void *g_dev, const void *w_dgrad_dev, co
                                   float *gw_dev, int dilation, float *bias_grad_dev, float mask_scale, void *colsum_workspace_dev,
                                   size_t colsum_workspace_bytes, void *wgrad_workspace_dev, size_t wgrad_workspace_bytes, int B, int H,
                                   int W, int cin, int cout, int ksize, void *stream);
+/* The same whole backward (3x3 with dilation < 3, or 1x1: merged grid; else two launches) for a convolution inside a residual block
+ * with a folded constant scale: res_dev (may be NULL; (B,H,W,cin) bf16) is added to the bf16-rounded data gradient before the mask, as
+ * dsrg_conv_igemm_residual_bf16; gw_scale_dev (may be NULL; (cout) f32): gw[o] = scale[o] * (the gradient of the scaled kernel the
+ * forward ran with).  No bias gradient.  mask_dev may be NULL. */
+int dsrg_conv_igemm_backward_residual_bf16(const void *g_dev, const void *w_dgrad_dev, const void *x_dev, const void *mask_dev,
+                                           const void *res_dev, void *gx_dev, float *gw_dev, const float *gw_scale_dev, int dilation,
+                                           void *wgrad_workspace_dev, size_t wgrad_workspace_bytes, int B, int H, int W, int cin, int cout,
+                                           int ksize, void *stream);
 /* The four fc8-SEC_k 1x1 classifiers and their Eltwise SUM (train-s.prototxt:461-744) in one pass with float32 weights,
  * float32 accumulation and a float32 NCHW result: out[b][o][hw] = sum_k ( x_k[(b,hw)][:] . w[k][o][:] + bias[k][o] ).
  * x_dev: host array of n_branches (<= 4) device pointers to (B*HW, K) bf16 row-major (NHWC) activations; w_dev

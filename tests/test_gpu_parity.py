@@ -1122,6 +1122,39 @@ def test_igemm_residual_store_equals_the_separate_passes(ops):
         ops.conv_igemm_residual(x, pk, None, res[:, :64], None, d, k, False)
 
 
+def test_igemm_backward_residual_and_scaled_pack(ops):
+    """dsrg_conv_igemm_backward_residual_bf16 (a bottleneck convolution's whole backward: merged grid for 1x1 and 3x3 dilation < 3, two
+    launches for dilation 4) against its pieces — data gradient bit-equal to conv_igemm_residual / conv_igemm_dgrad / conv_igemm, weight
+    gradient = conv_igemm_wgrad times the per-output scale up to fp32 reassociation (another pixel split); and the scaled pack against
+    multiply-then-pack, bit for bit"""
+    torch.manual_seed(13)
+    cl = torch.channels_last
+    for B, cin, cout, H, W, k, d in [(2, 256, 1024, 33, 33, 1, 1), (2, 256, 256, 33, 35, 3, 2), (2, 512, 512, 33, 33, 3, 4), (3, 1024, 256, 29, 31, 1, 1)]:
+        x = torch.relu(torch.randn(B, cin, H, W, device="cuda")).bfloat16().contiguous(memory_format=cl)
+        g = torch.randn(B, cout, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        res = torch.randn(B, cin, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+        w = (torch.randn(cout, cin, k, k, device="cuda") * (1.0 / (cin * k * k) ** 0.5)).contiguous(memory_format=cl)
+        scale = torch.rand(cout, device="cuda") + 0.5
+        pf, pd = ops.pack_conv_weight_pair(w, True, True, scale)
+        ws = (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=cl)
+        assert torch.equal(pf, ops.pack_conv_weight(ws)) and torch.equal(pd, ops.pack_conv_weight(ws, for_dgrad=True))
+        (gw_ref,) = ops.conv_igemm_wgrad([x], [g], [d], k)
+        gw_ref = gw_ref * scale.view(-1, 1, 1, 1)
+        for mask, r in [(x, res), (None, res), (x, None), (None, None)]:
+            gx, gw = ops.conv_igemm_backward_residual(g, pd, x, d, k, mask, r, scale)
+            if r is not None:
+                want = ops.conv_igemm_residual(g, pd, None, r, mask, d, k, False)
+            elif mask is not None:
+                want = ops.conv_igemm_dgrad([g], [pd], [mask], [d], k, 1.0, bias_grad=False)[0][0]
+            else:
+                want = ops.conv_igemm([g], [pd], None, [d], k, False)[0]
+            assert torch.equal(gx, want)
+            assert gw.is_contiguous(memory_format=cl) and (gw - gw_ref).abs().max() <= 2e-5 * gw_ref.abs().max() + 1e-6
+        slot = torch.zeros_like(w)
+        _, gw2 = ops.conv_igemm_backward_residual(g, pd, x, d, k, x, res, scale, gw_out=slot)
+        assert gw2 is slot and torch.equal(slot, gw)
+
+
 def test_resnet_shortcut_in_the_store_is_bit_identical_to_the_separate_passes(monkeypatch):
     """three bottlenecks (projection shortcut, then two identity shortcuts) with the shortcut's add + ReLU in the last convolution's
     store and its backward in the first convolution's data gradient (retrain._FUSE_RES) against the same blocks with add_relu /
