@@ -487,6 +487,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
         }
     }
     // the wave reads back its own rows only: LDS operations of one wave complete in order
+    const bool chv = nw + (lane & 15) * 8 < a.Cout;          // a 64-channel output: the upper half of the wave's 128 columns does not exist
     if (G.res) {                                             // (uniform) residual, then ReLU and / or the mask of the layer below
         const float floor2 = a.relu ? 0.0f : -__builtin_inff();
 #pragma unroll
@@ -496,9 +497,9 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
             for (int it = 0; it < 8; it++) {
                 const int m = row_pixel(wm * 64 + (h * 8 + it) * 4 + (lane >> 4));
                 const size_t at = (size_t)m * a.Cout + nw + (lane & 15) * 8;
-                rs[it] = m >= 0 ? *reinterpret_cast<const uint4 *>(G.res + at) : make_uint4(0, 0, 0, 0);
+                rs[it] = (m >= 0 && chv) ? *reinterpret_cast<const uint4 *>(G.res + at) : make_uint4(0, 0, 0, 0);
                 mk8[it] = !G.mask ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
-                                  : (m >= 0 ? *reinterpret_cast<const uint4 *>(G.mask + at) : make_uint4(0, 0, 0, 0));
+                                  : ((m >= 0 && chv) ? *reinterpret_cast<const uint4 *>(G.mask + at) : make_uint4(0, 0, 0, 0));
             }
 #pragma unroll
             for (int it = 0; it < 8; it++) {
@@ -516,7 +517,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
                     const uint32_t khi = (int32_t)y4[e] >= 0x10000 ? 0xffff0000u : 0u;
                     w4[e] = pack2(lo, hi) & (klo | khi);
                 }
-                if (m >= 0) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                if (m >= 0 && chv) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
             }
         }
         return;
@@ -527,7 +528,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
             const int p = it * 4 + (lane >> 4), ch = lane & 15;
             const int m = row_pixel(wm * 64 + p);
             const uint4 v = *reinterpret_cast<const uint4 *>(O + p * kOutRow + ch * 16);
-            if (m >= 0) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
+            if (m >= 0 && chv) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = v;
         }
         return;
     }
@@ -539,7 +540,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const int m = row_pixel(wm * 64 + it * 4 + (lane >> 4));
-            mk[it] = m >= 0 ? *reinterpret_cast<const uint4 *>(G.mask + (size_t)m * a.Cout + nw + (lane & 15) * 8) : make_uint4(0, 0, 0, 0);
+            mk[it] = (m >= 0 && chv) ? *reinterpret_cast<const uint4 *>(G.mask + (size_t)m * a.Cout + nw + (lane & 15) * 8) : make_uint4(0, 0, 0, 0);
         }
     } else {
 #pragma unroll
@@ -561,7 +562,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
             cs[2 * e] += __uint_as_float(w4[e] << 16);
             cs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
         }
-        if (m >= 0) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        if (m >= 0 && chv) *reinterpret_cast<uint4 *>(G.y + (size_t)m * a.Cout + nw + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
     if (G.colsum) {                                          // uniform for the workgroup
 #pragma unroll
@@ -584,7 +585,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs &a, const int bi
             const float *s3 = reinterpret_cast<const float *>(ig_lds + (wn * 4 + 3) * kOutWave);
             float *dst = G.colsum + (size_t)tm * a.Cout + nw;
             dst[lane] = (s0[lane] + s1[lane]) + (s2[lane] + s3[lane]);
-            dst[lane + 64] = (s0[lane + 64] + s1[lane + 64]) + (s2[lane + 64] + s3[lane + 64]);
+            if (nw + lane + 64 < a.Cout) dst[lane + 64] = (s0[lane + 64] + s1[lane + 64]) + (s2[lane + 64] + s3[lane + 64]);
         }
     }
 }
@@ -1210,6 +1211,12 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float *w, u
 bool conv_igemm_supported(int cin, int cout, int k) {
     return (k == 1 || k == 3) && cin >= 64 && cin % 64 == 0 && cout >= 128 && cout % 128 == 0;
 }
+// what the launch takes: also a 64-channel output (a wave's 128 output columns half empty: rows of w past cout read zeros through the
+// descriptor, the store skips them) — not the recommended route for a 3x3 layer (conv_direct.hip), but a 1x1 layer over many pixels
+// is bandwidth-bound either way (ResNet res2: 256 -> 64 at 129 x 129 x 10 pixels)
+static bool conv_igemm_launchable(int cin, int cout, int k) {
+    return (k == 1 || k == 3) && cin >= 64 && cin % 64 == 0 && (cout == 64 || (cout >= 128 && cout % 128 == 0));
+}
 
 std::atomic<int> g_igemm_variant{-1};      // dsrg_debug_set_igemm_variant (tests / tools); -1 = DSRG_IGEMM_VARIANT or the default
 static int igemm_variant() {
@@ -1375,8 +1382,8 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm: 1..4 groups");
     if (colsum && (!colsum_ws || colsum_ws_bytes < conv_igemm_colsum_workspace(ngroups, B, H, W, cout)))
         return set_error(DSRG_ERR_INVALID, "conv_igemm: column-sum scratch missing or too small");
-    if (!conv_igemm_supported(cin, cout, k))
-        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: cin %% 64 == 0, cout %% 128 == 0, k in (1, 3) required (got %d, %d, %d)",
+    if (!conv_igemm_launchable(cin, cout, k))
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm: cin %% 64 == 0, cout %% 128 == 0 (or cout = 64), k in (1, 3) required (got %d, %d, %d)",
                          cin, cout, k);
     const long long M = (long long)B * H * W;
     if (M <= 0 || M * cin * 2 >= 0x7fffffffLL || (long long)cout * k * k * cin * 2 >= 0x7fffffffLL || M * cout * 2 >= 0x7fffffff00LL)
@@ -1427,7 +1434,7 @@ int launch_conv_igemm(const void *const *x, const void *const *w, const float *c
     // different rounds overlap: fc6 x 4, 6.6 rounds, 810 us whole against 902 us dealt out).
     const int units = igemm_cus(), tiles_total = a.tiles_per_group * ngroups, nsteps = (cin / 64) * k * k;
     const bool sk_wins = tiles_total * 100 <= units * 60, sk_forced = igemm_variant() == 4;      // 4: tests / tools, wherever legal
-    if (!fused_bwd && t_split_cin == 0 && workspace && workspace_bytes >= conv_igemm_workspace() && ((default_form && sk_wins) || sk_forced) &&
+    if (!fused_bwd && t_split_cin == 0 && cout % 128 == 0 && workspace && workspace_bytes >= conv_igemm_workspace() && ((default_form && sk_wins) || sk_forced) &&
         (long long)tiles_total * nsteps >= (long long)units * 8 && tiles_total * 3 >= units) {
         IgemmSkArgs sk;
         sk.base = a;

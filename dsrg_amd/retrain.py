@@ -207,10 +207,13 @@ def _igemm_bn_route(x, conv, bn):
     forward AND the data-gradient launch take (conv_igemm: 64 | cin, 128 | cout, both ways round), a constant affine map"""
     from .ops import conv_igemm_supported
     k = conv.kernel_size[0]
+    # (a 1x1 layer also with 64 channels on either side — res2's 256 -> 64 -> 256 at 129 x 129: half-empty tiles, but the layer is
+    # bandwidth-bound and the library's GEMM for the shape runs 16 x 32 tiles, 203 us against ~40)
+    takes = lambda ci, co: conv_igemm_supported(ci, co, k) or (k == 1 and co == 64 and ci % 64 == 0 and ci >= 64)      # noqa: E731
     return (x.is_cuda and conv.stride == (1, 1) and k in (1, 3) and conv.kernel_size == (k, k) and
             conv.padding[0] == conv.dilation[0] * (k // 2) and conv.padding[0] == conv.padding[1] and conv.groups == 1 and conv.bias is None and
             not bn.weight.requires_grad and not bn.bias.requires_grad and
-            conv_igemm_supported(conv.in_channels, conv.out_channels, k) and conv_igemm_supported(conv.out_channels, conv.in_channels, k) and
+            takes(conv.in_channels, conv.out_channels) and takes(conv.out_channels, conv.in_channels) and
             x.shape[0] * x.shape[2] * x.shape[3] >= 2048)
 
 

@@ -270,8 +270,11 @@ def test_igemm_rejects_unsupported_shapes(ops):
     x = torch.zeros(1, 64, 4, 4, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=CL)
     with pytest.raises(ValueError):
         ops.conv_igemm([x], [torch.zeros(256, 1, 9, 64, device="cuda")], [None], [1], 3, False)      # float32 kernel
+    # (a 64-channel output is launchable — half-empty tiles, the ResNet res2 1x1 layers — though not the recommended route: supported() says no)
+    (y64,) = ops.conv_igemm([x], [torch.zeros(64, 1, 9, 64, device="cuda", dtype=torch.bfloat16)], [None], [1], 3, False)
+    assert tuple(y64.shape) == (1, 64, 4, 4) and not y64.float().abs().any()
     with pytest.raises(DsrgError):
-        ops.conv_igemm([x], [torch.zeros(64, 1, 9, 64, device="cuda", dtype=torch.bfloat16)], [None], [1], 3, False)
+        ops.conv_igemm([x], [torch.zeros(192, 1, 9, 64, device="cuda", dtype=torch.bfloat16)], [None], [1], 3, False)
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,k,dil", [
