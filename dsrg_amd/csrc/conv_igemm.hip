@@ -943,8 +943,8 @@ __device__ __forceinline__ void conv_igemm_wgrad_body(const IgemmWgradArgs &a, c
     const WgradGroup G = a.g[grp];
     const int taps = a.taps, Cin = a.Cin, Cout = a.Cout, W = a.W, H = a.H;
     // the 256 columns of a tile: one tap x 256 channels of x — or, for a 128-channel x (conv3_1), two taps x 128 channels
-    const bool two = Cin == 128;
-    const int ncb = two ? 1 : Cin >> 8;                     // 256-channel blocks of x per tap
+    const bool two = Cin == 128 && taps == 9;
+    const int ncb = two ? 1 : (Cin + 255) >> 8;             // 256-channel blocks of x per tap (the last one may be narrower)
     const int tap = two ? 2 * tc : tc / ncb, c0 = two ? 0 : (tc - tap * ncb) << 8, n0 = tn << 8;
     // ---- the pixels this tile sums over.  The reduction index q runs over the pixels of a RECTANGLE of every image, image-major,
     // raster order inside: the whole map — or (compact: dilated kernels) exactly the pixels whose tap lands inside the map: a tap of
@@ -978,6 +978,10 @@ __device__ __forceinline__ void conv_igemm_wgrad_body(const IgemmWgradArgs &a, c
         srcoff[i] = (uint32_t)(p * 64 + (q & 3) * 16);
         const int mytap = two ? tap + (p >> 2) : tap;       // pieces 4-7 of a two-tap tile belong to the second tap
         xsrcoff[i] = two ? (uint32_t)((p & 3) * 64 + (q & 3) * 16) : srcoff[i];
+        // channel counts that are no multiple of 256 (ResNet res2 / res3: 64, 128): the pieces of a 512-byte tile row past the tensor's
+        // own row must read zeros — bit 31 of the piece offset pushes the lane's address beyond the descriptor (both tensors < 2^31 bytes)
+        if (!two && (uint32_t)(c0 * 2) + xsrcoff[i] >= (uint32_t)(Cin * 2)) xsrcoff[i] |= 0x80000000u;
+        if ((uint32_t)(n0 * 2) + srcoff[i] >= (uint32_t)(Cout * 2)) srcoff[i] |= 0x80000000u;
         ltap[i] = mytap < taps;
         ldy[i] = taps == 9 ? (mytap / 3 - 1) * G.dil : 0;
         ldx[i] = taps == 9 ? (mytap % 3 - 1) * G.dil : 0;
@@ -1106,7 +1110,7 @@ __device__ __forceinline__ void conv_igemm_wgrad_body(const IgemmWgradArgs &a, c
         for (int j = 0; j < 2; j++) {
             const int col = wm * 64 + j * 32 + l31;
             const int etap = two ? tap + (col >> 7) : tap, c = two ? (col & 127) : c0 + col;
-            if (etap < taps) {
+            if (etap < taps && c < Cin && n0 + wn * 128 + i * 32 < Cout) {      // (32-row / 32-column blocks: channel counts are multiples of 64)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
@@ -1128,9 +1132,19 @@ struct IgemmBwdArgs {
     IgemmArgs d;
     IgemmWgradArgs w;
     int nd, nd_pad, nw;
+    int w_first, nw_pad;    // 1: the weight gradient's workgroups take the first block ids (they are dispatched first): the order for a layer
+                            // whose weight-gradient workgroups run longer than its data-gradient tiles (a 1x1 layer: tiles of 4 - 16 K-steps)
 };
 __global__ __launch_bounds__(512, 2) void conv_igemm_bwd_kernel(IgemmBwdArgs a) {
     const int id = (int)blockIdx.x;
+    if (a.w_first) {
+        if (id < a.nw_pad) {
+            if (id < a.nw) conv_igemm_wgrad_body(a.w, id, a.nw);
+        } else if (id - a.nw_pad < a.nd) {
+            conv_igemm_body<64, 2>(a.d, id - a.nw_pad, a.nd);
+        }
+        return;
+    }
     if (id < a.nd_pad) {
         if (id < a.nd) conv_igemm_body<64, 2>(a.d, id, a.nd);
     } else {
@@ -1155,7 +1169,15 @@ __global__ __launch_bounds__(256) void conv_igemm_wgrad_reduce_kernel(WgradReduc
     const float4 *p = reinterpret_cast<const float4 *>(a.part[blockIdx.y]) + e;
     void *gw = a.gw[blockIdx.y];
     float4 s = p[0];
-    for (int k = 1; k < a.ksplit; k++) {
+    int k = 1;
+    for (; k + 8 <= a.ksplit; k += 8) {                      // eight loads in flight, added in split order (the sum's bits do not change)
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(size_t)(k + u) * a.n4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < a.ksplit; k++) {
         const float4 v = p[(size_t)k * a.n4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -1569,7 +1591,13 @@ int launch_conv_igemm_residual(const void *x, const void *w, const float *bias, 
 bool conv_igemm_wgrad_supported(int cin, int cout, int k) {
     return (k == 1 || k == 3) && ((cin >= 256 && cin % 256 == 0) || (cin == 128 && k == 3)) && cout >= 256 && cout % 256 == 0;
 }
-static int wgrad_col_tiles(int cin, int k) { return cin == 128 ? (k * k + 1) / 2 : k * k * cin / 256; }
+// what the launch takes (conv_igemm_wgrad_supported: where it is the recommended route): any multiples of 64 channels — a tile is 256 outputs
+// x (one tap x 256 inputs), narrower tensors leave part of it empty (ResNet res2 / res3: 64 / 128 channels over 42 - 166 thousand pixels,
+// bandwidth-bound either way)
+static bool conv_igemm_wgrad_launchable(int cin, int cout, int k) {
+    return (k == 1 || k == 3) && cin >= 64 && cin % 64 == 0 && cout >= 64 && cout % 64 == 0;
+}
+static int wgrad_col_tiles(int cin, int k) { return (cin == 128 && k == 3) ? (k * k + 1) / 2 : k * k * ((cin + 255) / 256); }
 
 // pixel split of the weight-gradient launch: the number of workgroups per output tile that minimises
 // rounds of the chip x (K-steps per workgroup + a fixed cost per workgroup for prologue and the partial tile's write-out)
@@ -1603,9 +1631,9 @@ static int wgrad_ksplit_cap(long long M, int ks) {
 }
 
 size_t conv_igemm_wgrad_workspace(int ngroups, int B, int H, int W, int cin, int cout, int k) {
-    if (!conv_igemm_wgrad_supported(cin, cout, k) || ngroups < 1 || ngroups > 4) return 0;
+    if (!conv_igemm_wgrad_launchable(cin, cout, k) || ngroups < 1 || ngroups > 4) return 0;
     const long long M = (long long)B * H * W;
-    const int tiles = ngroups * (cout / 256) * wgrad_col_tiles(cin, k);
+    const int tiles = ngroups * ((cout + 255) / 256) * wgrad_col_tiles(cin, k);
     int ks = wgrad_ksplit(M, tiles, 256, (double)ngroups * cout * k * k * cin * 4.0);
     const int ks_mix = wgrad_ksplit(M, tiles, 256, (double)ngroups * cout * k * k * cin * 4.0, true);      // (a launch of dilated kernels picks among these)
     if (ks_mix > ks) ks = ks_mix;
@@ -1631,9 +1659,8 @@ static int launch_wgrad_reduce(const IgemmWgradArgs &a, void *const *gw, int ngr
 int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *const *gw, const int *dil, int ngroups, void *workspace,
                             size_t workspace_bytes, int B, int H, int W, int cin, int cout, int k, int out_bf16, hipStream_t stream) {
     if (ngroups < 1 || ngroups > 4) return set_error(DSRG_ERR_INVALID, "conv_igemm_wgrad: 1..4 groups");
-    if (!conv_igemm_wgrad_supported(cin, cout, k))
-        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm_wgrad: cin %% 256 == 0 (or 128 with k = 3), cout %% 256 == 0, k in (1, 3) required (got %d, %d, %d)",
-                         cin, cout, k);
+    if (!conv_igemm_wgrad_launchable(cin, cout, k))
+        return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm_wgrad: cin %% 64 == 0, cout %% 64 == 0, k in (1, 3) required (got %d, %d, %d)", cin, cout, k);
     const long long M = (long long)B * H * W;
     if (M <= 0 || M * cin * 2 >= 0x7fffffffLL || M * cout * 2 >= 0x7fffffffLL)
         return set_error(DSRG_ERR_UNSUPPORTED, "conv_igemm_wgrad: tensor too large for 32-bit buffer offsets");
@@ -1642,7 +1669,7 @@ int launch_conv_igemm_wgrad(const void *const *x, const void *const *g, void *co
     IgemmWgradArgs a;
     memset(&a, 0, sizeof(a));
     a.ngroups = ngroups; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = k * k; a.M = (int)M;
-    a.tiles_n = cout / 256;
+    a.tiles_n = (cout + 255) / 256;
     a.tiles_c = wgrad_col_tiles(cin, k);
     bool wants_mix = false;                                  // dilated kernels: workgroups of unequal length, see xcd_mix
     for (int q = 0; q < ngroups; q++) wants_mix = wants_mix || (k == 3 && dil && dil[q] >= 3);      // (whatever the variant: tests compare them bit for bit)
@@ -1720,6 +1747,7 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
     float *bgp[1] = {bias_grad};
     const int dils[1] = {dil};
     static const bool merged_on = [] { const char *e = getenv("DSRG_IGEMM_MERGED_BWD"); return !e || atoi(e) != 0; }();      // tools: A/B
+    static const bool w_first_on = [] { const char *e = getenv("DSRG_MERGED_W_FIRST"); return !e || atoi(e) != 0; }();      // tools: A/B
     static const bool merged_k1_on = [] { const char *e = getenv("DSRG_IGEMM_MERGED_K1"); return !e || atoi(e) != 0; }();    // tools: A/B (1x1 layers)
     const bool can_merge = merged_on && ((k == 3 && dil < 3) || (k == 1 && merged_k1_on)) && (igemm_variant() == 3 || igemm_variant() == 1 || igemm_variant() == 8 || igemm_variant() == 9);
     IgemmBwdArgs a;
@@ -1734,16 +1762,43 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
             // the pixel split of the weight gradient half, chosen for THIS grid: its workgroups fill the CUs the data gradient's
             // tiles leave idle and then the whole chip; what counts is when the last of them ends (merged_makespan)
             const long long M = (long long)B * H * W;
-            const int tiles = (cout / 256) * wgrad_col_tiles(cin, k), ks0 = wgrad_ksplit(M, tiles, 256, (double)cout * k * k * cin * 4.0), cap = wgrad_ksplit_cap(M, ks0);
+            const int tiles = ((cout + 255) / 256) * wgrad_col_tiles(cin, k), ks0 = wgrad_ksplit(M, tiles, 256, (double)cout * k * k * cin * 4.0), cap = wgrad_ksplit_cap(M, ks0);
             const double td = ((cout / 64) * k * k + 6) * 1.85;                  // us per data-gradient tile: K-steps + prologue / epilogue
             double best = -1.0;
             int best_ks = ks0;
-            for (int ks = 1; ks <= cap; ks++) {
+            // the search simulates up to 2 x 128 grids of ~1 000 blocks — 0.25 - 0.5 ms of host time, as much as the launch runs on the
+            // GPU: decided once per geometry (a ResNet-101 step has 77 of these launches)
+            struct Key { int B, H, W, cin, cout, k, nd; bool operator<(const Key &o) const { return memcmp(this, &o, sizeof(Key)) < 0; } };
+            static std::map<Key, std::pair<int, int>> memo;
+            static std::mutex memo_mutex;
+            Key key;
+            memset(&key, 0, sizeof(key));
+            key.B = B; key.H = H; key.W = W; key.cin = cin; key.cout = cout; key.k = k; key.nd = nd;
+            bool known = false;
+            {
+                std::lock_guard<std::mutex> lock(memo_mutex);
+                auto it = memo.find(key);
+                if (it != memo.end()) { best_ks = it->second.first; a.w_first = it->second.second; known = true; }
+            }
+            // (the block order is searched too for the shapes round 6 added — 1x1 layers, channel counts below 256: their data-gradient
+            // tiles are a few K-steps long, and long weight-gradient workgroups dispatched LAST would run on alone; the 3x3 layers of
+            // the VGG path keep the order they were tuned with)
+            const bool order_free = w_first_on && (k == 1 || cin < 256 || cout < 256);
+            for (int ks = 1; ks <= cap && !known; ks++) {
                 const long long chunk = ((M + ks - 1) / ks + 63) / 64 * 64;
                 if ((long long)(ks - 1) * chunk >= M) continue;                  // an empty last split
                 const double tw = (chunk / 64 + 8) * 2.3;                        // us per weight-gradient workgroup: steps + partial tile out
-                const double t = merged_makespan(nd, td, tiles * ks, tw) + 3.0 + 2.4 * ks * ((double)cout * k * k * cin / (512.0 * 4608.0));
-                if (best < 0.0 || t < best) { best = t; best_ks = ks; }
+                const double tail = 3.0 + 2.4 * ks * ((double)cout * k * k * cin / (512.0 * 4608.0));
+                const double t = merged_makespan(nd, td, tiles * ks, tw) + tail;
+                if (best < 0.0 || t < best) { best = t; best_ks = ks; a.w_first = 0; }
+                if (order_free) {
+                    const double t2 = merged_makespan(tiles * ks, tw, nd, td) + tail;
+                    if (t2 < best) { best = t2; best_ks = ks; a.w_first = 1; }
+                }
+            }
+            if (!known) {
+                std::lock_guard<std::mutex> lock(memo_mutex);
+                memo[key] = std::make_pair(best_ks, a.w_first);
             }
             static const bool pick_on = [] { const char *e = getenv("DSRG_MERGED_KS"); return !e || atoi(e) != 0; }();      // tools: A/B
             t_force_ksplit = pick_on ? best_ks : 0;
@@ -1761,11 +1816,11 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
         if (rc) return rc;
         return launch_conv_igemm_wgrad(xp, gp, gwp, dils, 1, wgrad_ws, wgrad_ws_bytes, B, H, W, cin, cout, k, 0, stream);
     }
-    a.nd = nd; a.nd_pad = (nd + 7) & ~7; a.nw = nw;
+    a.nd = nd; a.nd_pad = (nd + 7) & ~7; a.nw = nw; a.nw_pad = (nw + 7) & ~7;
     static LdsGrant grant;
     constexpr size_t lds = ICfg<64, 2>::LDS > (size_t)(2 * kWStage) ? ICfg<64, 2>::LDS : (size_t)(2 * kWStage);
     if (int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_bwd_kernel), lds, grant)) return rc2;
-    hipLaunchKernelGGL(conv_igemm_bwd_kernel, dim3(a.nd_pad + a.nw), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(conv_igemm_bwd_kernel, dim3(a.w_first ? a.nw_pad + a.nd : a.nd_pad + a.nw), dim3(512), lds, stream, a);
     DSRG_LAUNCH_CHECK();
     if (bias_grad) {
         const float *parts[1] = {a.d.g[0].colsum};

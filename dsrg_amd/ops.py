@@ -988,7 +988,15 @@ _igemm_ws = {}
 
 
 def conv_igemm_wgrad_supported(cin, cout, k):
-    """the shapes conv_igemm_wgrad serves: 256 | cout, 256 | cin (or cin = 128 for a 3x3 kernel), k in (1, 3)"""
+    """the shapes conv_igemm_wgrad is the recommended route for (full 256 x 256 tiles): 256 | cout, 256 | cin (or cin = 128 for a 3x3
+    kernel), k in (1, 3)"""
+    cin, cout, k = int(cin), int(cout), int(k)
+    return k in (1, 3) and ((cin >= 256 and cin % 256 == 0) or (cin == 128 and k == 3)) and cout >= 256 and cout % 256 == 0
+
+
+def conv_igemm_wgrad_launchable(cin, cout, k):
+    """the shapes the launch takes: any multiples of 64 channels (narrow tensors leave part of a tile empty — fine where the layer is
+    bandwidth-bound: ResNet res2 / res3, 64 / 128 channels over 42 - 166 thousand pixels)"""
     return _lib.lib().dsrg_conv_igemm_wgrad_workspace(1, 1, 8, 8, int(cin), int(cout), int(k)) > 0
 
 
@@ -1011,7 +1019,7 @@ def conv_igemm_wgrad(xs, gs, dilations, ksize, out_dtype=torch.float32, outs=Non
     L = _lib.lib()
     need = L.dsrg_conv_igemm_wgrad_workspace(n, B, H, W, cin, cout, ksize)
     if need == 0:
-        raise ValueError("conv_igemm_wgrad: 256 | cin (or cin = 128, k = 3), 256 | cout, k in (1, 3) required (got %d, %d, %d)" % (cin, cout, ksize))
+        raise ValueError("conv_igemm_wgrad: 64 | cin, 64 | cout, k in (1, 3) required (got %d, %d, %d)" % (cin, cout, ksize))
     key = (xs[0].device.index, torch.cuda.current_stream().cuda_stream)
     ws = _igemm_ws.get(key)                                          # per-stream scratch, reused across layers and steps
     if ws is None or ws.numel() < need:

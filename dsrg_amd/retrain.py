@@ -117,7 +117,7 @@ class _FoldedIgemmFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        from .ops import conv_igemm, conv_igemm_dgrad, conv_igemm_residual, conv_igemm_wgrad, conv_igemm_wgrad_supported, relu_mask
+        from .ops import conv_igemm, conv_igemm_dgrad, conv_igemm_residual, conv_igemm_wgrad, conv_igemm_wgrad_launchable, relu_mask
         x, w, scale, y = ctx.saved_tensors
         cout, cin, k, d = w.shape[0], w.shape[1], ctx.k, ctx.dil
         cl = torch.channels_last
@@ -135,7 +135,7 @@ class _FoldedIgemmFn(torch.autograd.Function):
         if not ctx.has_res and ctx.res_link is not None:
             shortcut, ctx.res_link.gm = ctx.res_link.gm, None
         gx = None
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _MERGED and conv_igemm_wgrad_supported(cin, cout, k) and \
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _MERGED and conv_igemm_wgrad_launchable(cin, cout, k) and \
                 x.is_contiguous(memory_format=cl):
             # the whole backward in one grid (the weight gradient's workgroups take the CUs the data gradient's tiles leave idle: a
             # 65 x 65 x 10 map is 166 pixel tiles), the scale on the weight gradient in its reduction, written into the reducer's slot
@@ -162,7 +162,7 @@ class _FoldedIgemmFn(torch.autograd.Function):
                 gx = conv_igemm([gm], [ctx.pd], None, [d], k, False)[0]
         gw = None
         if ctx.needs_input_grad[1]:
-            if conv_igemm_wgrad_supported(cin, cout, k):
+            if conv_igemm_wgrad_launchable(cin, cout, k):
                 (gwf,) = conv_igemm_wgrad([x], [gm], [d], k)                    # float32, channels_last
             else:
                 p = d * (k // 2)

@@ -321,7 +321,8 @@ int dsrg_conv3x3_wgrad_f32(const void *x_dev, const void *g_dev, float *gw_dev, 
 int dsrg_pack_conv_weight_direct_f32(const float *w_dev, void *fwd_dev, void *dgrad_dev, int cout, int cin, void *stream);
 /* Implicit-GEMM convolution for the wide layers (conv3_x, conv4_x, conv5_x, fc6_k, fc7_k of train-s.prototxt:161-736): 3x3
  * with any dilation ('same' zero padding) or 1x1, stride 1, cin % 64 == 0, cout % 256 == 0, NHWC bf16 in and out, fp32
- * accumulation, optional bias (cout f32) and ReLU in the epilogue; no im2col matrix is formed:
+ * accumulation, optional bias (cout f32) and ReLU in the epilogue (the launch also takes cout = 64 — half-empty channel tiles, for
+ * bandwidth-bound 1x1 layers; dsrg_conv_igemm_supported names the shapes it is the recommended route for); no im2col matrix is formed:
  *   y[b,y,x,o] = relu?( bias[o] + sum_{dy,dx,c} w[o][dy+1][dx+1][c] * x[b,y+dy*dil,x+dx*dil,c] )
  * Up to four independent problems of one geometry (the four ASPP branches) share a launch: x_dev, w_dev, bias_dev (may be
  * NULL, entries may be NULL), y_dev and dilation are HOST arrays of ngroups entries.  w_dev[g]: the kernel packed as
@@ -383,7 +384,9 @@ int dsrg_pack_conv_weight_scaled_f32(const float *w_dev, const float *scale_dev,
 int dsrg_sgd_pack_f32(int n, float *const *param_dev, const float *const *grad_dev, float *const *momentum_dev, void *const *fwd_dev,
                       void *const *dgrad_dev, const int *shape, const long long *numel, const float *lr, const float *weight_decay,
                       float momentum, void *stream);
-/* Weight gradient of the same convolutions, again without an im2col matrix (cin % 256 == 0, cout % 256 == 0, ksize 1 or 3):
+/* Weight gradient of the same convolutions, again without an im2col matrix (cin % 64 == 0, cout % 64 == 0, ksize 1 or 3; tiles of 256
+ * outputs x 256 inputs of one tap — full, hence the recommended route, where cin % 256 == 0 (or cin = 128 with a 3x3 kernel) and
+ * cout % 256 == 0; narrower tensors run partly empty tiles, which is fine where the layer is bandwidth-bound):
  *   gw[o][tap][c] = sum_{b,y,x} g[b,y,x,o] * x[b,y+dy*dil,x+dx*dil,c]      (zero padding; tap = 3 (dy+1) + dx+1)
  * x_dev[g] (B,H,W,cin) and g_dev[g] (B,H,W,cout) NHWC bf16; gw_dev[g] (cout, ksize*ksize, cin) = the memory of a channels_last
  * (cout, cin, ksize, ksize) tensor, float32 (out_bf16 = 0: the master weights' gradient, no cast behind it) or bf16; fp32

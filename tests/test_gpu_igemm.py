@@ -267,6 +267,7 @@ def test_igemm_rejects_unsupported_shapes(ops):
     assert ops.conv_igemm_supported(256, 128, 3) and not ops.conv_igemm_supported(512, 64, 3) and not ops.conv_igemm_supported(96, 256, 3)
     assert ops.conv_igemm_wgrad_supported(128, 256, 3) and not ops.conv_igemm_wgrad_supported(128, 256, 1)
     assert not ops.conv_igemm_wgrad_supported(64, 256, 3) and not ops.conv_igemm_wgrad_supported(256, 128, 3)
+    assert ops.conv_igemm_wgrad_launchable(64, 256, 1) and ops.conv_igemm_wgrad_launchable(128, 128, 3) and not ops.conv_igemm_wgrad_launchable(96, 256, 1)
     x = torch.zeros(1, 64, 4, 4, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=CL)
     with pytest.raises(ValueError):
         ops.conv_igemm([x], [torch.zeros(256, 1, 9, 64, device="cuda")], [None], [1], 3, False)      # float32 kernel
@@ -288,6 +289,14 @@ def test_igemm_rejects_unsupported_shapes(ops):
     (1, 3, 100, 256, 512, 3, 24),        # map wider than a step; dilation beyond the height
     (2, 27, 31, 128, 256, 3, 1),         # conv3_1: two taps of 128 channels per column tile, the tenth "tap" of the last tile empty
     (1, 81, 81, 128, 256, 3, 1),
+    (2, 37, 35, 256, 64, 1, 1),          # ResNet res2 / res3 (round 6): partly empty tiles — 64 outputs
+    (2, 37, 35, 64, 256, 1, 1),          #   64 inputs
+    (1, 50, 41, 64, 64, 1, 1),
+    (2, 33, 33, 128, 512, 1, 1),         #   128 inputs, 1x1 (not the two-tap form)
+    (2, 33, 33, 512, 128, 1, 1),
+    (2, 33, 35, 128, 128, 3, 1),         #   two-tap tiles, 128 outputs
+    (1, 29, 31, 64, 128, 3, 2),          #   a 3x3 kernel over 64 inputs
+    (1, 21, 23, 320, 192, 1, 1),         #   the last tile of each axis partly empty
 ])
 def test_igemm_weight_gradient_matches_torch(ops, B, H, W, cin, cout, k, dil):
     x, w, _ = _case(B, H, W, cin, cout, k, 9)
