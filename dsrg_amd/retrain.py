@@ -20,6 +20,7 @@ from .trainer import CaffeSGD
 
 _IGEMM_BN = _os.environ.get("DSRG_RESNET_IGEMM", "1") == "1"      # tools: A/B against round 5's im2col + library-GEMM bottlenecks
 _MERGED = _os.environ.get("DSRG_RESNET_MERGED_BWD", "1") == "1"   # tools / tests: 0 = data and weight gradient of a bottleneck convolution as two launches
+_ASPP_WGRAD = _os.environ.get("DSRG_ASPP_IGEMM_WGRAD", "1") == "1"   # tools: 0 = the ASPP classifiers' weight gradients by the library
 _FUSE_RES = _os.environ.get("DSRG_RESNET_FUSE_RES", "1") == "1"   # tools / tests: 0 = the shortcut's add + ReLU and its backward as passes of their own
 
 
@@ -315,13 +316,13 @@ class _AsppFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        from .ops import conv_igemm, pack_conv_weight
+        from .ops import conv_igemm, conv_igemm_wgrad, conv_igemm_wgrad_launchable, pack_conv_weight
         f, *ws = ctx.saved_tensors
         n, O = len(ws), ctx.O
         cl = torch.channels_last
         gb = g.float().sum((0, 2, 3))                                                  # the same for every branch
         g16 = g.to(torch.bfloat16)
-        gf = None
+        gf = gp = None
         if ctx.needs_input_grad[1]:
             # data gradient: the same launch on the flipped / transposed kernels, the 21 gradient channels padded to one 64-channel chunk
             gp = F.pad(g16, (0, 0, 0, 0, 0, 64 - O)).contiguous(memory_format=cl)
@@ -331,10 +332,17 @@ class _AsppFn(torch.autograd.Function):
             for gx in gxs[1:]:
                 gf = gf + gx                                                           # (bf16 sums, as autograd's own accumulation)
         gws = []
-        g16 = g16.contiguous(memory_format=cl)
-        for w, d in zip(ws, ctx.dils):
-            gws.append(torch.ops.aten.convolution_backward(g16, f, w.to(torch.bfloat16), None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
-                                                           [False, True, False])[1].float())
+        if _ASPP_WGRAD and conv_igemm_wgrad_launchable(f.shape[1], 64, 3) and n <= 4:
+            # the four weight gradients in one launch of the implicit-GEMM weight-gradient kernel (gradient channels padded to 64; each
+            # tap sums over the pixels it reaches only) — the library's kernel for a 21-output 3x3 layer ran 253 us per branch
+            if gp is None:
+                gp = F.pad(g16, (0, 0, 0, 0, 0, 64 - O)).contiguous(memory_format=cl)
+            gws = [gw[:O] for gw in conv_igemm_wgrad([f] * n, [gp] * n, list(ctx.dils), 3)]
+        else:
+            g16 = g16.contiguous(memory_format=cl)
+            for w, d in zip(ws, ctx.dils):
+                gws.append(torch.ops.aten.convolution_backward(g16, f, w.to(torch.bfloat16), None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                                                               [False, True, False])[1].float())
         return (None, gf) + tuple(gws) + (gb,) * n
 
 
