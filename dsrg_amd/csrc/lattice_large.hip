@@ -283,6 +283,15 @@ __global__ void lg_norm_kernel(LargeLattice L, int D1, const float *__restrict__
 
 // ---- CP-channel filter (Permutohedral::sseCompute, permutohedral.cpp:529-589); in/out are [N][CP]
 // one wave per vertex, lanes = channels: ordered accumulation of the vertex's row of (pixel, weight) entries
+// the splat's input is Q * norm (pairwise.cpp:66), stored per lattice by the update kernels.  Measured and dropped in round 6 (experiment
+// build, make EXP=2 EXPSRC=lattice_large exp): forming it inside the splat from Q and the pixel's norm (the same fp32 product; two
+// 96-byte row writes per pixel and iteration less, both lattices gather one array) — the splat is a chain of dependent gathers and the
+// extra norm load sits in it: 169 -> 229 us per batch-8 launch, 0.772 -> 0.807 ms per image (profiles/r06_crf_batch8_ab.txt)
+#if defined(DSRG_EXP) && (DSRG_EXP & 2)
+constexpr bool kSplatNormOnTheFly = true;
+#else
+constexpr bool kSplatNormOnTheFly = false;
+#endif
 __global__ __launch_bounds__(256) void lg_update_kernel(int N, int C, int CP, const float *__restrict__ neg_unary,
                                                         const float *__restrict__ t_g, const float *__restrict__ t_b,
                                                         int use_msgs, float *__restrict__ q, const float *__restrict__ norm_b,
@@ -315,8 +324,10 @@ __global__ __launch_bounds__(256) void lg_update_kernel(int N, int C, int CP, co
         const float v = row[(k / CP) * P + (k % CP)];
         q[i0 * CP + k] = v;
         // the splat's input, in = Q * norm (pairwise.cpp:66), formed once per pixel here instead of once per gather there
-        qn_b[i0 * CP + k] = v * norm_b[i0 + k / CP];
-        qn_g[i0 * CP + k] = v * norm_g[i0 + k / CP];
+        if (!kSplatNormOnTheFly) {
+            qn_b[i0 * CP + k] = v * norm_b[i0 + k / CP];
+            qn_g[i0 * CP + k] = v * norm_g[i0 + k / CP];
+        }
     }
 }
 // label-fastest [N][C] (host layout of DenseCRFWrapper) <-> padded rows [N][CP]
@@ -365,7 +376,14 @@ __device__ __forceinline__ float lg_splat_segment(const LargeLattice &L, uint32_
     for (uint32_t pos = p0; pos < p1; pos += U) {
         float x[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) x[u] = in[(size_t)px[u] * CP + lane];        // in = Q * norm, formed by the update kernel
+        for (int u = 0; u < U; u++) x[u] = in[(size_t)px[u] * CP + lane];
+        if (kSplatNormOnTheFly) {                            // in = Q: times the pixel's norm here (the same fp32 product the update kernel
+            float nm[U];                                     // used to store — two row writes and a second 79 MB input per iteration less)
+#pragma unroll
+            for (int u = 0; u < U; u++) nm[u] = L.norm[px[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = x[u] * nm[u];
+        }
         uint32_t npx[U];
         float nw[U];
         const bool more = pos + U < p1;
@@ -462,16 +480,46 @@ __device__ __forceinline__ void lg_blur_elem(const LargeLattice &L, int M, size_
     { float s = x1.w + x2.w; s = 0.5f * s; o.w = x0.w + s; }
     b[v * CP4 + q] = o;
 }
+#if defined(DSRG_EXP) && (DSRG_EXP & 1)       // experiment build: the linear work map of rounds 3-5 (make EXP=1 EXPSRC=lattice_large exp)
+#define DSRG_BLUR_STRIPS 0
+#endif
+#ifndef DSRG_BLUR_STRIPS
+#define DSRG_BLUR_STRIPS 1
+#endif
+constexpr bool kBlurStrips = DSRG_BLUR_STRIPS != 0;
 // axis j of the bilateral lattice and, while j < 3, of the Gaussian lattice
 __global__ void lg_blur2_kernel(LargeLattice Lb, LargeLattice Lg, int CP4, int j, int seq, const float4 *__restrict__ ab,
                                 float4 *__restrict__ bb, const float4 *__restrict__ ag, float4 *__restrict__ bg) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int Mb = *Lb.M, Mg = *Lg.M;
-    size_t v = idx / CP4;
-    const int q = (int)(idx - v * CP4);
-    if (v <= (size_t)Mb) { lg_blur_elem(Lb, Mb, v, q, CP4, j, seq, ab, bb); return; }
-    v -= (size_t)Mb + 1;
-    if (j < 3 && v <= (size_t)Mg) lg_blur_elem(Lg, Mg, v, q, CP4, j, seq, ag, bg);
+    if (!kBlurStrips) {
+        const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        size_t v = idx / CP4;
+        const int q = (int)(idx - v * CP4);
+        if (v <= (size_t)Mb) { lg_blur_elem(Lb, Mb, v, q, CP4, j, seq, ab, bb); return; }
+        v -= (size_t)Mb + 1;
+        if (j < 3 && v <= (size_t)Mg) lg_blur_elem(Lg, Mg, v, q, CP4, j, seq, ag, bg);
+        return;
+    }
+    // per XCD: its strip of the bilateral lattice's rows, then its strip of the Gaussian lattice's (vertex ids are image order: a
+    // vertex and its two neighbours along an axis lie in one image strip, so the three rows meet in one L2 — as the splat's and the
+    // slice's work maps, above)
+    const unsigned upb = blockDim.x / (unsigned)CP4 * (unsigned)CP4;      // threads of a block that hold (row, quad) units: whole rows only
+    const unsigned rows_pb = upb / (unsigned)CP4;
+    if (threadIdx.x >= upb) return;
+    const unsigned nb_b = xcd_strip_blocks((size_t)Mb + 1, rows_pb) / 8;
+    const unsigned x = blockIdx.x & 7u, sl = blockIdx.x >> 3;
+    const unsigned rl = threadIdx.x / (unsigned)CP4;
+    const int q = (int)(threadIdx.x - rl * (unsigned)CP4);
+    size_t end;
+    if (sl < nb_b) {
+        const long long f = xcd_strip_first(x | (sl << 3), (size_t)Mb + 1, rows_pb, &end);
+        const size_t v = (size_t)f + rl;
+        if (f >= 0 && v < end) lg_blur_elem(Lb, Mb, v, q, CP4, j, seq, ab, bb);
+    } else if (j < 3) {
+        const long long f = xcd_strip_first(x | ((sl - nb_b) << 3), (size_t)Mg + 1, rows_pb, &end);
+        const size_t v = (size_t)f + rl;
+        if (f >= 0 && v < end) lg_blur_elem(Lg, Mg, v, q, CP4, j, seq, ag, bg);
+    }
 }
 __device__ __forceinline__ float4 lg_slice_elem(const LargeLattice &L, int D1, size_t i, int q, int CP4, int seq,
                                                 const float4 *__restrict__ val, float neg_w) {
@@ -550,8 +598,10 @@ __global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, L
     for (int k = threadIdx.x; k < npix * CP; k += 256) {
         const float v = row[(k / CP) * P + (k % CP)];
         q_out[i0 * CP + k] = v;
-        qn_b[i0 * CP + k] = v * Lb.norm[i0 + k / CP];      // in = Q * norm (pairwise.cpp:66) for the next splat
-        qn_g[i0 * CP + k] = v * Lg.norm[i0 + k / CP];
+        if (!kSplatNormOnTheFly) {
+            qn_b[i0 * CP + k] = v * Lb.norm[i0 + k / CP];  // in = Q * norm (pairwise.cpp:66) for the next splat
+            qn_g[i0 * CP + k] = v * Lg.norm[i0 + k / CP];
+        }
     }
 }
 
@@ -987,7 +1037,8 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
         if (timed) DSRG_HIP_CHECK(hipEventRecord(c->prof.start[c->prof.used], s));
         hipLaunchKernelGGL(lg_splat2_kernel,
                            dim3(xcd_strip_blocks((size_t)Tb + 1, 256 >> lpv_shift) + xcd_strip_blocks((size_t)Tg + 1, 256 >> lpv_shift)),
-                           dim3(256), 0, s, c->Lb, c->Lg, CP, lpv_shift, c->qn_b, c->qn_g, c->val_a, c->val_a + g_off, c->part,
+                           dim3(256), 0, s, c->Lb, c->Lg, CP, lpv_shift, kSplatNormOnTheFly ? c->q : c->qn_b,
+                           kSplatNormOnTheFly ? c->q : c->qn_g, c->val_a, c->val_a + g_off, c->part,
                            c->part + (size_t)Tb * CP);
         if (nmulti > 0)
             hipLaunchKernelGGL(lg_combine_kernel, dim3(blocks_for((size_t)nmulti, 256 >> lpv_shift)), dim3(256), 0, s, c->Lb, c->Lg, CP,
@@ -996,7 +1047,10 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
         float *a = c->val_a, *b = c->val_b;
         for (int j = 0; j < 6; j++) {
             const size_t rows = j < 3 ? need : (size_t)Mb + 1;
-            hipLaunchKernelGGL(lg_blur2_kernel, dim3(blocks_for(rows * CP4, 256)), dim3(256), 0, s, c->Lb, c->Lg, CP4, j,
+            const unsigned rows_pb = 256u / (unsigned)CP4;
+            const unsigned nblk = kBlurStrips ? xcd_strip_blocks((size_t)Mb + 1, rows_pb) + (j < 3 ? xcd_strip_blocks((size_t)Mg + 1, rows_pb) : 0u)
+                                              : (unsigned)blocks_for(rows * CP4, 256);
+            hipLaunchKernelGGL(lg_blur2_kernel, dim3(nblk), dim3(256), 0, s, c->Lb, c->Lg, CP4, j,
                                c->C <= 2 ? 1 : 0, (const float4 *)a, (float4 *)b, (const float4 *)(a + g_off), (float4 *)(b + g_off));
             float *t = a; a = b; b = t;
         }
