@@ -543,6 +543,13 @@ __device__ __forceinline__ float4 lg_slice_elem(const LargeLattice &L, int D1, s
     o.x = neg_w * (acc.x * nv); o.y = neg_w * (acc.y * nv); o.z = neg_w * (acc.z * nv); o.w = neg_w * (acc.w * nv);
     return o;
 }
+// (Nimg, Npimg): batch mode — row i of the padded side is pixel i % Npimg of image i / Npimg, the caller's side holds the
+// images' Nimg pixels back to back; the slots' padding pixels read as zero rows and are never written out.  Npimg = 0: one image.
+__device__ __forceinline__ long long lg_user_row(size_t i, int Nimg, int Npimg) {
+    if (Npimg == 0) return (long long)i;
+    const size_t b = i / (size_t)Npimg, il = i - b * (size_t)Npimg;
+    return il < (size_t)Nimg ? (long long)(b * (size_t)Nimg + il) : -1;
+}
 // slice both lattices, subtract the messages from -unary (Gaussian first) and renormalise.  kSlicePix pixels per 256-thread
 // workgroup (403 workgroups of 256 pixels left the chip at 6 waves per CU: latency-bound gathers); the fp64-rounded exps run
 // over all threads (pixel x label), the column maximum and the label-order sum per pixel.
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, L
                                                               const float4 *__restrict__ val_b, const float4 *__restrict__ val_g,
                                                               float neg_wb, float neg_wg, const float *__restrict__ neg_unary,
                                                               float *__restrict__ q_out, float *__restrict__ qn_b,
-                                                              float *__restrict__ qn_g) {
+                                                              float *__restrict__ qn_g, int32_t *__restrict__ lab, int Nimg, int Npimg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *row = reinterpret_cast<float *>(smem);            // [kSlicePix][CP+1]
     const int P = CP + 1, CP4 = CP / 4, N = Lb.N;
@@ -593,25 +600,27 @@ __global__ __launch_bounds__(256) void lg_slice_update_kernel(LargeLattice Lb, L
         for (int c = 0; c < C; c++) sum = sum + r[c];
         for (int c = 0; c < C; c++) r[c] = r[c] / sum;
         for (int c = C; c < CP; c++) r[c] = 0.0f;
+        if (lab) {                                           // last iteration: the MAP label too (lg_argmax_rows_kernel's rule: first maximum),
+            const long long u = lg_user_row(i0 + threadIdx.x, Nimg, Npimg);      // so that reading the map costs no pass over Q
+            if (u >= 0) {
+                int m = 0;
+                float best = r[0];
+                for (int c = 1; c < C; c++) if (r[c] > best) { best = r[c]; m = c; }
+                lab[u] = m;
+            }
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < npix * CP; k += 256) {
         const float v = row[(k / CP) * P + (k % CP)];
-        q_out[i0 * CP + k] = v;
-        if (!kSplatNormOnTheFly) {
+        if (q_out) q_out[i0 * CP + k] = v;                   // (only the last iteration's Q is read by anybody: 96 bytes a pixel less before it,
+        if (!kSplatNormOnTheFly && qn_b) {                   //  and nobody splats after the last: 192 bytes less there)
             qn_b[i0 * CP + k] = v * Lb.norm[i0 + k / CP];  // in = Q * norm (pairwise.cpp:66) for the next splat
             qn_g[i0 * CP + k] = v * Lg.norm[i0 + k / CP];
         }
     }
 }
 
-// (Nimg, Npimg): batch mode — row i of the padded side is pixel i % Npimg of image i / Npimg, the caller's side holds the
-// images' Nimg pixels back to back; the slots' padding pixels read as zero rows and are never written out.  Npimg = 0: one image.
-__device__ __forceinline__ long long lg_user_row(size_t i, int Nimg, int Npimg) {
-    if (Npimg == 0) return (long long)i;
-    const size_t b = i / (size_t)Npimg, il = i - b * (size_t)Npimg;
-    return il < (size_t)Nimg ? (long long)(b * (size_t)Nimg + il) : -1;
-}
 __global__ void lg_pad_rows_kernel(int N, int C, int CP, const float *__restrict__ in, float *__restrict__ out, int negate,
                                    int Nimg, int Npimg) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -810,6 +819,7 @@ struct LargeCrf {
     bool async;                                // the entry points do not wait for the stream (the caller does: dsrg_crf_synchronize)
     float *neg_unary, *q;                  // [N][CP]
     float *qn_b, *qn_g;                    // [N][CP] q * norm of the bilateral / Gaussian kernel: the splat inputs
+    bool lab_valid;                        // `lab` holds the arg-max of the current Q (written by the last slice / update launch)
     float *val_a, *val_b;                  // ping-pong [(Mb+1) + (Mg+1)][CP], grown on demand: bilateral rows first
     size_t val_rows;
     float *part;                           // per-segment partial sums of the splat [T_b + T_g][CP], grown on demand
@@ -1058,8 +1068,11 @@ int large_crf_infer(LargeCrf *c, const dsrg_crf_params *prm, int n_iters) {
         hipLaunchKernelGGL(lg_slice_update_kernel, dim3(xcd_strip_blocks((size_t)c->N, kSlicePix)), dim3(T),
                            sizeof(float) * (kSlicePix * (size_t)(CP + 1) + kSlicePix), s, c->Lb, c->Lg, c->C, CP,
                            (const float4 *)c->val_a, (const float4 *)(c->val_b + g_off), -prm->w_bilateral,
-                           -prm->w_gaussian, c->neg_unary, c->q, c->qn_b, c->qn_g);
+                           -prm->w_gaussian, c->neg_unary, (it == n_iters - 1 || kSplatNormOnTheFly) ? c->q : nullptr,
+                           it == n_iters - 1 ? nullptr : c->qn_b, it == n_iters - 1 ? nullptr : c->qn_g,
+                           it == n_iters - 1 ? c->lab : nullptr, c->Nimg, c->Npimg);
     }
+    c->lab_valid = n_iters > 0;
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
@@ -1073,7 +1086,8 @@ int large_crf_read_q(LargeCrf *c, float *out_host) {
     return DSRG_OK;
 }
 int large_crf_read_map(LargeCrf *c, int32_t *labels_host) {
-    hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, c->stream, c->N, c->C, c->CP, c->q, c->lab,
+    if (!c->lab_valid)                                       // (no iteration ran: Q is the softmax of the unaries, lg_update_kernel)
+        hipLaunchKernelGGL(lg_argmax_rows_kernel, dim3(blocks_for(c->N, 256)), dim3(256), 0, c->stream, c->N, c->C, c->CP, c->q, c->lab,
                        c->Nimg, c->Npimg);
     DSRG_LAUNCH_CHECK();
     DSRG_HIP_CHECK(hipMemcpyAsync(labels_host, c->lab, sizeof(int32_t) * (size_t)c->nimg * c->Nimg, hipMemcpyDefault, c->stream));
