@@ -865,8 +865,10 @@ def main():
             tf = fl * 3 * B * world * args.steps / dt / 1e12 / world
             trainf_roofline = {"kernel": "backbone convolutions of the train-f step (implicit-GEMM / direct MFMA kernels of this repo; "
                                          "%s), whole step per GPU" % ("every convolution" if args.backbone == "vgg16" else
-                                                                      "7x7 stem, stride-2 projections, res2 and the 21-output weight "
-                                                                      "gradients stay on MIOpen / hipBLASLt"),
+                                                                      "every stride-1 bottleneck convolution and the ASPP head, shortcut "
+                                                                      "adds and ReLU backward in the convolutions' stores, data + weight "
+                                                                      "gradient in one grid; the 7x7 stem, res3's two stride-2 layers and "
+                                                                      "their gradients stay on MIOpen"),
                                "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
                                "flops_per_image_forward": fl,
                                "note": "3 x forward flops of the conv stack / step time (loss, pooling, residual adds, optimizer "
