@@ -344,9 +344,14 @@ def test_ms_record(device, steps, warmup, cpu=True):
         img = S.make_images(rng, 1, size=max(H, W), kind=["smooth", "noise", "dark_corner", "smooth"][k])[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]
         imgs.append(np.ascontiguousarray(np.transpose(img, (1, 2, 0))[:, :, ::-1]).clip(0, 255).astype(np.uint8))     # RGB uint8, as PIL hands it over
 
+    # the three forwards as captured HIP graphs (inference.GraphedForward: their input shapes are fixed by test-ms.py's resize);
+    # DSRG_TEST_MS_GRAPH=0: launch by launch, as before (1.4 ms per forward whatever the size: host-bound)
+    graphed = os.environ.get("DSRG_TEST_MS_GRAPH", "1") != "0"
+    fwd = I.GraphedForward(net) if graphed else None
+
     def one(i):
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            return I.predict_mask_ms(net, imgs[i % len(imgs)], smooth=True, device=device)
+            return I.predict_mask_ms(net, imgs[i % len(imgs)], smooth=True, device=device, forward=fwd)
     for i in range(warmup):
         one(i)
     torch.cuda.synchronize()
@@ -360,7 +365,7 @@ def test_ms_record(device, steps, warmup, cpu=True):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         e[0].record()
         for i in range(5):
-            probs = I._probs_from_scores(I.multiscale_scores(net, imgs[i % len(imgs)], device=device))
+            probs = I._probs_from_scores(I.multiscale_scores(net, imgs[i % len(imgs)], device=device, forward=fwd))
         e[1].record()
         unary = torch.log(probs).permute(1, 2, 0).contiguous()
         img_t = torch.as_tensor(imgs[0], device=device)
@@ -377,8 +382,8 @@ def test_ms_record(device, steps, warmup, cpu=True):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16 backbone forwards (fp32 heads), f64 zoom, f32 CRF", "data": "synthetic",
            "config": {"workload": "inference.predict_mask_ms: scales 241/321/401, CRF scale_factor 1, maxiter 10, one image per step"},
-           "forwards_zoom_softmax_ms": fwd_ms, "crf_argmax_ms": crf_ms,
-           "roofline": {"kernel": "the three VGG16-ASPP forwards (batch 1: 18-55 pixel tiles per layer, launch- and tile-quantisation-bound)",
+           "forwards_zoom_softmax_ms": fwd_ms, "crf_argmax_ms": crf_ms, "forwards_as_hip_graphs": graphed,
+           "roofline": {"kernel": "the three VGG16-ASPP forwards (batch 1: 18-55 pixel tiles per layer; replayed as HIP graphs, tile-quantisation-bound)",
                         "bound": "mfma", "achieved": flops / (fwd_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": flops / (fwd_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
                         "note": "the CRF half has its own record and roofline: modes.crf_fullres"},

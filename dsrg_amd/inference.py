@@ -53,14 +53,55 @@ def preprocess(image, size, device="cuda"):
     return x - torch.tensor(MEAN_PIXEL, dtype=torch.float32, device=device).view(1, 3, 1, 1)
 
 
+class GraphedForward(object):
+    """`net(x)` of an eval-mode network for the FIXED input shapes of the test-time loop (test-ms.py resizes every image to 241 / 321 /
+    401 before the forward, whatever its own size) as captured HIP graphs: one graph per input shape, captured at the first call with
+    that shape (after two eager warm-up passes on a side stream, which also size every scratch buffer the kernels' wrappers cache) and
+    replayed afterwards.  A batch-1 forward is ~40 launches of 10-30 us of GPU work each; issued one by one from Python it takes 1.4 ms
+    whatever the map size (host-bound), replayed it takes what the GPU needs.  The graph re-reads (and re-packs) the parameters at
+    every replay, so in-place weight updates are seen; the returned tensor is the graph's static output: consume it before the next
+    call with the same shape.  Capture happens under the autocast state of the first call — keep it the same afterwards."""
+
+    def __init__(self, net):
+        self.net = net
+        self._g = {}
+
+    def __call__(self, x):
+        key = (tuple(x.shape), x.dtype, torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
+        ent = self._g.get(key)
+        if ent is None:
+            ent = self._g[key] = self._capture(x)
+        graph, xs, ys = ent
+        xs.copy_(x)
+        graph.replay()
+        return ys
+
+    def _capture(self, x):
+        if self.net.training:
+            raise RuntimeError("GraphedForward needs an eval-mode network (no dropout stream inside a graph)")
+        xs = x.clone()
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                self.net(xs)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph), torch.no_grad():
+            ys = self.net(xs)
+        return graph, xs, ys
+
+
 @torch.no_grad()
-def multiscale_scores(net, image, sizes=(241, 321, 401), device="cuda"):
-    """sum over scales of the fc8 scores zoomed to the image resolution (test-ms.py:89-97) -> (C,H,W)"""
+def multiscale_scores(net, image, sizes=(241, 321, 401), device="cuda", forward=None):
+    """sum over scales of the fc8 scores zoomed to the image resolution (test-ms.py:89-97) -> (C,H,W).  forward: a callable used in
+    place of `net` for the forward passes (a GraphedForward of the same net, already in eval mode)"""
     d1, d2 = image.shape[0], image.shape[1]
     total = None
     with _eval_mode(net):
         for size in sizes:
-            scores = net(preprocess(image, size, device)).float()
+            scores = (forward or net)(preprocess(image, size, device)).float()
             scores = _zoom(scores, d1, d2)
             total = scores if total is None else total + scores
     return total[0]
@@ -72,9 +113,9 @@ def _probs_from_scores(scores, eps=0.00001):
 
 
 @torch.no_grad()
-def predict_mask_ms(net, image, smooth=True, sizes=(241, 321, 401), device="cuda"):
-    """test-ms.py:84-111 -> (H,W) int64 label mask"""
-    probs = _probs_from_scores(multiscale_scores(net, image, sizes, device))
+def predict_mask_ms(net, image, smooth=True, sizes=(241, 321, 401), device="cuda", forward=None):
+    """test-ms.py:84-111 -> (H,W) int64 label mask.  forward: see multiscale_scores"""
+    probs = _probs_from_scores(multiscale_scores(net, image, sizes, device, forward))
     if smooth:
         # scores, log-probabilities, CRF and arg-max all stay on the GPU; only the (H,W) mask crosses PCIe
         unary = torch.log(probs).permute(1, 2, 0).contiguous()

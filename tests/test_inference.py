@@ -142,3 +142,39 @@ def test_backbone_forward_replays_from_a_hip_graph():
         assert static.dtype == torch.float32 and torch.equal(static, fwd())
     with pytest.raises(ValueError):
         GraphedForward(net.train(), x)
+
+
+@pytest.mark.gpu
+def test_graphed_forward_equals_the_eager_forward():
+    """inference.GraphedForward (one captured HIP graph per input shape of the test-time loop) against the eager forward of the same
+    VGG16-ASPP: bit-equal scores for several inputs and both shapes, weights updated in place are seen by the next replay, and
+    predict_mask_ms gives the same mask either way"""
+    from dsrg_amd import inference as I, synthetic as S
+    from dsrg_amd.backbone import VGG16ASPP
+    torch.manual_seed(0)
+    dev = torch.device("cuda", 0)
+    net = VGG16ASPP().to(dev).to(memory_format=torch.channels_last).eval()
+    fwd = I.GraphedForward(net)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for rep in range(3):
+            for size in (241, 321):
+                x = torch.randn(1, 3, size, size, device=dev, generator=g) * 40.0
+                want = net(x).float().clone()
+                got = fwd(x).float().clone()
+                assert torch.equal(got, want), (rep, size)
+        assert len(fwd._g) == 2
+        with torch.no_grad():
+            net.fc8[0].weight.mul_(0.5) if hasattr(net, "fc8") else [p.mul_(0.5) for p in list(net.parameters())[-2:]]
+        x = torch.randn(1, 3, 241, 241, device=dev, generator=g) * 40.0
+        assert torch.equal(fwd(x).float(), net(x).float())
+        rng = np.random.default_rng(5)
+        H, W = 120, 160
+        im = (S.make_images(rng, 1, size=max(H, W))[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None]).transpose(1, 2, 0)
+        im = np.ascontiguousarray(im[:, :, ::-1]).clip(0, 255).astype(np.uint8)
+        a = I.predict_mask_ms(net, im, smooth=True, device=dev)
+        b = I.predict_mask_ms(net, im, smooth=True, device=dev, forward=fwd)
+        assert np.array_equal(a, b)
+    net.train()
+    with pytest.raises(RuntimeError):
+        I.GraphedForward(net)(torch.zeros(1, 3, 241, 241, device=dev))
