@@ -168,21 +168,29 @@ def CRF_device_batch(images, unary, maxiter=10, scale_factor=1.0, color_factor=1
     import torch
     B, H, W, M = unary.shape
     assert tuple(images.shape) == (B, H, W, 3)
-    if crf is None and torch.cuda.current_stream(unary.device) != torch.cuda.default_stream(unary.device):
-        torch.cuda.current_stream(unary.device).synchronize()     # the object API works on the null stream
+    # objects made here run on the CALLER's stream (bound for the call, unbound before they go back to the library's cache): no
+    # host synchronisation of the caller's stream up front and no detour over the null stream, which serialises every other stream
+    cur = torch.cuda.current_stream(unary.device)
+    bind = cur if (crf is None and cur != torch.cuda.default_stream(unary.device)) else None
     sxy_b, sxy_g = _BILATERAL_XY / scale_factor, _GAUSS_XY / scale_factor
     out = torch.empty((B, H, W) if want == "map" else (B, H, W, M), dtype=torch.int32 if want == "map" else torch.float32,
                       device=unary.device)
     for b0 in range(0, B, MAX_BATCH):
         n = min(MAX_BATCH, B - b0)
         obj = crf if (crf is not None and B <= MAX_BATCH) else DenseCRF(W, H, M, nimages=n)
-        obj.set_unary_energy((-unary[b0:b0 + n].to(torch.float32)).contiguous())
-        obj.add_pairwise_energy(_BILATERAL_W, sxy_b, sxy_b, color_factor, color_factor, color_factor, _GAUSS_W, sxy_g, sxy_g,
-                                images[b0:b0 + n].to(torch.uint8).contiguous())
-        if want == "map":
-            obj.map(maxiter, out=out[b0:b0 + n])
-        else:
-            obj.inference(maxiter, out=out[b0:b0 + n])
+        if bind is not None and obj is not crf:
+            obj.set_stream(bind)
+        try:
+            obj.set_unary_energy((-unary[b0:b0 + n].to(torch.float32)).contiguous())
+            obj.add_pairwise_energy(_BILATERAL_W, sxy_b, sxy_b, color_factor, color_factor, color_factor, _GAUSS_W, sxy_g, sxy_g,
+                                    images[b0:b0 + n].to(torch.uint8).contiguous())
+            if want == "map":
+                obj.map(maxiter, out=out[b0:b0 + n])
+            else:
+                obj.inference(maxiter, out=out[b0:b0 + n])
+        finally:
+            if bind is not None and obj is not crf:
+                obj.set_stream(None)
     return out
 
 

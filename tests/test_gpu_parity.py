@@ -1332,6 +1332,16 @@ def test_crf_batch_equals_single_image_calls_bit_for_bit(ops, O, H, W, C, B):
     for k in (0, B - 1):
         want_q = O.CRF(ims[k].cpu().numpy(), uns[k].cpu().numpy(), scale_factor=1.0)
         assert np.abs(q[k].cpu().numpy() - want_q).max() < CRF_TOL
+    # on a caller's side stream the cached objects are bound to THAT stream for the call (no detour over the null stream), inputs
+    # produced on the stream just before are seen, and the objects go back to the cache unbound
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        uns2 = uns * 1.0
+        q2 = CRF_device_batch(ims, uns2, scale_factor=1.0)
+    side.synchronize()
+    assert torch.equal(q2, q)
+    assert torch.equal(CRF_device_batch(ims, uns, scale_factor=1.0), q)
 
 
 def test_crf_batch_through_the_many_images_loop_and_its_limits(ops, O):
