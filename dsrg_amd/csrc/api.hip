@@ -513,6 +513,16 @@ extern "C" int dsrg_conv_igemm_residual_bf16(const void *x_dev, const void *w_de
     return launch_conv_igemm_residual(x_dev, w_dev, bias_dev, res_dev, mask_dev, y_dev, dilation, B, H, W, cin, cout, ksize, relu,
                                       static_cast<hipStream_t>(stream));
 }
+extern "C" int dsrg_aspp_shift_sum_f32(const void *y_dev, const float *bias_dev, float *out_dev, const int *offsets, int npairs, int outputs,
+                                       int channels, int B, int H, int W, void *stream) {
+    if (!y_dev || !out_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "aspp_shift_sum: bad arguments");
+    return launch_aspp_shift_sum(y_dev, bias_dev, out_dev, offsets, npairs, outputs, channels, B, H, W, static_cast<hipStream_t>(stream));
+}
+extern "C" int dsrg_aspp_shift_gather_bf16(const float *g_dev, void *gp_dev, const int *offsets, int npairs, int outputs, int channels, int B,
+                                           int H, int W, void *stream) {
+    if (!g_dev || !gp_dev || B < 1 || H < 1 || W < 1) return set_error(DSRG_ERR_INVALID, "aspp_shift_gather: bad arguments");
+    return launch_aspp_shift_gather(g_dev, gp_dev, offsets, npairs, outputs, channels, B, H, W, static_cast<hipStream_t>(stream));
+}
 extern "C" int dsrg_conv_igemm_split_f32(const void *x3_dev, const void *w_dev, const float *bias_dev, float *y_dev, int dilation, int B, int H,
                                          int W, int cin, int cout, int ksize, int relu, void *stream) {
     if (!x3_dev || !w_dev || !y_dev) return set_error(DSRG_ERR_INVALID, "NULL argument");

@@ -477,6 +477,68 @@ int launch_relu_mask(const void *g, const void *g2, const void *y, void *gm, siz
     return DSRG_OK;
 }
 
+// ---- the DeepLab-v2 ASPP head (ResNet-101: four dilated 3x3 classifiers 2048 -> 21 of ONE feature map, summed) as one 1x1 product -----
+// out[p][o] = sum_j W_j[o] . x[p + off_j] over the J = 36 (branch, tap) pairs: Y'[q][j O + o] = W_j[o] . x[q] is ONE 1x1 convolution of x
+// with the (J O) x cin matrix of all kernels' taps (no output channel padded from 21 to a 128-wide tile, x read once), and the head's
+// output gathers it: out[p][o] = bias[o] + sum_j Y'[p + off_j][j O + o] (zero outside the map; j ascending, fp32).  Backward: the
+// gradient of Y' is the scatter of g, G'[q][j O + o] = g[q - off_j][o], and the data / weight gradients are the 1x1 layer's.
+struct AsppShift {
+    int J, O, CT;           // (branch, tap) pairs, outputs per pair, channels of Y' / G' (J O rounded up; the rest zero)
+    int dy[36], dx[36];
+};
+__global__ __launch_bounds__(256) void aspp_shift_sum_kernel(const uint16_t *__restrict__ yp, const float *__restrict__ bias, float *__restrict__ out,
+                                                             AsppShift s, int B, int H, int W) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * H * W * s.O) return;
+    const size_t p = idx / s.O;
+    const int o = (int)(idx - p * s.O);
+    const int b = (int)(p / ((size_t)H * W)), rem = (int)(p - (size_t)b * H * W), y = rem / W, x = rem - y * W;
+    float acc = bias ? bias[o] : 0.0f;
+    for (int j = 0; j < s.J; j++) {
+        const int yy = y + s.dy[j], xx = x + s.dx[j];
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            acc = acc + __uint_as_float((uint32_t)yp[(((size_t)b * H + yy) * W + xx) * s.CT + j * s.O + o] << 16);
+    }
+    out[idx] = acc;
+}
+__global__ __launch_bounds__(256) void aspp_shift_gather_kernel(const float *__restrict__ g, uint16_t *__restrict__ gp, AsppShift s, int B, int H, int W) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * H * W * s.CT) return;
+    const size_t p = idx / s.CT;
+    const int c = (int)(idx - p * s.CT), j = c / s.O, o = c - j * s.O;
+    const int b = (int)(p / ((size_t)H * W)), rem = (int)(p - (size_t)b * H * W), y = rem / W, x = rem - y * W;
+    float v = 0.0f;
+    if (j < s.J) {
+        const int yy = y - s.dy[j], xx = x - s.dx[j];
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = g[(((size_t)b * H + yy) * W + xx) * s.O + o];
+    }
+    gp[idx] = (uint16_t)(pack_bf16(v, 0.0f) & 0xffffu);
+}
+static int aspp_shift_args(AsppShift &s, const int *offsets, int J, int O, int CT) {
+    if (!offsets || J < 1 || J > 36 || O < 1 || CT < J * O) return set_error(DSRG_ERR_INVALID, "aspp shift: 1..36 (dy, dx) pairs, CT >= J * O");
+    memset(&s, 0, sizeof(s));
+    s.J = J; s.O = O; s.CT = CT;
+    for (int j = 0; j < J; j++) { s.dy[j] = offsets[2 * j]; s.dx[j] = offsets[2 * j + 1]; }
+    return DSRG_OK;
+}
+int launch_aspp_shift_sum(const void *yp, const float *bias, float *out, const int *offsets, int J, int O, int CT, int B, int H, int W,
+                          hipStream_t stream) {
+    AsppShift s;
+    if (int rc = aspp_shift_args(s, offsets, J, O, CT)) return rc;
+    const size_t n = (size_t)B * H * W * O;
+    hipLaunchKernelGGL(aspp_shift_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)yp, bias, out, s, B, H, W);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+int launch_aspp_shift_gather(const float *g, void *gp, const int *offsets, int J, int O, int CT, int B, int H, int W, hipStream_t stream) {
+    AsppShift s;
+    if (int rc = aspp_shift_args(s, offsets, J, O, CT)) return rc;
+    const size_t n = (size_t)B * H * W * CT;
+    hipLaunchKernelGGL(aspp_shift_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, (uint16_t *)gp, s, B, H, W);
+    DSRG_LAUNCH_CHECK();
+    return DSRG_OK;
+}
+
 // ---- bias gradient of a (rows, C) bf16 matrix for any C <= 256 (the 21-channel fc8 outputs): column sums in f32 -------------
 // lanes walk the flat array, so a wave reads 128 contiguous bytes; thread t always meets channel (t % C) because the row
 // group a block advances by is a whole number of rows.  Partials per block, then bias_finalize_kernel.

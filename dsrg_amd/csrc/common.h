@@ -209,6 +209,9 @@ int launch_heads_bwd(const void *const *x, int nbr, const float *w, const float 
                      float *bias_grad = nullptr, void *colsum_ws = nullptr, size_t colsum_ws_bytes = 0);
 size_t heads_bwd_relu_workspace(int nbr, int M, int K);
 int launch_add_relu(const void *a, const void *b, void *y, size_t n, hipStream_t stream);
+int launch_aspp_shift_sum(const void *yp, const float *bias, float *out, const int *offsets, int J, int O, int CT, int B, int H, int W,
+                          hipStream_t stream);
+int launch_aspp_shift_gather(const float *g, void *gp, const int *offsets, int J, int O, int CT, int B, int H, int W, hipStream_t stream);
 int launch_relu_mask(const void *g, const void *g2, const void *y, void *gm, size_t n, hipStream_t stream);
 int launch_igemm_colsum(const float *const *parts, float *const *outs, int ngroups, int rows, int cout, hipStream_t stream);
 int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y, void *gin, float *bias_grad, float *part,

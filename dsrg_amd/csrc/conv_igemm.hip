@@ -1783,7 +1783,8 @@ int launch_conv_igemm_backward(const void *g, const void *wd, const void *x, con
             // (the block order is searched too for the shapes round 6 added — 1x1 layers, channel counts below 256: their data-gradient
             // tiles are a few K-steps long, and long weight-gradient workgroups dispatched LAST would run on alone; the 3x3 layers of
             // the VGG path keep the order they were tuned with)
-            const bool order_free = w_first_on && (k == 1 || cin < 256 || cout < 256);
+            static const bool order_all = [] { const char *e = getenv("DSRG_MERGED_ORDER_ALL"); return e && atoi(e) != 0; }();     // tools: A/B
+            const bool order_free = w_first_on && (order_all || k == 1 || cin < 256 || cout < 256);
             for (int ks = 1; ks <= cap && !known; ks++) {
                 const long long chunk = ((M + ks - 1) / ks + 63) / 64 * 64;
                 if ((long long)(ks - 1) * chunk >= M) continue;                  // an empty last split

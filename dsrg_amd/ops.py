@@ -861,6 +861,36 @@ def conv_igemm_residual(x, packed, bias, res, mask, dilation, ksize, relu):
     return y
 
 
+def aspp_shift_sum(y, offsets, outputs, bias=None):
+    """the gather half of an ASPP head run as one 1x1 convolution (dsrg_aspp_shift_sum_f32): y (B,CT,H,W) bf16 channels_last = the
+    1x1 product of the feature map with all (branch, tap) kernels stacked (pair j's outputs at channels j * outputs ..), offsets a list
+    of (dy, dx) per pair -> (B,outputs,H,W) float32 (channels_last strides): out[.,o,y,x] = bias[o] + sum_j y[., j outputs + o, y + dy_j,
+    x + dx_j], zero outside the map"""
+    B, CT, H, W = y.shape
+    J = len(offsets)
+    if not (y.is_cuda and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last) and 1 <= J <= 36 and J * outputs <= CT):
+        raise ValueError("aspp_shift_sum needs a bf16 channels_last (B,CT,H,W) tensor with CT >= pairs * outputs, at most 36 pairs")
+    out = torch.empty((B, H, W, outputs), dtype=torch.float32, device=y.device)
+    off = (ctypes.c_int * (2 * J))(*[int(v) for pair in offsets for v in pair])
+    b = None if bias is None else _f32c(bias, "bias")
+    check(_lib.lib().dsrg_aspp_shift_sum_f32(_ptr(y), _ptr(b), _ptr(out), off, J, int(outputs), CT, B, H, W, _stream()))
+    return out.permute(0, 3, 1, 2)
+
+
+def aspp_shift_gather(g, offsets, channels):
+    """the backward of aspp_shift_sum (dsrg_aspp_shift_gather_bf16): g (B,outputs,H,W) float32 -> the gradient of y, (B,channels,H,W) bf16
+    channels_last: gp[., j outputs + o, y, x] = bf16(g[., o, y - dy_j, x - dx_j]), zero outside the map and in the channels past J outputs"""
+    B, O, H, W = g.shape
+    J = len(offsets)
+    if not (g.is_cuda and 1 <= J <= 36 and J * O <= channels):
+        raise ValueError("aspp_shift_gather: at most 36 pairs, channels >= pairs * outputs")
+    gn = g.float().permute(0, 2, 3, 1).contiguous()                                    # (B,H,W,O): a view if g has channels_last strides
+    gp = torch.empty((B, channels, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+    off = (ctypes.c_int * (2 * J))(*[int(v) for pair in offsets for v in pair])
+    check(_lib.lib().dsrg_aspp_shift_gather_bf16(_ptr(gn), _ptr(gp), off, J, O, int(channels), B, H, W, _stream()))
+    return gp
+
+
 def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias_grad=True, gb_outs=None):
     """the data gradient of 1 .. 4 convolutions whose inputs were ReLU (+ Dropout) outputs, with that layer's backward folded
     in: gs[g] (B,cout_fwd,H,W) bf16 channels_last, packed_t[g] the flipped + transposed packing, masks[g] (B,cin_fwd,H,W) bf16

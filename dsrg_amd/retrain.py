@@ -20,7 +20,6 @@ from .trainer import CaffeSGD
 
 _IGEMM_BN = _os.environ.get("DSRG_RESNET_IGEMM", "1") == "1"      # tools: A/B against round 5's im2col + library-GEMM bottlenecks
 _MERGED = _os.environ.get("DSRG_RESNET_MERGED_BWD", "1") == "1"   # tools / tests: 0 = data and weight gradient of a bottleneck convolution as two launches
-_ASPP_WGRAD = _os.environ.get("DSRG_ASPP_IGEMM_WGRAD", "1") == "1"   # tools: 0 = the ASPP classifiers' weight gradients by the library
 _FUSE_RES = _os.environ.get("DSRG_RESNET_FUSE_RES", "1") == "1"   # tools / tests: 0 = the shortcut's add + ReLU and its backward as passes of their own
 
 
@@ -286,63 +285,58 @@ class _Bottleneck(nn.Module):
 
 
 class _AsppFn(torch.autograd.Function):
-    """the DeepLab-v2 ASPP head, sum over four dilated 3x3 classifiers (2048 -> 21, dilation 6 / 12 / 18 / 24) of one feature map, on
-    the implicit-GEMM kernels: the classifiers' 21 outputs are padded to the kernels' 128-channel tile (zero kernels: 6x the
-    flops of the unpadded product, still 4x faster than the library's 64 x 32-tile forward at this shape) and the four branches
-    share ONE launch each way (class-ordered pixel tiles skip the taps the dilation pushes off the 65 x 65 map).
-    apply(f, w_1..w_4, b_1..b_4): f bf16 channels_last; w, b the float32 master parameters -> (B, 21, H, W) float32."""
+    """the DeepLab-v2 ASPP head, sum over four dilated 3x3 classifiers (2048 -> 21, dilation 6 / 12 / 18 / 24) of one feature map, as
+    ONE 1x1 convolution on the implicit-GEMM kernels plus a shifted gather: out[p][o] = sum_j W_j[o] . f[p + off_j] over the 36
+    (branch, tap) pairs = the gather of Y' = f x [all 36 x 21 tap kernels stacked] (ops.aspp_shift_sum).  No output channel padded
+    from 21 to a 128-wide tile (the four-branch 3x3 launch multiplied 6x the real flops) and f is read once per pass instead of once per
+    tap; backward: the gradient of Y' is the scatter of g (ops.aspp_shift_gather), the data and weight gradient of the 1x1 layer run in
+    one grid (ops.conv_igemm_backward_residual).
+    apply(dils, f, w_1..w_n, b_1..b_n): f bf16 channels_last; w, b the float32 master parameters -> (B, 21, H, W) float32."""
 
     @staticmethod
     def forward(ctx, dils, f, *t):
-        from .ops import conv_igemm, pack_conv_weight_pair
+        from .ops import conv_igemm, pack_conv_weight_pair, aspp_shift_sum
         n = len(dils)
         ws, bs = t[:n], t[n:2 * n]
         O, cin = ws[0].shape[0], ws[0].shape[1]
         f = f if f.dtype == torch.bfloat16 else f.bfloat16()
         f = f if f.is_contiguous(memory_format=torch.channels_last) else f.contiguous(memory_format=torch.channels_last)
-        packs = []
-        for w in ws:
-            wp = F.pad(w.detach().float(), (0, 0, 0, 0, 0, 0, 0, 128 - O)).contiguous(memory_format=torch.channels_last)
-            packs.append(pack_conv_weight_pair(wp, True, False)[0])
-        zero = torch.zeros(128, dtype=torch.float32, device=f.device)
-        outs = conv_igemm([f] * n, packs, [zero] * n, list(dils), 3, False)
-        out = outs[0][:, :O].float()
-        for o in outs[1:]:
-            out = out + o[:, :O].float()
-        out = out + sum(b.detach().float() for b in bs).view(1, -1, 1, 1)
-        ctx.save_for_backward(f, *ws)
-        ctx.dils, ctx.O = tuple(dils), O
+        J = 9 * n
+        CT = (J * O + 127) // 128 * 128
+        offsets = [((tap // 3 - 1) * d, (tap % 3 - 1) * d) for d in dils for tap in range(9)]
+        # row j * O + o of the stacked kernel = w_branch[o, :, ky, kx], j = branch * 9 + ky * 3 + kx
+        wcat = torch.cat([w.detach().float().permute(2, 3, 0, 1).reshape(9 * O, cin) for w in ws])
+        wcat = F.pad(wcat, (0, 0, 0, CT - J * O)).view(CT, cin, 1, 1).contiguous(memory_format=torch.channels_last)
+        need_d = ctx.needs_input_grad[1]
+        pf, pd = pack_conv_weight_pair(wcat, True, need_d)
+        (yp,) = conv_igemm([f], [pf], None, [1], 1, False)
+        bias = bs[0].detach().float()
+        for b in bs[1:]:
+            bias = bias + b.detach().float()
+        out = aspp_shift_sum(yp, offsets, O, bias.contiguous())
+        ctx.save_for_backward(f)
+        ctx.pd, ctx.offsets, ctx.O, ctx.CT, ctx.n, ctx.cin = pd, offsets, O, CT, n, cin
         return out
 
     @staticmethod
     def backward(ctx, g):
-        from .ops import conv_igemm, conv_igemm_wgrad, conv_igemm_wgrad_launchable, pack_conv_weight
-        f, *ws = ctx.saved_tensors
-        n, O = len(ws), ctx.O
-        cl = torch.channels_last
+        from .ops import conv_igemm, conv_igemm_wgrad, conv_igemm_backward_residual, aspp_shift_gather
+        (f,) = ctx.saved_tensors
+        n, O, CT, cin = ctx.n, ctx.O, ctx.CT, ctx.cin
         gb = g.float().sum((0, 2, 3))                                                  # the same for every branch
-        g16 = g.to(torch.bfloat16)
-        gf = gp = None
-        if ctx.needs_input_grad[1]:
-            # data gradient: the same launch on the flipped / transposed kernels, the 21 gradient channels padded to one 64-channel chunk
-            gp = F.pad(g16, (0, 0, 0, 0, 0, 64 - O)).contiguous(memory_format=cl)
-            packs_d = [pack_conv_weight(F.pad(w.detach().to(torch.bfloat16), (0, 0, 0, 0, 0, 0, 0, 64 - O)), for_dgrad=True) for w in ws]
-            gxs = conv_igemm([gp] * n, packs_d, None, list(ctx.dils), 3, False)
-            gf = gxs[0]
-            for gx in gxs[1:]:
-                gf = gf + gx                                                           # (bf16 sums, as autograd's own accumulation)
-        gws = []
-        if _ASPP_WGRAD and conv_igemm_wgrad_launchable(f.shape[1], 64, 3) and n <= 4:
-            # the four weight gradients in one launch of the implicit-GEMM weight-gradient kernel (gradient channels padded to 64; each
-            # tap sums over the pixels it reaches only) — the library's kernel for a 21-output 3x3 layer ran 253 us per branch
-            if gp is None:
-                gp = F.pad(g16, (0, 0, 0, 0, 0, 64 - O)).contiguous(memory_format=cl)
-            gws = [gw[:O] for gw in conv_igemm_wgrad([f] * n, [gp] * n, list(ctx.dils), 3)]
-        else:
-            g16 = g16.contiguous(memory_format=cl)
-            for w, d in zip(ws, ctx.dils):
-                gws.append(torch.ops.aten.convolution_backward(g16, f, w.to(torch.bfloat16), None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
-                                                               [False, True, False])[1].float())
+        gp = aspp_shift_gather(g, ctx.offsets, CT)
+        need_w = any(ctx.needs_input_grad[2:2 + n])
+        gf = gw = None
+        if ctx.needs_input_grad[1] and need_w:
+            gf, gw = conv_igemm_backward_residual(gp, ctx.pd, f, 1, 1)
+        elif ctx.needs_input_grad[1]:
+            (gf,) = conv_igemm([gp], [ctx.pd], None, [1], 1, False)
+        elif need_w:
+            (gw,) = conv_igemm_wgrad([f], [gp], [1], 1)
+        gws = [None] * n
+        if gw is not None:
+            g2 = gw.reshape(CT, cin)
+            gws = [g2[b * 9 * O:(b + 1) * 9 * O].view(3, 3, O, cin).permute(2, 3, 0, 1) for b in range(n)]
         return (None, gf) + tuple(gws) + (gb,) * n
 
 
@@ -373,7 +367,8 @@ class ResNet101DeepLab(nn.Module):
         f = self.layers(self.stem(x))
         from .ops import conv_igemm_supported
         if _IGEMM_BN and f.is_cuda and (f.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)) \
-                and len(self.aspp) <= 4 and self.aspp[0].out_channels <= 64 and conv_igemm_supported(f.shape[1], 128, 3) and \
+                and len(self.aspp) <= 4 and 9 * len(self.aspp) * self.aspp[0].out_channels <= 2048 and conv_igemm_supported(f.shape[1], 128, 1) and \
+                f.shape[1] % 256 == 0 and \
                 f.shape[0] * f.shape[2] * f.shape[3] >= 2048 and all(m.kernel_size == (3, 3) and m.padding == m.dilation and m.stride == (1, 1)
                                                                       for m in self.aspp):
             return _AsppFn.apply(tuple(m.dilation[0] for m in self.aspp), f, *[m.weight for m in self.aspp], *[m.bias for m in self.aspp])

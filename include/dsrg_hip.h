@@ -362,6 +362,18 @@ int dsrg_conv_igemm_dgrad_bf16(const void *const *g_dev, const void *const *w_de
  * gradient that reaches the block input along the shortcut, mask = the block input, itself a ReLU output) gives, in one launch. */
 int dsrg_conv_igemm_residual_bf16(const void *x_dev, const void *w_dev, const float *bias_dev, const void *res_dev, const void *mask_dev,
                                   void *y_dev, int dilation, int B, int H, int W, int cin, int cout, int ksize, int relu, void *stream);
+/* The DeepLab-v2 ASPP head — J = branches x 9 (branch, tap) pairs of dilated 3x3 classifiers with `outputs` (21) channels each, all
+ * reading ONE feature map and summed (deeplabv2 prototxt: fc1_voc12_c0..c3 + Eltwise SUM) — as one 1x1 convolution plus a shifted
+ * gather: y = dsrg_conv_igemm_bf16(x, the (J outputs, rounded up to `channels`) x cin matrix of all kernels' taps, 1x1) and
+ *   out[b,y,x,o] = bias[o] + sum_j y[b, y + dy_j, x + dx_j, j outputs + o]        (zero outside the map; j ascending; fp32)
+ * (dsrg_aspp_shift_sum_f32; y (B,H,W,channels) bf16, out (B,H,W,outputs) f32, bias_dev (outputs) or NULL = the branches' biases
+ * summed).  Backward: gp[b,y,x,j outputs + o] = bf16(g[b, y - dy_j, x - dx_j, o]) (dsrg_aspp_shift_gather_bf16; channels past
+ * J outputs zero) is the gradient of y; the 1x1 layer's data / weight gradients follow.  offsets: HOST array of npairs (dy, dx)
+ * pairs, npairs <= 36.  No output channel is padded to a 128-wide tile and the feature map is read once per pass. */
+int dsrg_aspp_shift_sum_f32(const void *y_dev, const float *bias_dev, float *out_dev, const int *offsets, int npairs, int outputs,
+                            int channels, int B, int H, int W, void *stream);
+int dsrg_aspp_shift_gather_bf16(const float *g_dev, void *gp_dev, const int *offsets, int npairs, int outputs, int channels, int B, int H,
+                                int W, void *stream);
 int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, int *status_host);
 /* The two packed forms dsrg_conv_igemm_bf16 reads, from the float32 master kernel in ONE pass (cast included): w_dev
  * (cout, ksize*ksize, cin) f32 = the memory of a channels_last (cout, cin, ksize, ksize) parameter; fwd_dev (may be NULL):

@@ -1202,6 +1202,57 @@ def test_resnet_shortcut_in_the_store_is_bit_identical_to_the_separate_passes(mo
         assert torch.equal(blocks(x0), ya)
 
 
+def test_aspp_head_as_one_1x1_product_plus_shifted_gather(ops):
+    """the ResNet ASPP head (four dilated 3x3 classifiers of one map, summed) as ONE 1x1 convolution + ops.aspp_shift_sum, backward by
+    ops.aspp_shift_gather + the 1x1 layer's merged backward (retrain._AsppFn): the two shift kernels against torch index arithmetic
+    (exact), and the whole head — output, feature gradient, every kernel's and bias's gradient — against F.conv2d in float32 on the
+    same bf16-valued operands"""
+    import torch.nn.functional as F
+    from dsrg_amd import retrain as R
+    torch.manual_seed(21)
+    cl = torch.channels_last
+    B, H, W, O, CT = 2, 19, 23, 5, 128
+    offsets = [(-3, 0), (0, 2), (4, -5), (0, 0), (30, 0)]                               # (the last: every source outside the map)
+    y = torch.randn(B, CT, H, W, device="cuda").bfloat16().contiguous(memory_format=cl)
+    bias = torch.randn(O, device="cuda")
+    got = ops.aspp_shift_sum(y, offsets, O, bias)
+    want = bias.view(1, O, 1, 1).expand(B, O, H, W).clone()
+    yf = y.float()
+    for j, (dy, dx) in enumerate(offsets):
+        src = torch.zeros(B, O, H, W, device="cuda")
+        ys, ye, xs, xe = max(0, -dy), min(H, H - dy), max(0, -dx), min(W, W - dx)
+        if ye > ys and xe > xs:
+            src[:, :, ys:ye, xs:xe] = yf[:, j * O:(j + 1) * O, ys + dy:ye + dy, xs + dx:xe + dx]
+        want = want + src
+    assert torch.equal(got, want) and tuple(got.shape) == (B, O, H, W)
+    g = torch.randn(B, O, H, W, device="cuda")
+    gp = ops.aspp_shift_gather(g, offsets, CT)
+    wantp = torch.zeros(B, CT, H, W, device="cuda")
+    for j, (dy, dx) in enumerate(offsets):
+        ys, ye, xs, xe = max(0, dy), min(H, H + dy), max(0, dx), min(W, W + dx)
+        if ye > ys and xe > xs:
+            wantp[:, j * O:(j + 1) * O, ys:ye, xs:xe] = g[:, :, ys - dy:ye - dy, xs - dx:xe - dx]
+    assert torch.equal(gp, wantp.bfloat16()) and gp.is_contiguous(memory_format=cl)
+    # the whole head
+    B, cin, H, W, O, dils = 2, 256, 33, 35, 21, (6, 12, 18, 24)
+    f = torch.randn(B, cin, H, W, device="cuda").bfloat16().contiguous(memory_format=cl).requires_grad_(True)
+    ws = [(torch.randn(O, cin, 3, 3, device="cuda") * 0.02).bfloat16().float().contiguous(memory_format=cl).requires_grad_(True) for _ in dils]
+    bs = [torch.randn(O, device="cuda").requires_grad_(True) for _ in dils]
+    out = R._AsppFn.apply(dils, f, *ws, *bs)
+    gout = torch.randn(B, O, H, W, device="cuda")
+    out.backward(gout)
+    f32 = f.detach().float().requires_grad_(True)
+    ws32 = [w.detach().clone().requires_grad_(True) for w in ws]
+    bs32 = [b.detach().clone().requires_grad_(True) for b in bs]
+    ref = sum(F.conv2d(f32, w, b, padding=d, dilation=d) for w, b, d in zip(ws32, bs32, dils))
+    ref.backward(gout)
+    assert (out - ref).abs().max() <= 0.02 * ref.abs().max()                           # 36 bf16-rounded partial products per output
+    assert (f.grad.float() - f32.grad).abs().max() <= 0.02 * f32.grad.abs().max()
+    for w, w32, b, b32 in zip(ws, ws32, bs, bs32):
+        assert (w.grad - w32.grad).abs().max() <= 0.02 * w32.grad.abs().max()
+        assert (b.grad - b32.grad).abs().max() <= 1e-4 * b32.grad.abs().max() + 1e-4
+
+
 def test_add_relu_and_its_backward(ops):
     """ops.add_relu / ops.relu_mask (the fused tail of a ResNet bottleneck): relu(a + b) with one rounding, and (g (+ g2)) where y > 0"""
     torch.manual_seed(3)
