@@ -501,21 +501,29 @@ __global__ __launch_bounds__(256) void aspp_shift_sum_kernel(const uint16_t *__r
     }
     out[idx] = acc;
 }
-__global__ __launch_bounds__(256) void aspp_shift_gather_kernel(const float *__restrict__ g, uint16_t *__restrict__ gp, AsppShift s, int B, int H, int W) {
+__global__ __launch_bounds__(256) void aspp_shift_gather_kernel(const float *__restrict__ g, uint4 *__restrict__ gp, AsppShift s, int B, int H, int W) {
+    // eight channels (one 16-byte store) per thread
+    const int C8 = s.CT >> 3;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)B * H * W * s.CT) return;
-    const size_t p = idx / s.CT;
-    const int c = (int)(idx - p * s.CT), j = c / s.O, o = c - j * s.O;
+    if (idx >= (size_t)B * H * W * C8) return;
+    const size_t p = idx / C8;
+    const int c0 = (int)(idx - p * C8) << 3;
     const int b = (int)(p / ((size_t)H * W)), rem = (int)(p - (size_t)b * H * W), y = rem / W, x = rem - y * W;
-    float v = 0.0f;
-    if (j < s.J) {
-        const int yy = y - s.dy[j], xx = x - s.dx[j];
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = g[(((size_t)b * H + yy) * W + xx) * s.O + o];
+    int j = c0 / s.O, o = c0 - j * s.O;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        v[e] = 0.0f;
+        if (j < s.J) {
+            const int yy = y - s.dy[j], xx = x - s.dx[j];
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v[e] = g[(((size_t)b * H + yy) * W + xx) * s.O + o];
+        }
+        if (++o == s.O) { o = 0; j++; }
     }
-    gp[idx] = (uint16_t)(pack_bf16(v, 0.0f) & 0xffffu);
+    gp[idx] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
 static int aspp_shift_args(AsppShift &s, const int *offsets, int J, int O, int CT) {
-    if (!offsets || J < 1 || J > 36 || O < 1 || CT < J * O) return set_error(DSRG_ERR_INVALID, "aspp shift: 1..36 (dy, dx) pairs, CT >= J * O");
+    if (!offsets || J < 1 || J > 36 || O < 1 || CT < J * O || CT % 8) return set_error(DSRG_ERR_INVALID, "aspp shift: 1..36 (dy, dx) pairs, CT >= J * O, 8 | CT");
     memset(&s, 0, sizeof(s));
     s.J = J; s.O = O; s.CT = CT;
     for (int j = 0; j < J; j++) { s.dy[j] = offsets[2 * j]; s.dx[j] = offsets[2 * j + 1]; }
@@ -533,8 +541,8 @@ int launch_aspp_shift_sum(const void *yp, const float *bias, float *out, const i
 int launch_aspp_shift_gather(const float *g, void *gp, const int *offsets, int J, int O, int CT, int B, int H, int W, hipStream_t stream) {
     AsppShift s;
     if (int rc = aspp_shift_args(s, offsets, J, O, CT)) return rc;
-    const size_t n = (size_t)B * H * W * CT;
-    hipLaunchKernelGGL(aspp_shift_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, (uint16_t *)gp, s, B, H, W);
+    const size_t n = (size_t)B * H * W * (CT / 8);
+    hipLaunchKernelGGL(aspp_shift_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, (uint4 *)gp, s, B, H, W);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
