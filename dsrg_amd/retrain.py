@@ -169,7 +169,7 @@ class _FoldedIgemmFn(torch.autograd.Function):
                 gwf = torch.ops.aten.convolution_backward(gm, x, w.to(torch.bfloat16), None, [1, 1], [p, p], [d, d], False, [0, 0], 1,
                                                           [False, True, False])[1].float()
             gw = gwf * scale.view(-1, 1, 1, 1)
-        elif shortcut is not None and gx is None:
+        if shortcut is not None and gx is None:                                         # (cannot happen: the link is armed only by a node that computes one)
             raise RuntimeError("a shortcut gradient was left for a node that computes no data gradient")
         return gx, gw, None, None, None, None, None, None, gres, None
 
