@@ -360,6 +360,19 @@ def test_ms_record(device, steps, warmup, cpu=True):
         mask = one(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same loop with the CRFs of earlier images in flight under the next image's forwards (inference.predict_masks_ms_many): how
+    # a whole split (1 449 / 10 582 images) is run
+    npipe = max(64, steps)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        n_fl, n_b = int(os.environ.get("DSRG_TEST_MS_INFLIGHT", "3")), int(os.environ.get("DSRG_TEST_MS_BATCH", "1"))       # tools: A/B
+        for _ in I.predict_masks_ms_many(net, [imgs[i % len(imgs)] for i in range(8)], device=device, forward=fwd, in_flight=n_fl, batch=n_b):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in I.predict_masks_ms_many(net, [imgs[i % len(imgs)] for i in range(npipe)], device=device, forward=fwd, in_flight=n_fl, batch=n_b):
+            pass
+        torch.cuda.synchronize()
+        pipelined = npipe / (time.perf_counter() - t0)
     # the parts, each timed on its own (events): the three forwards + zooms + softmax, and the CRF + arg-max
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
@@ -383,6 +396,7 @@ def test_ms_record(device, steps, warmup, cpu=True):
            "dtype": "bf16 backbone forwards (fp32 heads), f64 zoom, f32 CRF", "data": "synthetic",
            "config": {"workload": "inference.predict_mask_ms: scales 241/321/401, CRF scale_factor 1, maxiter 10, one image per step"},
            "forwards_zoom_softmax_ms": fwd_ms, "crf_argmax_ms": crf_ms, "forwards_as_hip_graphs": graphed,
+           "images_per_s_crfs_in_flight": pipelined,
            "roofline": {"kernel": "the three VGG16-ASPP forwards (batch 1: 18-55 pixel tiles per layer; replayed as HIP graphs, tile-quantisation-bound)",
                         "bound": "mfma", "achieved": flops / (fwd_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": flops / (fwd_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,

@@ -125,6 +125,39 @@ def predict_mask_ms(net, image, smooth=True, sizes=(241, 321, 401), device="cuda
 
 
 @torch.no_grad()
+def predict_masks_ms_many(net, images, sizes=(241, 321, 401), device="cuda", forward=None, in_flight=3, batch=1):
+    """predict_mask_ms over many images (the loop of test-ms.py over a split's 1 449 / 10 582 images), as a generator of (H,W) int64
+    masks in order: the forwards of image i + 1 (on the caller's stream; `forward`: a GraphedForward) run while the CRFs of the images
+    before it are in flight on `in_flight` worker streams (crf.CRF_device_many; batch > 1: consecutive same-sized images share one
+    batched CRF call).  Same masks as predict_mask_ms image by image."""
+    from .crf import CRF_device_many
+
+    def pairs():
+        for image in images:
+            probs = _probs_from_scores(multiscale_scores(net, image, sizes, device, forward))
+            unary = torch.log(probs).permute(1, 2, 0).contiguous()
+            yield torch.as_tensor(np.asarray(image).astype('ubyte'), device=unary.device), unary
+
+    # the CRF workers come back from the library three times per image and need the interpreter lock for a few lines each time; the
+    # caller's thread, busy issuing torch ops, would keep it for Python's default 5 ms switch interval — longer than a whole CRF
+    import sys
+    interval = sys.getswitchinterval()
+    sys.setswitchinterval(min(interval, 1e-4))
+    # ... and the forwards go to a stream of their own: on the caller's (usually the null) stream they share a hardware queue with one of
+    # the CRF workers' streams or not, depending on how many streams the process made before — 178 or 240 images/s from run to run
+    import os
+    fstream = None if os.environ.get("DSRG_TEST_MS_FSTREAM", "1") == "0" else torch.cuda.Stream(device=device)      # 0: tools, A/B
+    try:
+        if fstream is not None:
+            fstream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(fstream):
+            for lab in CRF_device_many(pairs(), scale_factor=1.0, want="map", in_flight=in_flight, batch=batch):
+                yield lab.cpu().numpy().astype(np.int64)
+    finally:
+        sys.setswitchinterval(interval)
+
+
+@torch.no_grad()
 def predict_train_gt(net, image, labels, smooth=True, device="cuda"):
     """generate_train_gt.py:78-106: single-scale (321) softmax, zoomed to the image, CRF on log-probs,
     argmax restricted to background + the image-level labels -> (H,W) int64 pseudo-label mask"""

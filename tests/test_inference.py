@@ -178,3 +178,22 @@ def test_graphed_forward_equals_the_eager_forward():
     net.train()
     with pytest.raises(RuntimeError):
         I.GraphedForward(net)(torch.zeros(1, 3, 241, 241, device=dev))
+
+
+@pytest.mark.gpu
+def test_predict_masks_ms_many_equals_the_one_image_calls():
+    """inference.predict_masks_ms_many (forwards of the next image while the CRFs before it are in flight) against predict_mask_ms image
+    by image: same masks, in order, for images of two sizes, with and without graphed forwards and batched CRF calls"""
+    from dsrg_amd import inference as I, synthetic as S
+    rng = np.random.default_rng(9)
+    ims = []
+    for k, (H, W) in enumerate([(97, 131), (97, 131), (120, 90), (97, 131), (120, 90), (120, 90), (120, 90)]):
+        im = (S.make_images(rng, 1, size=max(H, W), kind=["smooth", "noise", "dark_corner"][k % 3])[0, :, :H, :W] + S.MEAN_PIXEL[:, None, None])
+        ims.append(np.ascontiguousarray(im.transpose(1, 2, 0)[:, :, ::-1]).clip(0, 255).astype(np.uint8))
+    net = TinyNet().cuda().eval()
+    want = [I.predict_mask_ms(net, im, smooth=True) for im in ims]
+    for kw in (dict(in_flight=3), dict(in_flight=2, batch=2, forward=I.GraphedForward(net))):
+        got = list(I.predict_masks_ms_many(net, ims, **kw))
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a.dtype == np.int64 and np.array_equal(a, b)
