@@ -26,6 +26,11 @@ for w in $WHAT; do
       timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/pmc_train_mfma -o train_mfma -- python $ROOT/bench.py --steps 6 --warmup 6 --no-fp32 --no-cpu-baseline --no-modes --no-profile > $ROOT/$OUT/train_mfma.log 2>&1
       f=$(find /tmp/pmc_train_mfma -name "*counter_collection.csv" | head -1)
       [ -n "$f" ] && cp $f $ROOT/$OUT/train_mfma_counter_collection.csv && echo "train_mfma: $(wc -l < $f) rows" ;;
+    train_lds)
+      rm -rf /tmp/pmc_train_lds
+      timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d /tmp/pmc_train_lds -o train_lds -- python $ROOT/bench.py --steps 4 --warmup 6 --no-fp32 --no-cpu-baseline --no-modes --no-profile > $ROOT/$OUT/train_lds.log 2>&1
+      f=$(find /tmp/pmc_train_lds -name "*counter_collection.csv" | head -1)
+      [ -n "$f" ] && cp $f $ROOT/$OUT/train_lds_counter_collection.csv && echo "train_lds: $(wc -l < $f) rows" ;;
   esac
 done
 cd $ROOT
