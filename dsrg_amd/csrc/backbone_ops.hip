@@ -1037,70 +1037,85 @@ __device__ __forceinline__ hbf16x8 tr_frag16(DSRG_LDS_AS unsigned char *p, int s
 }
 }  // namespace
 
-// forward: as heads_fwd_kernel (one workgroup = one 32-row tile, wave = branch), the x fragment is the lane's 16-byte load as it
-// is, the weight fragment its 32-byte load split in three
+// forward: as heads_fwd_kernel (wave = branch), the x fragment is the lane's 16-byte load as it is, the weight fragment its 32-byte
+// load split in three.  One workgroup = R 32-row tiles: the weight fragment (344 KB of W per workgroup, from L2) and its split are
+// shared by the R tiles — R = 2 halves both per row (round 6: 97 -> see profiles/r06_fused_backward_probe.txt); the rows' arithmetic
+// is the same either way (bit-identical outputs).
+template <int R>
 __global__ __launch_bounds__(256) void heads_fwd_split_kernel(HeadArgs a) {
-    __shared__ float part[4][16][64];
+    __shared__ float part[R][4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 32;
+    const int m0 = blockIdx.x * (32 * R);
     const int row = lane & 31, half = lane >> 5;
-    f32x16 acc0, acc1, acc2;
+    f32x16 acc[R][3];
 #pragma unroll
-    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; acc2[r] = 0.0f; }
+    for (int t = 0; t < R; t++)
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][q][r] = 0.0f;
     if (wave < a.nbr) {
-        const int mr = min(m0 + row, a.M - 1);                      // clamped rows are never stored
-        const uint16_t *xp = a.x[wave] + (size_t)mr * a.K + half * 8;
+        const uint16_t *xp[R];
+#pragma unroll
+        for (int t = 0; t < R; t++) xp[t] = a.x[wave] + (size_t)min(m0 + 32 * t + row, a.M - 1) * a.K + half * 8;      // clamped rows are never stored
         const float *wp = a.w + ((size_t)wave * a.O + min(row, a.O - 1)) * a.K + half * 8;
         constexpr int G = 4;                                        // 16-channel steps in flight (K % 256 == 0)
-        uint4 xv[G];
+        uint4 xv[G][R];
         float4 wv[G][2];
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            xv[u] = *reinterpret_cast<const uint4 *>(xp + u * 16);
+#pragma unroll
+            for (int t = 0; t < R; t++) xv[u][t] = *reinterpret_cast<const uint4 *>(xp[t] + u * 16);
             wv[u][0] = *reinterpret_cast<const float4 *>(wp + u * 16);
             wv[u][1] = *reinterpret_cast<const float4 *>(wp + u * 16 + 4);
         }
         for (int kb = 0; kb < a.K; kb += 16 * G) {
 #pragma unroll
             for (int u = 0; u < G; u++) {
-                const hbf16x8 xa = *reinterpret_cast<hbf16x8 *>(&xv[u]);
+                hbf16x8 xa[R];
+#pragma unroll
+                for (int t = 0; t < R; t++) xa[t] = *reinterpret_cast<hbf16x8 *>(&xv[u][t]);
                 const float wf[8] = {wv[u][0].x, wv[u][0].y, wv[u][0].z, wv[u][0].w, wv[u][1].x, wv[u][1].y, wv[u][1].z, wv[u][1].w};
                 const int kn = kb + 16 * G + u * 16;
                 if (kn < a.K) {
-#if !(DSRG_EXP & 1)
-                    xv[u] = *reinterpret_cast<const uint4 *>(xp + kn);
-#endif
-#if !(DSRG_EXP & 2)
+#pragma unroll
+                    for (int t = 0; t < R; t++) xv[u][t] = *reinterpret_cast<const uint4 *>(xp[t] + kn);
                     wv[u][0] = *reinterpret_cast<const float4 *>(wp + kn);
                     wv[u][1] = *reinterpret_cast<const float4 *>(wp + kn + 4);
-#endif
                 }
                 hbf16x8 w0, w1, w2;
                 split3(wf, w0, w1, w2);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, w0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, w1, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, w2, acc2, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < R; t++) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[t], w0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[t], w1, acc[t][1], 0, 0, 0);
+                    acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[t], w2, acc[t][2], 0, 0, 0);
+                }
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; r++) part[wave][r][lane] = acc0[r] + (acc1[r] + acc2[r]);
+    for (int t = 0; t < R; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) part[t][wave][r][lane] = acc[t][0][r] + (acc[t][1][r] + acc[t][2][r]);
     __syncthreads();
     const int col = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
     if (col < a.O) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int rr = r4 + q, m = m0 + rr;
-            if (m >= a.M) break;
-            const int hf = (rr >> 2) & 1, reg = (rr & 3) + 4 * (rr >> 3), ln = col + 32 * hf;
-            float s = 0.0f;
-            for (int k = 0; k < a.nbr; k++) {
-                const float sk = part[k][reg][ln] + (a.bias ? a.bias[k * a.O + col] : 0.0f);
-                s = k == 0 ? sk : s + sk;
+        for (int t = 0; t < R; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int rr = r4 + q, m = m0 + 32 * t + rr;
+                if (m >= a.M) break;
+                const int hf = (rr >> 2) & 1, reg = (rr & 3) + 4 * (rr >> 3), ln = col + 32 * hf;
+                float s = 0.0f;
+                for (int k = 0; k < a.nbr; k++) {
+                    const float sk = part[t][k][reg][ln] + (a.bias ? a.bias[k * a.O + col] : 0.0f);
+                    s = k == 0 ? sk : s + sk;
+                }
+                const int b = m / a.HW, hw = m - b * a.HW;
+                a.out[((size_t)b * a.O + col) * a.HW + hw] = s;
             }
-            const int b = m / a.HW, hw = m - b * a.HW;
-            a.out[((size_t)b * a.O + col) * a.HW + hw] = s;
-        }
     }
 }
 
@@ -1197,7 +1212,13 @@ int launch_heads_fwd(const void *const *x, int nbr, const float *w, const float 
     if (heads_f32_mfma())
         hipLaunchKernelGGL(heads_fwd_kernel, dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(heads_fwd_split_kernel, dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
+    {
+        static const int tiles = [] { const char *e = getenv("DSRG_HEAD_FWD_TILES"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }();      // tools: A/B
+        if (tiles == 4) hipLaunchKernelGGL(heads_fwd_split_kernel<4>, dim3((a.M + 127) / 128), dim3(256), 0, stream, a);
+        else if (tiles == 3) hipLaunchKernelGGL(heads_fwd_split_kernel<3>, dim3((a.M + 95) / 96), dim3(256), 0, stream, a);
+        else if (tiles == 2) hipLaunchKernelGGL(heads_fwd_split_kernel<2>, dim3((a.M + 63) / 64), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(heads_fwd_split_kernel<1>, dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
+    }
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
