@@ -55,42 +55,26 @@ def preprocess(image, size, device="cuda"):
 
 class GraphedForward(object):
     """`net(x)` of an eval-mode network for the FIXED input shapes of the test-time loop (test-ms.py resizes every image to 241 / 321 /
-    401 before the forward, whatever its own size) as captured HIP graphs: one graph per input shape, captured at the first call with
-    that shape (after two eager warm-up passes on a side stream, which also size every scratch buffer the kernels' wrappers cache) and
-    replayed afterwards.  A batch-1 forward is ~40 launches of 10-30 us of GPU work each; issued one by one from Python it takes 1.4 ms
-    whatever the map size (host-bound), replayed it takes what the GPU needs.  The graph re-reads (and re-packs) the parameters at
-    every replay, so in-place weight updates are seen; the returned tensor is the graph's static output: consume it before the next
-    call with the same shape.  Capture happens under the autocast state of the first call — keep it the same afterwards."""
+    401 before the forward, whatever its own size) as captured HIP graphs: one backbone.GraphedForward per input shape (and autocast
+    state), made at the first call with that shape and replayed afterwards.  A batch-1 forward is ~40 launches of 10-30 us of GPU
+    work each; issued one by one from Python it takes 1.4 ms whatever the map size (host-bound), replayed it takes what the GPU needs.
+    The graph re-reads (and re-packs) the parameters at every replay, so in-place weight updates are seen; the returned tensor is the
+    graph's static output: consume it before the next call with the same shape."""
 
     def __init__(self, net):
         self.net = net
         self._g = {}
 
     def __call__(self, x):
-        key = (tuple(x.shape), x.dtype, torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
-        ent = self._g.get(key)
-        if ent is None:
-            ent = self._g[key] = self._capture(x)
-        graph, xs, ys = ent
-        xs.copy_(x)
-        graph.replay()
-        return ys
-
-    def _capture(self, x):
-        if self.net.training:
-            raise RuntimeError("GraphedForward needs an eval-mode network (no dropout stream inside a graph)")
-        xs = x.clone()
-        side = torch.cuda.Stream(device=x.device)
-        side.wait_stream(torch.cuda.current_stream(x.device))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):
-                self.net(xs)
-        torch.cuda.current_stream(x.device).wait_stream(side)
-        torch.cuda.synchronize(x.device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph), torch.no_grad():
-            ys = self.net(xs)
-        return graph, xs, ys
+        amp = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        key = (tuple(x.shape), x.dtype, amp)
+        g = self._g.get(key)
+        if g is None:
+            from .backbone import GraphedForward as _OneShape
+            if self.net.training:
+                raise RuntimeError("GraphedForward needs an eval-mode network (no dropout stream inside a graph)")
+            g = self._g[key] = _OneShape(self.net, x, amp_dtype=amp)
+        return g(x)
 
 
 @torch.no_grad()
