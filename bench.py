@@ -450,13 +450,13 @@ def infer_record(device, rank, B, steps, warmup, use_graph=True):
             graph, graph_note = None, "eager (capture failed: %s)" % str(e)[:120]
 
     @torch.no_grad()
-    def one():
+    def one(replay_forward=True):
         # the bilateral lattices depend only on the image: built on a side stream underneath the backbone forward
         main = torch.cuda.current_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ops.crf_prepare(images, 21, 41, 41, ctx=ctx)
-        if graph is not None:
+        if graph is not None and replay_forward:
             scores = graph(x)
         else:
             with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -468,6 +468,29 @@ def infer_record(device, rank, B, steps, warmup, use_graph=True):
     for _ in range(warmup):
         one()
     torch.cuda.synchronize()
+    # the WHOLE step as one graph (forward replay + lattice build on the side stream + softmax + mean field + region growing: the
+    # supervision path sizes everything for the worst case and never asks the host anything, so it captures as it is): tried when
+    # DSRG_INFER_STEP_GRAPH=1 (tools: A/B); the results must equal the launch-by-launch step's
+    step_graph = None
+    if use_graph and os.environ.get("DSRG_INFER_STEP_GRAPH", "0") == "1":
+        try:
+            want = one().clone()
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                out2 = one(replay_forward=False)                 # (a graph cannot replay another while it is being captured: the forward is captured again, in line)
+            g2.replay()
+            torch.cuda.synchronize()
+            if not torch.equal(out2, want):
+                raise RuntimeError("replayed step differs")
+            step_graph = g2
+            graph_note += "; whole step (lattice build, softmax, CRF, SRG) replayed as one graph too"
+        except Exception as e:                                   # noqa: BLE001
+            graph_note += "; whole-step capture failed: %s" % str(e)[:160]
+    if step_graph is not None:
+        def one(replay_forward=True):                            # noqa: F811
+            step_graph.replay()
+            return out2
     t0 = time.perf_counter()
     for _ in range(steps):
         seeds = one()
