@@ -90,6 +90,8 @@ SIGNATURES = {
     "dsrg_pack_conv_weight_scaled_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "dsrg_aspp_shift_sum_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 6 + [_vp]),
     "dsrg_aspp_shift_gather_bf16": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_vp]),
+    "dsrg_defer_reductions": (_i, [_i]),
+    "dsrg_flush_reductions": (_i, [_vp]),
     "dsrg_conv_igemm_residual_bf16": (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     "dsrg_conv_igemm_split_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "dsrg_add_relu_bf16": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -74,27 +74,7 @@ __global__ __launch_bounds__(kRbThreads) void relu_bwd_bias_kernel(const uint4 *
 __global__ __launch_bounds__(256) void bias_finalize_kernel(const float *__restrict__ part, float *__restrict__ bias_grad,
                                                             int nblk, int C) {
     __shared__ float red[8][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < C) {
-        int b = sl;
-        for (; b + 24 < nblk; b += 32) {
-            s0 += part[(size_t)b * C + c];
-            s1 += part[(size_t)(b + 8) * C + c];
-            s2 += part[(size_t)(b + 16) * C + c];
-            s3 += part[(size_t)(b + 24) * C + c];
-        }
-        for (; b < nblk; b += 8) s0 += part[(size_t)b * C + c];
-    }
-    red[sl][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][cl];
-        bias_grad[c] = s;
-    }
+    bias_finalize_block(part, bias_grad, nblk, C, (int)blockIdx.x, red);
 }
 
 int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_grad, float *part, int part_blocks,
@@ -111,7 +91,8 @@ int launch_relu_bwd_bias(const void *g, const void *y, void *gm, float *bias_gra
     hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(nblk), dim3(kRbThreads), 0, stream, (const uint4 *)g, (const uint4 *)y,
                        (uint4 *)gm, part, (int)rows, C8, rpb, scale);
     DSRG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
+    if (!defer_reduction(1, part, bias_grad, nblk, C))
+        hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
@@ -577,7 +558,8 @@ int launch_bias_grad(const void *g, float *bias_grad, float *part, int part_bloc
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(bias_grad_kernel, dim3(nblk), dim3(kRbThreads), 0, stream, (const unsigned short *)g, part, (int)rows, C, rpb);
     DSRG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
+    if (!defer_reduction(1, part, bias_grad, nblk, C))
+        hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }
@@ -623,7 +605,8 @@ int launch_maxpool3x3_bwd_relu(const void *gout, const void *code, const void *y
         hipLaunchKernelGGL(maxpool3x3_s2_bwd_relu_kernel<false>, dim3(nblk), dim3(kRbThreads), 0, stream, (const uint4 *)gout,
                            (const uint2 *)code, (const uint4 *)nullptr, (uint4 *)gin, part, B, H, W, OH, OW, C8, ipb);
     DSRG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
+    if (!defer_reduction(1, part, bias_grad, nblk, C))
+        hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, bias_grad, nblk, C);
     DSRG_LAUNCH_CHECK();
     return DSRG_OK;
 }

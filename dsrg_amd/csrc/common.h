@@ -19,6 +19,60 @@ int set_error(int code, const char *fmt, ...);
     } while (0)
 #define DSRG_LAUNCH_CHECK() DSRG_HIP_CHECK(hipGetLastError())
 
+// ---- the small reductions that finish a bias gradient (column sums of a launch's per-tile partial rows; the direct kernels' per-block
+// partial rows), as device bodies shared by their own kernels and by the deferred multi-reduction (deferred.hip): same arithmetic,
+// same order, whoever runs them.
+// column sums of `rows` partial rows of `cout` floats: block bx owns channels [64 bx, 64 bx + 64), 1024 threads = 16 row slices
+__device__ __forceinline__ void colsum_block(const float *__restrict__ p, float *__restrict__ out, int rows, int cout, int bx, float (*red)[64]) {
+    const int cl = threadIdx.x & 63, c = bx * 64 + cl, q = threadIdx.x >> 6;
+    float s0 = 0.0f, s1 = 0.0f;
+    int r = q;
+    for (; r + 16 < rows; r += 32) {
+        s0 += p[(size_t)r * cout + c];
+        s1 += p[(size_t)(r + 16) * cout + c];
+    }
+    if (r < rows) s0 += p[(size_t)r * cout + c];
+    red[q][cl] = s0 + s1;
+    __syncthreads();
+    if (q == 0) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) t[k] = (red[4 * k][cl] + red[4 * k + 1][cl]) + (red[4 * k + 2][cl] + red[4 * k + 3][cl]);
+        out[c] = (t[0] + t[1]) + (t[2] + t[3]);
+    }
+}
+// 32 channels x 8 slices of `nblk` partial rows of C floats per block (threads 0-255; further threads of a larger block idle along);
+// slice sums are combined in slice order
+__device__ __forceinline__ void bias_finalize_block(const float *__restrict__ part, float *__restrict__ bias_grad, int nblk, int C, int bx,
+                                                    float (*red)[33]) {
+    const bool on = threadIdx.x < 256;
+    const int cl = threadIdx.x & 31, sl = (threadIdx.x >> 5) & 7;
+    const int c = bx * 32 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (on && c < C) {
+        int b = sl;
+        for (; b + 24 < nblk; b += 32) {
+            s0 += part[(size_t)b * C + c];
+            s1 += part[(size_t)(b + 8) * C + c];
+            s2 += part[(size_t)(b + 16) * C + c];
+            s3 += part[(size_t)(b + 24) * C + c];
+        }
+        for (; b < nblk; b += 8) s0 += part[(size_t)b * C + c];
+    }
+    if (on) red[sl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (on && sl == 0 && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        bias_grad[c] = s;
+    }
+}
+// Deferred form (dsrg_defer_reductions / dsrg_flush_reductions): while deferral is on, a launch that would end with one of the two
+// passes above records it instead — true: recorded, the caller launches nothing; false: not deferring (or the list is full).
+// kind 0: colsum_block over (rows, cols = cout); kind 1: bias_finalize_block over (rows = nblk, cols = C).
+bool defer_reduction(int kind, const float *part, float *out, int rows, int cols);
+
 // raise a kernel's dynamic-LDS limit (default 64 KiB) to `bytes`; `granted` caches what was set.
 // The limit is requested per need, not as a flat 160 KiB: static LDS (e.g. the variable behind
 // __syncthreads_or) counts against the same 160 KiB and an over-ask is rejected.

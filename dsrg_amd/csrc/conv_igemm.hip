@@ -1271,27 +1271,17 @@ struct ColsumArgs {
 };
 __global__ __launch_bounds__(1024) void igemm_colsum_kernel(ColsumArgs a) {
     __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, q = threadIdx.x >> 6;
-    const float *p = a.part[blockIdx.y];
-    float s0 = 0.0f, s1 = 0.0f;
-    int r = q;
-    for (; r + 16 < a.rows; r += 32) {
-        s0 += p[(size_t)r * a.cout + c];
-        s1 += p[(size_t)(r + 16) * a.cout + c];
-    }
-    if (r < a.rows) s0 += p[(size_t)r * a.cout + c];
-    red[q][cl] = s0 + s1;
-    __syncthreads();
-    if (q == 0) {
-        float t[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) t[k] = (red[4 * k][cl] + red[4 * k + 1][cl]) + (red[4 * k + 2][cl] + red[4 * k + 3][cl]);
-        a.out[blockIdx.y][c] = (t[0] + t[1]) + (t[2] + t[3]);
-    }
+    colsum_block(a.part[blockIdx.y], a.out[blockIdx.y], a.rows, a.cout, (int)blockIdx.x, red);
 }
 
 int launch_igemm_colsum(const float *const *parts, float *const *outs, int ngroups, int rows, int cout, hipStream_t stream) {
     if (ngroups < 1 || ngroups > 4 || cout % 64 || rows < 1) return set_error(DSRG_ERR_INVALID, "column sums: 1..4 groups, 64 | channels");
+    {   // deferred (dsrg_defer_reductions): all groups or none
+        int g = 0;
+        while (g < ngroups && defer_reduction(0, parts[g], outs[g], rows, cout)) g++;
+        if (g == ngroups) return DSRG_OK;
+        if (g > 0) return set_error(DSRG_ERR_INVALID, "column sums: the deferred-reduction list filled up in the middle of a launch's groups");
+    }
     ColsumArgs c;
     memset(&c, 0, sizeof(c));
     for (int g = 0; g < ngroups; g++) { c.part[g] = parts[g]; c.out[g] = outs[g]; }

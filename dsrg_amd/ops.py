@@ -27,6 +27,40 @@ def _f32c(t, name):
     return t
 
 
+# ---- deferred bias-gradient reductions (dsrg_defer_reductions / dsrg_flush_reductions) -------------------------------------------
+# Inside `with deferred_reductions():` the 5-7 us passes that finish a bias gradient (column sums of a data gradient's partial rows,
+# the direct kernels' block partials: fifteen per train-s step) are recorded by the library and run in ONE launch when the block
+# ends.  This module's part of the contract: every recorded launch gets partial-row scratch of its own (`_partial_rows`: a fresh
+# tensor instead of the cached one) and all such scratch stays alive until the flush is enqueued (`_defer_keep`).
+_defer = [False]
+_defer_keep = []
+
+
+def _keep_until_flush(*tensors):
+    if _defer[0]:
+        _defer_keep.extend(t for t in tensors if t is not None)
+
+
+@__import__("contextlib").contextmanager
+def deferred_reductions(enabled=True):
+    """inside: bias gradients returned by this module's launches are NOT final until the block ends (nothing may read them; autograd's
+    AccumulateGrad adopting a gradient of a parameter whose .grad is None is no read); on exit one launch finishes them all"""
+    if not enabled or _defer[0]:
+        yield
+        return
+    L = _lib.lib()
+    check(L.dsrg_defer_reductions(1))
+    _defer[0] = True
+    try:
+        yield
+    finally:
+        _defer[0] = False
+        rc = L.dsrg_flush_reductions(_stream())
+        L.dsrg_defer_reductions(0)
+        del _defer_keep[:]
+        check(rc)
+
+
 class Context(object):
     """dsrg_ctx_t: device workspace for up to max_batch images of shape (C,H,W)."""
 
@@ -406,6 +440,19 @@ _PARTIAL_BLOCKS = 512
 _partials = {}
 
 
+def _partial_rows(device, C):
+    """the partial-row scratch of a bias-gradient launch: the cached buffer of (device, C) — or, while the finishing passes are being
+    deferred (deferred_reductions), a buffer of the launch's own, kept until the flush"""
+    if _defer[0]:
+        part = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=device)
+        _defer_keep.append(part)
+        return part
+    part = _partials.get((device, C))
+    if part is None:
+        part = _partials[(device, C)] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=device)
+    return part
+
+
 def _dest(out, shape, dtype, device, channels_last=False):
     """`out` if it can take a kernel's result of this shape / dtype in place (a reducer's gradient slot: dense, the layout the
     kernel writes), else a fresh tensor"""
@@ -428,10 +475,7 @@ def relu_bwd_bias(g, y, scale=1.0, gb_out=None):
     g = g.contiguous(memory_format=cl)
     gm = torch.empty_like(y)
     gb = _dest(gb_out, (C,), torch.float32, y.device)
-    key = (y.device, C)
-    part = _partials.get(key)
-    if part is None:
-        part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=y.device)
+    part = _partial_rows(y.device, C)
     check(_lib.lib().dsrg_relu_bwd_bias_bf16(_ptr(g), _ptr(y), _ptr(gm), _ptr(gb), _ptr(part), _PARTIAL_BLOCKS,
                                              B * H * W, C, float(scale), _stream()))
     return gm, gb
@@ -444,10 +488,7 @@ def bias_grad(g):
         raise ValueError("bias_grad needs a bf16 CUDA tensor")
     g = g.contiguous(memory_format=torch.channels_last)
     gb = torch.empty(C, dtype=torch.float32, device=g.device)
-    key = (g.device, C)
-    part = _partials.get(key)
-    if part is None:
-        part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=g.device)
+    part = _partial_rows(g.device, C)
     if C % 8 == 0:                                   # 16-byte lanes, no mask, nothing stored
         check(_lib.lib().dsrg_relu_bwd_bias_bf16(_ptr(g), None, None, _ptr(gb), _ptr(part), _PARTIAL_BLOCKS,
                                                  B * H * W, C, 1.0, _stream()))
@@ -533,6 +574,7 @@ def conv3x3_direct_dgrad(g, weight_t, mask):
     gx = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=g.device, memory_format=cl)
     gb = torch.empty(cout, dtype=torch.float32, device=g.device)
     ws = torch.empty(L.dsrg_conv3x3_direct_dgrad_workspace(cout), dtype=torch.uint8, device=g.device)
+    _keep_until_flush(ws)
     check(L.dsrg_conv3x3_direct_dgrad_bf16(_ptr(g), _ptr(w), _ptr(mask), _ptr(gx), _ptr(gb), _ptr(ws), ws.numel(), B, H, W, C, cout,
                                            _stream()))
     return gx, gb
@@ -915,6 +957,7 @@ def conv_igemm_dgrad(gs, packed_t, masks, dilations, ksize, mask_scale=1.0, bias
     if bias_grad:
         gb = [_dest(gb_outs[i] if gb_outs is not None else None, (cout,), torch.float32, gs[0].device) for i in range(n)]
         ws = torch.empty(L.dsrg_conv_igemm_dgrad_workspace(n, B, H, W, cout), dtype=torch.uint8, device=gs[0].device)
+        _keep_until_flush(ws)
     check(L.dsrg_conv_igemm_dgrad_bf16(vp(*[g.data_ptr() for g in gs]), vp(*[p.data_ptr() for p in packed_t]),
                                        vp(*[m.data_ptr() for m in masks]), vp(*[o.data_ptr() for o in outs]),
                                        vp(*[b.data_ptr() for b in gb]) if gb else None,
@@ -953,6 +996,7 @@ def conv_igemm_backward(g, packed_d, x, dilation, mask=None, mask_scale=1.0, ksi
     if mask is not None:
         gb = _dest(gb_out, (cin,), torch.float32, g.device)
         cws = torch.empty(L.dsrg_conv_igemm_dgrad_workspace(1, B, H, W, cin), dtype=torch.uint8, device=g.device)
+        _keep_until_flush(cws)
     check(L.dsrg_conv_igemm_backward_bf16(_ptr(g), _ptr(packed_d), _ptr(x), _ptr(mask), _ptr(gx), _ptr(gw), int(dilation), _ptr(gb),
                                           float(mask_scale), _ptr(cws), cws.numel() if cws is not None else 0, _ptr(ws), ws.numel(),
                                           B, H, W, cin, cout, ksize, _stream()))
@@ -1100,6 +1144,7 @@ def heads_backward(xs, weight, g, need_gx=True, relu_scale=0.0):
     if relu_scale > 0.0 and need_gx:
         gb = torch.empty((n, K), dtype=torch.float32, device=g.device)
         ws = torch.empty(L.dsrg_heads_backward_relu_workspace(n, M, K), dtype=torch.uint8, device=g.device)
+        _keep_until_flush(ws)
         check(L.dsrg_heads_backward_relu_bf16(ptrs, n, _ptr(weight), _ptr(g), _ptr(gx), M * K * 2, _ptr(gw), _ptr(part),
                                               float(relu_scale), _ptr(gb), _ptr(ws), ws.numel(), B, H * W, K, O, _stream()))
         return [gx[k].permute(0, 3, 1, 2) for k in range(n)], gw, gb
@@ -1155,10 +1200,7 @@ def maxpool3x3_bwd_relu(gout, code, relu_out, stride=2, gb_out=None):
     gout = gout.contiguous(memory_format=cl)
     gin = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=gout.device, memory_format=cl)
     gb = _dest(gb_out, (C,), torch.float32, gout.device)
-    key = (gout.device, C)                                          # shared with relu_bwd_bias (same stream-ordering rule)
-    part = _partials.get(key)
-    if part is None:
-        part = _partials[key] = torch.empty(_PARTIAL_BLOCKS * C, dtype=torch.float32, device=gout.device)
+    part = _partial_rows(gout.device, C)                            # shared with relu_bwd_bias (same stream-ordering rule)
     check(_lib.lib().dsrg_maxpool3x3_bwd_relu_bf16(_ptr(gout), _ptr(code), _ptr(relu_out) if have_y else None, _ptr(gin), _ptr(gb), _ptr(part),
                                                    _PARTIAL_BLOCKS, B, H, W, OH, OW, C, _stream()))
     return gin, gb

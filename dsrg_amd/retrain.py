@@ -424,6 +424,9 @@ class RetrainTrainer(object):
             net = net.to(memory_format=torch.channels_last)
         self.net = self.model = net
         self.reducer = None
+        # the bias gradients' finishing passes as one launch behind backward: for the VGG backbone, whose nodes hand bias gradients on
+        # untouched (the ResNet route's library-GEMM nodes are not checked for that)
+        self.defer_bias = backbone == "vgg16" and torch.device(device).type == "cuda" and _os.environ.get("DSRG_DEFER_REDUCTIONS", "1") != "0"
         if (world_size > 1) if ddp is None else ddp:
             from .reducer import BucketedAllReduce           # as DSRGTrainer: gradients land in their all-reduce buckets
             self.reducer = BucketedAllReduce(list(net.parameters()), bucket_cap_mb=32)
@@ -450,7 +453,9 @@ class RetrainTrainer(object):
         with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             logits = self.model(x)
         loss = seg_softmax_loss(logits, interp_shrink(label, 8))
-        loss.backward()
+        from .ops import deferred_reductions
+        with deferred_reductions(self.defer_bias):             # (see DSRGTrainer.step)
+            loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()

@@ -169,6 +169,7 @@ class DSRGTrainer(object):
                 from .reducer import BucketedAllReduce
                 self.reducer = BucketedAllReduce(list(net.parameters()), bucket_cap_mb=bucket_cap_mb)
         self.opt = CaffeSGD(net.caffe_param_groups())
+        self.defer_bias = device.type == "cuda" and os.environ.get("DSRG_DEFER_REDUCTIONS", "1") != "0"      # 0: tools, A/B
         if snapshot is not None:
             self.load(snapshot)
         # per-rank dropout stream: seeded with the DISTRIBUTED rank, not the device ordinal — under a launcher that shows every
@@ -241,7 +242,11 @@ class DSRGTrainer(object):
             total, losses = self.loss_fn(logits, images, labels, cues, prepared=True)
         else:
             total, losses = self.loss_fn(logits, images, labels, cues)
-        total.backward()
+        # the fifteen 5-7 us passes that finish a bias gradient are recorded during backward and run as one launch behind it
+        # (ops.deferred_reductions: same bits; nothing reads a bias gradient before the reducer / the update)
+        from .ops import deferred_reductions
+        with deferred_reductions(self.defer_bias):
+            total.backward()
         if self.reducer is not None:
             self.reducer.finish()                           # the rest of the buckets out, the collectives joined; p.grad = the mean
         self.opt.step()

@@ -374,6 +374,17 @@ int dsrg_aspp_shift_sum_f32(const void *y_dev, const float *bias_dev, float *out
                             int channels, int B, int H, int W, void *stream);
 int dsrg_aspp_shift_gather_bf16(const float *g_dev, void *gp_dev, const int *offsets, int npairs, int outputs, int channels, int B, int H,
                                 int W, void *stream);
+/* Deferred bias-gradient reductions.  The launches that hand back a bias gradient (dsrg_conv_igemm_dgrad_bf16 / dsrg_conv_igemm_backward_bf16
+ * with bias_grad_dev, dsrg_conv3x3_direct_dgrad_bf16, dsrg_heads_backward_relu_bf16, dsrg_relu_bwd_bias_bf16, dsrg_bias_grad_bf16,
+ * dsrg_maxpool3x3_bwd_relu_bf16) end with a pass of 5-7 us that sums per-tile / per-block partial rows (fifteen such passes per
+ * train-s step, 96 us) and nothing reads a bias gradient before the update.  dsrg_defer_reductions(1): from now on these passes
+ * are RECORDED instead of launched (up to 48; beyond that they run as before); dsrg_flush_reductions(stream) runs everything
+ * recorded in ONE launch on `stream` — the same arithmetic in the same order, the gradients' bits do not change — and
+ * dsrg_defer_reductions(0) stops recording.  Process-wide.  The caller's duties while recording: the partial-row scratch it passed
+ * to each launch (workspace_dev / partial_dev) stays alive, and is not shared between launches, until the flush has been enqueued
+ * on the stream the launches ran on; nothing reads the bias gradients before it. */
+int dsrg_defer_reductions(int on);
+int dsrg_flush_reductions(void *stream);
 int dsrg_conv_igemm_workspace_status(const void *workspace_dev, void *stream, int *status_host);
 /* The two packed forms dsrg_conv_igemm_bf16 reads, from the float32 master kernel in ONE pass (cast included): w_dev
  * (cout, ksize*ksize, cin) f32 = the memory of a channels_last (cout, cin, ksize, ksize) parameter; fwd_dev (may be NULL):

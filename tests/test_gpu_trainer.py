@@ -460,6 +460,37 @@ def test_trainer_steps_with_the_sgd_pack_kernel_equal_torch_fused_sgd(ops, monke
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-5)
 
 
+def test_trainer_steps_with_deferred_bias_reductions_are_bit_identical(ops, monkeypatch):
+    """four DSRGTrainer steps at batch 16 with the bias gradients' finishing passes recorded during backward and run as ONE launch
+    behind it (ops.deferred_reductions, the default) against the same steps with every pass launched where it arises: the same device
+    code on the same partial rows — losses, weights and momentum buffers bit-equal; the library's list is empty and nothing is kept
+    afterwards; and a pass recorded beyond the list's capacity simply runs at once"""
+    from dsrg_amd import trainer as T, _lib
+    from dsrg_amd.backbone import VGG16ASPP
+    device = torch.device("cuda", 0)
+    images, labels, cues = _batch(16, seed=11)
+    out = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("DSRG_DEFER_REDUCTIONS", on)
+        torch.manual_seed(0)
+        tr = T.DSRGTrainer(device, seed=0, net=VGG16ASPP(dropout=0.0))
+        assert tr.defer_bias == (on == "1")
+        losses = [tr.step(images, labels, cues).detach().cpu() for _ in range(4)]
+        torch.cuda.synchronize()
+        out[on] = (torch.stack(losses), tr.weights_checksum().cpu(), [p.detach().clone() for p in tr.net.parameters()])
+        assert not ops._defer[0] and not ops._defer_keep
+        del tr
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1])
+    for a, b in zip(out["1"][2], out["0"][2]):
+        assert torch.equal(a, b)
+    # the op level: sixty bias gradients inside one block (the list holds 48), all right after the block
+    g = torch.randn(2, 64, 9, 11, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    want = ops.bias_grad(g).clone()
+    with ops.deferred_reductions():
+        got = [ops.bias_grad(g) for _ in range(60)]
+    assert all(torch.equal(t, want) for t in got)
+
+
 def test_bench_gpus_beyond_the_visible_ones_fails_in_one_line():
     """`python bench.py --gpus N` with fewer than N GPUs on the node: no traceback, one line naming the reason"""
     n = torch.cuda.device_count() + 1
